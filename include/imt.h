@@ -1,0 +1,225 @@
+/*
+ * imt.h -- C ABI of libimt_hip.so: the MI355X (gfx950) indexed-Merkle-tree hot path.
+ *
+ * Drop-in boundary for the one data-parallel path of
+ * aerius-labs/indexed-merkle-tree-halo2 (reference @ /root/reference): the Poseidon
+ * (T=3, RATE=2, R_F=8, R_P=57 over bn256::Fr) hashes and the depth-d Merkle-path
+ * recomputes behind
+ *     src/utils.rs                  IndexedMerkleTree::{new,get_root,get_proof,verify_proof}
+ *     src/indexed_merkle_tree.rs    verify_non_inclusion (:127), insert_leaf (:231),
+ *                                   compute_merkle_root (:78), and the test module's
+ *                                   update_idx_leaf / hash_nullifier_pre_images (:632-671)
+ * Each entry point names the reference interface it replaces.  INTEGRATION.md shows the
+ * Rust `extern "C"` binding a maintainer would add.
+ *
+ * Conventions
+ *  - every function returns IMT_OK (0) or a negative IMT_ERR_* code; nothing throws or
+ *    aborts across the ABI.  imt_last_error(ctx) gives a message for the last failure.
+ *  - a field element is 32 bytes.  IMT_FMT_CANONICAL: little-endian integer < p
+ *    (halo2curves Fr::to_repr()).  IMT_FMT_MONT256: the in-memory [u64;4] of a
+ *    halo2curves bn256::Fr (Montgomery, R = 2^256), for zero-copy from Rust.
+ *    IMT_FMT_DEVICE: the library's own resident format (Montgomery R = 2^261, reduced,
+ *    packed 8 x u32); only meaningful for buffers produced by this library.
+ *  - buffers are caller-allocated.  By default pointers are HOST pointers and the call
+ *    is synchronous.  With IMT_DEVICE_PTRS all data pointers are device pointers on the
+ *    context's device, the work is enqueued on the context's stream and the call returns
+ *    without synchronising; input errors are then reported by imt_ctx_sync().
+ *  - sibling arrays are LEVEL-MAJOR by default: sib[level][item] (coalesced on the
+ *    device).  IMT_SIB_ITEM_MAJOR selects sib[item][level], the order of the reference's
+ *    per-proof Vec<F> (src/utils.rs:63-85).
+ *  - an imt_ctx belongs to one host thread at a time (the reference's objects are
+ *    single-owner through &mut borrows: src/utils.rs:6-10).
+ *  - there is NO CPU fallback: without a usable HIP device imt_ctx_create fails with
+ *    IMT_ERR_NO_DEVICE.
+ */
+#ifndef IMT_H
+#define IMT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMT_OK 0
+#define IMT_ERR_NO_LEAVES (-1)    /* "Cannot create Merkle Tree with no leaves"  src/utils.rs:24-26 */
+#define IMT_ERR_ODD_LEAVES (-2)   /* "Leaves must be even"                       src/utils.rs:34-36 */
+#define IMT_ERR_NOT_POW2 (-3)     /* the index panic at src/utils.rs:45 for an even non-power-of-two */
+#define IMT_ERR_RANGE (-4)        /* an index / depth / capacity out of range (reference: slice panic) */
+#define IMT_ERR_NONCANONICAL (-5) /* a field element >= p (Fr::from_repr would return None) */
+#define IMT_ERR_ALLOC (-6)
+#define IMT_ERR_NO_DEVICE (-7)    /* no HIP device / runtime: this library has no CPU path */
+#define IMT_ERR_HIP (-8)          /* a HIP call failed; see imt_last_error */
+#define IMT_ERR_ARG (-9)          /* NULL pointer or inconsistent arguments */
+#define IMT_ERR_VALUE (-10)       /* value 0 or already present: the reference's circuit panics at
+                                     src/indexed_merkle_tree.rs:190 for such an insertion */
+#define IMT_ERR_FULL (-11)        /* indexed tree capacity exhausted */
+#define IMT_ERR_INTERNAL (-12)
+
+/* flags */
+#define IMT_FMT_CANONICAL 0u
+#define IMT_FMT_MONT256 1u
+#define IMT_FMT_DEVICE 2u
+#define IMT_FMT_MASK 3u
+#define IMT_DEVICE_PTRS 0x10u
+#define IMT_SIB_ITEM_MAJOR 0x20u
+#define IMT_ROOT_PER_ITEM 0x40u   /* root argument is root[n][32] instead of one root[32] */
+
+/* failure bits written per item by the relation checkers; each is one constraint or
+ * assert of the reference (src/indexed_merkle_tree.rs) */
+#define IMT_F_RANGE_PRED 0x01   /* select(is_largest, next_val==0, new<next_val) == 1   :182-191 */
+#define IMT_F_LOW_IN_ROOT 0x02  /* low leaf hashes up to the given root                  :196-204 */
+#define IMT_F_LOW_LT_NEW 0x04   /* low_leaf.val < new value                             :206-228 */
+#define IMT_F_ZERO_SLOT 0x08    /* the zero leaf sits at the new slot of the interim root :286-294 */
+#define IMT_F_NEXT_VAL 0x10     /* new_leaf.next_val == low_leaf.next_val               :296 */
+#define IMT_F_NEXT_IDX 0x20     /* new_leaf.next_idx == low_leaf.next_idx               :297 */
+#define IMT_F_NEW_ROOT 0x40     /* new root recomputes                                  :305-313 */
+#define IMT_F_BAD_BIT 0x80      /* a flag that must be 0/1 is not (gate.assert_bit      :41,54) */
+
+typedef struct imt_ctx imt_ctx;
+typedef struct imt_tree imt_tree;     /* dense tree: IndexedMerkleTree<'a,F,T,RATE> src/utils.rs:6-10 */
+typedef struct imt_itree imt_itree;   /* depth-d append-only indexed tree (sparse storage) */
+
+/* ---- context ------------------------------------------------------------------- */
+/* Builds the Poseidon tables (Poseidon::<Fr,3,2>::new(8,57), src/indexed_merkle_tree.rs:370)
+ * and uploads them to `device`.  device < 0 or no GPU -> IMT_ERR_NO_DEVICE. */
+int imt_ctx_create(int device, imt_ctx **out);
+void imt_ctx_destroy(imt_ctx *ctx);
+const char *imt_last_error(const imt_ctx *ctx);
+/* Use an existing hipStream_t (e.g. PyTorch's current stream); NULL = the context's own. */
+int imt_ctx_set_stream(imt_ctx *ctx, void *hip_stream);
+/* Wait for the stream and report deferred input errors (IMT_ERR_NONCANONICAL, ...). */
+int imt_ctx_sync(imt_ctx *ctx);
+/* ABI / build identification, e.g. "imt-hip gfx950 r1" */
+const char *imt_version(void);
+
+/* ---- a1 / a10: batched hashes -------------------------------------------------- */
+/* out[i] = Poseidon::update(&[in[i][0], in[i][1]]) ; squeeze_and_reset()
+ * replaces src/utils.rs:46-47,96-100 and hash_fix_len_array at indexed_merkle_tree.rs:92 */
+int imt_hash2_batch(imt_ctx *ctx, const void *in /*[n][2][32]*/, void *out /*[n][32]*/, size_t n,
+                    unsigned flags);
+/* 3-input leaf hash [val, next_val, next_idx]: indexed_merkle_tree.rs:193-194,271-275,299-303,663-668 */
+int imt_hash3_batch(imt_ctx *ctx, const void *in /*[n][3][32]*/, void *out /*[n][32]*/, size_t n,
+                    unsigned flags);
+/* the bare permutation on [n][3] states (test hook for the round schedule) */
+int imt_permute_batch(imt_ctx *ctx, const void *in /*[n][3][32]*/, void *out /*[n][3][32]*/, size_t n,
+                      unsigned flags);
+
+/* ---- a2 / a3 / a4: dense native tree ------------------------------------------- */
+/* IndexedMerkleTree::new (src/utils.rs:20-57): level-by-level build on the device.
+ * n_leaves == 0 -> IMT_ERR_NO_LEAVES; 1 -> root = leaf; odd -> IMT_ERR_ODD_LEAVES;
+ * even but not a power of two -> IMT_ERR_NOT_POW2. */
+int imt_tree_new(imt_ctx *ctx, const void *leaves /*[n][32]*/, size_t n_leaves, unsigned flags,
+                 imt_tree **out);
+void imt_tree_free(imt_tree *t);
+size_t imt_tree_num_levels(const imt_tree *t);           /* tree.len() */
+int imt_tree_get_root(imt_tree *t, void *root /*[32]*/, unsigned flags);          /* utils.rs:59-61 */
+/* get_proof (src/utils.rs:63-85): siblings and helpers (helper = 1 iff the node is a left
+ * child, :79) for one index; helper elements are written as field elements like the reference. */
+int imt_tree_get_proof(imt_tree *t, size_t index, void *proof /*[levels-1][32]*/,
+                       void *helper /*[levels-1][32] or NULL*/, unsigned flags);
+int imt_tree_get_proof_batch(imt_tree *t, const uint64_t *index /*[n]*/, size_t n,
+                             void *proof /*sib layout per flags*/, unsigned flags);
+/* copy one level out (tree[level]); n_out receives its length */
+int imt_tree_get_level(imt_tree *t, size_t level, void *out, size_t *n_out, unsigned flags);
+/* one-shot: build and return root (+ all levels concatenated bottom-up if levels != NULL) */
+int imt_tree_build(imt_ctx *ctx, const void *leaves, size_t n_leaves, void *levels /*[2n-1][32] or NULL*/,
+                   void *root /*[32]*/, unsigned flags);
+
+/* ---- a5 / a7 / a8 / a9: batched path recompute --------------------------------- */
+/* root_out[i] = fold of hash2 over depth siblings, order from the parity of index>>level
+ * (verify_proof, src/utils.rs:87-107; compute_merkle_root, indexed_merkle_tree.rs:78-96). */
+int imt_path_root_batch(imt_ctx *ctx, const void *leaf /*[n][32]*/, const uint64_t *index /*[n]*/,
+                        const void *sib, unsigned depth, size_t n, void *root_out /*[n][32]*/,
+                        unsigned flags);
+/* same with the circuit's helper bits: bit l of helper_mask[i] = proof_helper[l]
+ * (1 = current node is the left input of the hash, dual_mux :47-63) */
+int imt_compute_merkle_root_batch(imt_ctx *ctx, const void *leaf, const uint64_t *helper_mask,
+                                  const void *sib, unsigned depth, size_t n, void *root_out,
+                                  unsigned flags);
+/* ok_out[i] = 1 iff the recomputed root equals root (verify_proof's bool, utils.rs:106) */
+int imt_verify_proof_batch(imt_ctx *ctx, const void *leaf, const uint64_t *index, const void *root,
+                           const void *sib, unsigned depth, size_t n, uint8_t *ok_out /*[n]*/,
+                           unsigned flags);
+
+/* ---- a11 / a12 / a13: batched non-membership ----------------------------------- */
+/* verify_non_inclusion (indexed_merkle_tree.rs:127-229) on n items: fail_out[i] is a mask of
+ * IMT_F_* (0 = every constraint holds); root_out (optional) is the recomputed root. */
+int imt_non_membership_batch(imt_ctx *ctx, const void *root, const void *low_leaf /*[n][3][32]*/,
+                             const uint64_t *low_index /*[n]*/, const void *low_sib, unsigned depth,
+                             const void *new_val /*[n][32]*/, const uint8_t *is_largest /*[n]*/,
+                             size_t n, uint8_t *fail_out /*[n]*/, void *root_out /*[n][32] or NULL*/,
+                             unsigned flags);
+
+/* ---- a14: batched insert_leaf witness ------------------------------------------ */
+/* insert_leaf (indexed_merkle_tree.rs:231-314): recomputes the 3 leaf hashes and 4 paths per
+ * item and checks every constraint.  trace_out (optional) receives, level-major
+ * [7][n][32]: low_leaf_hash, root_from_low, new_low_leaf_hash, interim_root,
+ * zero_slot_root, new_leaf_hash, new_root_recomputed.
+ * new_index is the field element hashed into the rewritten low leaf (:265-269);
+ * new_path_index positions the new slot's path (the circuit's new_leaf_proof_helper bits).
+ * The reference never ties the two together; pass NULL to use new_index for both. */
+int imt_insert_witness_batch(imt_ctx *ctx, const void *old_root /*[n][32]*/,
+                             const void *low_leaf /*[n][3][32]*/, const uint64_t *low_index,
+                             const void *low_sib, const void *new_root /*[n][32]*/,
+                             const void *new_leaf /*[n][3][32]*/, const uint64_t *new_index,
+                             const uint64_t *new_path_index /*[n] or NULL = new_index*/,
+                             const void *new_sib, const uint8_t *is_largest, unsigned depth, size_t n,
+                             uint8_t *fail_out /*[n]*/, void *trace_out /*[7][n][32] or NULL*/,
+                             unsigned flags);
+
+/* ---- a15 (+ a2 at depth 32): stateful indexed tree ----------------------------- */
+/* A depth-`depth` tree whose leaf i is H(val,next_val,next_idx) of the i-th inserted value
+ * (leaf 0 = the {0,0,0} sentinel, empty slot = H(0,0,0): indexed_merkle_tree.rs:373-376).
+ * Only the filled prefix (up to `capacity` leaves, a power of two) is stored. */
+int imt_itree_new(imt_ctx *ctx, unsigned depth, uint64_t capacity, imt_itree **out);
+void imt_itree_free(imt_itree *t);
+uint64_t imt_itree_size(const imt_itree *t);      /* leaves in use, sentinel included */
+int imt_itree_root(imt_itree *t, void *root /*[32]*/, unsigned flags);
+
+/* outputs of a batch insertion; every pointer may be NULL; host or device per flags */
+typedef struct imt_insert_out {
+    uint64_t *low_index;     /* [n]        low leaf of insertion i (update_idx_leaf's 2nd result) */
+    void *low_leaf;          /* [n][3][32] the low leaf's preimage BEFORE insertion i */
+    uint8_t *is_largest;     /* [n]        low_leaf.next_val == 0 (:737-742) */
+    void *old_root;          /* [n][32]    root before insertion i */
+    void *interim_root;      /* [n][32]    after the low leaf was rewritten */
+    void *new_root;          /* [n][32]    after the new leaf was written */
+    void *new_leaf;          /* [n][3][32] preimage written at the new slot */
+    void *low_sib;           /* [depth][n][32] low-leaf proof against old_root (layout per flags) */
+    void *new_sib;           /* [depth][n][32] new-slot proof against interim_root / new_root */
+} imt_insert_out;
+
+/* n sequential insertions with the semantics of update_idx_leaf + rebuild (:632-660,
+ * :715-735): insertion i finds the low leaf among everything inserted before it, rewrites
+ * it, and writes the new leaf at index size+i.  All 2n path recomputes (2 + 2*depth hashes
+ * per insertion) run on the device as a level sweep over time-versioned nodes.
+ * vals[i] == 0, duplicates (within the batch or already present) -> IMT_ERR_VALUE, nothing
+ * changes.  Exceeding capacity -> IMT_ERR_FULL. */
+int imt_itree_insert_batch(imt_itree *t, const void *vals /*[n][32]*/, size_t n,
+                           const imt_insert_out *out /*may be NULL*/, unsigned flags);
+/* current siblings of leaf `index` for n indices (get_proof on the stored tree) */
+int imt_itree_get_proof_batch(imt_itree *t, const uint64_t *index, size_t n, void *sib,
+                              unsigned flags);
+/* preimages of n leaves */
+int imt_itree_get_leaves(imt_itree *t, const uint64_t *index, size_t n, void *preimage /*[n][3][32]*/,
+                         unsigned flags);
+/* low leaf (greatest val < v) for n candidate values; IMT_ERR_VALUE if some v is 0 or present */
+int imt_itree_find_low_batch(imt_itree *t, const void *vals /*[n][32]*/, size_t n,
+                             uint64_t *low_index /*[n]*/, unsigned flags);
+
+/* ---- e: multi-GPU helpers ------------------------------------------------------ */
+/* Root of a depth-`depth` tree whose 2^k subtrees of height `sub_height` have the given
+ * roots (k = log2(n_roots)); the levels above sub_height + k are extended with the
+ * all-empty subtree hashes.  Used after the all-gather of per-GPU subtree roots. */
+int imt_combine_subtree_roots(imt_ctx *ctx, const void *sub_roots /*[n_roots][32]*/, size_t n_roots,
+                              unsigned sub_height, unsigned depth, void *root /*[32]*/,
+                              unsigned flags);
+/* Z[0..depth]: hash of the empty subtree of each height, Z[0] = H(0,0,0) */
+int imt_zero_hashes(imt_ctx *ctx, unsigned depth, void *out /*[depth+1][32]*/, unsigned flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMT_H */

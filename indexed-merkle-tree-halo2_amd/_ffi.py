@@ -1,0 +1,83 @@
+"""ctypes binding of libimt_hip.so (the C ABI in include/imt.h).
+
+The library is the product; there is no Python or CPU fallback.  If the shared object is
+missing or cannot be loaded this module raises at import time, and creating a context
+without a usable MI355X raises ImtError(IMT_ERR_NO_DEVICE).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libimt_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+        "(or __graft_entry__.build()); there is no fallback implementation")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_void_p, c_size_t, c_uint, c_int, c_u64 = (ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int,
+                                            ctypes.c_uint64)
+P = ctypes.POINTER
+
+
+class InsertOut(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("low_index", "low_leaf", "is_largest", "old_root", "interim_root",
+                                        "new_root", "new_leaf", "low_sib", "new_sib")]
+
+
+# every symbol include/imt.h declares, with its signature
+SIGNATURES = {
+    "imt_version": (ctypes.c_char_p, []),
+    "imt_ctx_create": (c_int, [c_int, P(c_void_p)]),
+    "imt_ctx_destroy": (None, [c_void_p]),
+    "imt_last_error": (ctypes.c_char_p, [c_void_p]),
+    "imt_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "imt_ctx_sync": (c_int, [c_void_p]),
+    "imt_hash2_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint]),
+    "imt_hash3_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint]),
+    "imt_permute_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint]),
+    "imt_tree_new": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, P(c_void_p)]),
+    "imt_tree_free": (None, [c_void_p]),
+    "imt_tree_num_levels": (c_size_t, [c_void_p]),
+    "imt_tree_get_root": (c_int, [c_void_p, c_void_p, c_uint]),
+    "imt_tree_get_proof": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_uint]),
+    "imt_tree_get_proof_batch": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
+    "imt_tree_get_level": (c_int, [c_void_p, c_size_t, c_void_p, P(c_size_t), c_uint]),
+    "imt_tree_build": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_uint]),
+    "imt_path_root_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_size_t, c_void_p, c_uint]),
+    "imt_compute_merkle_root_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_size_t, c_void_p,
+                                              c_uint]),
+    "imt_verify_proof_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_size_t, c_void_p,
+                                       c_uint]),
+    "imt_non_membership_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_void_p,
+                                         c_void_p, c_size_t, c_void_p, c_void_p, c_uint]),
+    "imt_insert_witness_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_size_t, c_void_p, c_void_p,
+                                         c_uint]),
+    "imt_itree_new": (c_int, [c_void_p, c_uint, c_u64, P(c_void_p)]),
+    "imt_itree_free": (None, [c_void_p]),
+    "imt_itree_size": (c_u64, [c_void_p]),
+    "imt_itree_root": (c_int, [c_void_p, c_void_p, c_uint]),
+    "imt_itree_insert_batch": (c_int, [c_void_p, c_void_p, c_size_t, P(InsertOut), c_uint]),
+    "imt_itree_get_proof_batch": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
+    "imt_itree_get_leaves": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
+    "imt_itree_find_low_batch": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
+    "imt_combine_subtree_roots": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, c_uint, c_void_p, c_uint]),
+    "imt_zero_hashes": (c_int, [c_void_p, c_uint, c_void_p, c_uint]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)     # AttributeError here = the library does not export the symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+# error codes / flags of include/imt.h
+IMT_OK = 0
+ERR = dict(NO_LEAVES=-1, ODD_LEAVES=-2, NOT_POW2=-3, RANGE=-4, NONCANONICAL=-5, ALLOC=-6, NO_DEVICE=-7, HIP=-8,
+           ARG=-9, VALUE=-10, FULL=-11, INTERNAL=-12)
+FMT_CANONICAL, FMT_MONT256, FMT_DEVICE = 0, 1, 2
+DEVICE_PTRS, SIB_ITEM_MAJOR, ROOT_PER_ITEM = 0x10, 0x20, 0x40
+F_RANGE_PRED, F_LOW_IN_ROOT, F_LOW_LT_NEW, F_ZERO_SLOT, F_NEXT_VAL, F_NEXT_IDX, F_NEW_ROOT, F_BAD_BIT = (
+    0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80)

@@ -1,0 +1,390 @@
+"""Host-side mirror of the reference's interface for the hot path, on top of the C ABI.
+
+Names, argument meaning and error behaviour follow /root/reference:
+  IndexedMerkleTree.new / get_root / get_proof / verify_proof      src/utils.rs:19-108
+  verify_non_inclusion, insert_leaf                                src/indexed_merkle_tree.rs:127, :231
+  IndexedTree.insert_batch  = update_idx_leaf + rebuild, batched   src/indexed_merkle_tree.rs:632-671, :715-735
+Field elements are Python ints (canonical) at this level and numpy uint8[..., 32]
+little-endian arrays underneath.  All arithmetic happens in libimt_hip.so on the GPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import lib
+
+P_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+class ImtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"imt error {code}: {msg}")
+        self.code = code
+
+
+class ConstraintError(AssertionError):
+    """A constraint / assert of the reference's circuit does not hold; .mask has the IMT_F_* bits."""
+
+    def __init__(self, mask):
+        super().__init__(f"unsatisfied constraints, mask=0x{mask:02x}")
+        self.mask = mask
+
+
+def to_bytes(x):
+    """int or iterable of ints (any nesting) -> uint8 array [..., 32] little-endian."""
+    if isinstance(x, (int, np.integer)):
+        return np.frombuffer(int(x).to_bytes(32, "little"), dtype=np.uint8).copy()
+    a = [to_bytes(v) for v in x]
+    return np.stack(a) if a else np.zeros((0, 32), dtype=np.uint8)
+
+
+def to_int(b):
+    """uint8 array [..., 32] -> int or nested list of ints."""
+    b = np.asarray(b, dtype=np.uint8)
+    if b.ndim == 1:
+        return int.from_bytes(b.tobytes(), "little")
+    return [to_int(x) for x in b]
+
+
+def _arr(x, shape_tail):
+    a = np.ascontiguousarray(x, dtype=np.uint8)
+    if a.ndim < len(shape_tail) or tuple(a.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise ValueError(f"expected trailing shape {shape_tail}, got {a.shape}")
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class Context:
+    """imt_ctx: one per host thread; owns the Poseidon tables on one GPU."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        rc = lib.imt_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise ImtError(rc, "imt_ctx_create failed (no usable HIP device?)" if rc == _ffi.ERR["NO_DEVICE"]
+                           else "imt_ctx_create failed")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.imt_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ImtError(rc, lib.imt_last_error(self.h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._check(lib.imt_ctx_set_stream(self.h, ctypes.c_void_p(stream_ptr)))
+
+    def sync(self):
+        self._check(lib.imt_ctx_sync(self.h))
+
+    # ---- a1 / a10 ----
+    def hash2(self, pairs, fmt=0):
+        a = _arr(pairs, (2, 32))
+        n = a.shape[0]
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._check(lib.imt_hash2_batch(self.h, _p(a), _p(out), n, fmt))
+        return out
+
+    def hash3(self, triples, fmt=0):
+        a = _arr(triples, (3, 32))
+        n = a.shape[0]
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._check(lib.imt_hash3_batch(self.h, _p(a), _p(out), n, fmt))
+        return out
+
+    def permute(self, states, fmt=0):
+        a = _arr(states, (3, 32))
+        out = np.empty_like(a)
+        self._check(lib.imt_permute_batch(self.h, _p(a), _p(out), a.shape[0], fmt))
+        return out
+
+    # ---- a5 / a8 / a9 ----
+    def path_root(self, leaf, index, sib, depth, item_major=False, fmt=0):
+        leaf = _arr(leaf, (32,))
+        n = leaf.shape[0]
+        idx = np.ascontiguousarray(index, dtype=np.uint64)
+        sib = _arr(sib, (32,)) if depth else np.zeros((0, 32), np.uint8)
+        assert sib.size == depth * n * 32 and idx.size == n
+        out = np.empty((n, 32), dtype=np.uint8)
+        flags = fmt | (_ffi.SIB_ITEM_MAJOR if item_major else 0)
+        self._check(lib.imt_path_root_batch(self.h, _p(leaf), _p(idx), _p(sib), depth, n, _p(out), flags))
+        return out
+
+    def compute_merkle_root(self, leaf, helper_mask, sib, depth, item_major=False, fmt=0):
+        leaf = _arr(leaf, (32,))
+        n = leaf.shape[0]
+        hm = np.ascontiguousarray(helper_mask, dtype=np.uint64)
+        sib = _arr(sib, (32,)) if depth else np.zeros((0, 32), np.uint8)
+        out = np.empty((n, 32), dtype=np.uint8)
+        flags = fmt | (_ffi.SIB_ITEM_MAJOR if item_major else 0)
+        self._check(lib.imt_compute_merkle_root_batch(self.h, _p(leaf), _p(hm), _p(sib), depth, n, _p(out), flags))
+        return out
+
+    def verify_proof_batch(self, leaf, index, root, sib, depth, item_major=False, fmt=0):
+        leaf = _arr(leaf, (32,))
+        n = leaf.shape[0]
+        idx = np.ascontiguousarray(index, dtype=np.uint64)
+        root = _arr(root, (32,))
+        per_item = root.ndim == 2
+        sib = _arr(sib, (32,)) if depth else np.zeros((0, 32), np.uint8)
+        ok = np.empty(n, dtype=np.uint8)
+        flags = fmt | (_ffi.SIB_ITEM_MAJOR if item_major else 0) | (_ffi.ROOT_PER_ITEM if per_item else 0)
+        self._check(lib.imt_verify_proof_batch(self.h, _p(leaf), _p(idx), _p(root), _p(sib), depth, n, _p(ok), flags))
+        return ok.astype(bool)
+
+    # ---- a13 ----
+    def non_membership(self, root, low_leaf, low_index, low_sib, depth, new_val, is_largest, item_major=False,
+                       fmt=0, want_root=False):
+        low_leaf = _arr(low_leaf, (3, 32))
+        n = low_leaf.shape[0]
+        root = _arr(root, (32,))
+        per_item = root.ndim == 2
+        idx = np.ascontiguousarray(low_index, dtype=np.uint64)
+        sib = _arr(low_sib, (32,)) if depth else np.zeros((0, 32), np.uint8)
+        nv = _arr(new_val, (32,))
+        lg = np.ascontiguousarray(is_largest, dtype=np.uint8)
+        fail = np.empty(n, dtype=np.uint8)
+        rout = np.empty((n, 32), dtype=np.uint8) if want_root else None
+        flags = fmt | (_ffi.SIB_ITEM_MAJOR if item_major else 0) | (_ffi.ROOT_PER_ITEM if per_item else 0)
+        self._check(lib.imt_non_membership_batch(self.h, _p(root), _p(low_leaf), _p(idx), _p(sib), depth, _p(nv),
+                                                 _p(lg), n, _p(fail), _p(rout), flags))
+        return (fail, rout) if want_root else fail
+
+    # ---- a14 ----
+    def insert_witness(self, old_root, low_leaf, low_index, low_sib, new_root, new_leaf, new_index, new_sib,
+                       is_largest, depth, item_major=False, fmt=0, want_trace=False, new_path_index=None):
+        low_leaf = _arr(low_leaf, (3, 32))
+        n = low_leaf.shape[0]
+        args = [_arr(old_root, (32,)), low_leaf, np.ascontiguousarray(low_index, dtype=np.uint64),
+                _arr(low_sib, (32,)), _arr(new_root, (32,)), _arr(new_leaf, (3, 32)),
+                np.ascontiguousarray(new_index, dtype=np.uint64),
+                None if new_path_index is None else np.ascontiguousarray(new_path_index, dtype=np.uint64),
+                _arr(new_sib, (32,)), np.ascontiguousarray(is_largest, dtype=np.uint8)]
+        fail = np.empty(n, dtype=np.uint8)
+        trace = np.empty((7, n, 32), dtype=np.uint8) if want_trace else None
+        flags = fmt | (_ffi.SIB_ITEM_MAJOR if item_major else 0)
+        self._check(lib.imt_insert_witness_batch(self.h, *[_p(a) for a in args], depth, n, _p(fail), _p(trace), flags))
+        return (fail, trace) if want_trace else fail
+
+    # ---- e ----
+    def zero_hashes(self, depth, fmt=0):
+        out = np.empty((depth + 1, 32), dtype=np.uint8)
+        self._check(lib.imt_zero_hashes(self.h, depth, _p(out), fmt))
+        return out
+
+    def combine_subtree_roots(self, sub_roots, sub_height, depth, fmt=0):
+        r = _arr(sub_roots, (32,))
+        out = np.empty(32, dtype=np.uint8)
+        self._check(lib.imt_combine_subtree_roots(self.h, _p(r), r.shape[0], sub_height, depth, _p(out), fmt))
+        return out
+
+
+class IndexedMerkleTree:
+    """The reference's dense native tree (src/utils.rs:5-108) with the build on the GPU."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @classmethod
+    def new(cls, ctx, leaves):
+        """IndexedMerkleTree::new (src/utils.rs:20-57); `leaves` = ints or uint8[n,32]."""
+        a = to_bytes(leaves) if not isinstance(leaves, np.ndarray) else _arr(leaves, (32,))
+        h = ctypes.c_void_p()
+        rc = lib.imt_tree_new(ctx.h, _p(a) if a.size else None, a.shape[0], 0, ctypes.byref(h))
+        if rc == _ffi.ERR["NO_LEAVES"]:
+            raise ValueError("Cannot create Merkle Tree with no leaves")       # src/utils.rs:25
+        if rc == _ffi.ERR["ODD_LEAVES"]:
+            raise ValueError("Leaves must be even")                            # src/utils.rs:35
+        if rc == _ffi.ERR["NOT_POW2"]:
+            raise IndexError("index out of bounds (leaf count not a power of two)")   # panic at src/utils.rs:45
+        ctx._check(rc)
+        return cls(ctx, h)
+
+    def close(self):
+        if self.h:
+            lib.imt_tree_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_levels(self):
+        return lib.imt_tree_num_levels(self.h)
+
+    def get_root(self):
+        out = np.empty(32, dtype=np.uint8)
+        self.ctx._check(lib.imt_tree_get_root(self.h, _p(out), 0))
+        return to_int(out)
+
+    def get_level(self, level):
+        n = ctypes.c_size_t()
+        self.ctx._check(lib.imt_tree_get_level(self.h, level, None, ctypes.byref(n), 0))
+        out = np.empty((n.value, 32), dtype=np.uint8)
+        self.ctx._check(lib.imt_tree_get_level(self.h, level, _p(out), None, 0))
+        return out
+
+    def get_proof(self, index):
+        """(proof, proof_helper) as lists of ints: src/utils.rs:63-85."""
+        d = self.num_levels() - 1
+        proof = np.empty((d, 32), dtype=np.uint8)
+        helper = np.empty((d, 32), dtype=np.uint8)
+        rc = lib.imt_tree_get_proof(self.h, index, _p(proof), _p(helper), 0)
+        if rc == _ffi.ERR["RANGE"]:
+            raise IndexError("leaf index out of range")
+        self.ctx._check(rc)
+        return to_int(proof) if d else [], to_int(helper) if d else []
+
+    def get_proof_batch(self, index, item_major=False):
+        idx = np.ascontiguousarray(index, dtype=np.uint64)
+        d = self.num_levels() - 1
+        out = np.empty((idx.size, d, 32) if item_major else (d, idx.size, 32), dtype=np.uint8)
+        self.ctx._check(lib.imt_tree_get_proof_batch(self.h, _p(idx), idx.size, _p(out),
+                                                     _ffi.SIB_ITEM_MAJOR if item_major else 0))
+        return out
+
+    def verify_proof(self, leaf, index, root, proof):
+        """src/utils.rs:87-107 (the helper vector is not used, as in the reference)."""
+        p = to_bytes(proof) if len(proof) else np.zeros((0, 32), np.uint8)
+        ok = self.ctx.verify_proof_batch(to_bytes([leaf]), [index], to_bytes(root), p, len(proof), item_major=True)
+        return bool(ok[0])
+
+
+def _helper_mask(helper):
+    m = 0
+    for l, h in enumerate(helper):
+        if h not in (0, 1):
+            raise ConstraintError(_ffi.F_BAD_BIT)     # gate.assert_bit, src/indexed_merkle_tree.rs:54
+        m |= int(h) << l
+    return m
+
+
+def _helpers_to_index(helper):
+    # helper 1 = left child (src/utils.rs:79) -> index bit 0
+    m = _helper_mask(helper)
+    return (~m) & ((1 << len(helper)) - 1)
+
+
+def verify_non_inclusion(ctx, root, low_leaf, low_leaf_proof, low_leaf_proof_helper, new_leaf_value,
+                         is_new_leaf_largest):
+    """src/indexed_merkle_tree.rs:127-229 on one item.  low_leaf = (val, next_val, next_idx).
+    Raises ConstraintError where the reference panics (:190) or leaves a constraint unsatisfied."""
+    d = len(low_leaf_proof)
+    fail = ctx.non_membership(to_bytes(root), to_bytes([list(low_leaf)]), [_helpers_to_index(low_leaf_proof_helper)],
+                              to_bytes(low_leaf_proof), d, to_bytes([new_leaf_value]),
+                              [int(is_new_leaf_largest)], item_major=True)
+    if fail[0]:
+        raise ConstraintError(int(fail[0]))
+
+
+def insert_leaf(ctx, old_root, low_leaf, low_leaf_proof, low_leaf_proof_helper, new_root, new_leaf,
+                new_leaf_index, new_leaf_proof, new_leaf_proof_helper, is_new_leaf_largest):
+    """src/indexed_merkle_tree.rs:231-314 on one item; raises ConstraintError when the circuit
+    would be unsatisfied.  As in the reference, new_leaf_index is not tied to the helper bits."""
+    d = len(low_leaf_proof)
+    fail, trace = ctx.insert_witness(
+        to_bytes([old_root]), to_bytes([list(low_leaf)]), [_helpers_to_index(low_leaf_proof_helper)],
+        to_bytes(low_leaf_proof), to_bytes([new_root]), to_bytes([list(new_leaf)]), [new_leaf_index],
+        to_bytes(new_leaf_proof), [int(is_new_leaf_largest)], d, item_major=True, want_trace=True,
+        new_path_index=[_helpers_to_index(new_leaf_proof_helper)])
+    if fail[0]:
+        raise ConstraintError(int(fail[0]))
+    return trace
+
+
+class IndexedTree:
+    """Depth-d append-only indexed tree (imt_itree): leaf 0 is the {0,0,0} sentinel, insertion i
+    lands on leaf `size + i`, empty slots hash to H(0,0,0) (src/indexed_merkle_tree.rs:373-376)."""
+
+    def __init__(self, ctx, depth, capacity):
+        self.ctx, self.depth, self.capacity = ctx, depth, capacity
+        h = ctypes.c_void_p()
+        ctx._check(lib.imt_itree_new(ctx.h, depth, capacity, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.imt_itree_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return lib.imt_itree_size(self.h)
+
+    def root(self):
+        out = np.empty(32, dtype=np.uint8)
+        self.ctx._check(lib.imt_itree_root(self.h, _p(out), 0))
+        return to_int(out)
+
+    def insert_batch(self, vals, proofs=True, item_major=False):
+        """n sequential insertions (update_idx_leaf semantics); returns a dict of numpy arrays."""
+        v = to_bytes(vals) if not isinstance(vals, np.ndarray) else _arr(vals, (32,))
+        n, d = v.shape[0], self.depth
+        res = dict(low_index=np.empty(n, np.uint64), low_leaf=np.empty((n, 3, 32), np.uint8),
+                   is_largest=np.empty(n, np.uint8), old_root=np.empty((n, 32), np.uint8),
+                   interim_root=np.empty((n, 32), np.uint8), new_root=np.empty((n, 32), np.uint8),
+                   new_leaf=np.empty((n, 3, 32), np.uint8))
+        if proofs:
+            shape = (n, d, 32) if item_major else (d, n, 32)
+            res["low_sib"] = np.empty(shape, np.uint8)
+            res["new_sib"] = np.empty(shape, np.uint8)
+        out = _ffi.InsertOut(**{k: a.ctypes.data for k, a in res.items()})
+        flags = _ffi.SIB_ITEM_MAJOR if item_major else 0
+        rc = lib.imt_itree_insert_batch(self.h, _p(v), n, ctypes.byref(out), flags)
+        if rc == _ffi.ERR["VALUE"]:
+            raise ValueError(lib.imt_last_error(self.ctx.h).decode())
+        self.ctx._check(rc)
+        res["new_index"] = np.arange(self.size - n, self.size, dtype=np.uint64)
+        return res
+
+    def get_proof_batch(self, index, item_major=False):
+        idx = np.ascontiguousarray(index, dtype=np.uint64)
+        out = np.empty((idx.size, self.depth, 32) if item_major else (self.depth, idx.size, 32), dtype=np.uint8)
+        self.ctx._check(lib.imt_itree_get_proof_batch(self.h, _p(idx), idx.size, _p(out),
+                                                      _ffi.SIB_ITEM_MAJOR if item_major else 0))
+        return out
+
+    def get_leaves(self, index):
+        idx = np.ascontiguousarray(index, dtype=np.uint64)
+        out = np.empty((idx.size, 3, 32), dtype=np.uint8)
+        self.ctx._check(lib.imt_itree_get_leaves(self.h, _p(idx), idx.size, _p(out), 0))
+        return out
+
+    def find_low(self, vals):
+        v = to_bytes(vals) if not isinstance(vals, np.ndarray) else _arr(vals, (32,))
+        out = np.empty(v.shape[0], dtype=np.uint64)
+        rc = lib.imt_itree_find_low_batch(self.h, _p(v), v.shape[0], _p(out), 0)
+        if rc == _ffi.ERR["VALUE"]:
+            raise ValueError(lib.imt_last_error(self.ctx.h).decode())
+        self.ctx._check(rc)
+        return out
+
+    def non_membership_witness(self, vals):
+        """Witness for verify_non_inclusion of every value: low index, low leaf, siblings, flag."""
+        low = self.find_low(vals)
+        leaves = self.get_leaves(low)
+        sib = self.get_proof_batch(low)
+        largest = (leaves[:, 1, :].max(axis=1) == 0).astype(np.uint8)
+        return low, leaves, sib, largest

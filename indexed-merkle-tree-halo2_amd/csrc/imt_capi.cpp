@@ -1,0 +1,501 @@
+// imt_capi.cpp -- the extern "C" boundary declared in include/imt.h (context, batched
+// hashes, dense tree, path recompute, non-membership, insert witness, multi-GPU helpers).
+// Host code only; the kernels are in imt_kernels.hip / imt_sweep.hip.
+#include "imt_ctx.hpp"
+#include <cstring>
+#include <new>
+
+using namespace imt;
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+void* imt_ctx::dev_scratch(size_t slot, size_t bytes) {
+    if (slot >= scratch.size()) scratch.resize(slot + 1);
+    Scratch& s = scratch[slot];
+    if (s.cap >= bytes && s.p) return s.p;
+    if (s.p) {
+        hipStreamSynchronize(stream);
+        hipFree(s.p);
+        s.p = nullptr;
+        s.cap = 0;
+    }
+    size_t cap = bytes < 4096 ? 4096 : bytes + bytes / 4;
+    hipError_t e = hipMalloc(&s.p, cap);
+    if (e != hipSuccess) {
+        s.p = nullptr;
+        hip_fail(e, "hipMalloc(scratch)");
+        return nullptr;
+    }
+    s.cap = cap;
+    return s.p;
+}
+
+int imt_ctx::set_device() {
+    IMT_HIP(this, hipSetDevice(device));
+    return IMT_OK;
+}
+int imt_ctx::clear_err() {
+    IMT_HIP(this, hipMemsetAsync(d_err, 0, sizeof(int), stream));
+    return IMT_OK;
+}
+int imt_ctx::sync_and_check() {
+    int h = 0;
+    IMT_HIP(this, hipMemcpyAsync(&h, d_err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    IMT_HIP(this, hipStreamSynchronize(stream));
+    if (h) {
+        hipMemsetAsync(d_err, 0, sizeof(int), stream);
+        return fail(IMT_ERR_NONCANONICAL, "a field element in the input is not reduced (>= p)");
+    }
+    return IMT_OK;
+}
+
+extern "C" const char* imt_version(void) { return "imt-hip gfx950 r1"; }
+
+extern "C" int imt_ctx_create(int device, imt_ctx** out) {
+    if (!out) return IMT_ERR_ARG;
+    *out = nullptr;
+    if (device < 0) return IMT_ERR_NO_DEVICE;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) return IMT_ERR_NO_DEVICE;
+    imt_ctx* c = new (std::nothrow) imt_ctx();
+    if (!c) return IMT_ERR_ALLOC;
+    c->device = device;
+    std::string err;
+    if (!c->hp.init(err)) { delete c; return IMT_ERR_INTERNAL; }
+    dev::PoseidonConsts pc;
+    c->hp.fill_consts(pc);
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->own_stream)) != hipSuccess ||
+        (e = launch::upload_consts(pc)) != hipSuccess || (e = hipMalloc((void**)&c->d_err, sizeof(int))) != hipSuccess ||
+        (e = hipMalloc((void**)&c->d_zero, (IMT_MAX_DEPTH + 1) * 32)) != hipSuccess) {
+        if (c->own_stream) hipStreamDestroy(c->own_stream);
+        if (c->d_err) hipFree(c->d_err);
+        delete c;
+        return e == hipErrorNoDevice ? IMT_ERR_NO_DEVICE : IMT_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream);
+    launch::zero_chain(c->stream, c->d_zero, IMT_MAX_DEPTH);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+        imt_ctx_destroy(c);
+        return IMT_ERR_HIP;
+    }
+    *out = c;
+    return IMT_OK;
+}
+
+extern "C" void imt_ctx_destroy(imt_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& s : c->scratch)
+        if (s.p) hipFree(s.p);
+    if (c->d_err) hipFree(c->d_err);
+    if (c->d_zero) hipFree(c->d_zero);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" const char* imt_last_error(const imt_ctx* c) { return c ? c->last_error.c_str() : "null context"; }
+
+extern "C" int imt_ctx_set_stream(imt_ctx* c, void* s) {
+    if (!c) return IMT_ERR_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return IMT_OK;
+}
+
+extern "C" int imt_ctx_sync(imt_ctx* c) {
+    if (!c) return IMT_ERR_ARG;
+    int rc = c->set_device();
+    if (rc) return rc;
+    return c->sync_and_check();
+}
+
+// ------------------------------------------------------------------------------------
+// host/device pointer plumbing
+// ------------------------------------------------------------------------------------
+namespace {
+
+struct Io {
+    imt_ctx* c;
+    unsigned flags;
+    bool dev;
+    int rc = IMT_OK;
+    size_t next_slot = 0;
+    struct Pending { void* user; const uint8_t* d; size_t bytes; };
+    std::vector<Pending> outs;
+
+    Io(imt_ctx* ctx, unsigned f) : c(ctx), flags(f), dev((f & IMT_DEVICE_PTRS) != 0) {}
+
+    // device view of an input buffer
+    const uint8_t* in(const void* p, size_t bytes) {
+        if (rc || !bytes) return (const uint8_t*)p;
+        if (!p) { rc = c->fail(IMT_ERR_ARG, "null input pointer"); return nullptr; }
+        if (dev) return (const uint8_t*)p;
+        void* d = c->dev_scratch(next_slot++, bytes);
+        if (!d) { rc = IMT_ERR_HIP; return nullptr; }
+        hipError_t e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { rc = c->hip_fail(e, "hipMemcpyAsync H2D"); return nullptr; }
+        return (const uint8_t*)d;
+    }
+    // device buffer an output is produced into (NULL user pointer -> NULL)
+    uint8_t* out(void* p, size_t bytes) {
+        if (rc || !p || !bytes) return (uint8_t*)(rc ? nullptr : p);
+        if (dev) return (uint8_t*)p;
+        void* d = c->dev_scratch(next_slot++, bytes);
+        if (!d) { rc = IMT_ERR_HIP; return nullptr; }
+        outs.push_back({p, (const uint8_t*)d, bytes});
+        return (uint8_t*)d;
+    }
+    uint8_t* temp(size_t bytes) {
+        if (rc) return nullptr;
+        void* d = c->dev_scratch(next_slot++, bytes ? bytes : 1);
+        if (!d) rc = IMT_ERR_HIP;
+        return (uint8_t*)d;
+    }
+    // host-pointer mode: copy results back, synchronise and report input errors
+    int finish() {
+        if (rc) return rc;
+        if (dev) return IMT_OK;
+        for (auto& o : outs) {
+            hipError_t e = hipMemcpyAsync(o.user, o.d, o.bytes, hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) return c->hip_fail(e, "hipMemcpyAsync D2H");
+        }
+        return c->sync_and_check();
+    }
+};
+
+launch::SibLayout sib_layout(unsigned flags, unsigned depth, size_t n) {
+    if (flags & IMT_SIB_ITEM_MAJOR) return {1, depth};
+    return {n, 1};
+}
+
+int begin(imt_ctx* c, unsigned flags) {
+    if (!c) return IMT_ERR_ARG;
+    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
+    int rc = c->set_device();
+    if (rc) return rc;
+    if (!(flags & IMT_DEVICE_PTRS)) return c->clear_err();
+    return IMT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// a1 / a10
+// ------------------------------------------------------------------------------------
+static int hash_n(imt_ctx* c, const void* in, void* out, size_t n, int arity, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    if (n == 0) return IMT_OK;
+    if (!in || !out) return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    const uint8_t* d_in = io.in(in, n * 32 * (size_t)arity);
+    uint8_t* d_out = io.out(out, n * 32);
+    if (io.rc) return io.rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    launch::hash_batch(c->stream, d_in, d_out, n, arity, fmt, fmt, c->d_err);
+    return io.finish();
+}
+extern "C" int imt_hash2_batch(imt_ctx* c, const void* in, void* out, size_t n, unsigned flags) {
+    return hash_n(c, in, out, n, 2, flags);
+}
+extern "C" int imt_hash3_batch(imt_ctx* c, const void* in, void* out, size_t n, unsigned flags) {
+    return hash_n(c, in, out, n, 3, flags);
+}
+extern "C" int imt_permute_batch(imt_ctx* c, const void* in, void* out, size_t n, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    if (n == 0) return IMT_OK;
+    if (!in || !out) return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    const uint8_t* d_in = io.in(in, n * 96);
+    uint8_t* d_out = io.out(out, n * 96);
+    if (io.rc) return io.rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    launch::permute_batch(c->stream, d_in, d_out, n, fmt, fmt, c->d_err);
+    return io.finish();
+}
+
+// ------------------------------------------------------------------------------------
+// a2 / a3 / a4: dense tree
+// ------------------------------------------------------------------------------------
+extern "C" void imt_tree_free(imt_tree* t) {
+    if (!t) return;
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+    if (t->d_nodes) hipFree(t->d_nodes);
+    if (t->d_off) hipFree(t->d_off);
+    if (t->d_len) hipFree(t->d_len);
+    delete t;
+}
+
+extern "C" int imt_tree_new(imt_ctx* c, const void* leaves, size_t n, unsigned flags, imt_tree** out) {
+    if (!c || !out) return IMT_ERR_ARG;
+    *out = nullptr;
+    // the reference's checks, in its order (src/utils.rs:24-36), then the :45 panic
+    if (n == 0) return c->fail(IMT_ERR_NO_LEAVES, "Cannot create Merkle Tree with no leaves");
+    if (n != 1 && (n % 2) == 1) return c->fail(IMT_ERR_ODD_LEAVES, "Leaves must be even");
+    if (n & (n - 1)) return c->fail(IMT_ERR_NOT_POW2, "leaf count is even but not a power of two");
+    int rc = begin(c, flags & ~IMT_DEVICE_PTRS);   // always synchronous: the err word is checked below
+    if (rc) return rc;
+    if (!leaves) return c->fail(IMT_ERR_ARG, "null leaves");
+    imt_tree* t = new (std::nothrow) imt_tree();
+    if (!t) return c->fail(IMT_ERR_ALLOC, "out of host memory");
+    t->ctx = c;
+    t->n_leaves = n;
+    size_t nl = 1;
+    for (size_t m = n; m > 1; m >>= 1) nl++;
+    t->n_levels = nl;
+    uint64_t off = 0;
+    for (size_t l = 0; l < nl; l++) {
+        t->h_off.push_back(off);
+        t->h_len.push_back(n >> l);
+        off += n >> l;
+    }
+    hipError_t e;
+    if ((e = hipMalloc((void**)&t->d_nodes, off * 32)) != hipSuccess ||
+        (e = hipMalloc((void**)&t->d_off, nl * 8)) != hipSuccess ||
+        (e = hipMalloc((void**)&t->d_len, nl * 8)) != hipSuccess) {
+        imt_tree_free(t);
+        return c->hip_fail(e, "hipMalloc(tree)");
+    }
+    hipMemcpyAsync(t->d_off, t->h_off.data(), nl * 8, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(t->d_len, t->h_len.data(), nl * 8, hipMemcpyHostToDevice, c->stream);
+    Io io(c, flags);
+    const uint8_t* d_in = io.in(leaves, n * 32);
+    if (io.rc) { imt_tree_free(t); return io.rc; }
+    launch::convert(c->stream, d_in, t->d_nodes, n, flags & IMT_FMT_MASK, IMT_FMT_DEVICE, c->d_err);
+    for (size_t l = 1; l < nl; l++)   // while current_level.len() > 1 (src/utils.rs:41-51)
+        launch::tree_level(c->stream, t->d_nodes + t->h_off[l - 1] * 32, t->d_nodes + t->h_off[l] * 32, t->h_len[l]);
+    rc = c->sync_and_check();
+    if (rc) { imt_tree_free(t); return rc; }
+    *out = t;
+    return IMT_OK;
+}
+
+extern "C" size_t imt_tree_num_levels(const imt_tree* t) { return t ? t->n_levels : 0; }
+
+extern "C" int imt_tree_get_level(imt_tree* t, size_t level, void* out, size_t* n_out, unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (level >= t->n_levels) return c->fail(IMT_ERR_RANGE, "level %zu out of range", level);
+    if (n_out) *n_out = t->h_len[level];
+    if (!out) return IMT_OK;
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    Io io(c, flags);
+    const size_t n = t->h_len[level];
+    uint8_t* d = io.out(out, n * 32);
+    if (io.rc) return io.rc;
+    launch::convert(c->stream, t->d_nodes + t->h_off[level] * 32, d, n, IMT_FMT_DEVICE, flags & IMT_FMT_MASK, c->d_err);
+    return io.finish();
+}
+
+extern "C" int imt_tree_get_root(imt_tree* t, void* root, unsigned flags) {
+    if (!t || !root) return IMT_ERR_ARG;
+    return imt_tree_get_level(t, t->n_levels - 1, root, nullptr, flags);
+}
+
+extern "C" int imt_tree_get_proof_batch(imt_tree* t, const uint64_t* index, size_t n, void* proof, unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    const unsigned depth = (unsigned)(t->n_levels - 1);
+    if (n == 0 || depth == 0) return IMT_OK;
+    if (!index || !proof) return c->fail(IMT_ERR_ARG, "null buffer");
+    if (!(flags & IMT_DEVICE_PTRS))
+        for (size_t i = 0; i < n; i++)
+            if (index[i] >= t->n_leaves) return c->fail(IMT_ERR_RANGE, "leaf index %llu out of range", (unsigned long long)index[i]);
+    Io io(c, flags);
+    const uint64_t* d_idx = (const uint64_t*)io.in(index, n * 8);
+    uint8_t* d_out = io.out(proof, (size_t)depth * n * 32);
+    if (io.rc) return io.rc;
+    launch::TreeView tv{t->d_nodes, t->d_off, t->d_len, c->d_zero};
+    launch::gather_proof(c->stream, tv, d_idx, n, depth, d_out, sib_layout(flags, depth, n), flags & IMT_FMT_MASK);
+    return io.finish();
+}
+
+extern "C" int imt_tree_get_proof(imt_tree* t, size_t index, void* proof, void* helper, unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (index >= t->n_leaves) return c->fail(IMT_ERR_RANGE, "leaf index %zu out of range", index);
+    if (flags & IMT_DEVICE_PTRS) return c->fail(IMT_ERR_ARG, "imt_tree_get_proof takes host pointers");
+    uint64_t idx = index;
+    int rc = imt_tree_get_proof_batch(t, &idx, 1, proof, flags);
+    if (rc || !helper) return rc;
+    const unsigned depth = (unsigned)(t->n_levels - 1);
+    if (!depth) return IMT_OK;
+    Io io(c, flags);
+    uint8_t* d = io.out(helper, (size_t)depth * 32);
+    if (io.rc) return io.rc;
+    launch::write_helpers(c->stream, index, depth, d, flags & IMT_FMT_MASK);
+    return io.finish();
+}
+
+extern "C" int imt_tree_build(imt_ctx* c, const void* leaves, size_t n, void* levels, void* root, unsigned flags) {
+    imt_tree* t = nullptr;
+    int rc = imt_tree_new(c, leaves, n, flags, &t);
+    if (rc) return rc;
+    if (levels) {
+        for (size_t l = 0; l < t->n_levels && !rc; l++)
+            rc = imt_tree_get_level(t, l, (uint8_t*)levels + t->h_off[l] * 32, nullptr, flags);
+    }
+    if (!rc && root) rc = imt_tree_get_root(t, root, flags);
+    if (!rc && (flags & IMT_DEVICE_PTRS)) rc = c->sync_and_check();
+    imt_tree_free(t);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// a5 / a7 / a8 / a9
+// ------------------------------------------------------------------------------------
+static int path_common(imt_ctx* c, const void* leaf, const uint64_t* index, bool is_helper, const void* root,
+                       const void* sib, unsigned depth, size_t n, void* root_out, uint8_t* ok_out, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    if (depth > IMT_MAX_DEPTH) return c->fail(IMT_ERR_RANGE, "depth %u > %d", depth, IMT_MAX_DEPTH);
+    if (n == 0) return IMT_OK;
+    if (!leaf || !index || (depth && !sib)) return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    const uint8_t* d_leaf = io.in(leaf, n * 32);
+    const uint64_t* d_idx = (const uint64_t*)io.in(index, n * 8);
+    const uint8_t* d_sib = io.in(sib, (size_t)depth * n * 32);
+    const unsigned rstride = (flags & IMT_ROOT_PER_ITEM) ? 32 : 0;
+    const uint8_t* d_root = ok_out ? io.in(root, rstride ? n * 32 : 32) : nullptr;
+    uint8_t* d_out = io.out(root_out, n * 32);
+    uint8_t* d_ok = io.out(ok_out, n);
+    if (io.rc) return io.rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    launch::path_root(c->stream, d_leaf, nullptr, d_idx, is_helper, d_sib, sib_layout(flags, depth, n), depth, n, d_out,
+                      d_root, rstride, d_ok, fmt, fmt, c->d_err);
+    return io.finish();
+}
+extern "C" int imt_path_root_batch(imt_ctx* c, const void* leaf, const uint64_t* index, const void* sib,
+                                   unsigned depth, size_t n, void* root_out, unsigned flags) {
+    if (c && n && !root_out) return c->fail(IMT_ERR_ARG, "null root_out");
+    return path_common(c, leaf, index, false, nullptr, sib, depth, n, root_out, nullptr, flags);
+}
+extern "C" int imt_compute_merkle_root_batch(imt_ctx* c, const void* leaf, const uint64_t* helper_mask,
+                                             const void* sib, unsigned depth, size_t n, void* root_out,
+                                             unsigned flags) {
+    if (c && n && !root_out) return c->fail(IMT_ERR_ARG, "null root_out");
+    return path_common(c, leaf, helper_mask, true, nullptr, sib, depth, n, root_out, nullptr, flags);
+}
+extern "C" int imt_verify_proof_batch(imt_ctx* c, const void* leaf, const uint64_t* index, const void* root,
+                                      const void* sib, unsigned depth, size_t n, uint8_t* ok_out, unsigned flags) {
+    if (c && n && (!ok_out || !root)) return c->fail(IMT_ERR_ARG, "null root / ok_out");
+    return path_common(c, leaf, index, false, root, sib, depth, n, nullptr, ok_out, flags);
+}
+
+// ------------------------------------------------------------------------------------
+// a13
+// ------------------------------------------------------------------------------------
+extern "C" int imt_non_membership_batch(imt_ctx* c, const void* root, const void* low_leaf, const uint64_t* low_index,
+                                        const void* low_sib, unsigned depth, const void* new_val,
+                                        const uint8_t* is_largest, size_t n, uint8_t* fail_out, void* root_out,
+                                        unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    if (depth > IMT_MAX_DEPTH) return c->fail(IMT_ERR_RANGE, "depth %u > %d", depth, IMT_MAX_DEPTH);
+    if (n == 0) return IMT_OK;
+    if (!root || !low_leaf || !low_index || (depth && !low_sib) || !new_val || !is_largest || !fail_out)
+        return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    const unsigned rstride = (flags & IMT_ROOT_PER_ITEM) ? 32 : 0;
+    const uint8_t* d_root = io.in(root, rstride ? n * 32 : 32);
+    const uint8_t* d_low = io.in(low_leaf, n * 96);
+    const uint64_t* d_idx = (const uint64_t*)io.in(low_index, n * 8);
+    const uint8_t* d_sib = io.in(low_sib, (size_t)depth * n * 32);
+    const uint8_t* d_nv = io.in(new_val, n * 32);
+    const uint8_t* d_lg = io.in(is_largest, n);
+    uint8_t* d_fail = io.out(fail_out, n);
+    uint8_t* d_rout = io.out(root_out, n * 32);
+    if (io.rc) return io.rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    launch::non_membership(c->stream, d_root, rstride, d_low, d_idx, d_sib, sib_layout(flags, depth, n), depth, d_nv,
+                           d_lg, n, d_fail, d_rout, fmt, fmt, c->d_err);
+    return io.finish();
+}
+
+// ------------------------------------------------------------------------------------
+// a14
+// ------------------------------------------------------------------------------------
+extern "C" int imt_insert_witness_batch(imt_ctx* c, const void* old_root, const void* low_leaf,
+                                        const uint64_t* low_index, const void* low_sib, const void* new_root,
+                                        const void* new_leaf, const uint64_t* new_index,
+                                        const uint64_t* new_path_index, const void* new_sib,
+                                        const uint8_t* is_largest, unsigned depth, size_t n, uint8_t* fail_out,
+                                        void* trace_out, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    if (depth > IMT_MAX_DEPTH) return c->fail(IMT_ERR_RANGE, "depth %u > %d", depth, IMT_MAX_DEPTH);
+    if (n == 0) return IMT_OK;
+    if (!old_root || !low_leaf || !low_index || !new_root || !new_leaf || !new_index || !is_largest || !fail_out ||
+        (depth && (!low_sib || !new_sib)))
+        return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    const uint8_t* d_or = io.in(old_root, n * 32);
+    const uint8_t* d_ll = io.in(low_leaf, n * 96);
+    const uint64_t* d_li = (const uint64_t*)io.in(low_index, n * 8);
+    const uint8_t* d_ls = io.in(low_sib, (size_t)depth * n * 32);
+    const uint8_t* d_nr = io.in(new_root, n * 32);
+    const uint8_t* d_nl = io.in(new_leaf, n * 96);
+    const uint64_t* d_ni = (const uint64_t*)io.in(new_index, n * 8);
+    const uint64_t* d_np = new_path_index ? (const uint64_t*)io.in(new_path_index, n * 8) : d_ni;
+    const uint8_t* d_ns = io.in(new_sib, (size_t)depth * n * 32);
+    const uint8_t* d_lg = io.in(is_largest, n);
+    uint8_t* d_fail = io.out(fail_out, n);
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    uint8_t* d_trace_user = io.out(trace_out, 7 * n * 32);
+    uint8_t* d_trace = (d_trace_user && fmt == IMT_FMT_DEVICE) ? d_trace_user : io.temp(7 * n * 32);
+    if (io.rc) return io.rc;
+    launch::insert_witness(c->stream, d_or, d_ll, d_li, d_ls, d_nr, d_nl, d_ni, d_np, d_ns, sib_layout(flags, depth, n),
+                           d_lg, depth, n, d_fail, d_trace, fmt, fmt, c->d_err);
+    if (d_trace_user && d_trace_user != d_trace)
+        launch::convert(c->stream, d_trace, d_trace_user, 7 * n, IMT_FMT_DEVICE, fmt, c->d_err);
+    return io.finish();
+}
+
+// ------------------------------------------------------------------------------------
+// e: multi-GPU helpers
+// ------------------------------------------------------------------------------------
+extern "C" int imt_zero_hashes(imt_ctx* c, unsigned depth, void* out, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    if (depth > IMT_MAX_DEPTH) return c->fail(IMT_ERR_RANGE, "depth %u > %d", depth, IMT_MAX_DEPTH);
+    if (!out) return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    uint8_t* d = io.out(out, (size_t)(depth + 1) * 32);
+    if (io.rc) return io.rc;
+    launch::convert(c->stream, c->d_zero, d, depth + 1, IMT_FMT_DEVICE, flags & IMT_FMT_MASK, c->d_err);
+    return io.finish();
+}
+
+extern "C" int imt_combine_subtree_roots(imt_ctx* c, const void* sub_roots, size_t n_roots, unsigned sub_height,
+                                         unsigned depth, void* root, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    if (!sub_roots || !root) return c->fail(IMT_ERR_ARG, "null buffer");
+    if (n_roots == 0 || (n_roots & (n_roots - 1))) return c->fail(IMT_ERR_ARG, "n_roots must be a power of two");
+    unsigned k = 0;
+    while (((size_t)1 << k) < n_roots) k++;
+    if (depth > IMT_MAX_DEPTH || sub_height + k > depth) return c->fail(IMT_ERR_RANGE, "sub_height + log2(n_roots) > depth");
+    Io io(c, flags);
+    const uint8_t* d_in = io.in(sub_roots, n_roots * 32);
+    uint8_t* d_out = io.out(root, 32);
+    uint8_t* a = io.temp(n_roots * 32);
+    uint8_t* b = io.temp(n_roots * 32);
+    if (io.rc) return io.rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    launch::convert(c->stream, d_in, a, n_roots, fmt, IMT_FMT_DEVICE, c->d_err);
+    for (size_t m = n_roots; m > 1; m >>= 1) {
+        launch::tree_level(c->stream, a, b, m / 2);
+        std::swap(a, b);
+    }
+    launch::extend_root(c->stream, a, c->d_zero, sub_height + k, depth);
+    launch::convert(c->stream, a, d_out, 1, IMT_FMT_DEVICE, fmt, c->d_err);
+    return io.finish();
+}

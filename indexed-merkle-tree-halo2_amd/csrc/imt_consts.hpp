@@ -1,0 +1,36 @@
+// imt_consts.hpp -- plain structs shared by the host table generator (imt_params.cpp)
+// and the device code (imt_device.hpp).  No HIP types here.
+#pragma once
+#include <cstdint>
+
+namespace imt {
+namespace dev {
+
+constexpr int NL = 9;
+constexpr uint32_t MASK29 = (1u << 29) - 1;
+
+// one field element: nine 29-bit limbs, Montgomery form with R = 2^261
+struct Fe {
+    uint32_t v[NL];
+};
+
+constexpr int RF = 8, RP = 57;
+struct PoseidonConsts {
+    Fe rc_full[RF][3];    // rounds 0..3 as generated; round 61 carries the partial rounds' leftover
+    Fe rc_h2p2[3];        // rc_full[0] + (0,1,0): second permutation of a 2-input hash
+    Fe k_partial[RP];     // lane-0 constants of the partial rounds
+    Fe mds[3][3];
+    Fe pre[3][3];         // matrix of full round 3 (M followed by the first N')
+    Fe sp_row[RP][3];     // sparse round: new s0 = row . (y, s1, s2)
+    Fe sp_col[RP][2];     // sparse round: new s_i = s_i + col_i * y
+    Fe cap0;              // 2^64 in device form (initial capacity lane)
+    Fe one;               // 1 in device form
+    Fe from_canon;        // R^2: canonical integer -> device form
+    Fe from_mont256;      // R^2 / 2^256: halo2curves Montgomery form -> device form
+    Fe to_mont256;        // 2^256 as integer: device form -> halo2curves Montgomery form
+    Fe int_one;           // integer 1: device form -> canonical integer
+    Fe zero_leaf;         // H(0,0,0) in device form
+};
+
+}  // namespace dev
+}  // namespace imt

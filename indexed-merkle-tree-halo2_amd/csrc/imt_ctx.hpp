@@ -1,0 +1,58 @@
+// imt_ctx.hpp -- internal definition of the C-ABI handles (imt_capi.cpp, imt_itree.cpp).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "../../include/imt.h"
+#include "imt_launch.hpp"
+#include "imt_params.hpp"
+
+#define IMT_MAX_DEPTH 64
+
+struct imt_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    imt::HostPoseidon hp;
+    int* d_err = nullptr;             // device word: kernels OR 1 into it on a non-canonical input
+    uint8_t* d_zero = nullptr;        // Z[0..IMT_MAX_DEPTH] in device format
+    std::string last_error;
+    struct Scratch { void* p = nullptr; size_t cap = 0; };
+    std::vector<Scratch> scratch;     // grow-only staging buffers, indexed by slot
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        last_error = buf;
+        return code;
+    }
+    int hip_fail(hipError_t e, const char* what) {
+        return fail(IMT_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+    // device scratch of at least `bytes` in slot `slot`; nullptr on failure (last_error set)
+    void* dev_scratch(size_t slot, size_t bytes);
+    int set_device();
+    // zero the error word / read it back (synchronises the stream)
+    int clear_err();
+    int sync_and_check();
+};
+
+#define IMT_HIP(ctx, call)                                   \
+    do {                                                     \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess) return (ctx)->hip_fail(e__, #call); \
+    } while (0)
+
+struct imt_tree {
+    imt_ctx* ctx = nullptr;
+    size_t n_leaves = 0, n_levels = 0;
+    uint8_t* d_nodes = nullptr;          // all levels, bottom-up, device format
+    uint64_t* d_off = nullptr;           // [n_levels]
+    uint64_t* d_len = nullptr;           // [n_levels]
+    std::vector<uint64_t> h_off, h_len;
+};

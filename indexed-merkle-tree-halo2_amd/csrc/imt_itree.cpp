@@ -1,0 +1,588 @@
+// imt_itree.cpp -- the stateful depth-d indexed tree behind imt_itree_* (include/imt.h).
+//
+// Host side of the batch insertion: everything that needs no hashing -- the low-leaf
+// search of update_idx_leaf (/root/reference/src/indexed_merkle_tree.rs:632-660), the
+// leaf preimages at every time step, and the (position, time) order of the 2N leaf
+// events -- is computed here; all hashing runs on the GPU as the level sweep of
+// imt_sweep.hpp.  The plan buffers are double-buffered and uploaded on a second stream,
+// so with IMT_DEVICE_PTRS the host work of batch k+1 overlaps the kernels of batch k.
+#include "imt_ctx.hpp"
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <new>
+#include <numeric>
+
+using namespace imt;
+
+namespace {
+
+typedef std::array<uint64_t, 4> U256;   // little-endian limbs of a canonical integer
+
+inline bool lt256(const U256& a, const U256& b) {
+    for (int i = 3; i >= 0; i--)
+        if (a[i] != b[i]) return a[i] < b[i];
+    return false;
+}
+inline bool is_zero256(const U256& a) { return (a[0] | a[1] | a[2] | a[3]) == 0; }
+
+struct Pre {            // {val, next_val, next_idx}: src/utils.rs:12-17
+    U256 val, next_val;
+    uint64_t next_idx;
+};
+struct SortedEnt {
+    U256 val;
+    uint64_t idx;
+};
+
+inline void put_pre(uint8_t* dst, const U256& val, const U256& next_val, uint64_t next_idx) {
+    std::memcpy(dst, val.data(), 32);
+    std::memcpy(dst + 32, next_val.data(), 32);
+    std::memset(dst + 64, 0, 32);
+    std::memcpy(dst + 64, &next_idx, 8);
+}
+
+unsigned ceil_log2(uint64_t x) {
+    unsigned l = 0;
+    while (l < 63 && ((uint64_t)1 << l) < x) l++;
+    return l;
+}
+
+// one set of plan buffers (device + pinned host staging)
+struct PlanSet {
+    size_t cap_events = 0;       // capacity in events
+    unsigned cap_levels = 0;
+    uint8_t* h_pin = nullptr;    // pinned: [pre 96*E][node,time,rs,re 4*E each]
+    uint8_t* d_pre = nullptr;
+    uint32_t* d_tab[2][4] = {{nullptr}};   // ping-pong {node,time,rs,re}
+    uint32_t* d_from = nullptr;  // [levels][E]
+    int32_t* d_sibsrc = nullptr;
+    uint32_t* d_nodeb = nullptr;
+    uint32_t* d_timen = nullptr; // [levels][E] time table of level l+1
+    uint8_t* d_val[2] = {nullptr, nullptr};
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
+}  // namespace
+
+struct imt_itree {
+    imt_ctx* ctx = nullptr;
+    unsigned depth = 0;
+    uint64_t cap = 0, size = 0;
+    std::vector<uint64_t> h_off, h_len;
+    uint8_t* d_nodes = nullptr;
+    uint64_t* d_off = nullptr;
+    uint64_t* d_len = nullptr;
+    std::vector<Pre> pre;            // host mirror of the leaf preimages
+    std::vector<SortedEnt> sorted;   // leaves ordered by val
+    PlanSet plan[2];
+    int cur = 0;
+    hipStream_t up_stream = nullptr;
+    hipEvent_t up_done = nullptr;
+};
+
+static void plan_free(PlanSet& p) {
+    if (p.h_pin) hipHostFree(p.h_pin);
+    if (p.d_pre) hipFree(p.d_pre);
+    for (auto& pp : p.d_tab)
+        for (auto& q : pp)
+            if (q) hipFree(q);
+    if (p.d_from) hipFree(p.d_from);
+    if (p.d_sibsrc) hipFree(p.d_sibsrc);
+    if (p.d_nodeb) hipFree(p.d_nodeb);
+    if (p.d_timen) hipFree(p.d_timen);
+    for (auto& q : p.d_val)
+        if (q) hipFree(q);
+    hipEvent_t ev = p.done;
+    p = PlanSet();
+    p.done = ev;
+}
+
+static int plan_reserve(imt_ctx* c, PlanSet& p, size_t events, unsigned levels) {
+    if (p.cap_events >= events && p.cap_levels >= levels) return IMT_OK;
+    plan_free(p);
+    const size_t E = std::max(events + events / 4, (size_t)1024);
+    const unsigned L = std::max(levels, 1u);
+    hipError_t e = hipSuccess;
+    auto A = [&](void** ptr, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(ptr, bytes);
+    };
+    if (hipHostMalloc((void**)&p.h_pin, E * (96 + 16), hipHostMallocDefault) != hipSuccess)
+        return c->fail(IMT_ERR_ALLOC, "hipHostMalloc(plan staging) failed");
+    A((void**)&p.d_pre, E * 96);
+    for (int s = 0; s < 2; s++)
+        for (int j = 0; j < 4; j++) A((void**)&p.d_tab[s][j], E * 4);
+    A((void**)&p.d_from, (size_t)L * E * 4);
+    A((void**)&p.d_sibsrc, (size_t)L * E * 4);
+    A((void**)&p.d_nodeb, (size_t)L * E * 4);
+    A((void**)&p.d_timen, (size_t)L * E * 4);
+    A((void**)&p.d_val[0], E * 32);
+    A((void**)&p.d_val[1], E * 32);
+    if (e != hipSuccess) {
+        plan_free(p);
+        return c->hip_fail(e, "hipMalloc(plan)");
+    }
+    p.cap_events = E;
+    p.cap_levels = L;
+    return IMT_OK;
+}
+
+extern "C" void imt_itree_free(imt_itree* t) {
+    if (!t) return;
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+    if (t->up_stream) hipStreamSynchronize(t->up_stream);
+    for (auto& p : t->plan) {
+        plan_free(p);
+        if (p.done) hipEventDestroy(p.done);
+    }
+    if (t->up_done) hipEventDestroy(t->up_done);
+    if (t->up_stream) hipStreamDestroy(t->up_stream);
+    if (t->d_nodes) hipFree(t->d_nodes);
+    if (t->d_off) hipFree(t->d_off);
+    if (t->d_len) hipFree(t->d_len);
+    delete t;
+}
+
+extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_itree** out) {
+    if (!c || !out) return IMT_ERR_ARG;
+    *out = nullptr;
+    if (depth == 0 || depth > IMT_MAX_DEPTH) return c->fail(IMT_ERR_RANGE, "depth %u out of range", depth);
+    if (capacity < 2 || (capacity & (capacity - 1)) || capacity > ((uint64_t)1 << 31))
+        return c->fail(IMT_ERR_RANGE, "capacity must be a power of two in [2, 2^31]");
+    if (depth < 63 && capacity > ((uint64_t)1 << depth)) return c->fail(IMT_ERR_RANGE, "capacity exceeds 2^depth");
+    int rc = c->set_device();
+    if (rc) return rc;
+    imt_itree* t = new (std::nothrow) imt_itree();
+    if (!t) return c->fail(IMT_ERR_ALLOC, "out of host memory");
+    t->ctx = c;
+    t->depth = depth;
+    t->cap = capacity;
+    uint64_t off = 0;
+    for (unsigned l = 0; l <= depth; l++) {
+        uint64_t n = l < 63 ? capacity >> l : 0;
+        if (n == 0) n = 1;
+        t->h_off.push_back(off);
+        t->h_len.push_back(n);
+        off += n;
+    }
+    hipError_t e;
+    if ((e = hipMalloc((void**)&t->d_nodes, off * 32)) != hipSuccess ||
+        (e = hipMalloc((void**)&t->d_off, (depth + 1) * 8)) != hipSuccess ||
+        (e = hipMalloc((void**)&t->d_len, (depth + 1) * 8)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&t->up_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&t->up_done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&t->plan[0].done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&t->plan[1].done, hipEventDisableTiming)) != hipSuccess) {
+        imt_itree_free(t);
+        return c->hip_fail(e, "imt_itree_new allocation");
+    }
+    hipMemcpyAsync(t->d_off, t->h_off.data(), (depth + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(t->d_len, t->h_len.data(), (depth + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    for (unsigned l = 0; l <= depth; l++)   // every stored node starts as the empty subtree of its height
+        launch::fill_level(c->stream, t->d_nodes + t->h_off[l] * 32, t->h_len[l], c->d_zero + (size_t)l * 32);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+        imt_itree_free(t);
+        return c->hip_fail(e, "imt_itree_new init");
+    }
+    // leaf 0 is the {0,0,0} sentinel; its hash equals the empty-slot hash
+    t->pre.push_back(Pre{{0, 0, 0, 0}, {0, 0, 0, 0}, 0});
+    t->sorted.push_back(SortedEnt{{0, 0, 0, 0}, 0});
+    t->size = 1;
+    *out = t;
+    return IMT_OK;
+}
+
+extern "C" uint64_t imt_itree_size(const imt_itree* t) { return t ? t->size : 0; }
+
+extern "C" int imt_itree_root(imt_itree* t, void* root, unsigned flags) {
+    if (!t || !root) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    int rc = c->set_device();
+    if (rc) return rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    const uint8_t* src = t->d_nodes + t->h_off[t->depth] * 32;
+    if (flags & IMT_DEVICE_PTRS) {
+        launch::convert(c->stream, src, (uint8_t*)root, 1, IMT_FMT_DEVICE, fmt, c->d_err);
+        return IMT_OK;
+    }
+    uint8_t* d = (uint8_t*)c->dev_scratch(0, 32);
+    if (!d) return IMT_ERR_HIP;
+    launch::convert(c->stream, src, d, 1, IMT_FMT_DEVICE, fmt, c->d_err);
+    IMT_HIP(c, hipMemcpyAsync(root, d, 32, hipMemcpyDeviceToHost, c->stream));
+    IMT_HIP(c, hipStreamSynchronize(c->stream));
+    return IMT_OK;
+}
+
+// canonical host copy of n field elements given in any format / location
+static int fetch_canonical(imt_ctx* c, hipStream_t st, const void* vals, size_t n, unsigned flags, std::vector<U256>& out) {
+    out.resize(n);
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    const bool dev = flags & IMT_DEVICE_PTRS;
+    if (!dev && fmt == IMT_FMT_CANONICAL) {
+        std::memcpy(out.data(), vals, n * 32);
+    } else if (dev && fmt == IMT_FMT_CANONICAL) {
+        IMT_HIP(c, hipMemcpyAsync(out.data(), vals, n * 32, hipMemcpyDeviceToHost, st));
+        IMT_HIP(c, hipStreamSynchronize(st));
+    } else {
+        // convert on the device, then read back
+        uint8_t* d_in = (uint8_t*)vals;
+        if (!dev) {
+            d_in = (uint8_t*)c->dev_scratch(0, n * 32);
+            if (!d_in) return IMT_ERR_HIP;
+            IMT_HIP(c, hipMemcpyAsync(d_in, vals, n * 32, hipMemcpyHostToDevice, st));
+        }
+        uint8_t* d_out = (uint8_t*)c->dev_scratch(1, n * 32);
+        if (!d_out) return IMT_ERR_HIP;
+        launch::convert(st, d_in, d_out, n, fmt, IMT_FMT_CANONICAL, c->d_err);
+        IMT_HIP(c, hipMemcpyAsync(out.data(), d_out, n * 32, hipMemcpyDeviceToHost, st));
+        IMT_HIP(c, hipStreamSynchronize(st));
+    }
+    for (size_t i = 0; i < n; i++)
+        if (HField::geq_p(out[i].data())) return c->fail(IMT_ERR_NONCANONICAL, "value %zu is not reduced (>= p)", i);
+    return IMT_OK;
+}
+
+// position in t->sorted of the greatest val < v; IMT_ERR_VALUE if v == 0 or present
+static int find_pred(const imt_itree* t, const U256& v, size_t& pos) {
+    size_t lo = 0, hi = t->sorted.size();   // first entry with val >= v
+    while (lo < hi) {
+        size_t mid = (lo + hi) / 2;
+        if (lt256(t->sorted[mid].val, v)) lo = mid + 1; else hi = mid;
+    }
+    if (lo < t->sorted.size() && t->sorted[lo].val == v) return IMT_ERR_VALUE;
+    if (lo == 0) return IMT_ERR_VALUE;
+    pos = lo - 1;
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_find_low_batch(imt_itree* t, const void* vals, size_t n, uint64_t* low_index, unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (n == 0) return IMT_OK;
+    if (!vals || !low_index) return c->fail(IMT_ERR_ARG, "null buffer");
+    int rc = c->set_device();
+    if (rc) return rc;
+    std::vector<U256> v;
+    rc = fetch_canonical(c, c->stream, vals, n, flags, v);
+    if (rc) return rc;
+    std::vector<uint64_t> res(n);
+    for (size_t i = 0; i < n; i++) {
+        size_t pos;
+        if (find_pred(t, v[i], pos)) return c->fail(IMT_ERR_VALUE, "value %zu is zero or already in the tree", i);
+        res[i] = t->sorted[pos].idx;
+    }
+    if (flags & IMT_DEVICE_PTRS) {
+        IMT_HIP(c, hipMemcpy(low_index, res.data(), n * 8, hipMemcpyHostToDevice));
+    } else {
+        std::memcpy(low_index, res.data(), n * 8);
+    }
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_get_leaves(imt_itree* t, const uint64_t* index, size_t n, void* preimage, unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (n == 0) return IMT_OK;
+    if (!index || !preimage) return c->fail(IMT_ERR_ARG, "null buffer");
+    if (flags & IMT_DEVICE_PTRS) return c->fail(IMT_ERR_ARG, "imt_itree_get_leaves takes host pointers");
+    int rc = c->set_device();
+    if (rc) return rc;
+    std::vector<uint8_t> buf(n * 96);
+    for (size_t i = 0; i < n; i++) {
+        if (index[i] >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
+        if (index[i] < t->size) {
+            const Pre& p = t->pre[index[i]];
+            put_pre(&buf[i * 96], p.val, p.next_val, p.next_idx);
+        } else {
+            std::memset(&buf[i * 96], 0, 96);
+        }
+    }
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    if (fmt == IMT_FMT_CANONICAL) {
+        std::memcpy(preimage, buf.data(), n * 96);
+        return IMT_OK;
+    }
+    uint8_t* d_in = (uint8_t*)c->dev_scratch(0, n * 96);
+    uint8_t* d_out = (uint8_t*)c->dev_scratch(1, n * 96);
+    if (!d_in || !d_out) return IMT_ERR_HIP;
+    IMT_HIP(c, hipMemcpyAsync(d_in, buf.data(), n * 96, hipMemcpyHostToDevice, c->stream));
+    launch::convert(c->stream, d_in, d_out, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+    IMT_HIP(c, hipMemcpyAsync(preimage, d_out, n * 96, hipMemcpyDeviceToHost, c->stream));
+    IMT_HIP(c, hipStreamSynchronize(c->stream));
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_get_proof_batch(imt_itree* t, const uint64_t* index, size_t n, void* sib, unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (n == 0) return IMT_OK;
+    if (!index || !sib) return c->fail(IMT_ERR_ARG, "null buffer");
+    int rc = c->set_device();
+    if (rc) return rc;
+    const bool dev = flags & IMT_DEVICE_PTRS;
+    if (!dev)
+        for (size_t i = 0; i < n; i++)
+            if (index[i] >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
+    const unsigned depth = t->depth;
+    const uint64_t* d_idx = index;
+    uint8_t* d_out = (uint8_t*)sib;
+    if (!dev) {
+        d_idx = (const uint64_t*)c->dev_scratch(0, n * 8);
+        d_out = (uint8_t*)c->dev_scratch(1, (size_t)depth * n * 32);
+        if (!d_idx || !d_out) return IMT_ERR_HIP;
+        IMT_HIP(c, hipMemcpyAsync((void*)d_idx, index, n * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    launch::TreeView tv{t->d_nodes, t->d_off, t->d_len, c->d_zero};
+    launch::SibLayout lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, depth} : launch::SibLayout{n, 1};
+    launch::gather_proof(c->stream, tv, d_idx, n, depth, d_out, lay, flags & IMT_FMT_MASK);
+    if (!dev) {
+        IMT_HIP(c, hipMemcpyAsync(sib, d_out, (size_t)depth * n * 32, hipMemcpyDeviceToHost, c->stream));
+        IMT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return IMT_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// batch insertion
+// ------------------------------------------------------------------------------------
+extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, const imt_insert_out* out,
+                                      unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (n == 0) return IMT_OK;
+    if (!vals) return c->fail(IMT_ERR_ARG, "null vals");
+    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
+    if (n > ((size_t)1 << 30)) return c->fail(IMT_ERR_RANGE, "batch too large");
+    int rc = c->set_device();
+    if (rc) return rc;
+    const bool dev = flags & IMT_DEVICE_PTRS;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    const uint64_t M = t->size;
+    if (M + n > t->cap) return c->fail(IMT_ERR_FULL, "tree capacity %llu exceeded", (unsigned long long)t->cap);
+
+    // ---- 1. values, canonical, on the host.  With device pointers they are read on the side
+    //         stream, so the call does not wait for an earlier batch still running. ----
+    std::vector<U256> v;
+    rc = fetch_canonical(c, dev ? t->up_stream : c->stream, vals, n, flags, v);
+    if (rc) return rc;
+
+    // ---- 2. low leaf of every insertion (update_idx_leaf :639-658, as a predecessor search):
+    //         sort the batch, locate each value between two stored leaves, then unlink the batch
+    //         from that list in reverse insertion order: what is adjacent at unlink time is
+    //         exactly what had been inserted earlier. ----
+    std::vector<uint32_t> ord(n);
+    std::iota(ord.begin(), ord.end(), 0u);
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return lt256(v[a], v[b]); });
+    if (is_zero256(v[ord[0]])) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
+    for (size_t r = 1; r < n; r++)
+        if (v[ord[r]] == v[ord[r - 1]]) return c->fail(IMT_ERR_VALUE, "duplicate value inside the batch");
+    // neighbours: >= 0 -> rank of a batch element; < 0 -> ~(leaf index of a stored leaf); NONE
+    const int64_t NONE = INT64_MIN;
+    std::vector<int64_t> prv(n), nxt(n);
+    {
+        size_t q = 0;   // first stored entry with val >= current
+        const size_t S = t->sorted.size();
+        for (size_t r = 0; r < n; r++) {
+            const U256& x = v[ord[r]];
+            while (q < S && lt256(t->sorted[q].val, x)) q++;
+            if (q < S && t->sorted[q].val == x) return c->fail(IMT_ERR_VALUE, "value already in the tree");
+            // q >= 1 because the sentinel 0 is stored and x > 0
+            const bool same_gap_prev = r > 0 && !lt256(v[ord[r - 1]], t->sorted[q - 1].val) ;
+            prv[r] = same_gap_prev ? (int64_t)(r - 1) : ~(int64_t)t->sorted[q - 1].idx;
+            const bool next_in_gap = r + 1 < n && (q >= S || lt256(v[ord[r + 1]], t->sorted[q].val));
+            nxt[r] = next_in_gap ? (int64_t)(r + 1) : (q < S ? ~(int64_t)t->sorted[q].idx : NONE);
+        }
+    }
+    std::vector<uint32_t> rank_of(n);
+    for (size_t r = 0; r < n; r++) rank_of[ord[r]] = (uint32_t)r;
+    std::vector<int64_t> pred(n), succ(n);   // by insertion time
+    for (size_t ii = n; ii-- > 0;) {
+        const uint32_t r = rank_of[ii];
+        pred[ii] = prv[r];
+        succ[ii] = nxt[r];
+        if (prv[r] >= 0) nxt[prv[r]] = nxt[r];
+        if (nxt[r] >= 0) prv[nxt[r]] = prv[r];
+    }
+
+    // ---- 3. plan buffers ----
+    const size_t E = 2 * n;
+    const unsigned L0 = std::min(ceil_log2(M + n), t->depth);
+    PlanSet& P = t->plan[t->cur];
+    if (P.in_flight) {
+        IMT_HIP(c, hipEventSynchronize(P.done));
+        P.in_flight = false;
+    }
+    rc = plan_reserve(c, P, E, L0);
+    if (rc) return rc;
+    uint8_t* h_pre = P.h_pin;
+    uint32_t* h_tab = reinterpret_cast<uint32_t*>(P.h_pin + P.cap_events * 96);
+    uint32_t *h_node = h_tab, *h_time = h_tab + P.cap_events, *h_rs = h_tab + 2 * P.cap_events,
+             *h_re = h_tab + 3 * P.cap_events;
+
+    // ---- 4. events: preimages at every time step + host-side outputs ----
+    std::vector<uint64_t> o_low(n);
+    std::vector<uint8_t> o_largest(n);
+    std::vector<uint8_t> o_lowleaf(out && out->low_leaf ? n * 96 : 0), o_newleaf(out && out->new_leaf ? n * 96 : 0);
+    std::vector<uint64_t> keys(E);   // (pos << 32) | event
+    auto leaf_of = [&](int64_t ref) -> uint64_t { return ref >= 0 ? M + ord[ref] : (uint64_t)~ref; };
+    auto val_of = [&](int64_t ref) -> const U256& { return ref >= 0 ? v[ord[ref]] : t->pre[(size_t)~ref].val; };
+    static const U256 ZERO = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t low = leaf_of(pred[i]);
+        const U256& lowval = val_of(pred[i]);
+        const bool has_succ = succ[i] != NONE;
+        const U256& sval = has_succ ? val_of(succ[i]) : ZERO;
+        const uint64_t sidx = has_succ ? leaf_of(succ[i]) : 0;
+        o_low[i] = low;
+        o_largest[i] = has_succ ? 0 : 1;                               // :737-742
+        if (!o_lowleaf.empty()) put_pre(&o_lowleaf[i * 96], lowval, sval, sidx);
+        put_pre(h_pre + (2 * i) * 96, lowval, v[i], M + i);            // low leaf rewritten :655-656
+        put_pre(h_pre + (2 * i + 1) * 96, v[i], sval, sidx);           // new leaf inherits :650-654
+        if (!o_newleaf.empty()) std::memcpy(&o_newleaf[i * 96], h_pre + (2 * i + 1) * 96, 96);
+        keys[2 * i] = (low << 32) | (uint64_t)(2 * i);
+        keys[2 * i + 1] = ((M + i) << 32) | (uint64_t)(2 * i + 1);
+    }
+    std::sort(keys.begin(), keys.end());
+    for (size_t k = 0; k < E;) {
+        size_t j = k;
+        const uint32_t pos = (uint32_t)(keys[k] >> 32);
+        while (j < E && (uint32_t)(keys[j] >> 32) == pos) j++;
+        for (size_t x = k; x < j; x++) {
+            h_node[x] = pos;
+            h_time[x] = (uint32_t)keys[x];
+            h_rs[x] = (uint32_t)k;
+            h_re[x] = (uint32_t)j;
+        }
+        k = j;
+    }
+
+    // ---- 5. upload on the side stream; the compute stream waits for it ----
+    IMT_HIP(c, hipMemcpyAsync(P.d_pre, h_pre, E * 96, hipMemcpyHostToDevice, t->up_stream));
+    IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][0], h_node, E * 4, hipMemcpyHostToDevice, t->up_stream));
+    IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][1], h_time, E * 4, hipMemcpyHostToDevice, t->up_stream));
+    IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][2], h_rs, E * 4, hipMemcpyHostToDevice, t->up_stream));
+    IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][3], h_re, E * 4, hipMemcpyHostToDevice, t->up_stream));
+    IMT_HIP(c, hipEventRecord(t->up_done, t->up_stream));
+    hipStream_t s = c->stream;
+    IMT_HIP(c, hipStreamWaitEvent(s, t->up_done, 0));
+
+    // ---- 6. GPU outputs ----
+    const size_t sib_bytes = (size_t)t->depth * n * 32;
+    uint8_t *g_old = nullptr, *g_int = nullptr, *g_new = nullptr, *g_ls = nullptr, *g_ns = nullptr;
+    size_t slot = 2;
+    auto gpu_out = [&](void* user, size_t bytes) -> uint8_t* {
+        if (!user) return nullptr;
+        if (dev) return (uint8_t*)user;
+        return (uint8_t*)c->dev_scratch(slot++, bytes);
+    };
+    if (out) {
+        g_old = gpu_out(out->old_root, n * 32);
+        g_int = gpu_out(out->interim_root, n * 32);
+        g_new = gpu_out(out->new_root, n * 32);
+        g_ls = gpu_out(out->low_sib, sib_bytes);
+        g_ns = gpu_out(out->new_sib, sib_bytes);
+        if ((out->old_root && !g_old) || (out->interim_root && !g_int) || (out->new_root && !g_new) ||
+            (out->low_sib && !g_ls) || (out->new_sib && !g_ns))
+            return IMT_ERR_HIP;
+    }
+    launch::SibLayout lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->depth} : launch::SibLayout{n, 1};
+
+    // ---- 7. leaf hashes, index phase (no hashing), then the hash sweep ----
+    // (the leaf kernel reads the level-0 time table before the merges recycle that buffer)
+    launch::sweep_leaves(s, P.d_pre, P.d_tab[0][1], P.d_val[0], 0, (uint32_t)E, IMT_FMT_CANONICAL, c->d_err);
+    for (unsigned l = 0; l < L0; l++) {
+        const int a = l & 1, b = a ^ 1;
+        sweep::LevelTable in{P.d_tab[a][0], P.d_tab[a][1], P.d_tab[a][2], P.d_tab[a][3]};
+        sweep::LevelOut o{P.d_tab[b][0], P.d_tab[b][1], P.d_tab[b][2], P.d_tab[b][3],
+                          P.d_from + (size_t)l * P.cap_events, P.d_sibsrc + (size_t)l * P.cap_events,
+                          P.d_nodeb + (size_t)l * P.cap_events};
+        launch::merge_level(s, in, o, (uint32_t)E);
+        IMT_HIP(c, hipMemcpyAsync(P.d_timen + (size_t)l * P.cap_events, P.d_tab[b][1], E * 4, hipMemcpyDeviceToDevice, s));
+    }
+    for (unsigned l = 0; l < L0; l++) {
+        const uint8_t* vin = P.d_val[l & 1];
+        uint8_t* vout = P.d_val[(l & 1) ^ 1];
+        const size_t o = (size_t)l * P.cap_events;
+        launch::sweep_level(s, vin, vout, P.d_from + o, P.d_sibsrc + o, P.d_nodeb + o, P.d_timen + o,
+                            t->d_nodes + t->h_off[l] * 32, t->h_len[l], c->d_zero + (size_t)l * 32, 0, (uint32_t)E, g_ls,
+                            g_ns, lay, l, fmt);
+        launch::writeback(s, vin, P.d_from + o, P.d_nodeb + o, t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
+    }
+    if (g_old) launch::convert(s, t->d_nodes + t->h_off[t->depth] * 32, g_old, 1, IMT_FMT_DEVICE, fmt, c->d_err);
+    launch::sweep_top(s, P.d_val[L0 & 1], L0, t->depth, c->d_zero, t->d_nodes, t->d_off, 0, (uint32_t)E, (uint32_t)E,
+                      g_old, g_int, g_new, g_ls, g_ns, lay, fmt);
+    IMT_HIP(c, hipEventRecord(P.done, s));
+    P.in_flight = true;
+    t->cur ^= 1;
+
+    // ---- 8. host mirror ----
+    t->pre.resize(M + n);
+    for (size_t i = 0; i < n; i++) {
+        const bool has_succ = succ[i] != NONE;
+        Pre& lowp = t->pre[o_low[i]];
+        Pre& np = t->pre[M + i];
+        np.val = v[i];
+        np.next_val = has_succ ? val_of(succ[i]) : ZERO;
+        np.next_idx = has_succ ? leaf_of(succ[i]) : 0;
+        lowp.next_val = v[i];
+        lowp.next_idx = M + i;
+    }
+    {
+        std::vector<SortedEnt> merged;
+        merged.reserve(t->sorted.size() + n);
+        size_t q = 0;
+        for (size_t r = 0; r < n; r++) {
+            const U256& x = v[ord[r]];
+            while (q < t->sorted.size() && lt256(t->sorted[q].val, x)) merged.push_back(t->sorted[q++]);
+            merged.push_back(SortedEnt{x, M + ord[r]});
+        }
+        while (q < t->sorted.size()) merged.push_back(t->sorted[q++]);
+        t->sorted.swap(merged);
+    }
+    t->size = M + n;
+
+    // ---- 9. outputs ----
+    if (out) {
+        auto host_out = [&](void* user, const void* src, size_t bytes) -> int {
+            if (!user) return IMT_OK;
+            if (dev) {   // side stream: does not wait for the sweep; src is a local vector
+                IMT_HIP(c, hipMemcpyAsync(user, src, bytes, hipMemcpyHostToDevice, t->up_stream));
+                IMT_HIP(c, hipStreamSynchronize(t->up_stream));
+            } else {
+                std::memcpy(user, src, bytes);
+            }
+            return IMT_OK;
+        };
+        if ((rc = host_out(out->low_index, o_low.data(), n * 8))) return rc;
+        if ((rc = host_out(out->is_largest, o_largest.data(), n))) return rc;
+        if (fmt == IMT_FMT_CANONICAL) {
+            if ((rc = host_out(out->low_leaf, o_lowleaf.data(), n * 96))) return rc;
+            if ((rc = host_out(out->new_leaf, o_newleaf.data(), n * 96))) return rc;
+        } else {
+            for (int w = 0; w < 2; w++) {
+                void* user = w ? out->new_leaf : out->low_leaf;
+                if (!user) continue;
+                const std::vector<uint8_t>& src = w ? o_newleaf : o_lowleaf;
+                uint8_t* d_in = (uint8_t*)c->dev_scratch(slot++, n * 96);
+                if (!d_in) return IMT_ERR_HIP;
+                IMT_HIP(c, hipMemcpyAsync(d_in, src.data(), n * 96, hipMemcpyHostToDevice, s));
+                uint8_t* d_o = dev ? (uint8_t*)user : (uint8_t*)c->dev_scratch(slot++, n * 96);
+                if (!d_o) return IMT_ERR_HIP;
+                launch::convert(s, d_in, d_o, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+                if (!dev) IMT_HIP(c, hipMemcpyAsync(user, d_o, n * 96, hipMemcpyDeviceToHost, s));
+                IMT_HIP(c, hipStreamSynchronize(s));
+            }
+        }
+        if (!dev) {
+            if (out->old_root) IMT_HIP(c, hipMemcpyAsync(out->old_root, g_old, n * 32, hipMemcpyDeviceToHost, s));
+            if (out->interim_root) IMT_HIP(c, hipMemcpyAsync(out->interim_root, g_int, n * 32, hipMemcpyDeviceToHost, s));
+            if (out->new_root) IMT_HIP(c, hipMemcpyAsync(out->new_root, g_new, n * 32, hipMemcpyDeviceToHost, s));
+            if (out->low_sib) IMT_HIP(c, hipMemcpyAsync(out->low_sib, g_ls, sib_bytes, hipMemcpyDeviceToHost, s));
+            if (out->new_sib) IMT_HIP(c, hipMemcpyAsync(out->new_sib, g_ns, sib_bytes, hipMemcpyDeviceToHost, s));
+        }
+    }
+    if (!dev) IMT_HIP(c, hipStreamSynchronize(s));
+    return IMT_OK;
+}

@@ -1,0 +1,566 @@
+// imt_kernels.hip -- hand-written gfx950 (MI355X) kernels of the indexed-Merkle-tree path.
+//
+// One thread owns one hash chain: its 3x9-limb Poseidon state stays in VGPRs for all 65
+// rounds, round constants arrive as wave-uniform scalar loads (SGPR operands of
+// v_mad_u64_u32), and HBM is touched only for the 32-byte inputs / siblings / outputs.
+// The path is VALU-integer bound (about 80k v_mad_u64_u32 per permutation against
+// 32..100 bytes of traffic), so there is no LDS staging and no MFMA: nothing is reused
+// across lanes and there is no dense contraction ("Kernels").
+//
+// Reference rows: a1/a10 hash_batch, a2 tree_level, a4 gather_proof,
+// a5/a8/a9 path_root, a13 non_membership, a14 insert_witness, a15 sweep_* (imt_sweep.hip).
+#include "imt_device.hpp"
+#include "imt_launch.hpp"
+#include "imt_sweep.hpp"
+
+namespace imt {
+
+__constant__ dev::PoseidonConsts g_pc;
+
+namespace {
+using namespace dev;
+
+constexpr int BLOCK = 256;   // 4 waves = one per SIMD of a CU
+
+__device__ __forceinline__ size_t gtid() { return (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
+__device__ __forceinline__ void flag_err(int* err, bool ok) {
+    if (!ok) atomicOr(err, 1);
+}
+
+// integer value (not Montgomery) of a device-form element, canonical limbs
+__device__ __forceinline__ void to_int(Fe& r, const Fe& a) {
+    mont_mul(r, a, g_pc.int_one);
+    canonicalize(r);
+}
+__device__ __forceinline__ bool int_lt(const Fe& a, const Fe& b) {   // canonical limbs
+    bool lt = false;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        if (a.v[i] != b.v[i]) lt = a.v[i] < b.v[i];
+    }
+    return lt;
+}
+__device__ __forceinline__ void fe_from_u64(Fe& r, uint64_t x) {
+    Fe t;
+#pragma unroll
+    for (int i = 0; i < NL; i++) t.v[i] = 0;
+    t.v[0] = (uint32_t)x & MASK29;
+    t.v[1] = (uint32_t)(x >> 29) & MASK29;
+    t.v[2] = (uint32_t)(x >> 58);
+    mont_mul(r, t, g_pc.from_canon);
+    canonicalize(r);
+}
+
+// ---------------------------------------------------------------------------------
+// One hash chain: optional 3-input leaf hash, then `depth` 2-input hashes up the tree.
+// The loop keeps a single copy of the permutation in the instruction stream.
+//   right child at level l  <=>  bit l of idx is 1  (src/utils.rs:93-101)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void hash_chain(Fe& cur, bool has_leaf3, const Fe pre[3], uint64_t idx,
+                                           const uint8_t* sib, launch::SibLayout lay, size_t item,
+                                           unsigned depth, unsigned fmt_in, bool& ok,
+                                           uint8_t* leaf_hash_out /*device fmt or NULL*/) {
+#pragma unroll 1
+    for (int it = has_leaf3 ? -1 : 0; it < (int)depth; it++) {
+        Fe a, b, c;
+        const bool three = it < 0;
+        if (three) {
+            a = pre[0]; b = pre[1]; c = pre[2];
+        } else {
+            Fe sv;
+            ok &= load_fe(g_pc, sv, sib + ((uint64_t)it * lay.level_stride + item * lay.item_stride) * 32, fmt_in);
+            const bool right = (idx >> it) & 1;
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                a.v[i] = right ? sv.v[i] : cur.v[i];
+                b.v[i] = right ? cur.v[i] : sv.v[i];
+            }
+            c = a;
+        }
+        hash23(g_pc, cur, a, b, c, three);
+        if (three && leaf_hash_out) store_packed(leaf_hash_out, cur);
+    }
+}
+
+// ---- a1 / a10 --------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_hash_batch(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                      size_t n, int arity, unsigned fmt_in, unsigned fmt_out,
+                                                      int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    const uint8_t* p = in + i * 32 * (size_t)arity;
+    Fe a, b, c, o;
+    bool ok = load_fe(g_pc, a, p, fmt_in);
+    ok &= load_fe(g_pc, b, p + 32, fmt_in);
+    c = a;
+    if (arity == 3) ok &= load_fe(g_pc, c, p + 64, fmt_in);
+    hash23(g_pc, o, a, b, c, arity == 3);
+    store_fe(g_pc, out + i * 32, o, fmt_out);
+    flag_err(err, ok);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_permute_batch(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                         size_t n, unsigned fmt_in, unsigned fmt_out, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Fe s[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, s[j], in + (i * 3 + j) * 32, fmt_in);
+    permute(g_pc, s, g_pc.rc_full[0]);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        canonicalize(s[j]);
+        store_fe(g_pc, out + (i * 3 + j) * 32, s[j], fmt_out);
+    }
+    flag_err(err, ok);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_convert(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n,
+                                                   unsigned fmt_in, unsigned fmt_out, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Fe x;
+    bool ok = load_fe(g_pc, x, in + i * 32, fmt_in);
+    store_fe(g_pc, out + i * 32, x, fmt_out);
+    flag_err(err, ok);
+}
+
+// ---- a5 / a8 / a9 ----------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK)
+k_path_root(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3, const uint64_t* __restrict__ index,
+            int is_helper, const uint8_t* __restrict__ sib, launch::SibLayout lay, unsigned depth, size_t n,
+            uint8_t* __restrict__ root_out, const uint8_t* __restrict__ expect, unsigned expect_stride,
+            uint8_t* __restrict__ ok_out, unsigned fmt_in, unsigned fmt_out, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    bool ok = true;
+    Fe cur, pre[3];
+    if (leaf3) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, pre[j], leaf3 + (i * 3 + j) * 32, fmt_in);
+        cur = pre[0];
+    } else {
+        ok &= load_fe(g_pc, cur, leaf + i * 32, fmt_in);
+        pre[0] = pre[1] = pre[2] = cur;
+    }
+    uint64_t idx = index[i];
+    if (is_helper) idx = ~idx;   // helper 1 = left child (src/utils.rs:79)
+    hash_chain(cur, leaf3 != nullptr, pre, idx, sib, lay, i, depth, fmt_in, ok, nullptr);
+    if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
+    if (ok_out) {
+        Fe e;
+        ok &= load_fe(g_pc, e, expect + i * (size_t)expect_stride, fmt_in);
+        ok_out[i] = fe_eq(cur, e) ? 1 : 0;
+    }
+    flag_err(err, ok);
+}
+
+// ---- a13: verify_non_inclusion (src/indexed_merkle_tree.rs:127-229) ---------------
+__global__ void __launch_bounds__(BLOCK)
+k_non_membership(const uint8_t* __restrict__ root, unsigned root_stride, const uint8_t* __restrict__ low_leaf,
+                 const uint64_t* __restrict__ low_index, const uint8_t* __restrict__ sib, launch::SibLayout lay,
+                 unsigned depth, const uint8_t* __restrict__ new_val, const uint8_t* __restrict__ is_largest,
+                 size_t n, uint8_t* __restrict__ fail_out, uint8_t* __restrict__ root_out, unsigned fmt_in,
+                 unsigned fmt_out, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    bool ok = true;
+    Fe pre[3], nv, rt, cur;
+#pragma unroll
+    for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, pre[j], low_leaf + (i * 3 + j) * 32, fmt_in);
+    ok &= load_fe(g_pc, nv, new_val + i * 32, fmt_in);
+    ok &= load_fe(g_pc, rt, root + i * (size_t)root_stride, fmt_in);
+    unsigned fail = 0;
+    {
+        Fe nvi, lvi, lni;
+        to_int(nvi, nv); to_int(lvi, pre[0]); to_int(lni, pre[1]);
+        const unsigned s = is_largest[i];
+        if (s > 1) fail |= 0x80;                                    // assert_bit :41
+        const bool is_zero = fe_is_zero(pre[1]);                    // :143
+        const bool next_gr = int_lt(nvi, lni);                      // :180
+        if (!(s ? is_zero : next_gr)) fail |= 0x01;                 // :182-191
+        if (!int_lt(lvi, nvi)) fail |= 0x04;                        // :206-228
+    }
+    cur = pre[0];
+    hash_chain(cur, true, pre, low_index[i], sib, lay, i, depth, fmt_in, ok, nullptr);   // :193-204
+    if (!fe_eq(cur, rt)) fail |= 0x02;
+    fail_out[i] = (uint8_t)fail;
+    if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
+    flag_err(err, ok);
+}
+
+// ---- a14: insert_leaf (src/indexed_merkle_tree.rs:231-314) ------------------------
+// blockIdx.y selects one of the four chains of an item, so leaf-hash selection is uniform.
+// trace rows (device format): 0 low_leaf_hash, 1 root_from_low, 2 new_low_leaf_hash,
+// 3 interim_root, 4 zero_slot_root, 5 new_leaf_hash, 6 new_root_recomputed.
+__global__ void __launch_bounds__(BLOCK)
+k_insert_chains(const uint8_t* __restrict__ low_leaf, const uint64_t* __restrict__ low_index,
+                const uint8_t* __restrict__ low_sib, const uint8_t* __restrict__ new_leaf,
+                const uint64_t* __restrict__ new_index, const uint64_t* __restrict__ new_path_index,
+                const uint8_t* __restrict__ new_sib, launch::SibLayout lay, unsigned depth, size_t n,
+                uint8_t* __restrict__ trace, unsigned fmt_in, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    const int chain = blockIdx.y;
+    bool ok = true;
+    Fe pre[3], cur;
+    const uint8_t* sib = chain < 2 ? low_sib : new_sib;
+    const uint64_t idx = chain < 2 ? low_index[i] : new_path_index[i];
+    uint8_t* leaf_out = nullptr;
+    uint8_t* root_out;
+    if (chain == 0) {            // low leaf as given                       :193-204
+#pragma unroll
+        for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, pre[j], low_leaf + (i * 3 + j) * 32, fmt_in);
+        leaf_out = trace + (0 * n + i) * 32;
+        root_out = trace + (1 * n + i) * 32;
+    } else if (chain == 1) {     // {low.val, new.val, new_leaf_index}      :265-284
+        ok &= load_fe(g_pc, pre[0], low_leaf + (i * 3 + 0) * 32, fmt_in);
+        ok &= load_fe(g_pc, pre[1], new_leaf + (i * 3 + 0) * 32, fmt_in);
+        fe_from_u64(pre[2], new_index[i]);
+        leaf_out = trace + (2 * n + i) * 32;
+        root_out = trace + (3 * n + i) * 32;
+    } else if (chain == 2) {     // the zero leaf at the new slot           :286-294
+        pre[0] = pre[1] = pre[2] = g_pc.zero_leaf;
+        root_out = trace + (4 * n + i) * 32;
+    } else {                     // the new leaf                            :299-312
+#pragma unroll
+        for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, pre[j], new_leaf + (i * 3 + j) * 32, fmt_in);
+        leaf_out = trace + (5 * n + i) * 32;
+        root_out = trace + (6 * n + i) * 32;
+    }
+    cur = pre[0];
+    hash_chain(cur, chain != 2, pre, idx, sib, lay, i, depth, fmt_in, ok, leaf_out);
+    store_packed(root_out, cur);
+    flag_err(err, ok);
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_insert_check(const uint8_t* __restrict__ old_root, const uint8_t* __restrict__ low_leaf,
+               const uint8_t* __restrict__ new_root, const uint8_t* __restrict__ new_leaf,
+               const uint8_t* __restrict__ is_largest, size_t n, const uint8_t* __restrict__ trace,
+               uint8_t* __restrict__ fail_out, unsigned fmt_in, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    bool ok = true;
+    Fe low[3], nl[3], r0, r1, t;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        ok &= load_fe(g_pc, low[j], low_leaf + (i * 3 + j) * 32, fmt_in);
+        ok &= load_fe(g_pc, nl[j], new_leaf + (i * 3 + j) * 32, fmt_in);
+    }
+    ok &= load_fe(g_pc, r0, old_root + i * 32, fmt_in);
+    ok &= load_fe(g_pc, r1, new_root + i * 32, fmt_in);
+    unsigned fail = 0;
+    Fe nvi, lvi, lni;
+    to_int(nvi, nl[0]); to_int(lvi, low[0]); to_int(lni, low[1]);
+    const unsigned s = is_largest[i];
+    if (s > 1) fail |= 0x80;
+    if (!(s ? fe_is_zero(low[1]) : int_lt(nvi, lni))) fail |= 0x01;
+    if (!int_lt(lvi, nvi)) fail |= 0x04;
+    load_packed(t, trace + (1 * n + i) * 32);
+    if (!fe_eq(t, r0)) fail |= 0x02;
+    Fe interim, z;
+    load_packed(interim, trace + (3 * n + i) * 32);
+    load_packed(z, trace + (4 * n + i) * 32);
+    if (!fe_eq(z, interim)) fail |= 0x08;
+    if (!fe_eq(nl[1], low[1])) fail |= 0x10;
+    if (!fe_eq(nl[2], low[2])) fail |= 0x20;
+    load_packed(t, trace + (6 * n + i) * 32);
+    if (!fe_eq(t, r1)) fail |= 0x40;
+    fail_out[i] = (uint8_t)fail;
+    flag_err(err, ok);
+}
+
+// ---- a2: one level of the dense build (src/utils.rs:43-48) ------------------------
+__global__ void __launch_bounds__(BLOCK) k_tree_level(const uint8_t* __restrict__ prev, uint8_t* __restrict__ next,
+                                                      size_t n_parents) {
+    const size_t i = gtid();
+    if (i >= n_parents) return;
+    Fe a, b, o;
+    load_packed(a, prev + (2 * i) * 32);
+    load_packed(b, prev + (2 * i + 1) * 32);
+    hash2(g_pc, o, a, b);
+    store_packed(next + i * 32, o);
+}
+
+__global__ void k_zero_chain(uint8_t* out, unsigned depth) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fe cur = g_pc.zero_leaf;
+    store_packed(out, cur);
+#pragma unroll 1
+    for (unsigned l = 0; l < depth; l++) {
+        Fe o;
+        hash2(g_pc, o, cur, cur);
+        cur = o;
+        store_packed(out + (size_t)(l + 1) * 32, cur);
+    }
+}
+
+__global__ void k_extend_root(uint8_t* cur_io, const uint8_t* zero, unsigned from, unsigned to) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fe cur;
+    load_packed(cur, cur_io);
+#pragma unroll 1
+    for (unsigned l = from; l < to; l++) {
+        Fe z, o;
+        load_packed(z, zero + (size_t)l * 32);
+        hash2(g_pc, o, cur, z);
+        cur = o;
+    }
+    store_packed(cur_io, cur);
+}
+
+// ---- a4: get_proof (src/utils.rs:63-85) as a gather ------------------------------
+__global__ void __launch_bounds__(BLOCK) k_gather_proof(launch::TreeView tv, const uint64_t* __restrict__ index,
+                                                        size_t n, unsigned depth, uint8_t* __restrict__ out,
+                                                        launch::SibLayout lay, unsigned fmt_out) {
+    const size_t t = gtid();
+    if (t >= n * depth) return;
+    const size_t i = t % n;            // items fastest: coalesced level-major stores
+    const unsigned l = (unsigned)(t / n);
+    const uint64_t s = (index[i] >> l) ^ 1;
+    const uint8_t* src = s < tv.len[l] ? tv.nodes + (tv.off[l] + s) * 32 : tv.zero + (size_t)l * 32;
+    Fe x;
+    load_packed(x, src);
+    store_fe(g_pc, out + ((uint64_t)l * lay.level_stride + i * lay.item_stride) * 32, x, fmt_out);
+}
+
+__global__ void k_write_helpers(uint64_t index, unsigned depth, uint8_t* out, unsigned fmt_out) {
+    const unsigned l = threadIdx.x + blockIdx.x * blockDim.x;
+    if (l >= depth) return;
+    Fe x;
+    fe_from_u64(x, ((index >> l) & 1) ? 0 : 1);
+    store_fe(g_pc, out + (size_t)l * 32, x, fmt_out);
+}
+
+
+// ===================================================================================
+// a15: batch insertion as a level sweep over time-versioned nodes (imt_sweep.hpp)
+// ===================================================================================
+__global__ void __launch_bounds__(BLOCK) k_fill_level(uint8_t* __restrict__ nodes, size_t n,
+                                                      const uint8_t* __restrict__ zero_l) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    const Word4* z = reinterpret_cast<const Word4*>(zero_l);
+    Word4* o = reinterpret_cast<Word4*>(nodes + i * 32);
+    o[0] = z[0];
+    o[1] = z[1];
+}
+
+// leaf versions: slot k of level 0 holds H(preimage of event time0[k])   (:662-671)
+__global__ void __launch_bounds__(BLOCK)
+k_sweep_leaves(const uint8_t* __restrict__ pre, const uint32_t* __restrict__ time0, uint8_t* __restrict__ val0,
+               uint32_t k_begin, uint32_t k_count, unsigned fmt_in, int* err) {
+    const size_t t = gtid();
+    if (t >= k_count) return;
+    const uint32_t k = k_begin + (uint32_t)t;
+    const uint8_t* p = pre + (size_t)time0[k] * 96;
+    Fe a, b, c, o;
+    bool ok = load_fe(g_pc, a, p, fmt_in);
+    ok &= load_fe(g_pc, b, p + 32, fmt_in);
+    ok &= load_fe(g_pc, c, p + 64, fmt_in);
+    hash23(g_pc, o, a, b, c, true);
+    store_packed(val0 + (size_t)k * 32, o);
+    flag_err(err, ok);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_merge_level(sweep::LevelTable in, sweep::LevelOut out, uint32_t total) {
+    const size_t k = gtid();
+    if (k >= total) return;
+    sweep::merge_element(in, out, (uint32_t)k, total);
+}
+
+// level l -> l+1: one hash per event version; the sibling read is the proof element
+__global__ void __launch_bounds__(BLOCK)
+k_sweep_level(const uint8_t* __restrict__ val_in, uint8_t* __restrict__ val_out, const uint32_t* __restrict__ from,
+              const int32_t* __restrict__ sibsrc, const uint32_t* __restrict__ node_below,
+              const uint32_t* __restrict__ time_next, const uint8_t* __restrict__ tree_l, uint64_t len_l,
+              const uint8_t* __restrict__ zero_l, uint32_t k_begin, uint32_t k_count, uint8_t* __restrict__ low_sib,
+              uint8_t* __restrict__ new_sib, launch::SibLayout lay, unsigned level, unsigned fmt_out) {
+    const size_t t = gtid();
+    if (t >= k_count) return;
+    const uint32_t kp = k_begin + (uint32_t)t;
+    const uint32_t k = from[kp] & ~sweep::LAST_BIT;
+    const uint32_t n = node_below[kp];
+    const int32_t ss = sibsrc[kp];
+    const uint64_t sn = (uint64_t)(n ^ 1u);
+    const uint8_t* sp = ss >= 0 ? val_in + (size_t)ss * 32 : (sn < len_l ? tree_l + sn * 32 : zero_l);
+    Fe cur, sv, a, b, o;
+    load_packed(cur, val_in + (size_t)k * 32);
+    load_packed(sv, sp);
+    const bool right = n & 1u;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        a.v[i] = right ? sv.v[i] : cur.v[i];
+        b.v[i] = right ? cur.v[i] : sv.v[i];
+    }
+    hash23(g_pc, o, a, b, a, false);
+    store_packed(val_out + (size_t)kp * 32, o);
+    const uint32_t e = time_next[kp];
+    uint8_t* dst = (e & 1u) ? new_sib : low_sib;
+    if (dst) store_fe(g_pc, dst + ((uint64_t)level * lay.level_stride + (uint64_t)(e >> 1) * lay.item_stride) * 32, sv, fmt_out);
+}
+
+// final version of every touched node of level l goes back to the stored tree
+__global__ void __launch_bounds__(BLOCK)
+k_writeback(const uint8_t* __restrict__ val_l, const uint32_t* __restrict__ from,
+            const uint32_t* __restrict__ node_below, uint8_t* __restrict__ tree_l, uint32_t total) {
+    const size_t kp = gtid();
+    if (kp >= total) return;
+    const uint32_t f = from[kp];
+    if (!(f & sweep::LAST_BIT)) return;
+    const Word4* s = reinterpret_cast<const Word4*>(val_l + (size_t)(f & ~sweep::LAST_BIT) * 32);
+    Word4* d = reinterpret_cast<Word4*>(tree_l + (size_t)node_below[kp] * 32);
+    d[0] = s[0];
+    d[1] = s[1];
+}
+
+// levels [l0, depth): every event is alone in node 0 and its sibling is the empty subtree.
+// val is indexed by event id (the level-l0 order is pure time order).
+__global__ void __launch_bounds__(BLOCK)
+k_sweep_top(const uint8_t* __restrict__ val, unsigned l0, unsigned depth, const uint8_t* __restrict__ zero,
+            uint8_t* __restrict__ tree_nodes, const uint64_t* __restrict__ tree_off, uint32_t e_begin,
+            uint32_t e_count, uint32_t total, uint8_t* __restrict__ old_root, uint8_t* __restrict__ interim_root,
+            uint8_t* __restrict__ new_root, uint8_t* __restrict__ low_sib, uint8_t* __restrict__ new_sib,
+            launch::SibLayout lay, unsigned fmt_out) {
+    const size_t t = gtid();
+    if (t >= e_count) return;
+    const uint32_t e = e_begin + (uint32_t)t;
+    const bool last = e == total - 1;
+    Fe cur;
+    load_packed(cur, val + (size_t)e * 32);
+    if (last) store_packed(tree_nodes + tree_off[l0] * 32, cur);
+    uint8_t* dst = (e & 1u) ? new_sib : low_sib;
+#pragma unroll 1
+    for (unsigned l = l0; l < depth; l++) {
+        Fe z, o;
+        load_packed(z, zero + (size_t)l * 32);
+        if (dst) store_fe(g_pc, dst + ((uint64_t)l * lay.level_stride + (uint64_t)(e >> 1) * lay.item_stride) * 32, z, fmt_out);
+        hash23(g_pc, o, cur, z, cur, false);
+        cur = o;
+        if (last) store_packed(tree_nodes + tree_off[l + 1] * 32, cur);
+    }
+    const uint32_t i = e >> 1;
+    if (e & 1u) {
+        if (new_root) store_fe(g_pc, new_root + (size_t)i * 32, cur, fmt_out);
+        if (old_root && (size_t)i + 1 < (size_t)(total >> 1)) store_fe(g_pc, old_root + ((size_t)i + 1) * 32, cur, fmt_out);
+    } else {
+        if (interim_root) store_fe(g_pc, interim_root + (size_t)i * 32, cur, fmt_out);
+    }
+}
+
+inline unsigned nblk(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+}  // namespace
+
+// ===================================================================================
+namespace launch {
+
+hipError_t upload_consts(const dev::PoseidonConsts& pc) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pc), &pc, sizeof(pc), 0, hipMemcpyHostToDevice);
+}
+
+void hash_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, int arity, unsigned fmt_in,
+                unsigned fmt_out, int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_hash_batch, dim3(nblk(n)), dim3(BLOCK), 0, s, in, out, n, arity, fmt_in, fmt_out, err);
+}
+void permute_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, unsigned fmt_in, unsigned fmt_out,
+                   int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_permute_batch, dim3(nblk(n)), dim3(BLOCK), 0, s, in, out, n, fmt_in, fmt_out, err);
+}
+void convert(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, unsigned fmt_in, unsigned fmt_out,
+             int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_convert, dim3(nblk(n)), dim3(BLOCK), 0, s, in, out, n, fmt_in, fmt_out, err);
+}
+void path_root(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index, bool is_helper,
+               const uint8_t* sib, SibLayout lay, unsigned depth, size_t n, uint8_t* root_out,
+               const uint8_t* expect, unsigned expect_stride, uint8_t* ok_out, unsigned fmt_in, unsigned fmt_out,
+               int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_path_root, dim3(nblk(n)), dim3(BLOCK), 0, s, leaf, leaf3, index, is_helper ? 1 : 0, sib,
+                       lay, depth, n, root_out, expect, expect_stride, ok_out, fmt_in, fmt_out, err);
+}
+void non_membership(hipStream_t s, const uint8_t* root, unsigned root_stride, const uint8_t* low_leaf,
+                    const uint64_t* low_index, const uint8_t* sib, SibLayout lay, unsigned depth,
+                    const uint8_t* new_val, const uint8_t* is_largest, size_t n, uint8_t* fail_out,
+                    uint8_t* root_out, unsigned fmt_in, unsigned fmt_out, int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_non_membership, dim3(nblk(n)), dim3(BLOCK), 0, s, root, root_stride, low_leaf, low_index,
+                       sib, lay, depth, new_val, is_largest, n, fail_out, root_out, fmt_in, fmt_out, err);
+}
+void insert_witness(hipStream_t s, const uint8_t* old_root, const uint8_t* low_leaf, const uint64_t* low_index,
+                    const uint8_t* low_sib, const uint8_t* new_root, const uint8_t* new_leaf,
+                    const uint64_t* new_index, const uint64_t* new_path_index, const uint8_t* new_sib, SibLayout lay,
+                    const uint8_t* is_largest, unsigned depth, size_t n, uint8_t* fail_out, uint8_t* trace,
+                    unsigned fmt_in, unsigned fmt_out, int* err) {
+    (void)fmt_out;
+    if (!n) return;
+    hipLaunchKernelGGL(k_insert_chains, dim3(nblk(n), 4), dim3(BLOCK), 0, s, low_leaf, low_index, low_sib, new_leaf,
+                       new_index, new_path_index, new_sib, lay, depth, n, trace, fmt_in, err);
+    hipLaunchKernelGGL(k_insert_check, dim3(nblk(n)), dim3(BLOCK), 0, s, old_root, low_leaf, new_root, new_leaf,
+                       is_largest, n, trace, fail_out, fmt_in, err);
+}
+void tree_level(hipStream_t s, const uint8_t* prev, uint8_t* next, size_t n_parents) {
+    if (!n_parents) return;
+    hipLaunchKernelGGL(k_tree_level, dim3(nblk(n_parents)), dim3(BLOCK), 0, s, prev, next, n_parents);
+}
+void zero_chain(hipStream_t s, uint8_t* out, unsigned depth) {
+    hipLaunchKernelGGL(k_zero_chain, dim3(1), dim3(64), 0, s, out, depth);
+}
+void extend_root(hipStream_t s, uint8_t* cur, const uint8_t* zero, unsigned from, unsigned to) {
+    hipLaunchKernelGGL(k_extend_root, dim3(1), dim3(64), 0, s, cur, zero, from, to);
+}
+void gather_proof(hipStream_t s, TreeView tv, const uint64_t* index, size_t n, unsigned depth, uint8_t* out,
+                  SibLayout lay, unsigned fmt_out) {
+    if (!n || !depth) return;
+    hipLaunchKernelGGL(k_gather_proof, dim3(nblk(n * depth)), dim3(BLOCK), 0, s, tv, index, n, depth, out, lay,
+                       fmt_out);
+}
+void write_helpers(hipStream_t s, uint64_t index, unsigned depth, uint8_t* out, unsigned fmt_out) {
+    if (!depth) return;
+    hipLaunchKernelGGL(k_write_helpers, dim3((depth + 63) / 64), dim3(64), 0, s, index, depth, out, fmt_out);
+}
+
+
+void fill_level(hipStream_t s, uint8_t* nodes, size_t n, const uint8_t* zero_l) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fill_level, dim3(nblk(n)), dim3(BLOCK), 0, s, nodes, n, zero_l);
+}
+void sweep_leaves(hipStream_t s, const uint8_t* pre, const uint32_t* time0, uint8_t* val0, uint32_t k_begin,
+                  uint32_t k_count, unsigned fmt_in, int* err) {
+    if (!k_count) return;
+    hipLaunchKernelGGL(k_sweep_leaves, dim3(nblk(k_count)), dim3(BLOCK), 0, s, pre, time0, val0, k_begin, k_count,
+                       fmt_in, err);
+}
+void merge_level(hipStream_t s, sweep::LevelTable in, sweep::LevelOut out, uint32_t total) {
+    if (!total) return;
+    hipLaunchKernelGGL(k_merge_level, dim3(nblk(total)), dim3(BLOCK), 0, s, in, out, total);
+}
+void sweep_level(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const uint32_t* from, const int32_t* sibsrc,
+                 const uint32_t* node_below, const uint32_t* time_next, const uint8_t* tree_l, uint64_t len_l,
+                 const uint8_t* zero_l, uint32_t k_begin, uint32_t k_count, uint8_t* low_sib, uint8_t* new_sib,
+                 SibLayout lay, unsigned level, unsigned fmt_out) {
+    if (!k_count) return;
+    hipLaunchKernelGGL(k_sweep_level, dim3(nblk(k_count)), dim3(BLOCK), 0, s, val_in, val_out, from, sibsrc, node_below,
+                       time_next, tree_l, len_l, zero_l, k_begin, k_count, low_sib, new_sib, lay, level, fmt_out);
+}
+void writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const uint32_t* node_below, uint8_t* tree_l,
+               uint32_t total) {
+    if (!total) return;
+    hipLaunchKernelGGL(k_writeback, dim3(nblk(total)), dim3(BLOCK), 0, s, val_l, from, node_below, tree_l, total);
+}
+void sweep_top(hipStream_t s, const uint8_t* val, unsigned l0, unsigned depth, const uint8_t* zero, uint8_t* tree_nodes,
+               const uint64_t* tree_off, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
+               uint8_t* interim_root, uint8_t* new_root, uint8_t* low_sib, uint8_t* new_sib, SibLayout lay,
+               unsigned fmt_out) {
+    if (!e_count) return;
+    hipLaunchKernelGGL(k_sweep_top, dim3(nblk(e_count)), dim3(BLOCK), 0, s, val, l0, depth, zero, tree_nodes, tree_off,
+                       e_begin, e_count, total, old_root, interim_root, new_root, low_sib, new_sib, lay, fmt_out);
+}
+
+}  // namespace launch
+}  // namespace imt

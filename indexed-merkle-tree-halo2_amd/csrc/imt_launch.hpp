@@ -1,0 +1,89 @@
+// imt_launch.hpp -- host-callable launchers of the gfx950 kernels (imt_kernels.hip).
+// Everything is asynchronous on `stream`; pointers are device pointers.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+#include <cstdint>
+#include "imt_consts.hpp"
+#include "imt_sweep.hpp"
+
+namespace imt {
+namespace launch {
+
+// sibling array addressing in units of 32-byte elements:
+//   element(level, item) = sib + (level * level_stride + item * item_stride) * 32
+struct SibLayout {
+    uint64_t level_stride, item_stride;
+};
+
+// description of a stored tree: level l has `len[l]` nodes at nodes + off[l]*32; nodes
+// outside [0, len[l]) read as zero[l] (the empty-subtree hash of that height)
+struct TreeView {
+    const uint8_t* nodes;        // device format
+    const uint64_t* off;         // [depth+1] device array
+    const uint64_t* len;         // [depth+1] device array
+    const uint8_t* zero;         // [depth+1][32] device format, may be NULL when never needed
+};
+
+hipError_t upload_consts(const dev::PoseidonConsts& pc);
+
+void hash_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, int arity, unsigned fmt_in,
+                unsigned fmt_out, int* err);
+void permute_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, unsigned fmt_in,
+                   unsigned fmt_out, int* err);
+void convert(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, unsigned fmt_in,
+             unsigned fmt_out, int* err);
+
+// Path recompute.  leaf3 != NULL: the start value is hash3(leaf3[i]) ([n][3][32]);
+// otherwise leaf[i].  index bit l (or ~helper_mask bit l when is_helper) = node is a right
+// child at level l.  expect (optional, stride 0 or 32 bytes) -> ok_out[i].
+void path_root(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index,
+               bool is_helper, const uint8_t* sib, SibLayout lay, unsigned depth, size_t n,
+               uint8_t* root_out, const uint8_t* expect, unsigned expect_stride, uint8_t* ok_out,
+               unsigned fmt_in, unsigned fmt_out, int* err);
+
+void non_membership(hipStream_t s, const uint8_t* root, unsigned root_stride, const uint8_t* low_leaf,
+                    const uint64_t* low_index, const uint8_t* sib, SibLayout lay, unsigned depth,
+                    const uint8_t* new_val, const uint8_t* is_largest, size_t n, uint8_t* fail_out,
+                    uint8_t* root_out, unsigned fmt_in, unsigned fmt_out, int* err);
+
+// 4 chains per item; trace [7][n][32] (device buffer, required), then the check kernel
+void insert_witness(hipStream_t s, const uint8_t* old_root, const uint8_t* low_leaf,
+                    const uint64_t* low_index, const uint8_t* low_sib, const uint8_t* new_root,
+                    const uint8_t* new_leaf, const uint64_t* new_index, const uint64_t* new_path_index,
+                    const uint8_t* new_sib, SibLayout lay, const uint8_t* is_largest, unsigned depth, size_t n,
+                    uint8_t* fail_out, uint8_t* trace, unsigned fmt_in, unsigned fmt_out, int* err);
+
+// next[i] = hash2(prev[2i], prev[2i+1]), device format
+void tree_level(hipStream_t s, const uint8_t* prev, uint8_t* next, size_t n_parents);
+// chain: out[l+1] = hash2(out[l], out[l]) for l < depth, out[0] = H(0,0,0); one thread
+void zero_chain(hipStream_t s, uint8_t* out, unsigned depth);
+// cur = hash2(cur, zero[l]) for l in [from, to): extends a subtree root up the left spine
+void extend_root(hipStream_t s, uint8_t* cur, const uint8_t* zero, unsigned from, unsigned to);
+
+// siblings of `index[i]` at every level of a stored tree
+void gather_proof(hipStream_t s, TreeView tv, const uint64_t* index, size_t n, unsigned depth,
+                  uint8_t* out, SibLayout lay, unsigned fmt_out);
+// helper[l] = 1 iff (index >> l) is even, as field elements (get_proof, src/utils.rs:79)
+void write_helpers(hipStream_t s, uint64_t index, unsigned depth, uint8_t* out, unsigned fmt_out);
+
+
+// ---- batch insertion level sweep (imt_sweep.hpp) ----
+void fill_level(hipStream_t s, uint8_t* nodes, size_t n, const uint8_t* zero_l);
+void sweep_leaves(hipStream_t s, const uint8_t* pre, const uint32_t* time0, uint8_t* val0, uint32_t k_begin,
+                  uint32_t k_count, unsigned fmt_in, int* err);
+void merge_level(hipStream_t s, sweep::LevelTable in, sweep::LevelOut out, uint32_t total);
+// hashes slots [k_begin, k_begin + k_count) of level `level`+1 (a rank's share when sharded)
+void sweep_level(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const uint32_t* from, const int32_t* sibsrc,
+                 const uint32_t* node_below, const uint32_t* time_next, const uint8_t* tree_l, uint64_t len_l,
+                 const uint8_t* zero_l, uint32_t k_begin, uint32_t k_count, uint8_t* low_sib, uint8_t* new_sib,
+                 SibLayout lay, unsigned level, unsigned fmt_out);
+void writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const uint32_t* node_below, uint8_t* tree_l,
+               uint32_t total);
+void sweep_top(hipStream_t s, const uint8_t* val, unsigned l0, unsigned depth, const uint8_t* zero, uint8_t* tree_nodes,
+               const uint64_t* tree_off, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
+               uint8_t* interim_root, uint8_t* new_root, uint8_t* low_sib, uint8_t* new_sib, SibLayout lay,
+               unsigned fmt_out);
+
+}  // namespace launch
+}  // namespace imt

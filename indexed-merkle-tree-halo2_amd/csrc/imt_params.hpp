@@ -1,0 +1,37 @@
+// imt_params.hpp -- host-side Poseidon parameter generation for the product library.
+#pragma once
+#include "imt_consts.hpp"
+#include "imt_fr_host.hpp"
+#include <string>
+#include <vector>
+
+namespace imt {
+
+struct HostPoseidon {
+    HField F;
+    HFr rc[65][3];      // Grain round constants, plain schedule
+    HFr mds[3][3];      // Cauchy MDS
+    // optimised schedule (see imt_device.hpp::permute)
+    HFr rc_full[8][3];
+    HFr k_partial[57];
+    HFr pre[3][3];
+    HFr sp_row[57][3];
+    HFr sp_col[57][2];
+    HFr cap0;           // 2^64
+
+    // Generates everything and cross-checks the optimised schedule against the plain
+    // 65-round form on fixed states; returns false (with a message) on mismatch.
+    bool init(std::string& err);
+
+    void permute_plain(HFr s[3]) const;
+    void permute_opt(HFr s[3]) const;
+    HFr hash2(const HFr& a, const HFr& b) const;
+    HFr hash3(const HFr& a, const HFr& b, const HFr& c) const;
+
+    // device image: radix-2^29 limbs, Montgomery R = 2^261
+    dev::Fe to_dev(const HFr& x) const;
+    dev::Fe int_to_dev_limbs(const uint8_t le[32]) const;   // raw integer -> limbs, no domain change
+    void fill_consts(dev::PoseidonConsts& pc) const;
+};
+
+}  // namespace imt

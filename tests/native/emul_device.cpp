@@ -1,0 +1,76 @@
+// emul_device.cpp -- TEST-ONLY host build of the device arithmetic (imt_device.hpp) and
+// of the host table generator, so that `-m "not gpu"` tests can compare the radix-2^29
+// Montgomery code, the optimised Poseidon schedule and the index kernels' per-element
+// logic with the oracle on a machine without a GPU.  Not part of the shipped library.
+#include "imt_device.hpp"
+#include "imt_params.hpp"
+#include <cstring>
+#include <string>
+
+using namespace imt;
+static HostPoseidon* g_hp;
+static dev::PoseidonConsts g_consts;
+
+extern "C" int emul_init(void) {
+    if (g_hp) return 0;
+    g_hp = new HostPoseidon();
+    std::string err;
+    if (!g_hp->init(err)) return -1;
+    g_hp->fill_consts(g_consts);
+    return 0;
+}
+extern "C" int emul_consts_size(void) { return (int)sizeof(dev::PoseidonConsts); }
+
+// out = hash2/hash3 of canonical little-endian inputs, through the device code path
+extern "C" int emul_hash(const uint8_t* in, int arity, uint8_t* out, unsigned fmt_in, unsigned fmt_out) {
+    dev::Fe a, b, c, o;
+    bool ok = dev::load_fe(g_consts, a, in, fmt_in);
+    ok &= dev::load_fe(g_consts, b, in + 32, fmt_in);
+    c = a;
+    if (arity == 3) ok &= dev::load_fe(g_consts, c, in + 64, fmt_in);
+    dev::hash23(g_consts, o, a, b, c, arity == 3);
+    dev::store_fe(g_consts, out, o, fmt_out);
+    return ok ? 0 : -5;
+}
+extern "C" int emul_permute(const uint8_t* in, uint8_t* out) {
+    dev::Fe s[3];
+    bool ok = true;
+    for (int i = 0; i < 3; i++) ok &= dev::load_fe(g_consts, s[i], in + 32 * i, dev::FMT_CANONICAL);
+    dev::permute(g_consts, s, g_consts.rc_full[0]);
+    for (int i = 0; i < 3; i++) { dev::canonicalize(s[i]); dev::store_fe(g_consts, out + 32 * i, s[i], dev::FMT_CANONICAL); }
+    return ok ? 0 : -5;
+}
+// r = a*b (field product of canonical inputs) via mont_mul / mont_sqr
+extern "C" void emul_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, int use_sqr) {
+    dev::Fe x, y, r;
+    dev::load_fe(g_consts, x, a, dev::FMT_CANONICAL);
+    dev::load_fe(g_consts, y, b, dev::FMT_CANONICAL);
+    if (use_sqr) dev::mont_sqr(r, x); else dev::mont_mul(r, x, y);
+    dev::canonicalize(r);
+    dev::store_fe(g_consts, out, r, dev::FMT_CANONICAL);
+}
+extern "C" void emul_convert(const uint8_t* in, uint8_t* out, unsigned fmt_in, unsigned fmt_out) {
+    dev::Fe x;
+    dev::load_fe(g_consts, x, in, fmt_in);
+    dev::store_fe(g_consts, out, x, fmt_out);
+}
+// host-side (product) Poseidon used for table self-checks
+extern "C" void emul_host_hash(const uint8_t* in, int arity, uint8_t* out) {
+    HFr a, b, c;
+    g_hp->F.from_bytes(a, in);
+    g_hp->F.from_bytes(b, in + 32);
+    HFr h;
+    if (arity == 3) { g_hp->F.from_bytes(c, in + 64); h = g_hp->hash3(a, b, c); }
+    else h = g_hp->hash2(a, b);
+    g_hp->F.to_bytes(out, h);
+}
+
+// ---- index logic of the batch-insertion sweep (imt_sweep.hpp), one level on the host ----
+#include "imt_sweep.hpp"
+extern "C" void emul_merge_level(const uint32_t* node, const uint32_t* time, const uint32_t* rs, const uint32_t* re,
+                                 uint32_t total, uint32_t* o_node, uint32_t* o_time, uint32_t* o_rs, uint32_t* o_re,
+                                 uint32_t* o_from, int32_t* o_sibsrc, uint32_t* o_node_below) {
+    sweep::LevelTable in{node, time, rs, re};
+    sweep::LevelOut out{o_node, o_time, o_rs, o_re, o_from, o_sibsrc, o_node_below};
+    for (uint32_t k = 0; k < total; k++) sweep::merge_element(in, out, k, total);
+}

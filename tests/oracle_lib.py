@@ -1,0 +1,248 @@
+"""ctypes wrapper of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY:
+the checker the HIP path is compared against, never the thing shipped or measured."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+KAT_ZERO = 1960587138944869480785025106734196872454309951825657414575195034687326603497  # reference :248
+
+
+def b32(x):
+    return int(x).to_bytes(32, "little")
+
+
+def ints_to_arr(xs):
+    return np.frombuffer(b"".join(b32(x) for x in xs), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+class InsertTrace(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint8 * 32) for n in ("low_leaf_hash", "root_from_low", "new_low_leaf_hash",
+                                                   "interim_root", "zero_slot_root", "new_leaf_hash", "new_root")]
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.orc_poseidon_init()
+        lib.orc_sparse_size.restype = ctypes.c_uint64
+        lib.orc_tree_num_levels.restype = ctypes.c_size_t
+
+    # ---- hashes ----
+    def hash(self, xs):
+        out = ctypes.create_string_buffer(32)
+        rc = self.lib.orc_hash_var(out, b"".join(b32(x) for x in xs), ctypes.c_size_t(len(xs)))
+        assert rc == 0, rc
+        return int.from_bytes(out.raw, "little")
+
+    def hash2_batch(self, arr):  # uint8 [n,2,32] -> [n,32]
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        n = arr.shape[0]
+        out = np.empty((n, 32), dtype=np.uint8)
+        rc = self.lib.orc_hash2_batch(out.ctypes.data_as(ctypes.c_void_p), arr.ctypes.data_as(ctypes.c_void_p),
+                                      ctypes.c_size_t(n))
+        assert rc == 0, rc
+        return out
+
+    def hash3_batch(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        n = arr.shape[0]
+        out = np.empty((n, 32), dtype=np.uint8)
+        rc = self.lib.orc_hash3_batch(out.ctypes.data_as(ctypes.c_void_p), arr.ctypes.data_as(ctypes.c_void_p),
+                                      ctypes.c_size_t(n))
+        assert rc == 0, rc
+        return out
+
+    def permute(self, state3):
+        buf = ctypes.create_string_buffer(b"".join(b32(x) for x in state3), 96)
+        self.lib.orc_permute_bytes(buf)
+        return [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(3)]
+
+    def zero_hashes(self, depth):
+        out = np.empty((depth + 1, 32), dtype=np.uint8)
+        self.lib.orc_zero_hashes(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(depth))
+        return out
+
+    # ---- dense tree (src/utils.rs) ----
+    def tree_new(self, leaves_arr):
+        leaves_arr = np.ascontiguousarray(leaves_arr, dtype=np.uint8)
+        h = ctypes.c_void_p()
+        rc = self.lib.orc_tree_new(ctypes.byref(h), leaves_arr.ctypes.data_as(ctypes.c_void_p),
+                                   ctypes.c_size_t(leaves_arr.shape[0] if leaves_arr.size else 0))
+        return rc, h
+
+    def tree_free(self, h):
+        self.lib.orc_tree_free(h)
+
+    def tree_root(self, h):
+        out = ctypes.create_string_buffer(32)
+        self.lib.orc_tree_get_root(h, out)
+        return int.from_bytes(out.raw, "little")
+
+    def tree_level(self, h, level):
+        n = ctypes.c_size_t()
+        assert self.lib.orc_tree_level(h, ctypes.c_size_t(level), None, ctypes.byref(n)) == 0
+        out = np.empty((n.value, 32), dtype=np.uint8)
+        self.lib.orc_tree_level(h, ctypes.c_size_t(level), out.ctypes.data_as(ctypes.c_void_p), None)
+        return out
+
+    def tree_proof(self, h, index):
+        d = self.lib.orc_tree_num_levels(h) - 1
+        proof = np.empty((d, 32), dtype=np.uint8)
+        helper = np.empty((d, 32), dtype=np.uint8)
+        rc = self.lib.orc_tree_get_proof(h, ctypes.c_size_t(index), proof.ctypes.data_as(ctypes.c_void_p),
+                                         helper.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, rc
+        return proof, helper
+
+    def path_root(self, leaf, index, proof_arr):
+        proof_arr = np.ascontiguousarray(proof_arr, dtype=np.uint8)
+        out = ctypes.create_string_buffer(32)
+        rc = self.lib.orc_path_root(out, b32(leaf), ctypes.c_uint64(index),
+                                    proof_arr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(proof_arr.shape[0]))
+        assert rc == 0, rc
+        return int.from_bytes(out.raw, "little")
+
+    def compute_merkle_root(self, leaf, proof_arr, helper_arr):
+        proof_arr = np.ascontiguousarray(proof_arr, dtype=np.uint8)
+        helper_arr = np.ascontiguousarray(helper_arr, dtype=np.uint8)
+        out = ctypes.create_string_buffer(32)
+        rc = self.lib.orc_compute_merkle_root(out, b32(leaf), proof_arr.ctypes.data_as(ctypes.c_void_p),
+                                              helper_arr.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.c_size_t(proof_arr.shape[0]))
+        return rc, int.from_bytes(out.raw, "little")
+
+    def is_less_than_limbs(self, a, b):
+        return self.lib.orc_is_less_than_limbs(b32(a), b32(b))
+
+    # ---- circuit relations ----
+    def verify_non_inclusion(self, root, low_leaf3, proof_arr, helper_arr, new_val, largest):
+        proof_arr = np.ascontiguousarray(proof_arr, dtype=np.uint8)
+        helper_arr = np.ascontiguousarray(helper_arr, dtype=np.uint8)
+        lh = ctypes.create_string_buffer(32)
+        ro = ctypes.create_string_buffer(32)
+        ll = b"".join(b32(x) for x in low_leaf3)
+        f = self.lib.orc_verify_non_inclusion(b32(root), ll, proof_arr.ctypes.data_as(ctypes.c_void_p),
+                                              helper_arr.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.c_size_t(proof_arr.shape[0]), b32(new_val), int(largest), lh, ro)
+        return f, int.from_bytes(ro.raw, "little")
+
+    def insert_leaf(self, old_root, low_leaf3, low_proof, low_helper, new_root, new_leaf3, new_index, new_proof,
+                    new_helper, largest):
+        lp = np.ascontiguousarray(low_proof, dtype=np.uint8)
+        lh = np.ascontiguousarray(low_helper, dtype=np.uint8)
+        np_ = np.ascontiguousarray(new_proof, dtype=np.uint8)
+        nh = np.ascontiguousarray(new_helper, dtype=np.uint8)
+        tr = InsertTrace()
+        f = self.lib.orc_insert_leaf(b32(old_root), b"".join(b32(x) for x in low_leaf3),
+                                     lp.ctypes.data_as(ctypes.c_void_p), lh.ctypes.data_as(ctypes.c_void_p),
+                                     b32(new_root), b"".join(b32(x) for x in new_leaf3), ctypes.c_uint64(new_index),
+                                     np_.ctypes.data_as(ctypes.c_void_p), nh.ctypes.data_as(ctypes.c_void_p),
+                                     int(largest), ctypes.c_size_t(lp.shape[0]), ctypes.byref(tr))
+        trace = [int.from_bytes(bytes(getattr(tr, n)), "little") for n, _ in InsertTrace._fields_]
+        return f, trace
+
+    # ---- test-module insertion (:632-671) ----
+    def update_idx_leaf(self, pre_arr, new_val, new_val_idx):
+        """pre_arr uint8 [n,3,32], modified in place; returns low idx."""
+        low = ctypes.c_uint64()
+        rc = self.lib.orc_update_idx_leaf(pre_arr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(pre_arr.shape[0]),
+                                          b32(new_val), ctypes.c_uint64(new_val_idx), ctypes.byref(low))
+        assert rc == 0, rc
+        return low.value
+
+    # ---- sparse depth-d tree ----
+    def sparse_new(self, depth, cap):
+        h = ctypes.c_void_p()
+        rc = self.lib.orc_sparse_new(ctypes.byref(h), ctypes.c_uint(depth), ctypes.c_uint64(cap))
+        assert rc == 0, rc
+        return h
+
+    def sparse_free(self, h):
+        self.lib.orc_sparse_free(h)
+
+    def sparse_root(self, h):
+        out = ctypes.create_string_buffer(32)
+        self.lib.orc_sparse_root(h, out)
+        return int.from_bytes(out.raw, "little")
+
+    def sparse_insert(self, h, depth, val):
+        low = ctypes.c_uint64()
+        largest = ctypes.c_int()
+        ll = np.empty((3, 32), np.uint8)
+        ir = ctypes.create_string_buffer(32)
+        nr = ctypes.create_string_buffer(32)
+        lp = np.empty((depth, 32), np.uint8)
+        npf = np.empty((depth, 32), np.uint8)
+        rc = self.lib.orc_sparse_insert(h, b32(val), ctypes.byref(low), ll.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.byref(largest), ir, nr, lp.ctypes.data_as(ctypes.c_void_p),
+                                        npf.ctypes.data_as(ctypes.c_void_p))
+        return dict(rc=rc, low=low.value, largest=largest.value, low_leaf=ll,
+                    interim_root=int.from_bytes(ir.raw, "little"), new_root=int.from_bytes(nr.raw, "little"),
+                    low_proof=lp, new_proof=npf)
+
+    def sparse_proof(self, h, depth, index):
+        out = np.empty((depth, 32), np.uint8)
+        assert self.lib.orc_sparse_proof(h, ctypes.c_uint64(index), out.ctypes.data_as(ctypes.c_void_p)) == 0
+        return out
+
+    def sparse_preimage(self, h, index):
+        out = np.empty((3, 32), np.uint8)
+        assert self.lib.orc_sparse_preimage(h, ctypes.c_uint64(index), out.ctypes.data_as(ctypes.c_void_p)) == 0
+        return out
+
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is not None:
+        return _cached
+    so = os.path.join(ODIR, "liboracle.so")
+    srcs = [os.path.join(ODIR, f) for f in ("fr.c", "poseidon.c", "tree.c", "indexed.c", "sparse.c", "imt_oracle.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        r = subprocess.run(["make", "-C", ODIR, "liboracle.so"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    _cached = Oracle(ctypes.CDLL(so))
+    return _cached
+
+
+def synth_values(n, seed):
+    """Synthetic insertion values: xoshiro256** seeded from `seed`, 4 limbs, top 2
+    bits cleared, rejected until 0 < v < p, de-duplicated (mirrors the reference's random draw
+    at src/indexed_merkle_tree.rs:381-386)."""
+    mask = (1 << 64) - 1
+
+    def rotl(x, k):
+        return ((x << k) | (x >> (64 - k))) & mask
+
+    # splitmix64 seeding
+    s = []
+    z = seed & mask
+    for _ in range(4):
+        z = (z + 0x9E3779B97F4A7C15) & mask
+        x = z
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & mask
+        s.append(x ^ (x >> 31))
+    out, seen = [], set()
+    while len(out) < n:
+        limbs = []
+        for _ in range(4):
+            r = (rotl((s[1] * 5) & mask, 7) * 9) & mask
+            t = (s[1] << 17) & mask
+            s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]
+            s[2] ^= t
+            s[3] = rotl(s[3], 45)
+            limbs.append(r)
+        v = limbs[0] | (limbs[1] << 64) | (limbs[2] << 128) | ((limbs[3] & ((1 << 62) - 1)) << 192)
+        if 0 < v < P and v not in seen:
+            seen.add(v)
+            out.append(v)
+    return out

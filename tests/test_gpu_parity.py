@@ -1,0 +1,385 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs -- bit-exact, since everything is integer arithmetic mod p.  Mirrors the reference's
+own tests (src/indexed_merkle_tree.rs:349-810) and adds the cases it leaves out."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from oracle_lib import P, KAT_ZERO, ints_to_arr
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vectors.json")))
+
+
+def ints(a):
+    a = np.asarray(a, dtype=np.uint8)
+    return [int.from_bytes(x.tobytes(), "little") for x in a.reshape(-1, 32)]
+
+
+# ---------------------------------------------------------------- a1 / a10
+def test_kat_and_golden_vectors(imt, ctx):
+    assert ints(ctx.hash3(ints_to_arr([0, 0, 0]).reshape(1, 3, 32))) == [KAT_ZERO]      # reference :248
+    h2 = [e for e in GOLD["entries"] if e["kind"] == "hash2"]
+    h3 = [e for e in GOLD["entries"] if e["kind"] == "hash3"]
+    pm = [e for e in GOLD["entries"] if e["kind"] == "permute"]
+    out2 = ctx.hash2(ints_to_arr([int(x) for e in h2 for x in e["in"]]).reshape(-1, 2, 32))
+    assert ints(out2) == [int(e["out"]) for e in h2]
+    out3 = ctx.hash3(ints_to_arr([int(x) for e in h3 for x in e["in"]]).reshape(-1, 3, 32))
+    assert ints(out3) == [int(e["out"]) for e in h3]
+    outp = ctx.permute(ints_to_arr([int(x) for e in pm for x in e["in"]]).reshape(-1, 3, 32))
+    assert ints(outp) == [int(x) for e in pm for x in e["out"]]
+    z = ctx.zero_hashes(32)
+    for e in GOLD["entries"]:
+        if e["kind"] == "empty_root":
+            assert ints(z[int(e["in"][0])]) == [int(e["out"])]
+
+
+def test_hash_batches_random_and_ragged(imt, ctx, oracle):
+    rng = random.Random(10)
+    for n in (1, 63, 64, 65, 257, 1000):       # ragged against the 256-thread blocks
+        a = ints_to_arr([rng.randrange(P) for _ in range(2 * n)]).reshape(n, 2, 32)
+        assert (ctx.hash2(a) == oracle.hash2_batch(a)).all()
+        b = ints_to_arr([rng.randrange(P) for _ in range(3 * n)]).reshape(n, 3, 32)
+        assert (ctx.hash3(b) == oracle.hash3_batch(b)).all()
+    assert ctx.hash2(np.zeros((0, 2, 32), np.uint8)).shape == (0, 32)     # empty batch
+
+
+def test_formats_and_noncanonical(imt, ctx, oracle):
+    rng = random.Random(12)
+    R = 1 << 256
+    vals = [rng.randrange(P) for _ in range(64)]
+    want = oracle.hash2_batch(ints_to_arr(vals).reshape(-1, 2, 32))
+    got = ctx.hash2(ints_to_arr([v * R % P for v in vals]).reshape(-1, 2, 32), fmt=imt._ffi.FMT_MONT256)
+    assert ints(got) == [h * R % P for h in ints(want)]
+    bad = ints_to_arr([1, P]).reshape(1, 2, 32)
+    with pytest.raises(imt.ImtError) as ei:
+        ctx.hash2(bad)
+    assert ei.value.code == imt._ffi.ERR["NONCANONICAL"]
+    assert ints(ctx.hash2(ints_to_arr([1, 2]).reshape(1, 2, 32))) == [oracle.hash([1, 2])]   # context still usable
+
+
+# ---------------------------------------------------------------- a2 / a3 / a4 / a5
+def test_dense_tree_new_errors(imt, ctx):
+    with pytest.raises(ValueError, match="Cannot create Merkle Tree with no leaves"):
+        imt.IndexedMerkleTree.new(ctx, [])
+    with pytest.raises(ValueError, match="Leaves must be even"):
+        imt.IndexedMerkleTree.new(ctx, [1, 2, 3])
+    with pytest.raises(IndexError):
+        imt.IndexedMerkleTree.new(ctx, [1, 2, 3, 4, 5, 6])
+    t = imt.IndexedMerkleTree.new(ctx, [7])
+    assert t.get_root() == 7 and t.num_levels() == 1 and t.get_proof(0) == ([], [])
+
+
+@pytest.mark.parametrize("depth", [1, 3, 8])
+def test_dense_tree_matches_oracle(imt, ctx, oracle, depth):
+    rng = random.Random(depth)
+    n = 1 << depth
+    leaves = ints_to_arr([rng.randrange(P) for _ in range(n)])
+    t = imt.IndexedMerkleTree.new(ctx, leaves)
+    rc, ot = oracle.tree_new(leaves)
+    assert rc == 0 and t.num_levels() == depth + 1
+    for l in range(depth + 1):
+        assert (t.get_level(l) == oracle.tree_level(ot, l)).all()
+    assert t.get_root() == oracle.tree_root(ot)
+    for idx in sorted({0, 1, n - 1, rng.randrange(n)}):
+        proof, helper = t.get_proof(idx)
+        op, oh = oracle.tree_proof(ot, idx)
+        assert proof == ints(op) and helper == ints(oh)
+        leaf = ints(leaves[idx])[0]
+        assert t.verify_proof(leaf, idx, t.get_root(), proof)
+        assert not t.verify_proof(leaf ^ 1, idx, t.get_root(), proof)
+    with pytest.raises(IndexError):
+        t.get_proof(n)
+    oracle.tree_free(ot)
+
+
+def test_config1_depth8_16_insertions(imt, ctx, oracle):
+    """BASELINE config 1: depth 8, 16 sequential insertions through the reference's own dense
+    builder path (update_idx_leaf -> rehash -> IndexedMerkleTree::new), root after each."""
+    vals = oracle_lib.synth_values(16, 0x494D5401)
+    pre = np.zeros((256, 3, 32), np.uint8)
+    it = imt.IndexedTree(ctx, 8, 256)
+    for rnd, v in enumerate(vals):
+        oracle.update_idx_leaf(pre, v, rnd + 1)
+        dense = imt.IndexedMerkleTree.new(ctx, ctx.hash3(pre))
+        rc, ot = oracle.tree_new(oracle.hash3_batch(pre))
+        assert dense.get_root() == oracle.tree_root(ot)
+        it.insert_batch([v])
+        assert it.root() == dense.get_root()
+        oracle.tree_free(ot)
+
+
+def test_path_root_layouts_and_helpers(imt, ctx, oracle):
+    rng = random.Random(21)
+    n, d = 300, 32
+    leaf = [rng.randrange(P) for _ in range(n)]
+    idx = [rng.randrange(1 << d) for _ in range(n)]
+    sib = np.stack([ints_to_arr([rng.randrange(P) for _ in range(d)]) for _ in range(n)])   # [n][d][32]
+    want = [oracle.path_root(leaf[i], idx[i], sib[i]) for i in range(n)]
+    assert ints(ctx.path_root(ints_to_arr(leaf), idx, sib, d, item_major=True)) == want
+    lm = np.ascontiguousarray(sib.transpose(1, 0, 2))
+    assert ints(ctx.path_root(ints_to_arr(leaf), idx, lm, d)) == want
+    hm = [(~i) & ((1 << d) - 1) for i in idx]
+    assert ints(ctx.compute_merkle_root(ints_to_arr(leaf), hm, lm, d)) == want
+    ok = ctx.verify_proof_batch(ints_to_arr(leaf), idx, ints_to_arr(want), lm, d)
+    assert ok.all()
+    wrong = list(want); wrong[5] ^= 1
+    ok = ctx.verify_proof_batch(ints_to_arr(leaf), idx, ints_to_arr(wrong), lm, d)
+    assert not ok[5] and ok.sum() == n - 1
+    assert ints(ctx.path_root(ints_to_arr(leaf[:3]), idx[:3], np.zeros((0, 32), np.uint8), 0)) == leaf[:3]   # depth 0
+
+
+# ---------------------------------------------------------------- a15 + a13 + a14
+def _oracle_run(oracle, depth, cap, vals):
+    h = oracle.sparse_new(depth, cap)
+    rows = [oracle.sparse_insert(h, depth, v) for v in vals]
+    root = oracle.sparse_root(h)
+    return h, rows, root
+
+
+@pytest.mark.parametrize("depth,n,batches", [(3, 6, 1), (8, 40, 3), (32, 200, 1), (32, 300, 4)])
+def test_insert_batch_matches_sequential_oracle(imt, ctx, oracle, depth, n, batches):
+    if depth == 3:
+        vals = [30, 10, 20, 5, 50, 35]          # test_insert_leaf_multiple_round :683-690
+    else:
+        vals = oracle_lib.synth_values(n, 0x494D5402 + depth + batches)
+    cap = 8 if depth == 3 else 512
+    oh, rows, oroot = _oracle_run(oracle, depth, cap, vals)
+    t = imt.IndexedTree(ctx, depth, cap)
+    assert t.root() == ints(oracle.zero_hashes(depth)[depth])[0]
+    got = []
+    step = (len(vals) + batches - 1) // batches
+    for s in range(0, len(vals), step):
+        r = t.insert_batch(vals[s:s + step], item_major=True)
+        for i in range(len(vals[s:s + step])):
+            got.append({k: r[k][i] for k in r})
+    assert t.root() == oroot and t.size == len(vals) + 1
+    prev_root = ints(oracle.zero_hashes(depth)[depth])[0]
+    for i, (g, o) in enumerate(zip(got, rows)):
+        assert int(g["low_index"]) == o["low"] and int(g["is_largest"]) == o["largest"], i
+        assert (g["low_leaf"] == o["low_leaf"]).all(), i
+        assert ints(g["old_root"]) == [prev_root], i
+        assert ints(g["interim_root"]) == [o["interim_root"]], i
+        assert ints(g["new_root"]) == [o["new_root"]], i
+        assert (g["low_sib"] == o["low_proof"]).all(), i
+        assert (g["new_sib"] == o["new_proof"]).all(), i
+        assert int(g["new_index"]) == i + 1
+        prev_root = o["new_root"]
+    # stored tree == oracle tree: proofs and preimages of every filled leaf and the next empty one
+    idx = list(range(len(vals) + 2))
+    sib = t.get_proof_batch(idx, item_major=True)
+    leaves = t.get_leaves(idx)
+    for i in idx:
+        assert (sib[i] == oracle.sparse_proof(oh, depth, i)).all()
+        assert (leaves[i] == oracle.sparse_preimage(oh, i)).all()
+    oracle.sparse_free(oh)
+    if depth == 3:
+        for g, e in zip(got, GOLD["multi_round_depth3"]):
+            assert ints(g["new_root"]) == [int(e["new_root"])] and int(g["low_index"]) == e["low_idx"]
+
+
+def test_insert_batch_golden_depth32(imt, ctx):
+    run = GOLD["insert_run_depth32"]["rounds"]
+    t = imt.IndexedTree(ctx, 32, 64)
+    r = t.insert_batch([int(e["val"]) for e in run], proofs=False)
+    assert ints(r["new_root"]) == [int(e["new_root"]) for e in run]
+    assert ints(r["interim_root"]) == [int(e["interim_root"]) for e in run]
+    assert [int(x) for x in r["low_index"]] == [e["low_idx"] for e in run]
+
+
+def test_insert_batch_adversarial_orders(imt, ctx, oracle):
+    # ascending (every insertion is the new maximum), descending (leaf 0 is always the low leaf:
+    # one run of N events), and a sawtooth
+    for vals in (list(range(1, 65)), list(range(64, 0, -1)), [((i * 37) % 64) + 1 for i in range(64)]):
+        oh, rows, oroot = _oracle_run(oracle, 32, 128, vals)
+        t = imt.IndexedTree(ctx, 32, 128)
+        r = t.insert_batch(vals, proofs=False)
+        assert ints(r["new_root"]) == [o["new_root"] for o in rows]
+        assert [int(x) for x in r["low_index"]] == [o["low"] for o in rows]
+        assert t.root() == oroot
+        oracle.sparse_free(oh)
+
+
+def test_insert_batch_rejects_bad_values(imt, ctx):
+    t = imt.IndexedTree(ctx, 8, 16)
+    t.insert_batch([5, 9])
+    root = t.root()
+    for bad in ([0], [7, 7], [9], [3, 5]):
+        with pytest.raises(ValueError):
+            t.insert_batch(bad)
+    assert t.root() == root and t.size == 3            # nothing changed
+    with pytest.raises(imt.ImtError) as ei:
+        t.insert_batch(list(range(100, 114)))          # 3 + 14 > 16
+    assert ei.value.code == imt._ffi.ERR["FULL"]
+    with pytest.raises(imt.ImtError) as ei:
+        t.insert_batch([P])
+    assert ei.value.code == imt._ffi.ERR["NONCANONICAL"]
+    t.insert_batch(list(range(100, 113)))              # exactly full
+    assert t.size == 16
+
+
+def test_reference_tests_through_the_mirror_api(imt, ctx, oracle):
+    """test_insert_leaf / test_insert_leaf_multiple_round (:360-596, :679-803): native tree and
+    witnesses from the product, every insert_leaf constraint satisfied; then negative cases."""
+    rng = random.Random(31)
+    a = rng.getrandbits(254) % P
+    for vals in ([a, 42], [30, 10, 20, 5, 50, 35]):
+        n = 8
+        pre = np.zeros((n, 3, 32), np.uint8)
+        tree = imt.IndexedMerkleTree.new(ctx, ctx.hash3(pre))
+        for rnd, v in enumerate(vals):
+            old_root = tree.get_root()
+            old_pre = pre.copy()
+            low = oracle.update_idx_leaf(pre, v, rnd + 1)        # host list logic (hash-free)
+            low_proof, low_helper = tree.get_proof(low)
+            assert tree.verify_proof(ints(ctx.hash3(old_pre[low:low + 1]))[0], low, old_root, low_proof)
+            tree = imt.IndexedMerkleTree.new(ctx, ctx.hash3(pre))
+            new_proof, new_helper = tree.get_proof(rnd + 1)
+            new_root = tree.get_root()
+            new_leaf = ints(pre[rnd + 1])
+            low_leaf = ints(old_pre[low])
+            largest = new_leaf[1] == 0
+            trace = imt.insert_leaf(ctx, old_root, low_leaf, low_proof, low_helper, new_root, new_leaf, rnd + 1,
+                                    new_proof, new_helper, largest)
+            f, otrace = oracle.insert_leaf(old_root, low_leaf, ints_to_arr(low_proof), ints_to_arr(low_helper),
+                                           new_root, new_leaf, rnd + 1, ints_to_arr(new_proof),
+                                           ints_to_arr(new_helper), largest)
+            assert f == 0 and ints(trace[:, 0]) == otrace
+            imt.verify_non_inclusion(ctx, old_root, low_leaf, low_proof, low_helper, v, largest)
+            # negative cases: each breaks exactly the constraint it should
+            with pytest.raises(imt.ConstraintError) as ei:
+                imt.insert_leaf(ctx, old_root, low_leaf, low_proof, low_helper, new_root ^ 1, new_leaf, rnd + 1,
+                                new_proof, new_helper, largest)
+            assert ei.value.mask == imt._ffi.F_NEW_ROOT
+            with pytest.raises(imt.ConstraintError) as ei:
+                imt.verify_non_inclusion(ctx, old_root ^ 1, low_leaf, low_proof, low_helper, v, largest)
+            assert ei.value.mask == imt._ffi.F_LOW_IN_ROOT
+            with pytest.raises(imt.ConstraintError) as ei:
+                imt.verify_non_inclusion(ctx, old_root, low_leaf, low_proof, low_helper, v, not largest)
+            assert ei.value.mask & imt._ffi.F_RANGE_PRED
+            with pytest.raises(imt.ConstraintError) as ei:     # a value below the low leaf
+                imt.verify_non_inclusion(ctx, old_root, low_leaf, low_proof, low_helper, low_leaf[0], largest)
+            assert ei.value.mask & imt._ffi.F_LOW_LT_NEW
+
+
+def test_non_membership_batch_vs_oracle(imt, ctx, oracle):
+    depth, cap = 32, 256
+    vals = oracle_lib.synth_values(100, 0x494D5403)
+    t = imt.IndexedTree(ctx, depth, cap)
+    t.insert_batch(vals[:60], proofs=False)
+    root = t.root()
+    cand = vals[60:]
+    low, leaves, sib, largest = t.non_membership_witness(cand)
+    fail, rout = ctx.non_membership(imt.to_bytes(root), leaves, low, sib, depth, ints_to_arr(cand), largest,
+                                    want_root=True)
+    assert not fail.any() and ints(rout) == [root] * len(cand)
+    for i in range(len(cand)):
+        helper = ints_to_arr([1 - ((int(low[i]) >> l) & 1) for l in range(depth)])
+        f, r = oracle.verify_non_inclusion(root, ints(leaves[i]), sib[:, i], helper, cand[i], int(largest[i]))
+        assert f == 0 and r == root
+    # members are not non-members: the predicate fails for every inserted value
+    with pytest.raises(ValueError):
+        t.find_low(vals[:1])
+    fail = ctx.non_membership(imt.to_bytes(root), leaves, low, sib, depth, leaves[:, 0, :].copy(), largest)
+    assert (fail & imt._ffi.F_LOW_LT_NEW).all()
+    # per-item roots and a bad largest flag value
+    lg = largest.copy(); lg[0] = 2
+    fail = ctx.non_membership(np.repeat(imt.to_bytes(root)[None], len(cand), 0), leaves, low, sib, depth,
+                              ints_to_arr(cand), lg)
+    assert fail[0] & imt._ffi.F_BAD_BIT and not fail[1:].any()
+
+
+def test_insert_witness_batch_vs_oracle(imt, ctx, oracle):
+    depth, cap, n = 32, 256, 120
+    vals = oracle_lib.synth_values(n, 0x494D5404)
+    t = imt.IndexedTree(ctx, depth, cap)
+    r = t.insert_batch(vals)
+    fail, trace = ctx.insert_witness(r["old_root"], r["low_leaf"], r["low_index"], r["low_sib"], r["new_root"],
+                                     r["new_leaf"], r["new_index"], r["new_sib"], r["is_largest"], depth,
+                                     want_trace=True)
+    assert not fail.any()
+    assert (trace[3] == r["interim_root"]).all() and (trace[6] == r["new_root"]).all()
+    assert (trace[4] == r["interim_root"]).all()
+    for i in (0, 1, n // 2, n - 1):
+        hl = lambda idx: ints_to_arr([1 - ((int(idx) >> l) & 1) for l in range(depth)])
+        f, otr = oracle.insert_leaf(ints(r["old_root"][i])[0], ints(r["low_leaf"][i]), r["low_sib"][:, i],
+                                    hl(r["low_index"][i]), ints(r["new_root"][i])[0], ints(r["new_leaf"][i]),
+                                    int(r["new_index"][i]), r["new_sib"][:, i], hl(r["new_index"][i]),
+                                    int(r["is_largest"][i]))
+        assert f == 0 and ints(trace[:, i]) == otr
+    # corrupt one witness field per item class and see the right bit
+    nr = r["new_root"].copy(); nr[3, 0] ^= 1
+    nl = r["new_leaf"].copy(); nl[4, 2, 0] ^= 1
+    fail = ctx.insert_witness(r["old_root"], r["low_leaf"], r["low_index"], r["low_sib"], nr, nl, r["new_index"],
+                              r["new_sib"], r["is_largest"], depth)
+    assert fail[3] == imt._ffi.F_NEW_ROOT and fail[4] == (imt._ffi.F_NEXT_IDX | imt._ffi.F_NEW_ROOT)
+    assert not np.delete(fail, [3, 4]).any()
+
+
+def test_combine_subtree_roots(imt, ctx, oracle):
+    rng = random.Random(41)
+    leaves = ints_to_arr([rng.randrange(P) for _ in range(64)])
+    rc, ot = oracle.tree_new(leaves)
+    sub = oracle.tree_level(ot, 3)                      # 8 subtree roots of height 3
+    z = oracle.zero_hashes(32)
+    want = oracle.tree_root(ot)
+    for l in range(6, 32):
+        want = oracle.hash([want, ints(z[l])[0]])
+    assert ints(ctx.combine_subtree_roots(sub, 3, 32)) == [want]
+    assert ints(ctx.combine_subtree_roots(sub, 3, 6)) == [oracle.tree_root(ot)]
+    oracle.tree_free(ot)
+
+
+# ---------------------------------------------------------------- BASELINE-size properties
+def test_config2_full_size_properties(imt, ctx, oracle):
+    """depth 32, 2^16 insertions (BASELINE config 2), checked through size-independent properties:
+    (1) every insert_leaf constraint holds for every insertion (witness kernels, independent of the
+    sweep); (2) roots chain: old_root[i+1] == new_root[i]; (3) the final root equals an independent
+    bulk build (leaf hashes -> dense level kernels -> zero extension); (4) batch-split invariance;
+    (5) the first 256 insertions equal the sequential CPU oracle bit for bit."""
+    depth, n = 32, 1 << 16
+    vals = oracle_lib.synth_values(n, 0x494D5402)
+    t = imt.IndexedTree(ctx, depth, 1 << 17)
+    r = t.insert_batch(vals)
+    fail = ctx.insert_witness(r["old_root"], r["low_leaf"], r["low_index"], r["low_sib"], r["new_root"],
+                              r["new_leaf"], r["new_index"], r["new_sib"], r["is_largest"], depth)
+    assert not fail.any()
+    assert (r["old_root"][1:] == r["new_root"][:-1]).all()
+    assert ints(r["new_root"][-1]) == [t.root()]
+    # (3) independent bulk build of the final state
+    pre = t.get_leaves(np.arange(1 << 17))
+    dense = imt.IndexedMerkleTree.new(ctx, ctx.hash3(pre))
+    sub = imt.to_bytes([dense.get_root()])
+    assert ints(ctx.combine_subtree_roots(sub, 17, depth)) == [t.root()]
+    # (4) same values in 5 uneven batches
+    t2 = imt.IndexedTree(ctx, depth, 1 << 17)
+    cuts = [0, 1, 1000, 30000, 30001, n]
+    roots = [t2.insert_batch(vals[a:b], proofs=False)["new_root"] for a, b in zip(cuts, cuts[1:])]
+    assert (np.concatenate(roots) == r["new_root"]).all() and t2.root() == t.root()
+    # (5) prefix against the oracle
+    oh, rows, _ = _oracle_run(oracle, depth, 512, vals[:256])
+    assert ints(r["new_root"][:256]) == [o["new_root"] for o in rows]
+    assert ints(r["interim_root"][:256]) == [o["interim_root"] for o in rows]
+    oracle.sparse_free(oh)
+
+
+def test_config3_non_membership_2pow20_properties(imt, ctx):
+    """depth 32, 2^20 non-membership items against the config-2 tree: all accepted, every recomputed
+    root equals the tree root, and flipping the candidate to the low leaf's own value is rejected."""
+    depth = 32
+    t = imt.IndexedTree(ctx, depth, 1 << 17)
+    t.insert_batch(oracle_lib.synth_values(1 << 16, 0x494D5402), proofs=False)
+    root = t.root()
+    rng = np.random.default_rng(3)
+    cand = rng.integers(0, 256, size=(1 << 20, 32), dtype=np.uint8)
+    cand[:, 31] &= 0x0f                                    # < 2^252 < p, non-zero w.h.p., not members w.h.p.
+    low, leaves, sib, largest = t.non_membership_witness(cand)
+    fail, rout = ctx.non_membership(imt.to_bytes(root), leaves, low, sib, depth, cand, largest, want_root=True)
+    assert not fail.any()
+    assert (rout == imt.to_bytes(root)[None]).all()
+    fail = ctx.non_membership(imt.to_bytes(root), leaves, low, sib, depth, leaves[:, 0, :].copy(), largest)
+    assert (fail & imt._ffi.F_LOW_LT_NEW).all()

@@ -1,0 +1,161 @@
+"""CPU: the product's host logic and a host build of its device arithmetic, against the oracle.
+No compute call reaches the GPU library here (there is no GPU): we only check that it loads,
+exports every symbol include/imt.h declares, and refuses to run without a device."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from oracle_lib import P, b32
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(imt):
+    hdr = open(os.path.join(ROOT, "include", "imt.h")).read()
+    declared = set(re.findall(r"\b(imt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(imt.lib, name), f"libimt_hip.so does not export {name}"
+    assert declared == set(imt._ffi.SIGNATURES), declared ^ set(imt._ffi.SIGNATURES)
+    assert imt.lib.imt_version().startswith(b"imt-hip gfx950")
+
+
+def test_no_cpu_fallback(imt):
+    import torch
+    h = ctypes.c_void_p()
+    assert imt.lib.imt_ctx_create(-1, ctypes.byref(h)) == imt._ffi.ERR["NO_DEVICE"]
+    if not torch.cuda.is_available():
+        with pytest.raises(imt.ImtError) as ei:
+            imt.Context(0)
+        assert ei.value.code == imt._ffi.ERR["NO_DEVICE"]
+
+
+def _emul_hash(emul, xs, fi=0, fo=0):
+    out = ctypes.create_string_buffer(32)
+    rc = emul.emul_hash(b"".join(b32(x) for x in xs), len(xs), out, fi, fo)
+    return rc, int.from_bytes(out.raw, "little")
+
+
+def test_device_field_arithmetic_on_host(emul):
+    rng = random.Random(1)
+    cases = [(0, 0), (P - 1, P - 1), (1, P - 1), (P - 1, 2), ((1 << 253) + 12345, P - 7)]
+    cases += [(rng.randrange(P), rng.randrange(P)) for _ in range(3000)]
+    out = ctypes.create_string_buffer(32)
+    for x, y in cases:
+        emul.emul_mul(b32(x), b32(y), out, 0)
+        assert int.from_bytes(out.raw, "little") == x * y % P
+        emul.emul_mul(b32(x), b32(y), out, 1)
+        assert int.from_bytes(out.raw, "little") == x * x % P
+
+
+def test_device_poseidon_on_host_matches_oracle(emul, oracle):
+    rng = random.Random(2)
+    cases = [[0, 0], [0, 0, 0], [1, 2], [1, 2, 3], [P - 1, P - 1], [P - 1, P - 1, P - 1]]
+    cases += [[rng.randrange(P) for _ in range(rng.choice([2, 3]))] for _ in range(200)]
+    for c in cases:
+        rc, h = _emul_hash(emul, c)
+        assert rc == 0 and h == oracle.hash(c)
+        out = ctypes.create_string_buffer(32)
+        emul.emul_host_hash(b"".join(b32(x) for x in c), len(c), out)        # the table generator's own hash
+        assert int.from_bytes(out.raw, "little") == h
+    for _ in range(20):
+        st = [rng.randrange(P) for _ in range(3)]
+        o1 = ctypes.create_string_buffer(96)
+        emul.emul_permute(b"".join(map(b32, st)), o1)
+        assert [int.from_bytes(o1.raw[32 * i:32 * i + 32], "little") for i in range(3)] == oracle.permute(st)
+
+
+def test_boundary_formats_on_host(emul, oracle):
+    rng = random.Random(3)
+    R = 1 << 256
+    for _ in range(40):
+        c = [rng.randrange(P) for _ in range(2)]
+        rc, h = _emul_hash(emul, [x * R % P for x in c], 1, 1)       # halo2curves Montgomery in and out
+        assert rc == 0 and h == oracle.hash(c) * R % P
+        out = ctypes.create_string_buffer(32)
+        emul.emul_convert(b32(c[0]), out, 0, 1)
+        assert int.from_bytes(out.raw, "little") == c[0] * R % P
+        emul.emul_convert(b32(c[0]), out, 0, 2)                       # device format: R = 2^261, reduced
+        assert int.from_bytes(out.raw, "little") == (c[0] << 261) % P
+    assert _emul_hash(emul, [P, 0])[0] == -5                          # non-canonical input is flagged
+    assert _emul_hash(emul, [(1 << 256) - 1, 0])[0] == -5
+
+
+def _sweep_reference(events, base_fn, depth_levels):
+    """Brute force: replay events in time order on a dict tree; returns per level the list of
+    (node, time, sibling_source_time or None) for every event."""
+    latest = [dict() for _ in range(depth_levels + 1)]   # node -> time of latest version
+    per_level = [[] for _ in range(depth_levels)]
+    for t, pos in events:
+        latest[0][pos] = t
+        for l in range(depth_levels):
+            n = pos >> l
+            per_level[l].append((n, t, latest[l].get(n ^ 1)))
+            latest[l + 1][n >> 1] = t
+    return per_level
+
+
+def test_merge_element_against_bruteforce(emul):
+    rng = random.Random(4)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    for trial in range(30):
+        n_ins = rng.randrange(1, 40)
+        M = rng.randrange(1, 20)
+        events = []
+        for i in range(n_ins):
+            events.append((2 * i, rng.randrange(0, M + i)))     # low leaf: any earlier leaf
+            events.append((2 * i + 1, M + i))
+        total = len(events)
+        L0 = max(1, (M + n_ins - 1).bit_length())
+        ref = _sweep_reference(events, None, L0)
+        keys = sorted((pos, t) for t, pos in events)
+        node = np.array([k[0] for k in keys], np.uint32)
+        time = np.array([k[1] for k in keys], np.uint32)
+        rs = np.zeros(total, np.uint32); re_ = np.zeros(total, np.uint32)
+        k = 0
+        while k < total:
+            j = k
+            while j < total and node[j] == node[k]:
+                j += 1
+            rs[k:j] = k; re_[k:j] = j
+            k = j
+        for l in range(L0):
+            o = [np.zeros(total, np.uint32) for _ in range(5)]
+            sib = np.zeros(total, np.int32); nb = np.zeros(total, np.uint32)
+            emul.emul_merge_level(node.ctypes.data_as(u32p), time.ctypes.data_as(u32p), rs.ctypes.data_as(u32p),
+                                  re_.ctypes.data_as(u32p), total, *[a.ctypes.data_as(u32p) for a in o],
+                                  sib.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), nb.ctypes.data_as(u32p))
+            n2, t2, rs2, re2, frm = o
+            # next table is sorted by (node, time) with correct runs
+            order = sorted(range(total), key=lambda x: (int(node[x]) >> 1, int(time[x])))
+            assert [int(x) for x in frm & 0x7fffffff] == order
+            assert all(int(n2[i]) == int(node[order[i]]) >> 1 and int(t2[i]) == int(time[order[i]]) for i in range(total))
+            for i in range(total):
+                assert n2[rs2[i]] == n2[i] and n2[re2[i] - 1] == n2[i]
+                assert rs2[i] == 0 or n2[rs2[i] - 1] != n2[i]
+                assert re2[i] == total or n2[re2[i]] != n2[i]
+            # sibling source = newest older version of the sibling node, per the brute force
+            want = {(n, t): s for n, t, s in ref[l]}
+            for i in range(total):
+                src = int(sib[i])
+                got = None if src < 0 else int(time[src])
+                assert int(nb[i]) == int(node[order[i]])
+                assert got == want[(int(nb[i]), int(t2[i]))]
+                if src >= 0:
+                    assert int(node[src]) == int(nb[i]) ^ 1
+                last = bool(frm[i] >> 31)
+                kk = int(frm[i] & 0x7fffffff)
+                assert last == (kk == int(re_[kk]) - 1)
+            node, time, rs, re_ = n2, t2, rs2, re2
+        assert (node == 0).all() and [int(x) for x in time] == list(range(total))
+
+
+def test_synth_values_are_valid():
+    v = oracle_lib.synth_values(500, 0x494D5402)
+    assert len(set(v)) == 500 and all(0 < x < P for x in v)
+    assert v == oracle_lib.synth_values(500, 0x494D5402)
