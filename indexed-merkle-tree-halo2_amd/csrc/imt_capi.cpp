@@ -50,6 +50,56 @@ int imt_ctx::sync_and_check() {
     return IMT_OK;
 }
 
+hipEvent_t imt_ctx::prof_event() {
+    if (!prof_pool.empty()) {
+        hipEvent_t e = prof_pool.back();
+        prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+int imt_ctx::prof_begin(int cls) {
+    if (!profiling) return -1;
+    ProfPair p{prof_event(), prof_event(), cls};
+    if (!p.a || !p.b) return -1;
+    (void)hipEventRecord(p.a, stream);
+    prof_pending.push_back(p);
+    return (int)prof_pending.size() - 1;
+}
+void imt_ctx::prof_end(int idx) {
+    if (idx >= 0) (void)hipEventRecord(prof_pending[(size_t)idx].b, stream);
+}
+
+extern "C" int imt_profile_enable(imt_ctx* c, int on) {
+    if (!c) return IMT_ERR_ARG;
+    c->profiling = on != 0;
+    return IMT_OK;
+}
+extern "C" int imt_profile_read(imt_ctx* c, double* out) {
+    if (!c || !out) return IMT_ERR_ARG;
+    int rc = c->set_device();
+    if (rc) return rc;
+    IMT_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& p : c->prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->prof_ms[p.cls] += ms;
+            c->prof_n[p.cls] += 1;
+        }
+        c->prof_pool.push_back(p.a);
+        c->prof_pool.push_back(p.b);
+    }
+    c->prof_pending.clear();
+    for (int k = 0; k < IMT_PROF_CLASSES; k++) {
+        out[2 * k] = c->prof_ms[k];
+        out[2 * k + 1] = c->prof_n[k];
+        c->prof_ms[k] = c->prof_n[k] = 0;
+    }
+    return IMT_OK;
+}
+
 extern "C" const char* imt_version(void) { return "imt-hip gfx950 r1"; }
 
 extern "C" int imt_ctx_create(int device, imt_ctx** out) {
@@ -91,6 +141,8 @@ extern "C" void imt_ctx_destroy(imt_ctx* c) {
     hipStreamSynchronize(c->stream);
     for (auto& s : c->scratch)
         if (s.p) hipFree(s.p);
+    for (auto& p : c->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto& e : c->prof_pool) hipEventDestroy(e);
     if (c->d_err) hipFree(c->d_err);
     if (c->d_zero) hipFree(c->d_zero);
     if (c->own_stream) hipStreamDestroy(c->own_stream);

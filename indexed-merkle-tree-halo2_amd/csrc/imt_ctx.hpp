@@ -21,6 +21,17 @@ struct imt_ctx {
     std::string last_error;
     struct Scratch { void* p = nullptr; size_t cap = 0; };
     std::vector<Scratch> scratch;     // grow-only staging buffers, indexed by slot
+    // optional kernel timing (imt_profile_*)
+    bool profiling = false;
+    struct ProfPair { hipEvent_t a, b; int cls; };
+    std::vector<ProfPair> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[IMT_PROF_CLASSES] = {0};
+    double prof_n[IMT_PROF_CLASSES] = {0};
+    hipEvent_t prof_event();
+    // RAII-less helpers: begin returns an index into prof_pending (or -1 when off)
+    int prof_begin(int cls);
+    void prof_end(int idx);
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];

@@ -491,7 +491,10 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
 
     // ---- 7. leaf hashes, index phase (no hashing), then the hash sweep ----
     // (the leaf kernel reads the level-0 time table before the merges recycle that buffer)
+    int pf = c->prof_begin(IMT_PROF_LEAVES);
     launch::sweep_leaves(s, P.d_pre, P.d_tab[0][1], P.d_val[0], 0, (uint32_t)E, IMT_FMT_CANONICAL, c->d_err);
+    c->prof_end(pf);
+    pf = c->prof_begin(IMT_PROF_INDEX);
     for (unsigned l = 0; l < L0; l++) {
         const int a = l & 1, b = a ^ 1;
         sweep::LevelTable in{P.d_tab[a][0], P.d_tab[a][1], P.d_tab[a][2], P.d_tab[a][3]};
@@ -501,18 +504,25 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         launch::merge_level(s, in, o, (uint32_t)E);
         IMT_HIP(c, hipMemcpyAsync(P.d_timen + (size_t)l * P.cap_events, P.d_tab[b][1], E * 4, hipMemcpyDeviceToDevice, s));
     }
+    c->prof_end(pf);
     for (unsigned l = 0; l < L0; l++) {
         const uint8_t* vin = P.d_val[l & 1];
         uint8_t* vout = P.d_val[(l & 1) ^ 1];
         const size_t o = (size_t)l * P.cap_events;
+        pf = c->prof_begin(IMT_PROF_LEVEL);
         launch::sweep_level(s, vin, vout, P.d_from + o, P.d_sibsrc + o, P.d_nodeb + o, P.d_timen + o,
                             t->d_nodes + t->h_off[l] * 32, t->h_len[l], c->d_zero + (size_t)l * 32, 0, (uint32_t)E, g_ls,
                             g_ns, lay, l, fmt);
+        c->prof_end(pf);
+        pf = c->prof_begin(IMT_PROF_WRITEBACK);
         launch::writeback(s, vin, P.d_from + o, P.d_nodeb + o, t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
+        c->prof_end(pf);
     }
     if (g_old) launch::convert(s, t->d_nodes + t->h_off[t->depth] * 32, g_old, 1, IMT_FMT_DEVICE, fmt, c->d_err);
+    pf = c->prof_begin(IMT_PROF_TOP);
     launch::sweep_top(s, P.d_val[L0 & 1], L0, t->depth, c->d_zero, t->d_nodes, t->d_off, 0, (uint32_t)E, (uint32_t)E,
                       g_old, g_int, g_new, g_ls, g_ns, lay, fmt);
+    c->prof_end(pf);
     IMT_HIP(c, hipEventRecord(P.done, s));
     P.in_flight = true;
     t->cur ^= 1;

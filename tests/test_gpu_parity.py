@@ -147,7 +147,7 @@ def test_insert_batch_matches_sequential_oracle(imt, ctx, oracle, depth, n, batc
         vals = [30, 10, 20, 5, 50, 35]          # test_insert_leaf_multiple_round :683-690
     else:
         vals = oracle_lib.synth_values(n, 0x494D5402 + depth + batches)
-    cap = 8 if depth == 3 else 512
+    cap = min(512, 1 << depth)
     oh, rows, oroot = _oracle_run(oracle, depth, cap, vals)
     t = imt.IndexedTree(ctx, depth, cap)
     assert t.root() == ints(oracle.zero_hashes(depth)[depth])[0]
