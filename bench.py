@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- indexed-tree insertions/s at depth 32 over bn256::Fr on MI355X.
+
+A step = one batch of 2^16 sequential-semantics insertions (BASELINE.json configs[1]) through
+imt_itree_insert_batch: low-leaf search + leaf preimages on the host, all 2 + 2*32 hashes per
+insertion on the GPU (level sweep), every per-insertion output written to HBM: old / interim /
+new root and both 32-sibling proofs.  Values are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+N > 1: the value space is partitioned by v mod N; rank g owns the leaf-index range
+[g*2^(32-k), (g+1)*2^(32-k)) of the depth-32 tree as an indexed subtree of height 32-k (k = log2 N),
+and after every step the ranks all-gather their subtree roots (RCCL, 32 bytes each) and hash the top
+k levels.  Per-GPU work is fixed (weak scaling); there is no other data-path collective.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, algorithmic
+bytes of SURVEY.md 8d) and `cpu_baseline` (the C oracle, 1 thread, bounded sample) added, plus a
+`valu` object: the path is integer-VALU bound, so that is the roofline that says something.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DEPTH = 32
+BATCH = 1 << 16
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+BYTES_PER_INSERTION = 2320          # 2 paths x (32*32 + 96 + 8 + 32)
+HASHES_PER_INSERTION = 66           # 2 + 2*32
+BYTES_PER_PATH_LEVEL = 1160.0 / 33  # one event, one level: a path's 1160 B spread over its 33 hashes
+MADS_PER_HASH = 2 * 78246           # v_mad_u64_u32 per 2-permutation hash (instruction counts)
+HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_GMADS = 36443.0           # measured v_mad_u64_u32 lane-ops/ns (profiles/r01_valu_rates.txt, 8 waves/SIMD)
+
+
+def synth_values(total, residue, modulus, seed):
+    """Distinct random field elements v with 0 < v < p and v % modulus == residue (254-bit draws with
+    the top 2 bits cleared, rejected until < p: mirrors src/indexed_merkle_tree.rs:381-386)."""
+    rng = np.random.default_rng(seed)
+    out, seen = [], set()
+    while len(out) < total:
+        limbs = rng.integers(0, 1 << 64, size=(total + 1024, 4), dtype=np.uint64)
+        for row in limbs:
+            v = int(row[0]) | (int(row[1]) << 64) | (int(row[2]) << 128) | ((int(row[3]) & ((1 << 62) - 1)) << 192)
+            v = v - (v % modulus) + residue
+            if 0 < v < P and v not in seen:
+                seen.add(v)
+                out.append(v)
+                if len(out) == total:
+                    break
+    return np.frombuffer(b"".join(v.to_bytes(32, "little") for v in out), dtype=np.uint8).reshape(total, 32).copy()
+
+
+def cpu_baseline(vals, budget_s=15.0):
+    """The CPU oracle's sparse depth-32 insertion (oracle/sparse.c) on the first values of the same
+    workload, one thread, for about `budget_s` seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    orc = oracle_lib.load()
+    h = orc.sparse_new(DEPTH, 1 << 17)
+    n, t0 = 0, time.perf_counter()
+    lib = orc.lib
+    low = ctypes.c_uint64()
+    while n < vals.shape[0]:
+        rc = lib.orc_sparse_insert(h, vals[n].ctypes.data_as(ctypes.c_void_p), ctypes.byref(low), None, None, None,
+                                   None, None, None)
+        assert rc == 0
+        n += 1
+        if (n & 63) == 0 and time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    orc.sparse_free(h)
+    return {"value": n / dt, "unit": "insertions/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} insertions of the same depth-32 workload, C oracle (oracle/sparse.c), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world & (world - 1):
+        raise SystemExit("--gpus must be a power of two (subtrees of equal height)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import imt_amd
+    from imt_amd import _ffi
+    lib = imt_amd.lib
+    ctx = imt_amd.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    k = world.bit_length() - 1
+    depth = DEPTH - k
+    steps_total = args.warmup + args.steps
+    cap = 1 << (steps_total * BATCH).bit_length()
+    tree = imt_amd.IndexedTree(ctx, depth, cap)
+    vals_h = synth_values(steps_total * BATCH, rank, world, 0x494D5402 + rank)
+    dev = torch.device("cuda", local_rank)
+    vals = torch.from_numpy(vals_h).to(dev)
+
+    u8 = dict(dtype=torch.uint8, device=dev)
+    bufs = dict(low_index=torch.empty(BATCH, dtype=torch.int64, device=dev),
+                low_leaf=torch.empty((BATCH, 3, 32), **u8), is_largest=torch.empty(BATCH, **u8),
+                old_root=torch.empty((BATCH, 32), **u8), interim_root=torch.empty((BATCH, 32), **u8),
+                new_root=torch.empty((BATCH, 32), **u8), new_leaf=torch.empty((BATCH, 3, 32), **u8),
+                low_sib=torch.empty((depth, BATCH, 32), **u8), new_sib=torch.empty((depth, BATCH, 32), **u8))
+    out = _ffi.InsertOut(**{name: t.data_ptr() for name, t in bufs.items()})
+    flags = _ffi.DEVICE_PTRS | _ffi.FMT_CANONICAL
+    roots_all = torch.empty((world, 32), **u8)
+    root_buf = torch.empty(32, **u8)
+    top_root = torch.empty(32, **u8)
+
+    host_s = [0.0]
+
+    def step(i):
+        th = time.perf_counter()
+        rc = lib.imt_itree_insert_batch(tree.h, ctypes.c_void_p(vals.data_ptr() + i * BATCH * 32), BATCH,
+                                        ctypes.byref(out), flags)
+        host_s[0] += time.perf_counter() - th
+        if rc != 0:
+            raise RuntimeError(f"imt_itree_insert_batch: {rc} {lib.imt_last_error(ctx.h).decode()}")
+        if world > 1:   # the path's one exchange: subtree roots, then the top k levels on every rank
+            ctx._check(lib.imt_itree_root(tree.h, ctypes.c_void_p(root_buf.data_ptr()), flags))
+            dist.all_gather_into_tensor(roots_all, root_buf)
+            ctx._check(lib.imt_combine_subtree_roots(ctx.h, ctypes.c_void_p(roots_all.data_ptr()), world, depth,
+                                                     DEPTH, ctypes.c_void_p(top_root.data_ptr()), flags))
+
+    def sync():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    lib.imt_profile_enable(ctx.h, 1)
+    host_s[0] = 0.0
+    t0 = time.perf_counter()
+    for i in range(args.warmup, steps_total):
+        step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = (ctypes.c_double * 12)()
+    lib.imt_profile_read(ctx.h, prof)
+    lib.imt_profile_enable(ctx.h, 0)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        n_ins = args.steps * BATCH * world
+        value = n_ins / dt
+        names = ["k_sweep_leaves", "index(k_merge_level)", "k_sweep_level", "k_sweep_top", "k_writeback", "host_prepare"]
+        kern = {names[c]: {"ms_total": prof[2 * c], "launches": int(prof[2 * c + 1])} for c in range(6)}
+        gpu_ms = sum(v["ms_total"] for n_, v in kern.items() if n_ != "host_prepare")
+        # dominant kernel by time: one k_sweep_level launch hashes 2*BATCH events up one level
+        lv = kern["k_sweep_level"]
+        avg_ms = lv["ms_total"] / max(lv["launches"], 1)
+        alg_bytes = 2 * BATCH * BYTES_PER_PATH_LEVEL
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        hashes_per_s = 2 * BATCH / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+        res = {
+            "metric": "indexed-tree insertions/sec at depth=32 (bn256::Fr)", "value": value,
+            "unit": "insertions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 limbs (9 x 29-bit, Montgomery mod p), 64-bit accumulate",
+            "data": "synthetic",
+            "config": {"workload": "depth=32, 2^16 sequential-semantics insertions per step per GPU "
+                                   "(BASELINE configs[1]); per insertion: old/interim/new root + two 32-sibling "
+                                   "proofs written to HBM; values resident in HBM",
+                       "batch_per_gpu": BATCH, "depth": DEPTH, "subtree_height_per_gpu": depth,
+                       "parallelism": "single tree" if world == 1 else
+                       f"{world} value-partitioned subtrees by leaf-index range + RCCL all-gather of subtree roots per step",
+                       "hashes_per_insertion": 2 + 2 * depth},
+            "roofline": {"bound": "hbm", "kernel": "k_sweep_level", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "declared HBM per the contract; the kernel is integer-VALU bound, see valu"},
+            "valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep_level",
+                     "achieved_gmads": hashes_per_s * MADS_PER_HASH / 1e9, "peak_gmads": VALU_PEAK_GMADS,
+                     "frac": hashes_per_s * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS,
+                     "hashes_per_s": hashes_per_s},
+            "kernels": kern, "gpu_kernel_ms_per_step": gpu_ms / args.steps,
+            "host_call_ms_per_step": host_s[0] / args.steps * 1e3,
+            "host_prepare_ms_per_step": kern["host_prepare"]["ms_total"] / args.steps,
+            "whole_step_algorithmic_GBps": value * BYTES_PER_INSERTION / 1e9,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(vals_h)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

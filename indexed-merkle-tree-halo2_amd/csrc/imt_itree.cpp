@@ -9,6 +9,7 @@
 #include "imt_ctx.hpp"
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -30,8 +31,8 @@ struct Pre {            // {val, next_val, next_idx}: src/utils.rs:12-17
     U256 val, next_val;
     uint64_t next_idx;
 };
-struct SortedEnt {
-    U256 val;
+struct SortedEnt {      // 16 bytes: the value's top limb (ties resolved through pre[idx].val) + leaf index
+    uint64_t top;
     uint64_t idx;
 };
 
@@ -80,6 +81,14 @@ struct imt_itree {
     int cur = 0;
     hipStream_t up_stream = nullptr;
     hipEvent_t up_done = nullptr;
+    // reusable host work arrays of insert_batch
+    std::vector<uint32_t> w_ord, w_rank;
+    std::vector<std::pair<uint64_t, uint32_t>> w_sortkey;
+    std::vector<int64_t> w_prv, w_nxt, w_pred, w_succ;
+    std::vector<uint64_t> w_keys, w_keys2, w_low;
+    std::vector<uint8_t> w_largest;
+    std::vector<uint32_t> w_hist;
+    std::vector<SortedEnt> w_merged;
 };
 
 static void plan_free(PlanSet& p) {
@@ -188,7 +197,7 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
     }
     // leaf 0 is the {0,0,0} sentinel; its hash equals the empty-slot hash
     t->pre.push_back(Pre{{0, 0, 0, 0}, {0, 0, 0, 0}, 0});
-    t->sorted.push_back(SortedEnt{{0, 0, 0, 0}, 0});
+    t->sorted.push_back(SortedEnt{0, 0});
     t->size = 1;
     *out = t;
     return IMT_OK;
@@ -244,14 +253,23 @@ static int fetch_canonical(imt_ctx* c, hipStream_t st, const void* vals, size_t 
     return IMT_OK;
 }
 
+// stored entry e compared with value v: -1 / 0 / +1
+static inline int cmp_ent(const imt_itree* t, const SortedEnt& e, const U256& v) {
+    if (e.top != v[3]) return e.top < v[3] ? -1 : 1;
+    const U256& x = t->pre[e.idx].val;
+    for (int i = 2; i >= 0; i--)
+        if (x[i] != v[i]) return x[i] < v[i] ? -1 : 1;
+    return 0;
+}
+
 // position in t->sorted of the greatest val < v; IMT_ERR_VALUE if v == 0 or present
 static int find_pred(const imt_itree* t, const U256& v, size_t& pos) {
     size_t lo = 0, hi = t->sorted.size();   // first entry with val >= v
     while (lo < hi) {
         size_t mid = (lo + hi) / 2;
-        if (lt256(t->sorted[mid].val, v)) lo = mid + 1; else hi = mid;
+        if (cmp_ent(t, t->sorted[mid], v) < 0) lo = mid + 1; else hi = mid;
     }
-    if (lo < t->sorted.size() && t->sorted[lo].val == v) return IMT_ERR_VALUE;
+    if (lo < t->sorted.size() && cmp_ent(t, t->sorted[lo], v) == 0) return IMT_ERR_VALUE;
     if (lo == 0) return IMT_ERR_VALUE;
     pos = lo - 1;
     return IMT_OK;
@@ -362,6 +380,8 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     const uint64_t M = t->size;
     if (M + n > t->cap) return c->fail(IMT_ERR_FULL, "tree capacity %llu exceeded", (unsigned long long)t->cap);
 
+    const auto host_t0 = std::chrono::steady_clock::now();
+    double host_wait_ms = 0;
     // ---- 1. values, canonical, on the host.  With device pointers they are read on the side
     //         stream, so the call does not wait for an earlier batch still running. ----
     std::vector<U256> v;
@@ -372,32 +392,46 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     //         sort the batch, locate each value between two stored leaves, then unlink the batch
     //         from that list in reverse insertion order: what is adjacent at unlink time is
     //         exactly what had been inserted earlier. ----
-    std::vector<uint32_t> ord(n);
-    std::iota(ord.begin(), ord.end(), 0u);
-    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return lt256(v[a], v[b]); });
+    std::vector<uint32_t>& ord = t->w_ord;
+    {
+        std::vector<std::pair<uint64_t, uint32_t>>& sk = t->w_sortkey;   // (top limb, index): cheap compares
+        sk.resize(n);
+        for (size_t i = 0; i < n; i++) sk[i] = {v[i][3], (uint32_t)i};
+        std::sort(sk.begin(), sk.end(), [&](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) {
+            if (a.first != b.first) return a.first < b.first;
+            return lt256(v[a.second], v[b.second]);
+        });
+        ord.resize(n);
+        for (size_t i = 0; i < n; i++) ord[i] = sk[i].second;
+    }
     if (is_zero256(v[ord[0]])) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
     for (size_t r = 1; r < n; r++)
         if (v[ord[r]] == v[ord[r - 1]]) return c->fail(IMT_ERR_VALUE, "duplicate value inside the batch");
     // neighbours: >= 0 -> rank of a batch element; < 0 -> ~(leaf index of a stored leaf); NONE
     const int64_t NONE = INT64_MIN;
-    std::vector<int64_t> prv(n), nxt(n);
+    std::vector<int64_t>&prv = t->w_prv, &nxt = t->w_nxt;
+    prv.resize(n);
+    nxt.resize(n);
     {
         size_t q = 0;   // first stored entry with val >= current
         const size_t S = t->sorted.size();
         for (size_t r = 0; r < n; r++) {
             const U256& x = v[ord[r]];
-            while (q < S && lt256(t->sorted[q].val, x)) q++;
-            if (q < S && t->sorted[q].val == x) return c->fail(IMT_ERR_VALUE, "value already in the tree");
+            while (q < S && cmp_ent(t, t->sorted[q], x) < 0) q++;
+            if (q < S && cmp_ent(t, t->sorted[q], x) == 0) return c->fail(IMT_ERR_VALUE, "value already in the tree");
             // q >= 1 because the sentinel 0 is stored and x > 0
-            const bool same_gap_prev = r > 0 && !lt256(v[ord[r - 1]], t->sorted[q - 1].val) ;
+            const bool same_gap_prev = r > 0 && cmp_ent(t, t->sorted[q - 1], v[ord[r - 1]]) < 0;
             prv[r] = same_gap_prev ? (int64_t)(r - 1) : ~(int64_t)t->sorted[q - 1].idx;
-            const bool next_in_gap = r + 1 < n && (q >= S || lt256(v[ord[r + 1]], t->sorted[q].val));
+            const bool next_in_gap = r + 1 < n && (q >= S || cmp_ent(t, t->sorted[q], v[ord[r + 1]]) > 0);
             nxt[r] = next_in_gap ? (int64_t)(r + 1) : (q < S ? ~(int64_t)t->sorted[q].idx : NONE);
         }
     }
-    std::vector<uint32_t> rank_of(n);
+    std::vector<uint32_t>& rank_of = t->w_rank;
+    rank_of.resize(n);
     for (size_t r = 0; r < n; r++) rank_of[ord[r]] = (uint32_t)r;
-    std::vector<int64_t> pred(n), succ(n);   // by insertion time
+    std::vector<int64_t>&pred = t->w_pred, &succ = t->w_succ;   // by insertion time
+    pred.resize(n);
+    succ.resize(n);
     for (size_t ii = n; ii-- > 0;) {
         const uint32_t r = rank_of[ii];
         pred[ii] = prv[r];
@@ -410,11 +444,13 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     const size_t E = 2 * n;
     const unsigned L0 = std::min(ceil_log2(M + n), t->depth);
     PlanSet& P = t->plan[t->cur];
-    if (P.in_flight) {
+    if (P.in_flight) {   // back-pressure: at most two batches in flight
+        const auto w0 = std::chrono::steady_clock::now();
         IMT_HIP(c, hipEventSynchronize(P.done));
+        host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
         P.in_flight = false;
     }
-    rc = plan_reserve(c, P, E, L0);
+    rc = plan_reserve(c, P, E, t->depth);   // all levels up front: growing later would stall the pipeline
     if (rc) return rc;
     uint8_t* h_pre = P.h_pin;
     uint32_t* h_tab = reinterpret_cast<uint32_t*>(P.h_pin + P.cap_events * 96);
@@ -422,10 +458,13 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
              *h_re = h_tab + 3 * P.cap_events;
 
     // ---- 4. events: preimages at every time step + host-side outputs ----
-    std::vector<uint64_t> o_low(n);
-    std::vector<uint8_t> o_largest(n);
+    std::vector<uint64_t>& o_low = t->w_low;
+    std::vector<uint8_t>& o_largest = t->w_largest;
+    o_low.resize(n);
+    o_largest.resize(n);
     std::vector<uint8_t> o_lowleaf(out && out->low_leaf ? n * 96 : 0), o_newleaf(out && out->new_leaf ? n * 96 : 0);
-    std::vector<uint64_t> keys(E);   // (pos << 32) | event
+    std::vector<uint64_t>& keys = t->w_keys;   // (pos << 32) | event
+    keys.resize(E);
     auto leaf_of = [&](int64_t ref) -> uint64_t { return ref >= 0 ? M + ord[ref] : (uint64_t)~ref; };
     auto val_of = [&](int64_t ref) -> const U256& { return ref >= 0 ? v[ord[ref]] : t->pre[(size_t)~ref].val; };
     static const U256 ZERO = {0, 0, 0, 0};
@@ -444,7 +483,22 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         keys[2 * i] = (low << 32) | (uint64_t)(2 * i);
         keys[2 * i + 1] = ((M + i) << 32) | (uint64_t)(2 * i + 1);
     }
-    std::sort(keys.begin(), keys.end());
+    {   // stable LSD radix sort on the 32-bit position (two 16-bit passes); events are already in time order
+        std::vector<uint64_t>& tmp = t->w_keys2;
+        std::vector<uint32_t>& hist = t->w_hist;
+        tmp.resize(E);
+        hist.resize(1u << 16);
+        for (int pass = 0; pass < 2; pass++) {
+            const int sh = 32 + 16 * pass;
+            std::vector<uint64_t>& src = pass ? tmp : keys;
+            std::vector<uint64_t>& dst = pass ? keys : tmp;
+            std::fill(hist.begin(), hist.end(), 0u);
+            for (size_t x = 0; x < E; x++) hist[(src[x] >> sh) & 0xffff]++;
+            uint32_t run = 0;
+            for (auto& hcount : hist) { const uint32_t cnt = hcount; hcount = run; run += cnt; }
+            for (size_t x = 0; x < E; x++) dst[hist[(src[x] >> sh) & 0xffff]++] = src[x];
+        }
+    }
     for (size_t k = 0; k < E;) {
         size_t j = k;
         const uint32_t pos = (uint32_t)(keys[k] >> 32);
@@ -540,13 +594,14 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         lowp.next_idx = M + i;
     }
     {
-        std::vector<SortedEnt> merged;
+        std::vector<SortedEnt>& merged = t->w_merged;
+        merged.clear();
         merged.reserve(t->sorted.size() + n);
         size_t q = 0;
         for (size_t r = 0; r < n; r++) {
             const U256& x = v[ord[r]];
-            while (q < t->sorted.size() && lt256(t->sorted[q].val, x)) merged.push_back(t->sorted[q++]);
-            merged.push_back(SortedEnt{x, M + ord[r]});
+            while (q < t->sorted.size() && cmp_ent(t, t->sorted[q], x) < 0) merged.push_back(t->sorted[q++]);
+            merged.push_back(SortedEnt{x[3], M + ord[r]});
         }
         while (q < t->sorted.size()) merged.push_back(t->sorted[q++]);
         t->sorted.swap(merged);
@@ -592,6 +647,11 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
             if (out->low_sib) IMT_HIP(c, hipMemcpyAsync(out->low_sib, g_ls, sib_bytes, hipMemcpyDeviceToHost, s));
             if (out->new_sib) IMT_HIP(c, hipMemcpyAsync(out->new_sib, g_ns, sib_bytes, hipMemcpyDeviceToHost, s));
         }
+    }
+    if (c->profiling) {
+        c->prof_ms[IMT_PROF_HOST] +=
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count() - host_wait_ms;
+        c->prof_n[IMT_PROF_HOST] += 1;
     }
     if (!dev) IMT_HIP(c, hipStreamSynchronize(s));
     return IMT_OK;
