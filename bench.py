@@ -40,6 +40,10 @@ BYTES_PER_PATH_LEVEL = 1160.0 / 33  # one event, one level: a path's 1160 B spre
 MADS_PER_HASH = 2 * 78246           # v_mad_u64_u32 per 2-permutation hash (instruction counts)
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GMADS = 36443.0           # measured v_mad_u64_u32 lane-ops/ns (profiles/r01_valu_rates.txt, 8 waves/SIMD)
+# HBM bytes of one k_sweep_level launch at E = 2^17 events from the PMC passes in
+# profiles/r01_pmc_hbm_traffic.txt: 2 x FETCH_SIZE (gfx950 reports half of 16-B/lane reads,
+# MI355X_MICROARCH.md "HBM") + WRITE_SIZE, counter unit KB
+PMC_TRAFFIC_SWEEP_LEVEL = int((2 * 3835.9 + 8192.7) * 1024)
 
 
 def synth_values(total, residue, modulus, seed):
@@ -99,12 +103,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if world & (world - 1):
         raise SystemExit("--gpus must be a power of two (subtrees of equal height)")
+    # rehearsal switches (one-GPU box): IMT_BENCH_DEVICE pins every rank to one device and
+    # IMT_BENCH_COLLECTIVE=gloo runs the root exchange through host memory.  The driver's runs use
+    # neither: one rank per GPU, backend "nccl" (= RCCL over xGMI).
+    if "IMT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["IMT_BENCH_DEVICE"])
+    backend = os.environ.get("IMT_BENCH_COLLECTIVE", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import imt_amd
     from imt_amd import _ffi
@@ -145,7 +158,12 @@ def main():
             raise RuntimeError(f"imt_itree_insert_batch: {rc} {lib.imt_last_error(ctx.h).decode()}")
         if world > 1:   # the path's one exchange: subtree roots, then the top k levels on every rank
             ctx._check(lib.imt_itree_root(tree.h, ctypes.c_void_p(root_buf.data_ptr()), flags))
-            dist.all_gather_into_tensor(roots_all, root_buf)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(roots_all, root_buf)
+            else:   # rehearsal only
+                parts = [torch.empty(32, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, root_buf.cpu())
+                roots_all.copy_(torch.stack(parts))
             ctx._check(lib.imt_combine_subtree_roots(ctx.h, ctypes.c_void_p(roots_all.data_ptr()), world, depth,
                                                      DEPTH, ctypes.c_void_p(top_root.data_ptr()), flags))
 
@@ -169,7 +187,7 @@ def main():
     lib.imt_profile_read(ctx.h, prof)
     lib.imt_profile_enable(ctx.h, 0)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -199,7 +217,10 @@ def main():
                        f"{world} value-partitioned subtrees by leaf-index range + RCCL all-gather of subtree roots per step",
                        "hashes_per_insertion": 2 + 2 * depth},
             "roofline": {"bound": "hbm", "kernel": "k_sweep_level", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": PMC_TRAFFIC_SWEEP_LEVEL,
+                         "traffic_source": "profiles/r01_pmc_hbm_traffic.txt (separate --pmc passes; value arrays, "
+                                           "index tables and the proof store are counted, the 35 B/hash algorithmic "
+                                           "figure counts only path inputs)",
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "declared HBM per the contract; the kernel is integer-VALU bound, see valu"},
             "valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep_level",

@@ -23,6 +23,8 @@ struct PoseidonConsts {
     Fe pre[3][3];         // matrix of full round 3 (M followed by the first N')
     Fe sp_row[RP][3];     // sparse round: new s0 = row . (y, s1, s2)
     Fe sp_col[RP][2];     // sparse round: new s_i = s_i + col_i * y
+    Fe sp_gamma[RP];      // row[p][1]*col[p-1][0] + row[p][2]*col[p-1][1]: lets round p use the linear
+                          // lanes as they were BEFORE round p-1 (two rounds share one reduction each)
     Fe cap0;              // 2^64 in device form (initial capacity lane)
     Fe one;               // 1 in device form
     Fe from_canon;        // R^2: canonical integer -> device form

@@ -59,7 +59,8 @@ IMT_HD constexpr uint32_t p29(int i) {
 //   r = (sum_t a[t]*b[t] + addend*R + m*p) / R,   r < sum/R + addend + p
 // Preconditions (column accumulators must stay below 2^64):
 //   NT*9*max(a limb)*max(b limb) + 9*2^58 + 2^35 < 2^64
-// which holds for NT=3 with 29-bit limbs, and for NT=1 with 30-bit limbs on both sides.
+// which holds for NT<=4 with 29-bit limbs (45 * 2^58 < 2^64), and for NT=1 with 30-bit limbs on
+// both sides.
 // Output limbs are normalised (< 2^29; the top limb holds whatever is left).
 // ---------------------------------------------------------------------------------
 template <int NT, bool ADD>
@@ -227,36 +228,57 @@ IMT_HD void sbox(Fe& x) {   // x <- x^5; limbs of x < 2^30
 
 // One permutation, optimised schedule (same values as the plain 65-round form):
 //   rounds 0..3   : s += c_r; x^5 on all lanes; s = M s  (round 3 uses PRE = N' M)
-//   rounds 4..60  : s0 += k_p; s0 = s0^5; s = Sparse_p s
+//   rounds 4..60  : s0 += k_p; y = s0^5; s0 = row_p . (y, s1, s2); s_i += col_p,i * y
 //   rounds 61..64 : as 0..3 (round 61's constants carry the partial rounds' leftover)
-// One loop so that the full-round body exists once in the instruction stream.
+// The 57 partial rounds run in pairs: the second round of a pair takes the linear lanes as they
+// were before the first one (its row product gets the extra term gamma * y_first), so each linear
+// lane is reduced once per pair, REDC(s_i R + col_p,i y_first + col_p+1,i y_second), instead of once
+// per round: 11 products + 4 reductions per pair instead of 10 + 6.  The odd 57th round runs
+// through the same code with y_second = 0.
+// One loop so that each body exists once in the instruction stream.
 // `first_rc` replaces the round-0 constants (sponge padding folded in by the caller).
 // Entry: limbs normalised.  Exit: limbs normalised, every lane < 2p.
 IMT_HD void permute(const PoseidonConsts& pc, Fe s[3], const Fe* first_rc) {
+    constexpr int NSTEP = RF + (RP + 1) / 2;   // 4 full, 29 partial pairs, 4 full
 #pragma unroll 1
-    for (int r = 0; r < RF + RP; r++) {
-        if (r < RF / 2 || r >= RF / 2 + RP) {
-            const int fr = r < RF / 2 ? r : r - RP;
-            const Fe* rc = (r == 0) ? first_rc : pc.rc_full[fr];
+    for (int st = 0; st < NSTEP; st++) {
+        if (st < RF / 2 || st >= RF / 2 + (RP + 1) / 2) {
+            const int fr = st < RF / 2 ? st : st - (RP + 1) / 2;
+            const Fe* rc = (st == 0) ? first_rc : pc.rc_full[fr];
             add_lazy(s[0], s[0], rc[0]);
             add_lazy(s[1], s[1], rc[1]);
             add_lazy(s[2], s[2], rc[2]);
             sbox(s[0]); sbox(s[1]); sbox(s[2]);
-            const Fe(*mat)[3] = (r == RF / 2 - 1) ? pc.pre : pc.mds;
+            const Fe(*mat)[3] = (st == RF / 2 - 1) ? pc.pre : pc.mds;
             Fe n0, n1, n2;
             mont_dot<3, false>(n0, mat[0], s, s[0]);
             mont_dot<3, false>(n1, mat[1], s, s[0]);
             mont_dot<3, false>(n2, mat[2], s, s[0]);
             s[0] = n0; s[1] = n1; s[2] = n2;
         } else {
-            const int p = r - RF / 2;
-            Fe v[3], n0;
+            const int p = 2 * (st - RF / 2);
+            const bool second = p + 1 < RP;
+            Fe v[4], y[2], n0;
             add_lazy(v[0], s[0], pc.k_partial[p]);
             sbox(v[0]);
             v[1] = s[1]; v[2] = s[2];
             mont_dot<3, false>(n0, pc.sp_row[p], v, v[0]);
-            mont_dot<1, true>(s[1], &pc.sp_col[p][0], &v[0], s[1]);
-            mont_dot<1, true>(s[2], &pc.sp_col[p][1], &v[0], s[2]);
+            y[0] = v[0];
+#pragma unroll
+            for (int i = 0; i < NL; i++) y[1].v[i] = 0;
+            if (second) {
+                add_lazy(v[0], n0, pc.k_partial[p + 1]);
+                sbox(v[0]);
+                v[3] = y[0];
+                const Fe c4[4] = {pc.sp_row[p + 1][0], pc.sp_row[p + 1][1], pc.sp_row[p + 1][2], pc.sp_gamma[p + 1]};
+                mont_dot<4, false>(n0, c4, v, v[0]);
+                y[1] = v[0];
+            }
+            const int q = second ? p + 1 : p;    // with y[1] = 0 the second column constant is unused
+            const Fe c1[2] = {pc.sp_col[p][0], pc.sp_col[q][0]};
+            const Fe c2[2] = {pc.sp_col[p][1], pc.sp_col[q][1]};
+            mont_dot<2, true>(s[1], c1, y, s[1]);
+            mont_dot<2, true>(s[2], c2, y, s[2]);
             s[0] = n0;
         }
     }

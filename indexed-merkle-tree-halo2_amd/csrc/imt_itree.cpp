@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -382,12 +383,22 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
 
     const auto host_t0 = std::chrono::steady_clock::now();
     double host_wait_ms = 0;
+    static const bool trace = getenv("IMT_TRACE_HOST") != nullptr;
+    auto lap_t = host_t0;
+    double laps[10] = {0};
+    auto lap = [&](int k) {
+        if (!trace) return;
+        auto now = std::chrono::steady_clock::now();
+        laps[k] += std::chrono::duration<double, std::milli>(now - lap_t).count();
+        lap_t = now;
+    };
     // ---- 1. values, canonical, on the host.  With device pointers they are read on the side
     //         stream, so the call does not wait for an earlier batch still running. ----
     std::vector<U256> v;
     rc = fetch_canonical(c, dev ? t->up_stream : c->stream, vals, n, flags, v);
     if (rc) return rc;
 
+    lap(0);
     // ---- 2. low leaf of every insertion (update_idx_leaf :639-658, as a predecessor search):
     //         sort the batch, locate each value between two stored leaves, then unlink the batch
     //         from that list in reverse insertion order: what is adjacent at unlink time is
@@ -440,6 +451,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         if (nxt[r] >= 0) prv[nxt[r]] = prv[r];
     }
 
+    lap(1);
     // ---- 3. plan buffers ----
     const size_t E = 2 * n;
     const unsigned L0 = std::min(ceil_log2(M + n), t->depth);
@@ -457,6 +469,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     uint32_t *h_node = h_tab, *h_time = h_tab + P.cap_events, *h_rs = h_tab + 2 * P.cap_events,
              *h_re = h_tab + 3 * P.cap_events;
 
+    lap(2);
     // ---- 4. events: preimages at every time step + host-side outputs ----
     std::vector<uint64_t>& o_low = t->w_low;
     std::vector<uint8_t>& o_largest = t->w_largest;
@@ -483,6 +496,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         keys[2 * i] = (low << 32) | (uint64_t)(2 * i);
         keys[2 * i + 1] = ((M + i) << 32) | (uint64_t)(2 * i + 1);
     }
+    lap(3);
     {   // stable LSD radix sort on the 32-bit position (two 16-bit passes); events are already in time order
         std::vector<uint64_t>& tmp = t->w_keys2;
         std::vector<uint32_t>& hist = t->w_hist;
@@ -512,6 +526,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         k = j;
     }
 
+    lap(4);
     // ---- 5. upload on the side stream; the compute stream waits for it ----
     IMT_HIP(c, hipMemcpyAsync(P.d_pre, h_pre, E * 96, hipMemcpyHostToDevice, t->up_stream));
     IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][0], h_node, E * 4, hipMemcpyHostToDevice, t->up_stream));
@@ -543,6 +558,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     }
     launch::SibLayout lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->depth} : launch::SibLayout{n, 1};
 
+    lap(5);
     // ---- 7. leaf hashes, index phase (no hashing), then the hash sweep ----
     // (the leaf kernel reads the level-0 time table before the merges recycle that buffer)
     int pf = c->prof_begin(IMT_PROF_LEAVES);
@@ -581,6 +597,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     P.in_flight = true;
     t->cur ^= 1;
 
+    lap(6);
     // ---- 8. host mirror ----
     t->pre.resize(M + n);
     for (size_t i = 0; i < n; i++) {
@@ -608,6 +625,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     }
     t->size = M + n;
 
+    lap(7);
     // ---- 9. outputs ----
     if (out) {
         auto host_out = [&](void* user, const void* src, size_t bytes) -> int {
@@ -648,6 +666,10 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
             if (out->new_sib) IMT_HIP(c, hipMemcpyAsync(out->new_sib, g_ns, sib_bytes, hipMemcpyDeviceToHost, s));
         }
     }
+    lap(8);
+    if (trace)
+        fprintf(stderr, "[imt host] fetch %.2f search %.2f plan(wait incl) %.2f events %.2f sort %.2f upload %.2f launch %.2f mirror %.2f outputs %.2f ms\n",
+                laps[0], laps[1], laps[2], laps[3], laps[4], laps[5], laps[6], laps[7], laps[8]);
     if (c->profiling) {
         c->prof_ms[IMT_PROF_HOST] +=
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count() - host_wait_ms;

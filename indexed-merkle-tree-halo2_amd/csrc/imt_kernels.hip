@@ -284,9 +284,17 @@ __global__ void __launch_bounds__(BLOCK) k_tree_level(const uint8_t* __restrict_
     store_packed(next + i * 32, o);
 }
 
+// keeps a wave-uniform chain on the vector ALU: hipcc otherwise runs an all-constant chain on the
+// scalar unit, where one hash takes ~1.6 ms (64 of them made context creation take 100 ms)
+__device__ __forceinline__ void force_vector(Fe& x) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) asm volatile("" : "+v"(x.v[i]));
+}
+
 __global__ void k_zero_chain(uint8_t* out, unsigned depth) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Fe cur = g_pc.zero_leaf;
+    force_vector(cur);
     store_packed(out, cur);
 #pragma unroll 1
     for (unsigned l = 0; l < depth; l++) {
@@ -301,6 +309,7 @@ __global__ void k_extend_root(uint8_t* cur_io, const uint8_t* zero, unsigned fro
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Fe cur;
     load_packed(cur, cur_io);
+    force_vector(cur);
 #pragma unroll 1
     for (unsigned l = from; l < to; l++) {
         Fe z, o;

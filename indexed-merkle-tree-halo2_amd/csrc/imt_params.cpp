@@ -237,6 +237,9 @@ void HostPoseidon::fill_consts(dev::PoseidonConsts& pc) const {
     pc.rc_h2p2[0] = to_dev(rc_full[0][0]);
     pc.rc_h2p2[1] = to_dev(F.add(rc_full[0][1], F.one()));
     pc.rc_h2p2[2] = to_dev(rc_full[0][2]);
+    pc.sp_gamma[0] = to_dev(F.zero());
+    for (int p = 1; p < 57; p++)
+        pc.sp_gamma[p] = to_dev(F.add(F.mul(sp_row[p][1], sp_col[p - 1][0]), F.mul(sp_row[p][2], sp_col[p - 1][1])));
     for (int p = 0; p < 57; p++) {
         pc.k_partial[p] = to_dev(k_partial[p]);
         for (int i = 0; i < 3; i++) pc.sp_row[p][i] = to_dev(sp_row[p][i]);

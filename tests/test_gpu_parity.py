@@ -320,6 +320,54 @@ def test_insert_witness_batch_vs_oracle(imt, ctx, oracle):
     assert not np.delete(fail, [3, 4]).any()
 
 
+def test_device_pointer_mode_matches_host_mode(imt, ctx):
+    """IMT_DEVICE_PTRS (what bench.py uses): torch-allocated buffers, asynchronous on torch's stream,
+    pipelined over 3 batches, halo2curves Montgomery format in and out."""
+    import ctypes
+    import torch
+    depth, n, R = 32, 512, 1 << 256
+    vals = oracle_lib.synth_values(3 * n, 0x494D5405)
+    t_host = imt.IndexedTree(ctx, depth, 4096)
+    want = [t_host.insert_batch(vals[i * n:(i + 1) * n]) for i in range(3)]
+    c2 = imt.Context(0)
+    c2.set_stream(torch.cuda.current_stream().cuda_stream)
+    t_dev = imt.IndexedTree(c2, depth, 4096)
+    dev = torch.device("cuda", 0)
+    vm = torch.from_numpy(ints_to_arr([v * R % P for v in vals])).to(dev)
+    outs = []
+    flags = imt._ffi.DEVICE_PTRS | imt._ffi.FMT_MONT256
+    for i in range(3):
+        b = dict(low_index=torch.empty(n, dtype=torch.int64, device=dev),
+                 is_largest=torch.empty(n, dtype=torch.uint8, device=dev),
+                 low_leaf=torch.empty((n, 3, 32), dtype=torch.uint8, device=dev),
+                 new_leaf=torch.empty((n, 3, 32), dtype=torch.uint8, device=dev),
+                 old_root=torch.empty((n, 32), dtype=torch.uint8, device=dev),
+                 interim_root=torch.empty((n, 32), dtype=torch.uint8, device=dev),
+                 new_root=torch.empty((n, 32), dtype=torch.uint8, device=dev),
+                 low_sib=torch.empty((depth, n, 32), dtype=torch.uint8, device=dev),
+                 new_sib=torch.empty((depth, n, 32), dtype=torch.uint8, device=dev))
+        o = imt._ffi.InsertOut(**{k: v.data_ptr() for k, v in b.items()})
+        rc = imt.lib.imt_itree_insert_batch(t_dev.h, ctypes.c_void_p(vm.data_ptr() + i * n * 32), n, ctypes.byref(o), flags)
+        assert rc == 0, imt.lib.imt_last_error(c2.h)
+        outs.append(b)
+    c2.sync()
+    torch.cuda.synchronize()
+    to_mont = lambda a: [x * R % P for x in ints(a)]
+    for i in range(3):
+        for k in ("old_root", "interim_root", "new_root"):
+            assert ints(outs[i][k].cpu().numpy()) == to_mont(want[i][k]), (i, k)
+        for k in ("low_leaf", "new_leaf"):
+            assert ints(outs[i][k].cpu().numpy()) == to_mont(want[i][k]), (i, k)
+        assert (outs[i]["low_index"].cpu().numpy().astype(np.uint64) == want[i]["low_index"]).all()
+        assert (outs[i]["is_largest"].cpu().numpy() == want[i]["is_largest"]).all()
+        for k in ("low_sib", "new_sib"):
+            got = outs[i][k].cpu().numpy()
+            assert ints(got[:, ::37]) == to_mont(want[i][k][:, ::37]), (i, k)
+    assert t_dev.root() == t_host.root()
+    t_dev.close()
+    c2.close()
+
+
 def test_combine_subtree_roots(imt, ctx, oracle):
     rng = random.Random(41)
     leaves = ints_to_arr([rng.randrange(P) for _ in range(64)])
