@@ -37,7 +37,7 @@ P = 2188824287183927522224640574525727508854836440041603434369820418657580849561
 BYTES_PER_INSERTION = 2320          # 2 paths x (32*32 + 96 + 8 + 32)
 HASHES_PER_INSERTION = 66           # 2 + 2*32
 BYTES_PER_PATH_LEVEL = 1160.0 / 33  # one event, one level: a path's 1160 B spread over its 33 hashes
-MADS_PER_HASH = 2 * 78246           # v_mad_u64_u32 per 2-permutation hash (instruction counts)
+MADS_PER_HASH = 2 * 76140           # v_mad_u64_u32 per 2-permutation hash
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GMADS = 36443.0           # measured v_mad_u64_u32 lane-ops/ns (profiles/r01_valu_rates.txt, 8 waves/SIMD)
 # HBM bytes of one k_sweep_level launch at E = 2^17 events from the PMC passes in
@@ -143,6 +143,7 @@ def main():
                 low_sib=torch.empty((depth, BATCH, 32), **u8), new_sib=torch.empty((depth, BATCH, 32), **u8))
     out = _ffi.InsertOut(**{name: t.data_ptr() for name, t in bufs.items()})
     flags = _ffi.DEVICE_PTRS | _ffi.FMT_CANONICAL
+    ins_flags = flags | (0 if os.environ.get("IMT_NO_PIPELINE") else _ffi.PIPELINE)
     roots_all = torch.empty((world, 32), **u8)
     root_buf = torch.empty(32, **u8)
     top_root = torch.empty(32, **u8)
@@ -152,7 +153,7 @@ def main():
     def step(i):
         th = time.perf_counter()
         rc = lib.imt_itree_insert_batch(tree.h, ctypes.c_void_p(vals.data_ptr() + i * BATCH * 32), BATCH,
-                                        ctypes.byref(out), flags)
+                                        ctypes.byref(out), ins_flags)
         host_s[0] += time.perf_counter() - th
         if rc != 0:
             raise RuntimeError(f"imt_itree_insert_batch: {rc} {lib.imt_last_error(ctx.h).decode()}")
@@ -226,7 +227,10 @@ def main():
             "valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep_level",
                      "achieved_gmads": hashes_per_s * MADS_PER_HASH / 1e9, "peak_gmads": VALU_PEAK_GMADS,
                      "frac": hashes_per_s * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS,
-                     "hashes_per_s": hashes_per_s},
+                     "hashes_per_s": hashes_per_s,
+                     "whole_step_frac": value / world * (2 + 2 * depth) * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS,
+                     "note": "per-kernel figures include time shared with the pipelined k_sweep_top of the "
+                             "previous batch; whole_step_frac = all hashes of the step / wall time"},
             "kernels": kern, "gpu_kernel_ms_per_step": gpu_ms / args.steps,
             "host_call_ms_per_step": host_s[0] / args.steps * 1e3,
             "host_prepare_ms_per_step": kern["host_prepare"]["ms_total"] / args.steps,

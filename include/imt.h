@@ -65,6 +65,11 @@ extern "C" {
 #define IMT_DEVICE_PTRS 0x10u
 #define IMT_SIB_ITEM_MAJOR 0x20u
 #define IMT_ROOT_PER_ITEM 0x40u   /* root argument is root[n][32] instead of one root[32] */
+#define IMT_PIPELINE 0x80u        /* imt_itree_insert_batch with IMT_DEVICE_PTRS only: consecutive batches run on two
+                                     internal streams one tree level apart, so two hash kernels share the GPU.
+                                     The outputs of such a batch are ordered by imt_ctx_sync() (or by the next
+                                     imt_itree_root / get_proof / non-pipelined call on the tree), not by
+                                     the context's stream. */
 
 /* failure bits written per item by the relation checkers; each is one constraint or
  * assert of the reference (src/indexed_merkle_tree.rs) */

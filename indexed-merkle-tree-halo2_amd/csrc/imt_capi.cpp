@@ -60,16 +60,16 @@ hipEvent_t imt_ctx::prof_event() {
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
-int imt_ctx::prof_begin(int cls) {
+int imt_ctx::prof_begin(int cls, hipStream_t on) {
     if (!profiling) return -1;
     ProfPair p{prof_event(), prof_event(), cls};
     if (!p.a || !p.b) return -1;
-    (void)hipEventRecord(p.a, stream);
+    (void)hipEventRecord(p.a, on ? on : stream);
     prof_pending.push_back(p);
     return (int)prof_pending.size() - 1;
 }
-void imt_ctx::prof_end(int idx) {
-    if (idx >= 0) (void)hipEventRecord(prof_pending[(size_t)idx].b, stream);
+void imt_ctx::prof_end(int idx, hipStream_t on) {
+    if (idx >= 0) (void)hipEventRecord(prof_pending[(size_t)idx].b, on ? on : stream);
 }
 
 extern "C" int imt_profile_enable(imt_ctx* c, int on) {
@@ -82,6 +82,7 @@ extern "C" int imt_profile_read(imt_ctx* c, double* out) {
     int rc = c->set_device();
     if (rc) return rc;
     IMT_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto st : c->side_streams) IMT_HIP(c, hipStreamSynchronize(st));
     for (auto& p : c->prof_pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -161,6 +162,7 @@ extern "C" int imt_ctx_sync(imt_ctx* c) {
     if (!c) return IMT_ERR_ARG;
     int rc = c->set_device();
     if (rc) return rc;
+    for (auto st : c->side_streams) IMT_HIP(c, hipStreamSynchronize(st));
     return c->sync_and_check();
 }
 

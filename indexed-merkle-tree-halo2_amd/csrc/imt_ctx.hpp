@@ -30,8 +30,9 @@ struct imt_ctx {
     double prof_n[IMT_PROF_CLASSES] = {0};
     hipEvent_t prof_event();
     // RAII-less helpers: begin returns an index into prof_pending (or -1 when off)
-    int prof_begin(int cls);
-    void prof_end(int idx);
+    int prof_begin(int cls, hipStream_t on = nullptr);
+    void prof_end(int idx, hipStream_t on = nullptr);
+    std::vector<hipStream_t> side_streams;   // internal streams imt_ctx_sync must also drain
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];

@@ -62,8 +62,11 @@ struct PlanSet {
     uint32_t* d_nodeb = nullptr;
     uint32_t* d_timen = nullptr; // [levels][E] time table of level l+1
     uint8_t* d_val[2] = {nullptr, nullptr};
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;           // recorded after the batch's last kernel
+    hipEvent_t wb_done[IMT_MAX_DEPTH + 1] = {nullptr};   // recorded after k_writeback of each level
     bool in_flight = false;
+    bool pipelined = false;              // ran on a pipeline stream (IMT_PIPELINE)
+    unsigned l0 = 0;                     // its L0
 };
 
 }  // namespace
@@ -78,10 +81,18 @@ struct imt_itree {
     uint64_t* d_len = nullptr;
     std::vector<Pre> pre;            // host mirror of the leaf preimages
     std::vector<SortedEnt> sorted;   // leaves ordered by val
-    PlanSet plan[2];
+    static constexpr int NSETS = 3;      // host work may run two batches ahead of the GPU
+    PlanSet plan[NSETS];
     int cur = 0;
+    uint64_t batch_no = 0;
     hipStream_t up_stream = nullptr;
     hipEvent_t up_done = nullptr;
+    // IMT_PIPELINE: consecutive batches alternate between two internal streams and run one level
+    // apart (batch k+1 sweeps level l once batch k has written level l back), so two hash kernels
+    // share the GPU and the SIMDs see twice the waves of a single 2^16 batch.
+    hipStream_t pipe_stream[2] = {nullptr, nullptr};
+    hipEvent_t user_mark = nullptr;  // position of the context's stream when a pipelined call starts
+    bool pipe_pending = false;       // pipelined work the context's stream has not been ordered behind
     // reusable host work arrays of insert_batch
     std::vector<uint32_t> w_ord, w_rank;
     std::vector<std::pair<uint64_t, uint32_t>> w_sortkey;
@@ -104,9 +115,10 @@ static void plan_free(PlanSet& p) {
     if (p.d_timen) hipFree(p.d_timen);
     for (auto& q : p.d_val)
         if (q) hipFree(q);
-    hipEvent_t ev = p.done;
-    p = PlanSet();
-    p.done = ev;
+    PlanSet keep;
+    keep.done = p.done;
+    for (int l = 0; l <= IMT_MAX_DEPTH; l++) keep.wb_done[l] = p.wb_done[l];
+    p = keep;
 }
 
 static int plan_reserve(imt_ctx* c, PlanSet& p, size_t events, unsigned levels) {
@@ -146,9 +158,19 @@ extern "C" void imt_itree_free(imt_itree* t) {
     for (auto& p : t->plan) {
         plan_free(p);
         if (p.done) hipEventDestroy(p.done);
+        for (auto& e : p.wb_done)
+            if (e) hipEventDestroy(e);
     }
     if (t->up_done) hipEventDestroy(t->up_done);
     if (t->up_stream) hipStreamDestroy(t->up_stream);
+    for (auto& ps : t->pipe_stream) {
+        if (!ps) continue;
+        hipStreamSynchronize(ps);
+        auto& ss = t->ctx->side_streams;
+        ss.erase(std::remove(ss.begin(), ss.end(), ps), ss.end());
+        hipStreamDestroy(ps);
+    }
+    if (t->user_mark) hipEventDestroy(t->user_mark);
     if (t->d_nodes) hipFree(t->d_nodes);
     if (t->d_off) hipFree(t->d_off);
     if (t->d_len) hipFree(t->d_len);
@@ -183,11 +205,23 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
         (e = hipMalloc((void**)&t->d_len, (depth + 1) * 8)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&t->up_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&t->up_done, hipEventDisableTiming)) != hipSuccess ||
+        // different priorities: the runtime may otherwise map both streams to one hardware queue, which
+        // serialises them (seen with rocprofv3: same Queue_Id, zero overlap)
+        (e = hipStreamCreateWithPriority(&t->pipe_stream[0], hipStreamNonBlocking, 0)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&t->pipe_stream[1], hipStreamNonBlocking, -1)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&t->user_mark, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&t->plan[0].done, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&t->plan[1].done, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&t->plan[1].done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&t->plan[2].done, hipEventDisableTiming)) != hipSuccess) {
         imt_itree_free(t);
         return c->hip_fail(e, "imt_itree_new allocation");
     }
+    for (auto& pl : t->plan)
+        for (unsigned l = 0; l <= depth; l++)
+            if ((e = hipEventCreateWithFlags(&pl.wb_done[l], hipEventDisableTiming)) != hipSuccess) {
+                imt_itree_free(t);
+                return c->hip_fail(e, "hipEventCreate");
+            }
     hipMemcpyAsync(t->d_off, t->h_off.data(), (depth + 1) * 8, hipMemcpyHostToDevice, c->stream);
     hipMemcpyAsync(t->d_len, t->h_len.data(), (depth + 1) * 8, hipMemcpyHostToDevice, c->stream);
     for (unsigned l = 0; l <= depth; l++)   // every stored node starts as the empty subtree of its height
@@ -200,7 +234,18 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
     t->pre.push_back(Pre{{0, 0, 0, 0}, {0, 0, 0, 0}, 0});
     t->sorted.push_back(SortedEnt{0, 0});
     t->size = 1;
+    c->side_streams.push_back(t->pipe_stream[0]);
+    c->side_streams.push_back(t->pipe_stream[1]);
     *out = t;
+    return IMT_OK;
+}
+
+// order the context's stream behind every pipelined batch still in flight
+static int join_top(imt_itree* t) {
+    if (!t->pipe_pending) return IMT_OK;
+    for (auto& pl : t->plan)
+        if (pl.in_flight && pl.pipelined) IMT_HIP(t->ctx, hipStreamWaitEvent(t->ctx->stream, pl.done, 0));
+    t->pipe_pending = false;
     return IMT_OK;
 }
 
@@ -211,6 +256,7 @@ extern "C" int imt_itree_root(imt_itree* t, void* root, unsigned flags) {
     imt_ctx* c = t->ctx;
     int rc = c->set_device();
     if (rc) return rc;
+    if ((rc = join_top(t))) return rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     const uint8_t* src = t->d_nodes + t->h_off[t->depth] * 32;
     if (flags & IMT_DEVICE_PTRS) {
@@ -344,6 +390,7 @@ extern "C" int imt_itree_get_proof_batch(imt_itree* t, const uint64_t* index, si
     if (!dev)
         for (size_t i = 0; i < n; i++)
             if (index[i] >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
+    if ((rc = join_top(t))) return rc;
     const unsigned depth = t->depth;
     const uint64_t* d_idx = index;
     uint8_t* d_out = (uint8_t*)sib;
@@ -456,7 +503,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     const size_t E = 2 * n;
     const unsigned L0 = std::min(ceil_log2(M + n), t->depth);
     PlanSet& P = t->plan[t->cur];
-    if (P.in_flight) {   // back-pressure: at most two batches in flight
+    if (P.in_flight) {   // back-pressure: at most NSETS batches in flight
         const auto w0 = std::chrono::steady_clock::now();
         IMT_HIP(c, hipEventSynchronize(P.done));
         host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
@@ -534,7 +581,19 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][2], h_rs, E * 4, hipMemcpyHostToDevice, t->up_stream));
     IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][3], h_re, E * 4, hipMemcpyHostToDevice, t->up_stream));
     IMT_HIP(c, hipEventRecord(t->up_done, t->up_stream));
+    const bool pipelined = dev && (flags & IMT_PIPELINE);
     hipStream_t s = c->stream;
+    const PlanSet* prev = nullptr;      // the batch before this one, if it is still on a pipeline stream
+    if (pipelined) {
+        s = t->pipe_stream[t->batch_no & 1];
+        IMT_HIP(c, hipEventRecord(t->user_mark, c->stream));     // inputs produced on the user's stream
+        IMT_HIP(c, hipStreamWaitEvent(s, t->user_mark, 0));
+        const PlanSet& o = t->plan[(t->cur + imt_itree::NSETS - 1) % imt_itree::NSETS];
+        if (o.in_flight && o.pipelined) prev = &o;
+        t->pipe_pending = true;
+    } else {
+        if ((rc = join_top(t))) return rc;
+    }
     IMT_HIP(c, hipStreamWaitEvent(s, t->up_done, 0));
 
     // ---- 6. GPU outputs ----
@@ -561,41 +620,51 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     lap(5);
     // ---- 7. leaf hashes, index phase (no hashing), then the hash sweep ----
     // (the leaf kernel reads the level-0 time table before the merges recycle that buffer)
-    int pf = c->prof_begin(IMT_PROF_LEAVES);
+    int pf = c->prof_begin(IMT_PROF_LEAVES, s);
     launch::sweep_leaves(s, P.d_pre, P.d_tab[0][1], P.d_val[0], 0, (uint32_t)E, IMT_FMT_CANONICAL, c->d_err);
-    c->prof_end(pf);
-    pf = c->prof_begin(IMT_PROF_INDEX);
+    c->prof_end(pf, s);
+    pf = c->prof_begin(IMT_PROF_INDEX, s);
     for (unsigned l = 0; l < L0; l++) {
         const int a = l & 1, b = a ^ 1;
-        sweep::LevelTable in{P.d_tab[a][0], P.d_tab[a][1], P.d_tab[a][2], P.d_tab[a][3]};
-        sweep::LevelOut o{P.d_tab[b][0], P.d_tab[b][1], P.d_tab[b][2], P.d_tab[b][3],
+        // time table of level l: the uploaded one for l = 0, otherwise slot l-1 of d_timen
+        const uint32_t* time_in = l == 0 ? P.d_tab[0][1] : P.d_timen + (size_t)(l - 1) * P.cap_events;
+        sweep::LevelTable in{P.d_tab[a][0], time_in, P.d_tab[a][2], P.d_tab[a][3]};
+        sweep::LevelOut o{P.d_tab[b][0], P.d_timen + (size_t)l * P.cap_events, P.d_tab[b][2], P.d_tab[b][3],
                           P.d_from + (size_t)l * P.cap_events, P.d_sibsrc + (size_t)l * P.cap_events,
                           P.d_nodeb + (size_t)l * P.cap_events};
         launch::merge_level(s, in, o, (uint32_t)E);
-        IMT_HIP(c, hipMemcpyAsync(P.d_timen + (size_t)l * P.cap_events, P.d_tab[b][1], E * 4, hipMemcpyDeviceToDevice, s));
     }
-    c->prof_end(pf);
+    c->prof_end(pf, s);
     for (unsigned l = 0; l < L0; l++) {
         const uint8_t* vin = P.d_val[l & 1];
         uint8_t* vout = P.d_val[(l & 1) ^ 1];
         const size_t o = (size_t)l * P.cap_events;
-        pf = c->prof_begin(IMT_PROF_LEVEL);
+        // stored level l must hold the previous batch's final versions: its write-back of that level,
+        // or (at and above its L0) its top kernel
+        if (prev) IMT_HIP(c, hipStreamWaitEvent(s, l < prev->l0 ? prev->wb_done[l] : prev->done, 0));
+        pf = c->prof_begin(IMT_PROF_LEVEL, s);
         launch::sweep_level(s, vin, vout, P.d_from + o, P.d_sibsrc + o, P.d_nodeb + o, P.d_timen + o,
                             t->d_nodes + t->h_off[l] * 32, t->h_len[l], c->d_zero + (size_t)l * 32, 0, (uint32_t)E, g_ls,
                             g_ns, lay, l, fmt);
-        c->prof_end(pf);
-        pf = c->prof_begin(IMT_PROF_WRITEBACK);
+        c->prof_end(pf, s);
+        pf = c->prof_begin(IMT_PROF_WRITEBACK, s);
         launch::writeback(s, vin, P.d_from + o, P.d_nodeb + o, t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
-        c->prof_end(pf);
+        c->prof_end(pf, s);
+        if (pipelined) IMT_HIP(c, hipEventRecord(P.wb_done[l], s));
     }
+    // the top kernel reads the stored root (old_root[0]) and rewrites the stored upper levels
+    if (prev) IMT_HIP(c, hipStreamWaitEvent(s, prev->done, 0));
     if (g_old) launch::convert(s, t->d_nodes + t->h_off[t->depth] * 32, g_old, 1, IMT_FMT_DEVICE, fmt, c->d_err);
-    pf = c->prof_begin(IMT_PROF_TOP);
+    pf = c->prof_begin(IMT_PROF_TOP, s);
     launch::sweep_top(s, P.d_val[L0 & 1], L0, t->depth, c->d_zero, t->d_nodes, t->d_off, 0, (uint32_t)E, (uint32_t)E,
                       g_old, g_int, g_new, g_ls, g_ns, lay, fmt);
-    c->prof_end(pf);
+    c->prof_end(pf, s);
     IMT_HIP(c, hipEventRecord(P.done, s));
+    P.pipelined = pipelined;
+    P.l0 = L0;
     P.in_flight = true;
-    t->cur ^= 1;
+    t->cur = (t->cur + 1) % imt_itree::NSETS;
+    t->batch_no++;
 
     lap(6);
     // ---- 8. host mirror ----

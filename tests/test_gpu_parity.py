@@ -335,7 +335,7 @@ def test_device_pointer_mode_matches_host_mode(imt, ctx):
     dev = torch.device("cuda", 0)
     vm = torch.from_numpy(ints_to_arr([v * R % P for v in vals])).to(dev)
     outs = []
-    flags = imt._ffi.DEVICE_PTRS | imt._ffi.FMT_MONT256
+    flags = imt._ffi.DEVICE_PTRS | imt._ffi.FMT_MONT256 | imt._ffi.PIPELINE   # top kernel on its own stream
     for i in range(3):
         b = dict(low_index=torch.empty(n, dtype=torch.int64, device=dev),
                  is_largest=torch.empty(n, dtype=torch.uint8, device=dev),

@@ -7,7 +7,7 @@ from imt_amd import _ffi
 ctx = imt_amd.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 dev = torch.device("cuda", 0)
-for lg in (15, 16, 17, 18, 19, 20, 21):
+for lg in [int(x) for x in os.environ.get("LGS", "15,16,17,18,19,20,21").split(",")]:
     n = 1 << lg
     a = torch.randint(0, 256, (n, 2, 32), dtype=torch.uint8, device=dev)
     a[:, :, 31] &= 0x0f
