@@ -129,9 +129,9 @@ def main():
     k = world.bit_length() - 1
     depth = DEPTH - k
     steps_total = args.warmup + args.steps
-    cap = 1 << (steps_total * BATCH).bit_length()
+    cap = 1 << ((steps_total + 2) * BATCH).bit_length()
     tree = imt_amd.IndexedTree(ctx, depth, cap)
-    vals_h = synth_values(steps_total * BATCH, rank, world, 0x494D5402 + rank)
+    vals_h = synth_values((steps_total + 2) * BATCH, rank, world, 0x494D5402 + rank)
     dev = torch.device("cuda", local_rank)
     vals = torch.from_numpy(vals_h).to(dev)
 
@@ -151,22 +151,29 @@ def main():
     host_s = [0.0]
 
     def step(i):
+        nonlocal ins_flags
         th = time.perf_counter()
         rc = lib.imt_itree_insert_batch(tree.h, ctypes.c_void_p(vals.data_ptr() + i * BATCH * 32), BATCH,
                                         ctypes.byref(out), ins_flags)
         host_s[0] += time.perf_counter() - th
         if rc != 0:
             raise RuntimeError(f"imt_itree_insert_batch: {rc} {lib.imt_last_error(ctx.h).decode()}")
-        if world > 1:   # the path's one exchange: subtree roots, then the top k levels on every rank
-            ctx._check(lib.imt_itree_root(tree.h, ctypes.c_void_p(root_buf.data_ptr()), flags))
-            if backend == "nccl":
-                dist.all_gather_into_tensor(roots_all, root_buf)
-            else:   # rehearsal only
-                parts = [torch.empty(32, dtype=torch.uint8) for _ in range(world)]
-                dist.all_gather(parts, root_buf.cpu())
-                roots_all.copy_(torch.stack(parts))
-            ctx._check(lib.imt_combine_subtree_roots(ctx.h, ctypes.c_void_p(roots_all.data_ptr()), world, depth,
-                                                     DEPTH, ctypes.c_void_p(top_root.data_ptr()), flags))
+        if world > 1 and i > 0:
+            # the path's one exchange: subtree roots, then the top k levels on every rank.  It runs one
+            # step behind (the root after batch i-1) so that it waits for a finished batch instead of
+            # stalling the two in flight; the last batch's root is exchanged after the loop.
+            exchange(1)
+
+    def exchange(lag):
+        ctx._check(lib.imt_itree_root_lagged(tree.h, lag, ctypes.c_void_p(root_buf.data_ptr()), flags))
+        if backend == "nccl":
+            dist.all_gather_into_tensor(roots_all, root_buf)
+        else:   # rehearsal only
+            parts = [torch.empty(32, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, root_buf.cpu())
+            roots_all.copy_(torch.stack(parts))
+        ctx._check(lib.imt_combine_subtree_roots(ctx.h, ctypes.c_void_p(roots_all.data_ptr()), world, depth, DEPTH,
+                                                 ctypes.c_void_p(top_root.data_ptr()), flags))
 
     def sync():
         ctx.sync()
@@ -182,10 +189,25 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, steps_total):
         step(i)
+    if world > 1:
+        exchange(0)
     sync()
     dt = time.perf_counter() - t0
     prof = (ctypes.c_double * 12)()
     lib.imt_profile_read(ctx.h, prof)
+    # Kernel attribution pass (not part of `value`): two more steps WITHOUT IMT_PIPELINE, so that each
+    # kernel has the GPU to itself and its HIP-event duration is a clean roofline input.  In the timed
+    # region two hash kernels of consecutive batches share the SIMDs and stretch each other.
+    b2b = (ctypes.c_double * 12)()
+    extra = 2 if steps_total + 2 <= vals.shape[0] // BATCH else 0
+    if extra:
+        saved = ins_flags
+        ins_flags = flags
+        for i in range(steps_total, steps_total + extra):
+            step(i)
+        sync()
+        lib.imt_profile_read(ctx.h, b2b)
+        ins_flags = saved
     lib.imt_profile_enable(ctx.h, 0)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -201,6 +223,7 @@ def main():
         # dominant kernel by time: one k_sweep_level launch hashes 2*BATCH events up one level
         lv = kern["k_sweep_level"]
         avg_ms = lv["ms_total"] / max(lv["launches"], 1)
+        b2b_avg_ms = b2b[4] / b2b[5] if b2b[5] else None
         alg_bytes = 2 * BATCH * BYTES_PER_PATH_LEVEL
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         hashes_per_s = 2 * BATCH / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
@@ -223,6 +246,11 @@ def main():
                                            "index tables and the proof store are counted, the 35 B/hash algorithmic "
                                            "figure counts only path inputs)",
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "back_to_back": None if not b2b_avg_ms else {
+                             "avg_launch_ms": b2b_avg_ms, "achieved": alg_bytes / (b2b_avg_ms * 1e-3) / 1e9,
+                             "frac": alg_bytes / (b2b_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "valu_frac": 2 * BATCH / (b2b_avg_ms * 1e-3) * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS,
+                             "what": "2 extra un-pipelined steps after the timed region: the kernel alone on the GPU"},
                          "note": "declared HBM per the contract; the kernel is integer-VALU bound, see valu"},
             "valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep_level",
                      "achieved_gmads": hashes_per_s * MADS_PER_HASH / 1e9, "peak_gmads": VALU_PEAK_GMADS,

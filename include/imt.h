@@ -196,6 +196,10 @@ int imt_itree_new(imt_ctx *ctx, unsigned depth, uint64_t capacity, imt_itree **o
 void imt_itree_free(imt_itree *t);
 uint64_t imt_itree_size(const imt_itree *t);      /* leaves in use, sentinel included */
 int imt_itree_root(imt_itree *t, void *root /*[32]*/, unsigned flags);
+/* Root as it was after the batch inserted `lag` calls ago (0 = the latest batch, 1 = the one before;
+ * lag <= 1).  Orders the context's stream behind THAT batch only, so with IMT_PIPELINE a root
+ * exchange that lags one step does not stall the batches still in flight. */
+int imt_itree_root_lagged(imt_itree *t, unsigned lag, void *root /*[32]*/, unsigned flags);
 
 /* outputs of a batch insertion; every pointer may be NULL; host or device per flags */
 typedef struct imt_insert_out {

@@ -62,6 +62,7 @@ SIGNATURES = {
     "imt_itree_free": (None, [c_void_p]),
     "imt_itree_size": (c_u64, [c_void_p]),
     "imt_itree_root": (c_int, [c_void_p, c_void_p, c_uint]),
+    "imt_itree_root_lagged": (c_int, [c_void_p, c_uint, c_void_p, c_uint]),
     "imt_itree_insert_batch": (c_int, [c_void_p, c_void_p, c_size_t, P(InsertOut), c_uint]),
     "imt_itree_get_proof_batch": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
     "imt_itree_get_leaves": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),

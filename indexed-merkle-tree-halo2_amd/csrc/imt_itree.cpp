@@ -62,6 +62,8 @@ struct PlanSet {
     uint32_t* d_nodeb = nullptr;
     uint32_t* d_timen = nullptr; // [levels][E] time table of level l+1
     uint8_t* d_val[2] = {nullptr, nullptr};
+    uint8_t* d_root = nullptr;           // stored root right after this batch (device format)
+    bool has_root = false;
     hipEvent_t done = nullptr;           // recorded after the batch's last kernel
     hipEvent_t wb_done[IMT_MAX_DEPTH + 1] = {nullptr};   // recorded after k_writeback of each level
     bool in_flight = false;
@@ -115,6 +117,7 @@ static void plan_free(PlanSet& p) {
     if (p.d_timen) hipFree(p.d_timen);
     for (auto& q : p.d_val)
         if (q) hipFree(q);
+    if (p.d_root) hipFree(p.d_root);
     PlanSet keep;
     keep.done = p.done;
     for (int l = 0; l <= IMT_MAX_DEPTH; l++) keep.wb_done[l] = p.wb_done[l];
@@ -141,6 +144,7 @@ static int plan_reserve(imt_ctx* c, PlanSet& p, size_t events, unsigned levels) 
     A((void**)&p.d_timen, (size_t)L * E * 4);
     A((void**)&p.d_val[0], E * 32);
     A((void**)&p.d_val[1], E * 32);
+    A((void**)&p.d_root, 32);
     if (e != hipSuccess) {
         plan_free(p);
         return c->hip_fail(e, "hipMalloc(plan)");
@@ -266,6 +270,29 @@ extern "C" int imt_itree_root(imt_itree* t, void* root, unsigned flags) {
     uint8_t* d = (uint8_t*)c->dev_scratch(0, 32);
     if (!d) return IMT_ERR_HIP;
     launch::convert(c->stream, src, d, 1, IMT_FMT_DEVICE, fmt, c->d_err);
+    IMT_HIP(c, hipMemcpyAsync(root, d, 32, hipMemcpyDeviceToHost, c->stream));
+    IMT_HIP(c, hipStreamSynchronize(c->stream));
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_root_lagged(imt_itree* t, unsigned lag, void* root, unsigned flags) {
+    if (!t || !root) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (lag > 1) return c->fail(IMT_ERR_RANGE, "lag must be 0 or 1");
+    int rc = c->set_device();
+    if (rc) return rc;
+    if (t->batch_no <= lag) return c->fail(IMT_ERR_RANGE, "no batch %u calls ago", lag);
+    const PlanSet& P = t->plan[(t->cur + 2 * imt_itree::NSETS - 1 - (int)lag) % imt_itree::NSETS];
+    if (!P.has_root) return c->fail(IMT_ERR_INTERNAL, "batch root not recorded");
+    IMT_HIP(c, hipStreamWaitEvent(c->stream, P.done, 0));
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    if (flags & IMT_DEVICE_PTRS) {
+        launch::convert(c->stream, P.d_root, (uint8_t*)root, 1, IMT_FMT_DEVICE, fmt, c->d_err);
+        return IMT_OK;
+    }
+    uint8_t* d = (uint8_t*)c->dev_scratch(0, 32);
+    if (!d) return IMT_ERR_HIP;
+    launch::convert(c->stream, P.d_root, d, 1, IMT_FMT_DEVICE, fmt, c->d_err);
     IMT_HIP(c, hipMemcpyAsync(root, d, 32, hipMemcpyDeviceToHost, c->stream));
     IMT_HIP(c, hipStreamSynchronize(c->stream));
     return IMT_OK;
@@ -659,6 +686,8 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     launch::sweep_top(s, P.d_val[L0 & 1], L0, t->depth, c->d_zero, t->d_nodes, t->d_off, 0, (uint32_t)E, (uint32_t)E,
                       g_old, g_int, g_new, g_ls, g_ns, lay, fmt);
     c->prof_end(pf, s);
+    IMT_HIP(c, hipMemcpyAsync(P.d_root, t->d_nodes + t->h_off[t->depth] * 32, 32, hipMemcpyDeviceToDevice, s));
+    P.has_root = true;
     IMT_HIP(c, hipEventRecord(P.done, s));
     P.pipelined = pipelined;
     P.l0 = L0;

@@ -363,6 +363,12 @@ def test_device_pointer_mode_matches_host_mode(imt, ctx):
         for k in ("low_sib", "new_sib"):
             got = outs[i][k].cpu().numpy()
             assert ints(got[:, ::37]) == to_mont(want[i][k][:, ::37]), (i, k)
+    # lagged roots: after 3 batches, lag 0 / 1 are the roots after batch 3 / batch 2
+    for lag, want_root in ((0, want[2]["new_root"][-1]), (1, want[1]["new_root"][-1])):
+        buf = np.empty(32, np.uint8)
+        assert imt.lib.imt_itree_root_lagged(t_dev.h, lag, buf.ctypes.data_as(ctypes.c_void_p), 0) == 0
+        assert (buf == want_root).all()
+    assert imt.lib.imt_itree_root_lagged(t_dev.h, 2, buf.ctypes.data_as(ctypes.c_void_p), 0) == imt._ffi.ERR["RANGE"]
     assert t_dev.root() == t_host.root()
     t_dev.close()
     c2.close()
