@@ -228,6 +228,13 @@ int imt_itree_get_proof_batch(imt_itree *t, const uint64_t *index, size_t n, voi
 /* preimages of n leaves */
 int imt_itree_get_leaves(imt_itree *t, const uint64_t *index, size_t n, void *preimage /*[n][3][32]*/,
                          unsigned flags);
+/* Checkpoint / resume and bulk build.  The snapshot of a tree is its leaf preimages in index order
+ * (imt_itree_get_leaves over [0, size)): the reference's serde leaf {val, next_val, next_idx}
+ * (src/utils.rs:12-17).  imt_itree_load replaces the tree's contents with n such leaves: it checks
+ * on the host that they form one sorted linked list starting at the {0,..} sentinel (IMT_ERR_VALUE
+ * otherwise), then rebuilds every stored level on the GPU (n leaf hashes + one pass of k_tree_level
+ * per level: about 2 hashes per leaf, the "final root only" build of SURVEY.md 8d). */
+int imt_itree_load(imt_itree *t, const void *preimages /*[n][3][32]*/, uint64_t n, unsigned flags);
 /* low leaf (greatest val < v) for n candidate values; IMT_ERR_VALUE if some v is 0 or present */
 int imt_itree_find_low_batch(imt_itree *t, const void *vals /*[n][32]*/, size_t n,
                              uint64_t *low_index /*[n]*/, unsigned flags);

@@ -372,6 +372,18 @@ class IndexedTree:
         self.ctx._check(lib.imt_itree_get_leaves(self.h, _p(idx), idx.size, _p(out), 0))
         return out
 
+    def snapshot(self):
+        """Leaf preimages [size, 3, 32] in index order: the checkpoint of the tree."""
+        return self.get_leaves(np.arange(self.size, dtype=np.uint64))
+
+    def load(self, preimages):
+        """Replace the contents with a snapshot (bulk rebuild on the GPU)."""
+        a = _arr(preimages, (3, 32))
+        rc = lib.imt_itree_load(self.h, _p(a), a.shape[0], 0)
+        if rc == _ffi.ERR["VALUE"]:
+            raise ValueError(lib.imt_last_error(self.ctx.h).decode())
+        self.ctx._check(rc)
+
     def find_low(self, vals):
         v = to_bytes(vals) if not isinstance(vals, np.ndarray) else _arr(vals, (32,))
         out = np.empty(v.shape[0], dtype=np.uint64)

@@ -438,6 +438,77 @@ extern "C" int imt_itree_get_proof_batch(imt_itree* t, const uint64_t* index, si
 }
 
 // ------------------------------------------------------------------------------------
+// snapshot load / bulk build
+// ------------------------------------------------------------------------------------
+extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (!preimages || n == 0) return c->fail(IMT_ERR_ARG, "null / empty snapshot");
+    if (n > t->cap) return c->fail(IMT_ERR_FULL, "snapshot has %llu leaves, capacity is %llu", (unsigned long long)n,
+                                   (unsigned long long)t->cap);
+    int rc = c->set_device();
+    if (rc) return rc;
+    if ((rc = join_top(t))) return rc;
+    for (auto& pl : t->plan)
+        if (pl.in_flight) { IMT_HIP(c, hipEventSynchronize(pl.done)); pl.in_flight = false; pl.pipelined = false; }
+    // canonical host copy (3 elements per leaf)
+    std::vector<U256> flat;
+    rc = fetch_canonical(c, c->stream, preimages, (size_t)n * 3, flags, flat);
+    if (rc) return rc;
+    // ---- list check: sorted by val, next pointers = successor in that order, last points to 0 ----
+    for (uint64_t i = 0; i < n; i++)
+        if (flat[3 * i + 2][1] | flat[3 * i + 2][2] | flat[3 * i + 2][3] || flat[3 * i + 2][0] >= n)
+            return c->fail(IMT_ERR_VALUE, "leaf %llu: next_idx out of range", (unsigned long long)i);
+    if (!is_zero256(flat[0])) return c->fail(IMT_ERR_VALUE, "leaf 0 must be the {0,..} sentinel");
+    std::vector<uint64_t> order(n);
+    std::iota(order.begin(), order.end(), (uint64_t)0);
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return lt256(flat[3 * a], flat[3 * b]); });
+    static const U256 ZERO = {0, 0, 0, 0};
+    for (uint64_t r = 0; r < n; r++) {
+        const uint64_t i = order[r];
+        if (r + 1 < n) {
+            const uint64_t j = order[r + 1];
+            if (flat[3 * i] == flat[3 * j]) return c->fail(IMT_ERR_VALUE, "duplicate value in snapshot");
+            if (!(flat[3 * i + 1] == flat[3 * j]) || flat[3 * i + 2][0] != j)
+                return c->fail(IMT_ERR_VALUE, "leaf %llu does not point to its successor", (unsigned long long)i);
+        } else if (!(flat[3 * i + 1] == ZERO) || flat[3 * i + 2][0] != 0) {
+            return c->fail(IMT_ERR_VALUE, "the largest leaf must have next_val = next_idx = 0");
+        }
+    }
+    // ---- device rebuild ----
+    hipStream_t s = c->stream;
+    if ((rc = c->clear_err())) return rc;
+    uint8_t* d_pre = (uint8_t*)c->dev_scratch(2, (size_t)n * 96);
+    if (!d_pre) return IMT_ERR_HIP;
+    IMT_HIP(c, hipMemcpyAsync(d_pre, flat.data(), (size_t)n * 96, hipMemcpyHostToDevice, s));
+    for (unsigned l = 0; l <= t->depth; l++)
+        launch::fill_level(s, t->d_nodes + t->h_off[l] * 32, t->h_len[l], c->d_zero + (size_t)l * 32);
+    launch::hash_batch(s, d_pre, t->d_nodes, (size_t)n, 3, IMT_FMT_CANONICAL, IMT_FMT_DEVICE, c->d_err);
+    uint64_t filled = n;
+    for (unsigned l = 0; l < t->depth; l++) {
+        const uint64_t parents = (filled + 1) / 2;
+        if (t->h_len[l] >= 2) {
+            launch::tree_level(s, t->d_nodes + t->h_off[l] * 32, t->d_nodes + t->h_off[l + 1] * 32, parents);
+        } else {   // a single stored node: its sibling is the empty subtree of this height
+            IMT_HIP(c, hipMemcpyAsync(t->d_nodes + t->h_off[l + 1] * 32, t->d_nodes + t->h_off[l] * 32, 32,
+                                      hipMemcpyDeviceToDevice, s));
+            launch::extend_root(s, t->d_nodes + t->h_off[l + 1] * 32, c->d_zero, l, l + 1);
+        }
+        filled = parents;
+    }
+    rc = c->sync_and_check();
+    if (rc) return rc;
+    // ---- host mirror ----
+    t->pre.resize(n);
+    t->sorted.resize(n);
+    for (uint64_t i = 0; i < n; i++) t->pre[i] = Pre{flat[3 * i], flat[3 * i + 1], flat[3 * i + 2][0]};
+    for (uint64_t r = 0; r < n; r++) t->sorted[r] = SortedEnt{flat[3 * order[r]][3], order[r]};
+    t->size = n;
+    for (auto& pl : t->plan) pl.has_root = false;
+    return IMT_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // batch insertion
 // ------------------------------------------------------------------------------------
 extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, const imt_insert_out* out,

@@ -204,6 +204,43 @@ def test_insert_batch_adversarial_orders(imt, ctx, oracle):
         oracle.sparse_free(oh)
 
 
+def test_random_small_batches_differential(imt, ctx, oracle):
+    """Many small batches with values that share their top limbs (the sorted index compares the top
+    limb first and falls back to the full value), growing through several L0 transitions."""
+    rng = random.Random(99)
+    for trial in range(8):
+        depth = rng.choice([6, 9, 32])
+        cap = 64
+        shape = trial % 3
+        if shape == 0:
+            pool = list(range(1, 400))                                  # top limbs all zero
+        elif shape == 1:
+            pool = [(7 << 192) + x for x in range(1, 400)]              # equal non-zero top limb
+        else:
+            pool = [rng.randrange(1, P) for _ in range(300)] + list(range(1, 100))
+        rng.shuffle(pool)
+        t = imt.IndexedTree(ctx, depth, cap)
+        oh = oracle.sparse_new(depth, cap)
+        used = 0
+        while t.size < cap:
+            n = min(rng.randrange(1, 10), cap - t.size)
+            vals = pool[used:used + n]
+            used += n
+            r = t.insert_batch(vals, item_major=True)
+            for i, v in enumerate(vals):
+                o = oracle.sparse_insert(oh, depth, v)
+                assert o["rc"] == 0
+                assert int(r["low_index"][i]) == o["low"] and int(r["is_largest"][i]) == o["largest"]
+                assert ints(r["new_root"][i]) == [o["new_root"]] and ints(r["interim_root"][i]) == [o["interim_root"]]
+                assert (r["low_sib"][i] == o["low_proof"]).all() and (r["new_sib"][i] == o["new_proof"]).all()
+                assert (r["low_leaf"][i] == o["low_leaf"]).all()
+            assert t.root() == oracle.sparse_root(oh)
+        with pytest.raises(imt.ImtError):
+            t.insert_batch([pool[used]])            # full
+        oracle.sparse_free(oh)
+        t.close()
+
+
 def test_insert_batch_rejects_bad_values(imt, ctx):
     t = imt.IndexedTree(ctx, 8, 16)
     t.insert_batch([5, 9])
@@ -372,6 +409,45 @@ def test_device_pointer_mode_matches_host_mode(imt, ctx):
     assert t_dev.root() == t_host.root()
     t_dev.close()
     c2.close()
+
+
+def test_snapshot_load_roundtrip(imt, ctx, oracle):
+    depth = 32
+    vals = oracle_lib.synth_values(700, 0x494D5406)
+    a = imt.IndexedTree(ctx, depth, 1024)
+    a.insert_batch(vals[:500], proofs=False)
+    snap = a.snapshot()
+    b = imt.IndexedTree(ctx, depth, 2048)            # a different capacity on purpose
+    b.load(snap)
+    assert b.root() == a.root() and b.size == a.size
+    idx = [0, 1, 250, 500, 501, 777]
+    assert (b.get_proof_batch(idx) == a.get_proof_batch(idx)).all()
+    ra = a.insert_batch(vals[500:], proofs=True)     # both continue identically after the resume
+    rb = b.insert_batch(vals[500:], proofs=True)
+    for k in ("low_index", "new_root", "interim_root", "low_sib", "new_sib", "low_leaf"):
+        assert (ra[k] == rb[k]).all(), k
+    assert a.root() == b.root()
+    # corrupted snapshots are refused and leave the tree as it was
+    root_before = b.root()
+    bad = snap.copy(); bad[3, 1, 0] ^= 1             # next_val no longer the successor
+    with pytest.raises(ValueError):
+        b.load(bad)
+    bad = snap.copy(); bad[0, 0, 0] = 1              # leaf 0 is not the sentinel
+    with pytest.raises(ValueError):
+        b.load(bad)
+    assert b.root() == root_before
+    # bulk build == oracle: small tree, every level
+    c = imt.IndexedTree(ctx, 8, 64)
+    c.insert_batch(list(range(10, 40)), proofs=False)
+    d = imt.IndexedTree(ctx, 8, 64)
+    d.load(c.snapshot())
+    oh = oracle.sparse_new(8, 64)
+    for v in range(10, 40):
+        oracle.sparse_insert(oh, 8, v)
+    assert d.root() == oracle.sparse_root(oh)
+    for i in (0, 5, 30, 31, 63):
+        assert (d.get_proof_batch([i])[:, 0] == oracle.sparse_proof(oh, 8, i)).all()
+    oracle.sparse_free(oh)
 
 
 def test_combine_subtree_roots(imt, ctx, oracle):
