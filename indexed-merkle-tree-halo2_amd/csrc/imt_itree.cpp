@@ -7,6 +7,7 @@
 // imt_sweep.hpp.  The plan buffers are double-buffered and uploaded on a second stream,
 // so with IMT_DEVICE_PTRS the host work of batch k+1 overlaps the kernels of batch k.
 #include "imt_ctx.hpp"
+#include "imt_prep.hpp"
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -62,6 +63,7 @@ struct PlanSet {
     uint32_t* d_nodeb = nullptr;
     uint32_t* d_timen = nullptr; // [levels][E] time table of level l+1
     uint8_t* d_val[2] = {nullptr, nullptr};
+    prep::Workspace ws;                  // IMT_GPU_PREP scratch
     uint8_t* d_root = nullptr;           // stored root right after this batch (device format)
     bool has_root = false;
     hipEvent_t done = nullptr;           // recorded after the batch's last kernel
@@ -83,6 +85,13 @@ struct imt_itree {
     uint64_t* d_len = nullptr;
     std::vector<Pre> pre;            // host mirror of the leaf preimages
     std::vector<SortedEnt> sorted;   // leaves ordered by val
+    // device-resident index (IMT_GPU_PREP): values in leaf order + leaf indices in value order.
+    // The host mirror and the device index are each refreshed from the other on demand.
+    uint8_t* d_val = nullptr;        // [cap][32] canonical
+    uint32_t* d_sorted[2] = {nullptr, nullptr};
+    int sorted_cur = 0;
+    bool mirror_valid = true, dev_index_valid = true;
+    int* h_err_pin = nullptr;        // pinned word for the prepare kernels' error bits
     static constexpr int NSETS = 3;      // host work may run two batches ahead of the GPU
     PlanSet plan[NSETS];
     int cur = 0;
@@ -118,13 +127,16 @@ static void plan_free(PlanSet& p) {
     for (auto& q : p.d_val)
         if (q) hipFree(q);
     if (p.d_root) hipFree(p.d_root);
+    for (void* q : {(void*)p.ws.iota, (void*)p.ws.bsorted, (void*)p.ws.gap, (void*)p.ws.st, (void*)p.ws.low,
+                    (void*)p.ws.succ, (void*)p.ws.keys, (void*)p.ws.keys_sorted, p.ws.tmp, (void*)p.ws.err})
+        if (q) hipFree(q);
     PlanSet keep;
     keep.done = p.done;
     for (int l = 0; l <= IMT_MAX_DEPTH; l++) keep.wb_done[l] = p.wb_done[l];
     p = keep;
 }
 
-static int plan_reserve(imt_ctx* c, PlanSet& p, size_t events, unsigned levels) {
+static int plan_reserve(imt_ctx* c, PlanSet& p, size_t events, unsigned levels, size_t tree_cap) {
     if (p.cap_events >= events && p.cap_levels >= levels) return IMT_OK;
     plan_free(p);
     const size_t E = std::max(events + events / 4, (size_t)1024);
@@ -145,6 +157,23 @@ static int plan_reserve(imt_ctx* c, PlanSet& p, size_t events, unsigned levels) 
     A((void**)&p.d_val[0], E * 32);
     A((void**)&p.d_val[1], E * 32);
     A((void**)&p.d_root, 32);
+    {   // GPU-prepare workspace for E/2 insertions
+        const size_t N = E / 2;
+        int lv = 1;
+        while (((size_t)1 << lv) <= N) lv++;
+        p.ws.cap_n = N;
+        A((void**)&p.ws.iota, N * 4);
+        A((void**)&p.ws.bsorted, N * 4);
+        A((void**)&p.ws.gap, N * 4);
+        A((void**)&p.ws.st, (size_t)lv * N * 4);
+        A((void**)&p.ws.low, N * 4);
+        A((void**)&p.ws.succ, N * 4);
+        A((void**)&p.ws.keys, E * 8);
+        A((void**)&p.ws.keys_sorted, E * 8);
+        p.ws.tmp_bytes = prep::temp_bytes_needed(N, tree_cap);
+        A((void**)&p.ws.tmp, p.ws.tmp_bytes);
+        A((void**)&p.ws.err, sizeof(int));
+    }
     if (e != hipSuccess) {
         plan_free(p);
         return c->hip_fail(e, "hipMalloc(plan)");
@@ -178,6 +207,10 @@ extern "C" void imt_itree_free(imt_itree* t) {
     if (t->d_nodes) hipFree(t->d_nodes);
     if (t->d_off) hipFree(t->d_off);
     if (t->d_len) hipFree(t->d_len);
+    if (t->d_val) hipFree(t->d_val);
+    for (auto q : t->d_sorted)
+        if (q) hipFree(q);
+    if (t->h_err_pin) hipHostFree(t->h_err_pin);
     delete t;
 }
 
@@ -204,7 +237,11 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
         off += n;
     }
     hipError_t e;
-    if ((e = hipMalloc((void**)&t->d_nodes, off * 32)) != hipSuccess ||
+    if ((e = hipMalloc((void**)&t->d_val, capacity * 32)) != hipSuccess ||
+        (e = hipMalloc((void**)&t->d_sorted[0], capacity * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&t->d_sorted[1], capacity * 4)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&t->h_err_pin, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipMalloc((void**)&t->d_nodes, off * 32)) != hipSuccess ||
         (e = hipMalloc((void**)&t->d_off, (depth + 1) * 8)) != hipSuccess ||
         (e = hipMalloc((void**)&t->d_len, (depth + 1) * 8)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&t->up_stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -226,6 +263,8 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
                 imt_itree_free(t);
                 return c->hip_fail(e, "hipEventCreate");
             }
+    hipMemsetAsync(t->d_val, 0, 32, c->stream);          // leaf 0: the sentinel value 0
+    hipMemsetAsync(t->d_sorted[0], 0, 4, c->stream);     // sorted index = [leaf 0]
     hipMemcpyAsync(t->d_off, t->h_off.data(), (depth + 1) * 8, hipMemcpyHostToDevice, c->stream);
     hipMemcpyAsync(t->d_len, t->h_len.data(), (depth + 1) * 8, hipMemcpyHostToDevice, c->stream);
     for (unsigned l = 0; l <= depth; l++)   // every stored node starts as the empty subtree of its height
@@ -250,6 +289,47 @@ static int join_top(imt_itree* t) {
     for (auto& pl : t->plan)
         if (pl.in_flight && pl.pipelined) IMT_HIP(t->ctx, hipStreamWaitEvent(t->ctx->stream, pl.done, 0));
     t->pipe_pending = false;
+    return IMT_OK;
+}
+
+// host mirror <- device index (after IMT_GPU_PREP batches)
+static int ensure_mirror(imt_itree* t) {
+    if (t->mirror_valid) return IMT_OK;
+    imt_ctx* c = t->ctx;
+    const size_t M = t->size;
+    std::vector<U256> vals(M);
+    std::vector<uint32_t> order(M);
+    IMT_HIP(c, hipStreamSynchronize(t->up_stream));
+    IMT_HIP(c, hipMemcpy(vals.data(), t->d_val, M * 32, hipMemcpyDeviceToHost));
+    IMT_HIP(c, hipMemcpy(order.data(), t->d_sorted[t->sorted_cur], M * 4, hipMemcpyDeviceToHost));
+    static const U256 ZERO = {0, 0, 0, 0};
+    t->pre.resize(M);
+    t->sorted.resize(M);
+    for (size_t r = 0; r < M; r++) {
+        const uint32_t i = order[r];
+        t->sorted[r] = SortedEnt{vals[i][3], i};
+        t->pre[i].val = vals[i];
+        t->pre[i].next_val = r + 1 < M ? vals[order[r + 1]] : ZERO;
+        t->pre[i].next_idx = r + 1 < M ? order[r + 1] : 0;
+    }
+    t->mirror_valid = true;
+    return IMT_OK;
+}
+// device index <- host mirror (after host-prepared batches or a snapshot load)
+static int ensure_device_index(imt_itree* t) {
+    if (t->dev_index_valid) return IMT_OK;
+    imt_ctx* c = t->ctx;
+    int rc = ensure_mirror(t);
+    if (rc) return rc;
+    const size_t M = t->size;
+    std::vector<U256> vals(M);
+    std::vector<uint32_t> order(M);
+    for (size_t i = 0; i < M; i++) vals[i] = t->pre[i].val;
+    for (size_t r = 0; r < M; r++) order[r] = (uint32_t)t->sorted[r].idx;
+    IMT_HIP(c, hipStreamSynchronize(t->up_stream));
+    IMT_HIP(c, hipMemcpy(t->d_val, vals.data(), M * 32, hipMemcpyHostToDevice));
+    IMT_HIP(c, hipMemcpy(t->d_sorted[t->sorted_cur], order.data(), M * 4, hipMemcpyHostToDevice));
+    t->dev_index_valid = true;
     return IMT_OK;
 }
 
@@ -356,6 +436,7 @@ extern "C" int imt_itree_find_low_batch(imt_itree* t, const void* vals, size_t n
     if (!vals || !low_index) return c->fail(IMT_ERR_ARG, "null buffer");
     int rc = c->set_device();
     if (rc) return rc;
+    if ((rc = ensure_mirror(t))) return rc;
     std::vector<U256> v;
     rc = fetch_canonical(c, c->stream, vals, n, flags, v);
     if (rc) return rc;
@@ -381,6 +462,7 @@ extern "C" int imt_itree_get_leaves(imt_itree* t, const uint64_t* index, size_t 
     if (flags & IMT_DEVICE_PTRS) return c->fail(IMT_ERR_ARG, "imt_itree_get_leaves takes host pointers");
     int rc = c->set_device();
     if (rc) return rc;
+    if ((rc = ensure_mirror(t))) return rc;
     std::vector<uint8_t> buf(n * 96);
     for (size_t i = 0; i < n; i++) {
         if (index[i] >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
@@ -504,6 +586,8 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
     for (uint64_t i = 0; i < n; i++) t->pre[i] = Pre{flat[3 * i], flat[3 * i + 1], flat[3 * i + 2][0]};
     for (uint64_t r = 0; r < n; r++) t->sorted[r] = SortedEnt{flat[3 * order[r]][3], order[r]};
     t->size = n;
+    t->mirror_valid = true;
+    t->dev_index_valid = false;
     for (auto& pl : t->plan) pl.has_root = false;
     return IMT_OK;
 }
@@ -537,9 +621,17 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         laps[k] += std::chrono::duration<double, std::milli>(now - lap_t).count();
         lap_t = now;
     };
+    const bool gpu_prep = (flags & IMT_GPU_PREP) != 0;
+    std::vector<U256> v;
+    std::vector<uint32_t>& ord = t->w_ord;
+    const int64_t NONE = INT64_MIN;
+    std::vector<int64_t>&prv = t->w_prv, &nxt = t->w_nxt;
+    std::vector<uint32_t>& rank_of = t->w_rank;
+    std::vector<int64_t>&pred = t->w_pred, &succ = t->w_succ;   // by insertion time
+    if (!gpu_prep) {
     // ---- 1. values, canonical, on the host.  With device pointers they are read on the side
     //         stream, so the call does not wait for an earlier batch still running. ----
-    std::vector<U256> v;
+    if ((rc = ensure_mirror(t))) return rc;
     rc = fetch_canonical(c, dev ? t->up_stream : c->stream, vals, n, flags, v);
     if (rc) return rc;
 
@@ -548,7 +640,6 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     //         sort the batch, locate each value between two stored leaves, then unlink the batch
     //         from that list in reverse insertion order: what is adjacent at unlink time is
     //         exactly what had been inserted earlier. ----
-    std::vector<uint32_t>& ord = t->w_ord;
     {
         std::vector<std::pair<uint64_t, uint32_t>>& sk = t->w_sortkey;   // (top limb, index): cheap compares
         sk.resize(n);
@@ -564,8 +655,6 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     for (size_t r = 1; r < n; r++)
         if (v[ord[r]] == v[ord[r - 1]]) return c->fail(IMT_ERR_VALUE, "duplicate value inside the batch");
     // neighbours: >= 0 -> rank of a batch element; < 0 -> ~(leaf index of a stored leaf); NONE
-    const int64_t NONE = INT64_MIN;
-    std::vector<int64_t>&prv = t->w_prv, &nxt = t->w_nxt;
     prv.resize(n);
     nxt.resize(n);
     {
@@ -582,10 +671,8 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
             nxt[r] = next_in_gap ? (int64_t)(r + 1) : (q < S ? ~(int64_t)t->sorted[q].idx : NONE);
         }
     }
-    std::vector<uint32_t>& rank_of = t->w_rank;
     rank_of.resize(n);
     for (size_t r = 0; r < n; r++) rank_of[ord[r]] = (uint32_t)r;
-    std::vector<int64_t>&pred = t->w_pred, &succ = t->w_succ;   // by insertion time
     pred.resize(n);
     succ.resize(n);
     for (size_t ii = n; ii-- > 0;) {
@@ -595,6 +682,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         if (prv[r] >= 0) nxt[prv[r]] = nxt[r];
         if (nxt[r] >= 0) prv[nxt[r]] = prv[r];
     }
+    }   // !gpu_prep
 
     lap(1);
     // ---- 3. plan buffers ----
@@ -607,7 +695,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
         P.in_flight = false;
     }
-    rc = plan_reserve(c, P, E, t->depth);   // all levels up front: growing later would stall the pipeline
+    rc = plan_reserve(c, P, E, t->depth, t->cap);   // all levels up front: growing later would stall the pipeline
     if (rc) return rc;
     uint8_t* h_pre = P.h_pin;
     uint32_t* h_tab = reinterpret_cast<uint32_t*>(P.h_pin + P.cap_events * 96);
@@ -618,14 +706,20 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     // ---- 4. events: preimages at every time step + host-side outputs ----
     std::vector<uint64_t>& o_low = t->w_low;
     std::vector<uint8_t>& o_largest = t->w_largest;
-    o_low.resize(n);
-    o_largest.resize(n);
-    std::vector<uint8_t> o_lowleaf(out && out->low_leaf ? n * 96 : 0), o_newleaf(out && out->new_leaf ? n * 96 : 0);
-    std::vector<uint64_t>& keys = t->w_keys;   // (pos << 32) | event
-    keys.resize(E);
+    std::vector<uint8_t> o_lowleaf(!gpu_prep && out && out->low_leaf ? n * 96 : 0),
+        o_newleaf(!gpu_prep && out && out->new_leaf ? n * 96 : 0);
+    // hash-free outputs of the GPU prepare path (device buffers: the user's, or scratch in host mode)
+    uint64_t* gp_low = nullptr;
+    uint8_t *gp_largest = nullptr, *gp_lowleaf = nullptr, *gp_newleaf = nullptr;
+    size_t slot = 2;
     auto leaf_of = [&](int64_t ref) -> uint64_t { return ref >= 0 ? M + ord[ref] : (uint64_t)~ref; };
     auto val_of = [&](int64_t ref) -> const U256& { return ref >= 0 ? v[ord[ref]] : t->pre[(size_t)~ref].val; };
     static const U256 ZERO = {0, 0, 0, 0};
+    if (!gpu_prep) {
+    o_low.resize(n);
+    o_largest.resize(n);
+    std::vector<uint64_t>& keys = t->w_keys;   // (pos << 32) | event
+    keys.resize(E);
     for (size_t i = 0; i < n; i++) {
         const uint64_t low = leaf_of(pred[i]);
         const U256& lowval = val_of(pred[i]);
@@ -678,6 +772,47 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][1], h_time, E * 4, hipMemcpyHostToDevice, t->up_stream));
     IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][2], h_rs, E * 4, hipMemcpyHostToDevice, t->up_stream));
     IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][3], h_re, E * 4, hipMemcpyHostToDevice, t->up_stream));
+    } else {
+        // ---- 4'/5'. the same on the GPU (imt_prep.hip), on the side stream ----
+        if ((rc = ensure_device_index(t))) return rc;
+        hipStream_t ps = t->up_stream;
+        const uint8_t* d_vals = (const uint8_t*)vals;
+        if (!dev) {
+            uint8_t* up = (uint8_t*)c->dev_scratch(slot++, n * 32);
+            if (!up) return IMT_ERR_HIP;
+            IMT_HIP(c, hipMemcpyAsync(up, vals, n * 32, hipMemcpyHostToDevice, ps));
+            d_vals = up;
+        }
+        IMT_HIP(c, hipMemsetAsync(P.ws.err, 0, sizeof(int), ps));
+        if (fmt != IMT_FMT_CANONICAL) {
+            uint8_t* can = (uint8_t*)c->dev_scratch(slot++, n * 32);
+            if (!can) return IMT_ERR_HIP;
+            launch::convert(ps, d_vals, can, n, fmt, IMT_FMT_CANONICAL, P.ws.err);   // sets bit 0 = non-canonical
+            d_vals = can;
+        }
+        if (out) {
+            auto dev_out = [&](void* user, size_t bytes) -> void* {
+                if (!user) return nullptr;
+                return dev ? user : c->dev_scratch(slot++, bytes);
+            };
+            gp_low = (uint64_t*)dev_out(out->low_index, n * 8);
+            gp_largest = (uint8_t*)dev_out(out->is_largest, n);
+            gp_lowleaf = (uint8_t*)dev_out(out->low_leaf, n * 96);
+            gp_newleaf = (uint8_t*)dev_out(out->new_leaf, n * 96);
+        }
+        prep::run(ps, P.ws, d_vals, t->d_val, t->d_sorted[t->sorted_cur], t->d_sorted[t->sorted_cur ^ 1], (uint32_t)M,
+                  (uint32_t)n, P.d_pre, P.d_tab[0][0], P.d_tab[0][1], P.d_tab[0][2], P.d_tab[0][3], gp_low, gp_largest,
+                  gp_lowleaf, gp_newleaf);
+        IMT_HIP(c, hipMemcpyAsync(t->h_err_pin, P.ws.err, sizeof(int), hipMemcpyDeviceToHost, ps));
+        const auto w0 = std::chrono::steady_clock::now();
+        IMT_HIP(c, hipStreamSynchronize(ps));       // the batch is committed only if its values are acceptable
+        host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        const int perr = *t->h_err_pin;
+        if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
+        if (perr & prep::ERR_ZERO) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
+        if (perr & prep::ERR_DUPLICATE) return c->fail(IMT_ERR_VALUE, "duplicate value (inside the batch or already in the tree)");
+        t->sorted_cur ^= 1;
+    }
     IMT_HIP(c, hipEventRecord(t->up_done, t->up_stream));
     const bool pipelined = dev && (flags & IMT_PIPELINE);
     hipStream_t s = c->stream;
@@ -697,7 +832,6 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     // ---- 6. GPU outputs ----
     const size_t sib_bytes = (size_t)t->depth * n * 32;
     uint8_t *g_old = nullptr, *g_int = nullptr, *g_new = nullptr, *g_ls = nullptr, *g_ns = nullptr;
-    size_t slot = 2;
     auto gpu_out = [&](void* user, size_t bytes) -> uint8_t* {
         if (!user) return nullptr;
         if (dev) return (uint8_t*)user;
@@ -768,6 +902,11 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
 
     lap(6);
     // ---- 8. host mirror ----
+    if (gpu_prep) {
+        t->size = M + n;
+        t->mirror_valid = false;     // rebuilt from the device index when a host-side call needs it
+    } else {
+    t->dev_index_valid = false;
     t->pre.resize(M + n);
     for (size_t i = 0; i < n; i++) {
         const bool has_succ = succ[i] != NONE;
@@ -793,6 +932,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         t->sorted.swap(merged);
     }
     t->size = M + n;
+    }   // !gpu_prep
 
     lap(7);
     // ---- 9. outputs ----
@@ -807,6 +947,19 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
             }
             return IMT_OK;
         };
+        if (gpu_prep) {
+            // written by k_events in canonical form; other formats are converted in place behind up_done
+            if (fmt != IMT_FMT_CANONICAL) {
+                if (gp_lowleaf) launch::convert(s, gp_lowleaf, gp_lowleaf, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+                if (gp_newleaf) launch::convert(s, gp_newleaf, gp_newleaf, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+            }
+            if (!dev) {
+                if (gp_low) IMT_HIP(c, hipMemcpyAsync(out->low_index, gp_low, n * 8, hipMemcpyDeviceToHost, s));
+                if (gp_largest) IMT_HIP(c, hipMemcpyAsync(out->is_largest, gp_largest, n, hipMemcpyDeviceToHost, s));
+                if (gp_lowleaf) IMT_HIP(c, hipMemcpyAsync(out->low_leaf, gp_lowleaf, n * 96, hipMemcpyDeviceToHost, s));
+                if (gp_newleaf) IMT_HIP(c, hipMemcpyAsync(out->new_leaf, gp_newleaf, n * 96, hipMemcpyDeviceToHost, s));
+            }
+        } else {
         if ((rc = host_out(out->low_index, o_low.data(), n * 8))) return rc;
         if ((rc = host_out(out->is_largest, o_largest.data(), n))) return rc;
         if (fmt == IMT_FMT_CANONICAL) {
@@ -827,6 +980,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
                 IMT_HIP(c, hipStreamSynchronize(s));
             }
         }
+        }   // !gpu_prep
         if (!dev) {
             if (out->old_root) IMT_HIP(c, hipMemcpyAsync(out->old_root, g_old, n * 32, hipMemcpyDeviceToHost, s));
             if (out->interim_root) IMT_HIP(c, hipMemcpyAsync(out->interim_root, g_int, n * 32, hipMemcpyDeviceToHost, s));

@@ -1,0 +1,61 @@
+// imt_prep.hpp -- GPU-side preparation of a batch insertion ("GPU low-leaf
+// search"): everything imt_itree.cpp otherwise does on the host between receiving the values and
+// launching the hash sweep -- the low-leaf search of update_idx_leaf
+// (/root/reference/src/indexed_merkle_tree.rs:639-658), the event preimages and the
+// (position, time) order of the events -- as device kernels over a device-resident index.
+//
+// Device index of a tree: val[cap][32] (canonical integers, leaf order) and sorted[size] (leaf
+// indices in ascending value order).  Leaf indices ARE insertion times, so "the low leaf of v at
+// the time it is inserted" is the nearest element to the left of v, in value order, with a
+// smaller leaf index: an all-nearest-smaller-values problem, solved per batch with a sparse
+// min-table over the batch in value order plus the gap (number of stored values below) of each
+// new value.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace imt {
+namespace prep {
+
+constexpr uint32_t NONE = 0xffffffffu;
+// error bits written by the kernels
+constexpr int ERR_NONCANONICAL = 1, ERR_ZERO = 2, ERR_DUPLICATE = 4;
+
+struct Workspace {            // per plan set, sized for `cap_n` insertions
+    size_t cap_n = 0;
+    uint32_t* iota = nullptr;      // [n]   M+i
+    uint32_t* bsorted = nullptr;   // [n]   new leaf indices in value order
+    uint32_t* gap = nullptr;       // [n]   stored values below each new value
+    uint32_t* st = nullptr;        // [levels][n] sparse min-table of insertion times
+    uint32_t* low = nullptr;       // [n]   by insertion time
+    uint32_t* succ = nullptr;      // [n]
+    uint64_t* keys = nullptr;      // [2n]  (position << 32) | event
+    uint64_t* keys_sorted = nullptr;
+    void* tmp = nullptr;           // rocPRIM temporary storage
+    size_t tmp_bytes = 0;
+    int* err = nullptr;            // device word
+};
+
+size_t temp_bytes_needed(size_t n, size_t max_size);
+
+// Everything up to (and including) the level-0 tables and the new sorted index.
+//   vals      [n][32] canonical, device
+//   d_val     device index values; rows [M, M+n) are written
+//   sorted_old[M] -> sorted_new[M+n]
+//   pre       [2n][96] event preimages (canonical)
+//   node/time/rs/re  level-0 tables [2n]
+//   o_* user outputs (device pointers, any may be NULL): low_index u64[n], is_largest u8[n],
+//        low_leaf / new_leaf [n][3][32] canonical
+// Errors are OR-ed into ws.err (ERR_*); nothing outside rows [M, M+n) of d_val, sorted_new and the
+// workspace is written, so a failed batch leaves the tree untouched.
+void run(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val, const uint32_t* sorted_old,
+         uint32_t* sorted_new, uint32_t M, uint32_t n, uint8_t* pre, uint32_t* node, uint32_t* time, uint32_t* rs,
+         uint32_t* re, uint64_t* o_low_index, uint8_t* o_is_largest, uint8_t* o_low_leaf, uint8_t* o_new_leaf);
+
+// predecessor search only (imt_itree_find_low_batch): low[i] = leaf index of the greatest value < vals[i]
+void find_low(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
+              uint64_t* low_index, int* err);
+
+}  // namespace prep
+}  // namespace imt

@@ -1,0 +1,61 @@
+// imt_prep_logic.hpp -- per-element logic of the GPU batch preparation (imt_prep.hip), kept free of
+// HIP types so tests/native/ can run it on the host against a brute force.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define IMT_PL_HD __host__ __device__ __forceinline__
+#else
+#define IMT_PL_HD inline
+#endif
+
+namespace imt {
+namespace prep {
+
+// 256-bit little-endian integers stored as 32 bytes
+IMT_PL_HD bool lt256(const uint8_t* a, const uint8_t* b) {
+    const uint64_t* x = reinterpret_cast<const uint64_t*>(a);
+    const uint64_t* y = reinterpret_cast<const uint64_t*>(b);
+    for (int i = 3; i >= 0; i--)
+        if (x[i] != y[i]) return x[i] < y[i];
+    return false;
+}
+IMT_PL_HD bool eq256(const uint8_t* a, const uint8_t* b) {
+    const uint64_t* x = reinterpret_cast<const uint64_t*>(a);
+    const uint64_t* y = reinterpret_cast<const uint64_t*>(b);
+    return x[0] == y[0] && x[1] == y[1] && x[2] == y[2] && x[3] == y[3];
+}
+
+// number of stored values (sorted[0..M) indexes val) strictly below x
+IMT_PL_HD uint32_t count_below(const uint8_t* val, const uint32_t* sorted, uint32_t M, const uint8_t* x) {
+    uint32_t lo = 0, hi = M;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (lt256(val + (uint64_t)sorted[mid] * 32, x)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Sparse min-table st[k][j] = min(t[j .. j + 2^k)), rows of length n (entries with j + 2^k > n unused).
+// Nearest position left of j whose value is < t[j]; returns n ("none") if there is none.
+IMT_PL_HD uint32_t nearest_smaller_left(const uint32_t* st, uint32_t n, int levels, uint32_t j) {
+    const uint32_t t = st[j];
+    uint32_t p = j;                       // invariant: every entry in [p, j) is > t
+    for (int k = levels - 1; k >= 0; k--) {
+        const uint32_t w = 1u << k;
+        if (p >= w && st[(uint64_t)k * n + (p - w)] > t) p -= w;
+    }
+    return p > 0 ? p - 1 : n;
+}
+IMT_PL_HD uint32_t nearest_smaller_right(const uint32_t* st, uint32_t n, int levels, uint32_t j) {
+    const uint32_t t = st[j];
+    uint32_t p = j + 1;                   // invariant: every entry in (j, p) is > t
+    for (int k = levels - 1; k >= 0; k--) {
+        const uint32_t w = 1u << k;
+        if (p + w <= n && st[(uint64_t)k * n + p] > t) p += w;
+    }
+    return p < n ? p : n;
+}
+
+}  // namespace prep
+}  // namespace imt

@@ -34,7 +34,7 @@ def emul():
     csrc = os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc")
     srcs = [os.path.join(ROOT, "tests", "native", "emul_device.cpp"), os.path.join(csrc, "imt_params.cpp")]
     deps = srcs + [os.path.join(csrc, f) for f in ("imt_device.hpp", "imt_consts.hpp", "imt_sweep.hpp",
-                                                    "imt_params.hpp", "imt_fr_host.hpp")]
+                                                    "imt_params.hpp", "imt_fr_host.hpp", "imt_prep_logic.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", csrc, "-o", so] + srcs, ROOT)
     lib = ctypes.CDLL(so)

@@ -74,3 +74,22 @@ extern "C" void emul_merge_level(const uint32_t* node, const uint32_t* time, con
     sweep::LevelOut out{o_node, o_time, o_rs, o_re, o_from, o_sibsrc, o_node_below};
     for (uint32_t k = 0; k < total; k++) sweep::merge_element(in, out, k, total);
 }
+
+// ---- GPU-prepare logic (imt_prep_logic.hpp) on the host ----
+#include "imt_prep_logic.hpp"
+extern "C" void emul_sparse_table(uint32_t* st, uint32_t n, int levels) {
+    for (int k = 1; k < levels; k++)
+        for (uint32_t j = 0; j + (1u << k) <= n; j++) {
+            uint32_t a = st[(uint64_t)(k - 1) * n + j], b = st[(uint64_t)(k - 1) * n + j + (1u << (k - 1))];
+            st[(uint64_t)k * n + j] = a < b ? a : b;
+        }
+}
+extern "C" uint32_t emul_nsl(const uint32_t* st, uint32_t n, int levels, uint32_t j) {
+    return imt::prep::nearest_smaller_left(st, n, levels, j);
+}
+extern "C" uint32_t emul_nsr(const uint32_t* st, uint32_t n, int levels, uint32_t j) {
+    return imt::prep::nearest_smaller_right(st, n, levels, j);
+}
+extern "C" uint32_t emul_count_below(const uint8_t* val, const uint32_t* sorted, uint32_t M, const uint8_t* x) {
+    return imt::prep::count_below(val, sorted, M, x);
+}

@@ -241,6 +241,54 @@ def test_random_small_batches_differential(imt, ctx, oracle):
         t.close()
 
 
+def test_gpu_prepare_equals_host_prepare(imt, ctx, oracle):
+    """IMT_GPU_PREP (device-side low-leaf search and event building) against the host path, batch by
+    batch, including adversarial orders, mixed modes on one tree, and the error cases."""
+    rng = random.Random(123)
+    keys = ("low_index", "is_largest", "low_leaf", "new_leaf", "old_root", "interim_root", "new_root", "low_sib",
+            "new_sib")
+    streams = [oracle_lib.synth_values(900, 0x494D5407), list(range(1, 901)), list(range(900, 0, -1)),
+               [((i * 389) % 900) + 1 for i in range(900)], [(9 << 200) + x for x in range(1, 901)]]
+    for vals in streams:
+        a = imt.IndexedTree(ctx, 32, 1024)     # host prepare
+        b = imt.IndexedTree(ctx, 32, 1024)     # GPU prepare
+        m = imt.IndexedTree(ctx, 32, 1024)     # alternating
+        pos, k = 0, 0
+        while pos < len(vals):
+            n = min(rng.choice([1, 2, 5, 33, 64, 200]), len(vals) - pos)
+            chunk = vals[pos:pos + n]
+            ra = a.insert_batch(chunk)
+            rb = b.insert_batch(chunk, gpu_prep=True)
+            rm = m.insert_batch(chunk, gpu_prep=(k % 2 == 1))
+            for key in keys:
+                assert (ra[key] == rb[key]).all(), (key, pos)
+                assert (ra[key] == rm[key]).all(), (key, pos)
+            pos += n
+            k += 1
+        assert a.root() == b.root() == m.root()
+        probe = [v + 1 for v in vals[:50] if v + 1 not in set(vals)] or [P - 5]
+        assert (a.find_low(probe) == b.find_low(probe)).all()           # mirror rebuilt from the device index
+        assert (a.snapshot() == b.snapshot()).all() and (a.snapshot() == m.snapshot()).all()
+    # the sequential oracle agrees (one stream is enough: the host path is checked against it elsewhere)
+    oh, rows, oroot = _oracle_run(oracle, 32, 256, streams[0][:150])
+    t = imt.IndexedTree(ctx, 32, 256)
+    r = t.insert_batch(streams[0][:150], gpu_prep=True)
+    assert ints(r["new_root"]) == [o["new_root"] for o in rows] and t.root() == oroot
+    assert [int(x) for x in r["low_index"]] == [o["low"] for o in rows]
+    oracle.sparse_free(oh)
+    # error cases leave the tree untouched
+    root, size = t.root(), t.size
+    for bad in ([0], [7, 7], [streams[0][3]], [5, streams[0][10], 6]):
+        with pytest.raises(ValueError):
+            t.insert_batch(bad, gpu_prep=True)
+    with pytest.raises(imt.ImtError) as ei:
+        t.insert_batch([P + 1], gpu_prep=True)
+    assert ei.value.code == imt._ffi.ERR["NONCANONICAL"]
+    assert t.root() == root and t.size == size
+    r2 = t.insert_batch([5, 6], gpu_prep=True)              # and it still works afterwards
+    assert t.size == size + 2
+
+
 def test_insert_batch_rejects_bad_values(imt, ctx):
     t = imt.IndexedTree(ctx, 8, 16)
     t.insert_batch([5, 9])

@@ -159,3 +159,39 @@ def test_synth_values_are_valid():
     v = oracle_lib.synth_values(500, 0x494D5402)
     assert len(set(v)) == 500 and all(0 < x < P for x in v)
     assert v == oracle_lib.synth_values(500, 0x494D5402)
+
+
+def test_prepare_logic_nearest_smaller_and_count_below(emul):
+    """imt_prep_logic.hpp: the sparse-table nearest-smaller searches and the 256-bit lower bound."""
+    rng = random.Random(8)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    for n in (1, 2, 3, 7, 8, 9, 100, 257):
+        for trial in range(4):
+            t = list(range(n))
+            if trial == 1:
+                t.reverse()
+            elif trial >= 2:
+                rng.shuffle(t)
+            levels = 1
+            while (1 << levels) <= n:
+                levels += 1
+            st = np.zeros(levels * n, np.uint32)
+            st[:n] = t
+            emul.emul_sparse_table(st.ctypes.data_as(u32p), n, levels)
+            for j in range(n):
+                want_l = next((i for i in range(j - 1, -1, -1) if t[i] < t[j]), n)
+                want_r = next((i for i in range(j + 1, n) if t[i] < t[j]), n)
+                assert emul.emul_nsl(st.ctypes.data_as(u32p), n, levels, j) == want_l
+                assert emul.emul_nsr(st.ctypes.data_as(u32p), n, levels, j) == want_r
+    vals = sorted(rng.sample(range(1, 10 ** 6), 50)) + [(5 << 200) + 3, (5 << 200) + 9, P - 1]
+    vals = [0] + sorted(vals)
+    perm = list(range(len(vals)))
+    rng.shuffle(perm)                                  # leaf order != value order
+    store = [0] * len(vals)
+    for rank, leaf in enumerate(perm):
+        store[leaf] = vals[rank]
+    val = np.frombuffer(b"".join(b32(x) for x in store), np.uint8).copy()
+    srt = np.array(perm, np.uint32)
+    for x in vals + [1, 77, (5 << 200) + 4, P - 2, 10 ** 6 + 1]:
+        got = emul.emul_count_below(val.ctypes.data_as(ctypes.c_void_p), srt.ctypes.data_as(u32p), len(vals), b32(x))
+        assert got == sum(1 for y in vals if y < x)
