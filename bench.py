@@ -144,6 +144,9 @@ def main():
     out = _ffi.InsertOut(**{name: t.data_ptr() for name, t in bufs.items()})
     flags = _ffi.DEVICE_PTRS | _ffi.FMT_CANONICAL
     ins_flags = flags | (0 if os.environ.get("IMT_NO_PIPELINE") else _ffi.PIPELINE)
+    gpu_prep = os.environ.get("IMT_BENCH_PREP", "gpu") == "gpu"     # low-leaf search + event build on the GPU
+    if not gpu_prep:
+        ins_flags |= _ffi.HOST_PREP
     roots_all = torch.empty((world, 32), **u8)
     root_buf = torch.empty(32, **u8)
     top_root = torch.empty(32, **u8)
@@ -202,7 +205,7 @@ def main():
     extra = 2 if steps_total + 2 <= vals.shape[0] // BATCH else 0
     if extra:
         saved = ins_flags
-        ins_flags = flags
+        ins_flags = flags | (0 if gpu_prep else _ffi.HOST_PREP)
         for i in range(steps_total, steps_total + extra):
             step(i)
         sync()
@@ -239,7 +242,8 @@ def main():
                        "batch_per_gpu": BATCH, "depth": DEPTH, "subtree_height_per_gpu": depth,
                        "parallelism": "single tree" if world == 1 else
                        f"{world} value-partitioned subtrees by leaf-index range + RCCL all-gather of subtree roots per step",
-                       "hashes_per_insertion": 2 + 2 * depth},
+                       "hashes_per_insertion": 2 + 2 * depth,
+                       "prepare": "gpu (imt_prep.hip)" if gpu_prep else "host"},
             "roofline": {"bound": "hbm", "kernel": "k_sweep_level", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": PMC_TRAFFIC_SWEEP_LEVEL,
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.txt (separate --pmc passes; value arrays, "

@@ -65,9 +65,10 @@ extern "C" {
 #define IMT_DEVICE_PTRS 0x10u
 #define IMT_SIB_ITEM_MAJOR 0x20u
 #define IMT_ROOT_PER_ITEM 0x40u   /* root argument is root[n][32] instead of one root[32] */
-#define IMT_GPU_PREP 0x100u       /* imt_itree_insert_batch: do the low-leaf search, the event preimages and the
-                                     event ordering on the GPU (device-resident sorted index) instead of on
-                                     the host.  Same results; the host then only launches kernels. */
+#define IMT_HOST_PREP 0x100u      /* imt_itree_insert_batch: do the low-leaf search, the event preimages and the
+                                     event ordering on the host instead of on the GPU (the default keeps a
+                                     device-resident sorted index and the host only launches kernels).
+                                     Same results either way; the two can be mixed on one tree. */
 #define IMT_PIPELINE 0x80u        /* imt_itree_insert_batch with IMT_DEVICE_PTRS only: consecutive batches run on two
                                      internal streams one tree level apart, so two hash kernels share the GPU.
                                      The outputs of such a batch are ordered by imt_ctx_sync() (or by the next

@@ -338,7 +338,7 @@ class IndexedTree:
         self.ctx._check(lib.imt_itree_root(self.h, _p(out), 0))
         return to_int(out)
 
-    def insert_batch(self, vals, proofs=True, item_major=False, gpu_prep=False):
+    def insert_batch(self, vals, proofs=True, item_major=False, host_prep=False):
         """n sequential insertions (update_idx_leaf semantics); returns a dict of numpy arrays."""
         v = to_bytes(vals) if not isinstance(vals, np.ndarray) else _arr(vals, (32,))
         n, d = v.shape[0], self.depth
@@ -351,7 +351,7 @@ class IndexedTree:
             res["low_sib"] = np.empty(shape, np.uint8)
             res["new_sib"] = np.empty(shape, np.uint8)
         out = _ffi.InsertOut(**{k: a.ctypes.data for k, a in res.items()})
-        flags = (_ffi.SIB_ITEM_MAJOR if item_major else 0) | (_ffi.GPU_PREP if gpu_prep else 0)
+        flags = (_ffi.SIB_ITEM_MAJOR if item_major else 0) | (_ffi.HOST_PREP if host_prep else 0)
         rc = lib.imt_itree_insert_batch(self.h, _p(v), n, ctypes.byref(out), flags)
         if rc == _ffi.ERR["VALUE"]:
             raise ValueError(lib.imt_last_error(self.ctx.h).decode())

@@ -63,7 +63,7 @@ struct PlanSet {
     uint32_t* d_nodeb = nullptr;
     uint32_t* d_timen = nullptr; // [levels][E] time table of level l+1
     uint8_t* d_val[2] = {nullptr, nullptr};
-    prep::Workspace ws;                  // IMT_GPU_PREP scratch
+    prep::Workspace ws;                  // GPU-prepare scratch
     uint8_t* d_root = nullptr;           // stored root right after this batch (device format)
     bool has_root = false;
     hipEvent_t done = nullptr;           // recorded after the batch's last kernel
@@ -85,7 +85,7 @@ struct imt_itree {
     uint64_t* d_len = nullptr;
     std::vector<Pre> pre;            // host mirror of the leaf preimages
     std::vector<SortedEnt> sorted;   // leaves ordered by val
-    // device-resident index (IMT_GPU_PREP): values in leaf order + leaf indices in value order.
+    // device-resident index (default prepare path): values in leaf order + leaf indices in value order.
     // The host mirror and the device index are each refreshed from the other on demand.
     uint8_t* d_val = nullptr;        // [cap][32] canonical
     uint32_t* d_sorted[2] = {nullptr, nullptr};
@@ -292,7 +292,7 @@ static int join_top(imt_itree* t) {
     return IMT_OK;
 }
 
-// host mirror <- device index (after IMT_GPU_PREP batches)
+// host mirror <- device index (after GPU-prepared batches)
 static int ensure_mirror(imt_itree* t) {
     if (t->mirror_valid) return IMT_OK;
     imt_ctx* c = t->ctx;
@@ -621,7 +621,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         laps[k] += std::chrono::duration<double, std::milli>(now - lap_t).count();
         lap_t = now;
     };
-    const bool gpu_prep = (flags & IMT_GPU_PREP) != 0;
+    const bool gpu_prep = (flags & IMT_HOST_PREP) == 0;
     std::vector<U256> v;
     std::vector<uint32_t>& ord = t->w_ord;
     const int64_t NONE = INT64_MIN;

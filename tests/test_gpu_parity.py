@@ -242,7 +242,7 @@ def test_random_small_batches_differential(imt, ctx, oracle):
 
 
 def test_gpu_prepare_equals_host_prepare(imt, ctx, oracle):
-    """IMT_GPU_PREP (device-side low-leaf search and event building) against the host path, batch by
+    """The default device-side low-leaf search and event building against IMT_HOST_PREP, batch by
     batch, including adversarial orders, mixed modes on one tree, and the error cases."""
     rng = random.Random(123)
     keys = ("low_index", "is_largest", "low_leaf", "new_leaf", "old_root", "interim_root", "new_root", "low_sib",
@@ -257,9 +257,9 @@ def test_gpu_prepare_equals_host_prepare(imt, ctx, oracle):
         while pos < len(vals):
             n = min(rng.choice([1, 2, 5, 33, 64, 200]), len(vals) - pos)
             chunk = vals[pos:pos + n]
-            ra = a.insert_batch(chunk)
-            rb = b.insert_batch(chunk, gpu_prep=True)
-            rm = m.insert_batch(chunk, gpu_prep=(k % 2 == 1))
+            ra = a.insert_batch(chunk, host_prep=True)
+            rb = b.insert_batch(chunk)
+            rm = m.insert_batch(chunk, host_prep=(k % 2 == 0))
             for key in keys:
                 assert (ra[key] == rb[key]).all(), (key, pos)
                 assert (ra[key] == rm[key]).all(), (key, pos)
@@ -272,7 +272,7 @@ def test_gpu_prepare_equals_host_prepare(imt, ctx, oracle):
     # the sequential oracle agrees (one stream is enough: the host path is checked against it elsewhere)
     oh, rows, oroot = _oracle_run(oracle, 32, 256, streams[0][:150])
     t = imt.IndexedTree(ctx, 32, 256)
-    r = t.insert_batch(streams[0][:150], gpu_prep=True)
+    r = t.insert_batch(streams[0][:150])
     assert ints(r["new_root"]) == [o["new_root"] for o in rows] and t.root() == oroot
     assert [int(x) for x in r["low_index"]] == [o["low"] for o in rows]
     oracle.sparse_free(oh)
@@ -280,30 +280,31 @@ def test_gpu_prepare_equals_host_prepare(imt, ctx, oracle):
     root, size = t.root(), t.size
     for bad in ([0], [7, 7], [streams[0][3]], [5, streams[0][10], 6]):
         with pytest.raises(ValueError):
-            t.insert_batch(bad, gpu_prep=True)
+            t.insert_batch(bad)
     with pytest.raises(imt.ImtError) as ei:
-        t.insert_batch([P + 1], gpu_prep=True)
+        t.insert_batch([P + 1])
     assert ei.value.code == imt._ffi.ERR["NONCANONICAL"]
     assert t.root() == root and t.size == size
-    r2 = t.insert_batch([5, 6], gpu_prep=True)              # and it still works afterwards
+    r2 = t.insert_batch([5, 6])                             # and it still works afterwards
     assert t.size == size + 2
 
 
-def test_insert_batch_rejects_bad_values(imt, ctx):
+@pytest.mark.parametrize("host_prep", [False, True])
+def test_insert_batch_rejects_bad_values(imt, ctx, host_prep):
     t = imt.IndexedTree(ctx, 8, 16)
-    t.insert_batch([5, 9])
+    t.insert_batch([5, 9], host_prep=host_prep)
     root = t.root()
     for bad in ([0], [7, 7], [9], [3, 5]):
         with pytest.raises(ValueError):
-            t.insert_batch(bad)
+            t.insert_batch(bad, host_prep=host_prep)
     assert t.root() == root and t.size == 3            # nothing changed
     with pytest.raises(imt.ImtError) as ei:
-        t.insert_batch(list(range(100, 114)))          # 3 + 14 > 16
+        t.insert_batch(list(range(100, 114)), host_prep=host_prep)          # 3 + 14 > 16
     assert ei.value.code == imt._ffi.ERR["FULL"]
     with pytest.raises(imt.ImtError) as ei:
-        t.insert_batch([P])
+        t.insert_batch([P], host_prep=host_prep)
     assert ei.value.code == imt._ffi.ERR["NONCANONICAL"]
-    t.insert_batch(list(range(100, 113)))              # exactly full
+    t.insert_batch(list(range(100, 113)), host_prep=host_prep)              # exactly full
     assert t.size == 16
 
 
@@ -432,7 +433,8 @@ def test_device_pointer_mode_matches_host_mode(imt, ctx):
                  low_sib=torch.empty((depth, n, 32), dtype=torch.uint8, device=dev),
                  new_sib=torch.empty((depth, n, 32), dtype=torch.uint8, device=dev))
         o = imt._ffi.InsertOut(**{k: v.data_ptr() for k, v in b.items()})
-        rc = imt.lib.imt_itree_insert_batch(t_dev.h, ctypes.c_void_p(vm.data_ptr() + i * n * 32), n, ctypes.byref(o), flags)
+        rc = imt.lib.imt_itree_insert_batch(t_dev.h, ctypes.c_void_p(vm.data_ptr() + i * n * 32), n, ctypes.byref(o),
+                                            flags | (imt._ffi.HOST_PREP if i == 1 else 0))
         assert rc == 0, imt.lib.imt_last_error(c2.h)
         outs.append(b)
     c2.sync()
