@@ -243,6 +243,15 @@ int imt_itree_load(imt_itree *t, const void *preimages /*[n][3][32]*/, uint64_t 
 int imt_itree_find_low_batch(imt_itree *t, const void *vals /*[n][32]*/, size_t n,
                              uint64_t *low_index /*[n]*/, unsigned flags);
 
+/* Witness of verify_non_inclusion for n candidate values against the current tree, produced on the
+ * GPU from the device-resident index: the low leaf (greatest stored value below the candidate), its
+ * preimage, the is_largest flag and its `depth` siblings.  Outputs feed imt_non_membership_batch
+ * unchanged.  Any output pointer may be NULL.  IMT_ERR_VALUE if a candidate is 0 or already stored. */
+int imt_itree_non_membership_witness(imt_itree *t, const void *vals /*[n][32]*/, size_t n,
+                                     uint64_t *low_index /*[n]*/, void *low_leaf /*[n][3][32]*/,
+                                     uint8_t *is_largest /*[n]*/, void *low_sib /*[depth][n][32]*/,
+                                     unsigned flags);
+
 /* ---- e: multi-GPU helpers ------------------------------------------------------ */
 /* Root of a depth-`depth` tree whose 2^k subtrees of height `sub_height` have the given
  * roots (k = log2(n_roots)); the levels above sub_height + k are extended with the

@@ -66,6 +66,8 @@ SIGNATURES = {
     "imt_itree_insert_batch": (c_int, [c_void_p, c_void_p, c_size_t, P(InsertOut), c_uint]),
     "imt_itree_get_proof_batch": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
     "imt_itree_get_leaves": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
+    "imt_itree_non_membership_witness": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_uint]),
     "imt_itree_load": (c_int, [c_void_p, c_void_p, c_u64, c_uint]),
     "imt_itree_find_low_batch": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
     "imt_combine_subtree_roots": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, c_uint, c_void_p, c_uint]),

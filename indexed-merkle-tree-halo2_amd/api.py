@@ -393,10 +393,23 @@ class IndexedTree:
         self.ctx._check(rc)
         return out
 
-    def non_membership_witness(self, vals):
-        """Witness for verify_non_inclusion of every value: low index, low leaf, siblings, flag."""
-        low = self.find_low(vals)
-        leaves = self.get_leaves(low)
-        sib = self.get_proof_batch(low)
-        largest = (leaves[:, 1, :].max(axis=1) == 0).astype(np.uint8)
+    def non_membership_witness(self, vals, host=False):
+        """Witness for verify_non_inclusion of every value: (low index, low leaf, siblings, is_largest).
+        Built on the GPU from the device-resident index; host=True uses the host mirror instead."""
+        if host:
+            low = self.find_low(vals)
+            leaves = self.get_leaves(low)
+            sib = self.get_proof_batch(low)
+            largest = (leaves[:, 1, :].max(axis=1) == 0).astype(np.uint8)
+            return low, leaves, sib, largest
+        v = to_bytes(vals) if not isinstance(vals, np.ndarray) else _arr(vals, (32,))
+        n = v.shape[0]
+        low = np.empty(n, np.uint64)
+        leaves = np.empty((n, 3, 32), np.uint8)
+        largest = np.empty(n, np.uint8)
+        sib = np.empty((self.depth, n, 32), np.uint8)
+        rc = lib.imt_itree_non_membership_witness(self.h, _p(v), n, _p(low), _p(leaves), _p(largest), _p(sib), 0)
+        if rc == _ffi.ERR["VALUE"]:
+            raise ValueError(lib.imt_last_error(self.ctx.h).decode())
+        self.ctx._check(rc)
         return low, leaves, sib, largest

@@ -520,6 +520,77 @@ extern "C" int imt_itree_get_proof_batch(imt_itree* t, const uint64_t* index, si
 }
 
 // ------------------------------------------------------------------------------------
+// non-membership witness on the GPU
+// ------------------------------------------------------------------------------------
+extern "C" int imt_itree_non_membership_witness(imt_itree* t, const void* vals, size_t n, uint64_t* low_index,
+                                                void* low_leaf, uint8_t* is_largest, void* low_sib, unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (n == 0) return IMT_OK;
+    if (!vals) return c->fail(IMT_ERR_ARG, "null vals");
+    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
+    if (n > ((size_t)1 << 31)) return c->fail(IMT_ERR_RANGE, "batch too large");
+    int rc = c->set_device();
+    if (rc) return rc;
+    if ((rc = ensure_device_index(t))) return rc;
+    if ((rc = join_top(t))) return rc;
+    const bool dev = flags & IMT_DEVICE_PTRS;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    hipStream_t s = c->stream;
+    IMT_HIP(c, hipStreamSynchronize(t->up_stream));     // the index may have been written on the side stream
+    size_t slot = 0;
+    auto scratch = [&](size_t bytes) { return (uint8_t*)c->dev_scratch(slot++, bytes); };
+    const uint8_t* d_vals = (const uint8_t*)vals;
+    if (!dev) {
+        uint8_t* up = scratch(n * 32);
+        if (!up) return IMT_ERR_HIP;
+        IMT_HIP(c, hipMemcpyAsync(up, vals, n * 32, hipMemcpyHostToDevice, s));
+        d_vals = up;
+    }
+    int* d_perr = (int*)scratch(sizeof(int));
+    if (!d_perr) return IMT_ERR_HIP;
+    IMT_HIP(c, hipMemsetAsync(d_perr, 0, sizeof(int), s));
+    if (fmt != IMT_FMT_CANONICAL) {
+        uint8_t* can = scratch(n * 32);
+        if (!can) return IMT_ERR_HIP;
+        launch::convert(s, d_vals, can, n, fmt, IMT_FMT_CANONICAL, d_perr);
+        d_vals = can;
+    }
+    auto outbuf = [&](void* user, size_t bytes) -> uint8_t* {
+        if (!user) return nullptr;
+        return dev ? (uint8_t*)user : scratch(bytes);
+    };
+    // the low index is needed on the device for the proof gather even if the caller does not want it
+    uint64_t* g_low = (uint64_t*)(low_index && dev ? (uint8_t*)low_index : scratch(n * 8));
+    uint8_t* g_leaf = outbuf(low_leaf, n * 96);
+    uint8_t* g_lg = outbuf(is_largest, n);
+    const size_t sib_bytes = (size_t)t->depth * n * 32;
+    uint8_t* g_sib = outbuf(low_sib, sib_bytes);
+    if (!g_low || (low_leaf && !g_leaf) || (is_largest && !g_lg) || (low_sib && !g_sib)) return IMT_ERR_HIP;
+    prep::nm_witness(s, d_vals, t->d_val, t->d_sorted[t->sorted_cur], (uint32_t)t->size, (uint32_t)n, g_low, g_leaf, g_lg,
+                     d_perr);
+    if (g_leaf && fmt != IMT_FMT_CANONICAL) launch::convert(s, g_leaf, g_leaf, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+    if (g_sib) {
+        launch::TreeView tv{t->d_nodes, t->d_off, t->d_len, c->d_zero};
+        launch::SibLayout lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->depth} : launch::SibLayout{n, 1};
+        launch::gather_proof(s, tv, g_low, n, t->depth, g_sib, lay, fmt);
+    }
+    int perr = 0;
+    IMT_HIP(c, hipMemcpyAsync(&perr, d_perr, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (!dev) {
+        if (low_index) IMT_HIP(c, hipMemcpyAsync(low_index, g_low, n * 8, hipMemcpyDeviceToHost, s));
+        if (low_leaf) IMT_HIP(c, hipMemcpyAsync(low_leaf, g_leaf, n * 96, hipMemcpyDeviceToHost, s));
+        if (is_largest) IMT_HIP(c, hipMemcpyAsync(is_largest, g_lg, n, hipMemcpyDeviceToHost, s));
+        if (low_sib) IMT_HIP(c, hipMemcpyAsync(low_sib, g_sib, sib_bytes, hipMemcpyDeviceToHost, s));
+    }
+    IMT_HIP(c, hipStreamSynchronize(s));
+    if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a candidate is not reduced (>= p)");
+    if (perr & (prep::ERR_ZERO | prep::ERR_DUPLICATE))
+        return c->fail(IMT_ERR_VALUE, "a candidate is 0 or already in the tree (it has no non-membership witness)");
+    return IMT_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // snapshot load / bulk build
 // ------------------------------------------------------------------------------------
 extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, unsigned flags) {

@@ -168,6 +168,28 @@ __global__ void __launch_bounds__(BLOCK) k_find_low(const uint8_t* __restrict__ 
     low_index[i] = sorted[g - 1];
 }
 
+__global__ void __launch_bounds__(BLOCK)
+k_nm_witness(const uint8_t* __restrict__ vals, const uint8_t* __restrict__ d_val, const uint32_t* __restrict__ sorted,
+             uint32_t M, uint32_t n, uint64_t* __restrict__ low_index, uint8_t* __restrict__ low_leaf,
+             uint8_t* __restrict__ is_largest, int* err) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* x = vals + (uint64_t)i * 32;
+    if (geq_p(x)) atomicOr(err, ERR_NONCANONICAL);
+    uint32_t g = count_below(d_val, sorted, M, x);
+    if (g == 0) { atomicOr(err, ERR_ZERO); g = 1; }
+    if (g < M && eq256(d_val + (uint64_t)sorted[g] * 32, x)) atomicOr(err, ERR_DUPLICATE);
+    const uint32_t lo = sorted[g - 1];
+    if (low_index) low_index[i] = lo;
+    if (is_largest) is_largest[i] = g == M ? 1 : 0;
+    if (low_leaf) {        // the stored list: a leaf points at its successor in value order
+        uint8_t* o = low_leaf + (uint64_t)i * 96;
+        copy32(o, d_val + (uint64_t)lo * 32);
+        if (g < M) { copy32(o + 32, d_val + (uint64_t)sorted[g] * 32); put_u64(o + 64, sorted[g]); }
+        else { zero32(o + 32); zero32(o + 64); }
+    }
+}
+
 int levels_for(uint32_t n) {
     int k = 1;
     while ((1u << k) <= n) k++;
@@ -206,6 +228,13 @@ void run(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val, cons
     hipLaunchKernelGGL(k_runs, dim3(nblk(2 * (size_t)n)), dim3(BLOCK), 0, s, ws.keys_sorted, 2 * n, node, time, rs, re);
     tb = ws.tmp_bytes;
     (void)rocprim::merge(ws.tmp, tb, sorted_old, ws.bsorted, sorted_new, (size_t)M, (size_t)n, ValLess{d_val}, s);
+}
+
+void nm_witness(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
+                uint64_t* low_index, uint8_t* low_leaf, uint8_t* is_largest, int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_nm_witness, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, sorted, M, n, low_index, low_leaf,
+                       is_largest, err);
 }
 
 void find_low(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,

@@ -53,6 +53,11 @@ void run(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val, cons
          uint32_t* sorted_new, uint32_t M, uint32_t n, uint8_t* pre, uint32_t* node, uint32_t* time, uint32_t* rs,
          uint32_t* re, uint64_t* o_low_index, uint8_t* o_is_largest, uint8_t* o_low_leaf, uint8_t* o_new_leaf);
 
+// non-membership witness: low leaf index, its preimage {val, next_val, next_idx} (canonical) and the
+// is_largest flag of every candidate; any output may be NULL
+void nm_witness(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
+                uint64_t* low_index, uint8_t* low_leaf, uint8_t* is_largest, int* err);
+
 // predecessor search only (imt_itree_find_low_batch): low[i] = leaf index of the greatest value < vals[i]
 void find_low(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
               uint64_t* low_index, int* err);

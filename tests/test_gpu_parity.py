@@ -367,9 +367,17 @@ def test_non_membership_batch_vs_oracle(imt, ctx, oracle):
         helper = ints_to_arr([1 - ((int(low[i]) >> l) & 1) for l in range(depth)])
         f, r = oracle.verify_non_inclusion(root, ints(leaves[i]), sib[:, i], helper, cand[i], int(largest[i]))
         assert f == 0 and r == root
+    # the host-mirror route gives the same witness
+    hl, hleaves, hsib, hlg = t.non_membership_witness(cand, host=True)
+    assert (hl == low).all() and (hleaves == leaves).all() and (hsib == sib).all() and (hlg == largest).all()
     # members are not non-members: the predicate fails for every inserted value
     with pytest.raises(ValueError):
         t.find_low(vals[:1])
+    for bad in (vals[:1], [0]):
+        with pytest.raises(ValueError):
+            t.non_membership_witness(bad)
+    with pytest.raises(imt.ImtError):
+        t.non_membership_witness([P])
     fail = ctx.non_membership(imt.to_bytes(root), leaves, low, sib, depth, leaves[:, 0, :].copy(), largest)
     assert (fail & imt._ffi.F_LOW_LT_NEW).all()
     # per-item roots and a bad largest flag value
