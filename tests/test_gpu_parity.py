@@ -555,6 +555,63 @@ def test_config2_full_size_properties(imt, ctx, oracle):
     oracle.sparse_free(oh)
 
 
+def test_pipelined_growth_stress_properties(imt, ctx):
+    """2^18 insertions as 8 pipelined device-pointer batches of 2^15 (L0 grows 15 -> 18 on the way, so
+    both the overlapped and the joined schedule run), GPU prepare; every insert_leaf constraint is then
+    re-checked by the independent witness kernels, the root chain is continuous and the final root
+    equals a bulk rebuild from the snapshot."""
+    import ctypes
+    import torch
+    depth, nb, bs = 32, 8, 1 << 15
+    dev = torch.device("cuda", 0)
+    c2 = imt.Context(0)
+    c2.set_stream(torch.cuda.current_stream().cuda_stream)
+    t = imt.IndexedTree(c2, depth, 1 << 19)
+    rng = np.random.default_rng(17)
+    raw = rng.integers(0, 256, size=(nb * bs, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x0f
+    raw[:, 0] |= 1                                      # non-zero; 252-bit randoms are distinct w.h.p.
+    vals = torch.from_numpy(raw).to(dev)
+    outs = []
+    flags = imt._ffi.DEVICE_PTRS | imt._ffi.PIPELINE
+    for b in range(nb):
+        o = dict(low_index=torch.empty(bs, dtype=torch.int64, device=dev),
+                 is_largest=torch.empty(bs, dtype=torch.uint8, device=dev),
+                 low_leaf=torch.empty((bs, 3, 32), dtype=torch.uint8, device=dev),
+                 new_leaf=torch.empty((bs, 3, 32), dtype=torch.uint8, device=dev),
+                 old_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
+                 interim_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
+                 new_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
+                 low_sib=torch.empty((depth, bs, 32), dtype=torch.uint8, device=dev),
+                 new_sib=torch.empty((depth, bs, 32), dtype=torch.uint8, device=dev))
+        st = imt._ffi.InsertOut(**{k: v.data_ptr() for k, v in o.items()})
+        rc = imt.lib.imt_itree_insert_batch(t.h, ctypes.c_void_p(vals.data_ptr() + b * bs * 32), bs, ctypes.byref(st), flags)
+        assert rc == 0, imt.lib.imt_last_error(c2.h)
+        outs.append(o)
+    c2.sync()
+    torch.cuda.synchronize()
+    prev = None
+    for b, o in enumerate(outs):
+        new_index = torch.arange(1 + b * bs, 1 + (b + 1) * bs, dtype=torch.int64, device=dev)
+        fail = torch.empty(bs, dtype=torch.uint8, device=dev)
+        P_ = lambda x: ctypes.c_void_p(x.data_ptr())
+        rc = imt.lib.imt_insert_witness_batch(c2.h, P_(o["old_root"]), P_(o["low_leaf"]), P_(o["low_index"]), P_(o["low_sib"]),
+                                              P_(o["new_root"]), P_(o["new_leaf"]), P_(new_index), None, P_(o["new_sib"]),
+                                              P_(o["is_largest"]), depth, bs, P_(fail), None, imt._ffi.DEVICE_PTRS)
+        assert rc == 0
+        c2.sync()
+        assert int(fail.max()) == 0, b
+        assert bool((o["old_root"][1:] == o["new_root"][:-1]).all())
+        if prev is not None:
+            assert bool((o["old_root"][0] == prev).all())
+        prev = o["new_root"][-1].clone()
+    assert ints(prev.cpu().numpy()) == [t.root()]
+    t2 = imt.IndexedTree(c2, depth, 1 << 19)
+    t2.load(t.snapshot())
+    assert t2.root() == t.root()
+    t.close(); t2.close(); c2.close()
+
+
 def test_config3_non_membership_2pow20_properties(imt, ctx):
     """depth 32, 2^20 non-membership items against the config-2 tree: all accepted, every recomputed
     root equals the tree root, and flipping the candidate to the low leaf's own value is rejected."""
