@@ -1,6 +1,6 @@
 // imt_capi.cpp -- the extern "C" boundary declared in include/imt.h (context, batched
 // hashes, dense tree, path recompute, non-membership, insert witness, multi-GPU helpers).
-// Host code only; the kernels are in imt_kernels.hip / imt_sweep.hip.
+// Host code only; the kernels are in imt_kernels.hip and imt_prep.hip.
 #include "imt_ctx.hpp"
 #include <cstring>
 #include <new>

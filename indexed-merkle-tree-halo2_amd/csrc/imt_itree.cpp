@@ -1,11 +1,12 @@
 // imt_itree.cpp -- the stateful depth-d indexed tree behind imt_itree_* (include/imt.h).
 //
-// Host side of the batch insertion: everything that needs no hashing -- the low-leaf
-// search of update_idx_leaf (/root/reference/src/indexed_merkle_tree.rs:632-660), the
-// leaf preimages at every time step, and the (position, time) order of the 2N leaf
-// events -- is computed here; all hashing runs on the GPU as the level sweep of
-// imt_sweep.hpp.  The plan buffers are double-buffered and uploaded on a second stream,
-// so with IMT_DEVICE_PTRS the host work of batch k+1 overlaps the kernels of batch k.
+// A batch insertion has a hash-free part -- the low-leaf search of update_idx_leaf
+// (/root/reference/src/indexed_merkle_tree.rs:632-660), the leaf preimages at every time
+// step and the (position, time) order of the 2N leaf events -- and the hashing, which is the
+// level sweep of imt_sweep.hpp on the GPU.  The hash-free part runs on the GPU too by default
+// (imt_prep.hip, over a device-resident sorted index); IMT_HOST_PREP selects the equivalent host
+// code in this file.  Plan buffers exist three times and are filled on a side stream, so with
+// IMT_DEVICE_PTRS | IMT_PIPELINE consecutive batches overlap on two compute streams.
 #include "imt_ctx.hpp"
 #include "imt_prep.hpp"
 #include <algorithm>

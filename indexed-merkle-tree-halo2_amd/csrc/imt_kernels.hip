@@ -3,12 +3,13 @@
 // One thread owns one hash chain: its 3x9-limb Poseidon state stays in VGPRs for all 65
 // rounds, round constants arrive as wave-uniform scalar loads (SGPR operands of
 // v_mad_u64_u32), and HBM is touched only for the 32-byte inputs / siblings / outputs.
-// The path is VALU-integer bound (about 80k v_mad_u64_u32 per permutation against
+// The path is VALU-integer bound (about 76k v_mad_u64_u32 per permutation against
 // 32..100 bytes of traffic), so there is no LDS staging and no MFMA: nothing is reused
 // across lanes and there is no dense contraction ("Kernels").
 //
 // Reference rows: a1/a10 hash_batch, a2 tree_level, a4 gather_proof,
-// a5/a8/a9 path_root, a13 non_membership, a14 insert_witness, a15 sweep_* (imt_sweep.hip).
+// a5/a8/a9 path_root, a13 non_membership, a14 insert_witness, a15 sweep_* (index logic in imt_sweep.hpp;
+// the hash-free batch preparation is a separate translation unit, imt_prep.hip).
 #include "imt_device.hpp"
 #include "imt_launch.hpp"
 #include "imt_sweep.hpp"
