@@ -252,6 +252,35 @@ int imt_itree_non_membership_witness(imt_itree *t, const void *vals /*[n][32]*/,
                                      uint8_t *is_largest /*[n]*/, void *low_sib /*[depth][n][32]*/,
                                      unsigned flags);
 
+/* ---- e: one tree on several GPUs, sequential semantics (single sorted list) ------------------
+ * Every rank holds a replica of the tree and calls the same sequence with the same values; the hashing
+ * of each step is split by slot range between the ranks, and the caller all-gathers the value arrays in
+ * between (RCCL).  A batch of n insertions has E = 2n events; level l has E slots for l = 0..l0 (l0 =
+ * ceil(log2(size + n))), val[l] is [E][32] in the library's device format.  All data pointers are
+ * device pointers; work is enqueued on the context's stream.
+ *   begin   : values (host or device per flags; identical on all ranks) -> plan; E and l0 returned.
+ *             IMT_ERR_VALUE / IMT_ERR_NONCANONICAL / IMT_ERR_FULL exactly as imt_itree_insert_batch.
+ *   leaves  : val0[k] for slots [k_begin, k_begin + k_count)
+ *   level   : val_out[k] (level l+1) for a slot range, from the COMPLETE val_in (level l)
+ *   top     : from the complete val[l0]: root after every event of [e_begin, +e_count) -> roots[e][32]
+ *             (device format); the rank whose range contains the last event also fills top_path
+ *             ([depth - l0 + 1][32], the stored nodes above l0), which the caller broadcasts.
+ *   extract : witnesses of insertions [ins_begin, +ins_count) (any subset, any rank) from the complete
+ *             val[0..l0] and roots: every field of imt_insert_out, rows indexed from ins_begin;
+ *             formats / sibling layout per flags (level stride = ins_count).
+ *   end     : write the batch into the replica (needs the complete val[0..l0] and top_path). */
+int imt_itree_batch_begin(imt_itree *t, const void *vals /*[n][32]*/, size_t n, unsigned flags,
+                          uint32_t *events_out, uint32_t *l0_out);
+int imt_itree_batch_leaves(imt_itree *t, void *val0, uint32_t k_begin, uint32_t k_count);
+int imt_itree_batch_level(imt_itree *t, unsigned level, const void *val_in, void *val_out, uint32_t k_begin,
+                          uint32_t k_count);
+int imt_itree_batch_top(imt_itree *t, const void *val_l0, uint32_t e_begin, uint32_t e_count, void *roots,
+                        void *top_path);
+int imt_itree_batch_extract(imt_itree *t, const void *const *val_levels /*host array of l0+1 device ptrs*/,
+                            const void *roots, uint32_t ins_begin, uint32_t ins_count,
+                            const imt_insert_out *out, unsigned flags);
+int imt_itree_batch_end(imt_itree *t, const void *const *val_levels, const void *top_path);
+
 /* ---- e: multi-GPU helpers ------------------------------------------------------ */
 /* Root of a depth-`depth` tree whose 2^k subtrees of height `sub_height` have the given
  * roots (k = log2(n_roots)); the levels above sub_height + k are extended with the

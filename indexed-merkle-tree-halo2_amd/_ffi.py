@@ -70,6 +70,13 @@ SIGNATURES = {
                                                  c_uint]),
     "imt_itree_load": (c_int, [c_void_p, c_void_p, c_u64, c_uint]),
     "imt_itree_find_low_batch": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
+    "imt_itree_batch_begin": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, P(ctypes.c_uint32), P(ctypes.c_uint32)]),
+    "imt_itree_batch_leaves": (c_int, [c_void_p, c_void_p, ctypes.c_uint32, ctypes.c_uint32]),
+    "imt_itree_batch_level": (c_int, [c_void_p, c_uint, c_void_p, c_void_p, ctypes.c_uint32, ctypes.c_uint32]),
+    "imt_itree_batch_top": (c_int, [c_void_p, c_void_p, ctypes.c_uint32, ctypes.c_uint32, c_void_p, c_void_p]),
+    "imt_itree_batch_extract": (c_int, [c_void_p, P(c_void_p), c_void_p, ctypes.c_uint32, ctypes.c_uint32, P(InsertOut),
+                                        c_uint]),
+    "imt_itree_batch_end": (c_int, [c_void_p, P(c_void_p), c_void_p]),
     "imt_combine_subtree_roots": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, c_uint, c_void_p, c_uint]),
     "imt_zero_hashes": (c_int, [c_void_p, c_uint, c_void_p, c_uint]),
 }

@@ -65,6 +65,8 @@ struct PlanSet {
     uint32_t* d_timen = nullptr; // [levels][E] time table of level l+1
     uint8_t* d_val[2] = {nullptr, nullptr};
     prep::Workspace ws;                  // GPU-prepare scratch
+    uint32_t* d_slot = nullptr;          // [levels + 1][E] slot of every event per level (sharded mode)
+    const uint8_t** d_valptr = nullptr;  // [levels + 1] device array of level value pointers (sharded mode)
     uint8_t* d_root = nullptr;           // stored root right after this batch (device format)
     bool has_root = false;
     hipEvent_t done = nullptr;           // recorded after the batch's last kernel
@@ -93,6 +95,8 @@ struct imt_itree {
     int sorted_cur = 0;
     bool mirror_valid = true, dev_index_valid = true;
     int* h_err_pin = nullptr;        // pinned word for the prepare kernels' error bits
+    // a sharded batch between imt_itree_batch_begin and _end
+    struct Pending { bool active = false; size_t n = 0; unsigned l0 = 0; int set = 0; } pending;
     static constexpr int NSETS = 3;      // host work may run two batches ahead of the GPU
     PlanSet plan[NSETS];
     int cur = 0;
@@ -128,6 +132,10 @@ static void plan_free(PlanSet& p) {
     for (auto& q : p.d_val)
         if (q) hipFree(q);
     if (p.d_root) hipFree(p.d_root);
+    if (p.d_slot) hipFree(p.d_slot);
+    if (p.d_valptr) hipFree(p.d_valptr);
+    for (void* q : {(void*)p.ws.o_low, (void*)p.ws.o_largest, (void*)p.ws.o_lowleaf, (void*)p.ws.o_newleaf})
+        if (q) hipFree(q);
     for (void* q : {(void*)p.ws.iota, (void*)p.ws.bsorted, (void*)p.ws.gap, (void*)p.ws.st, (void*)p.ws.low,
                     (void*)p.ws.succ, (void*)p.ws.keys, (void*)p.ws.keys_sorted, p.ws.tmp, (void*)p.ws.err})
         if (q) hipFree(q);
@@ -174,7 +182,13 @@ static int plan_reserve(imt_ctx* c, PlanSet& p, size_t events, unsigned levels, 
         p.ws.tmp_bytes = prep::temp_bytes_needed(N, tree_cap);
         A((void**)&p.ws.tmp, p.ws.tmp_bytes);
         A((void**)&p.ws.err, sizeof(int));
+        A((void**)&p.ws.o_low, N * 8);
+        A((void**)&p.ws.o_largest, N);
+        A((void**)&p.ws.o_lowleaf, N * 96);
+        A((void**)&p.ws.o_newleaf, N * 96);
     }
+    A((void**)&p.d_slot, (size_t)(L + 1) * E * 4);
+    A((void**)&p.d_valptr, (size_t)(L + 1) * sizeof(void*));
     if (e != hipSuccess) {
         plan_free(p);
         return c->hip_fail(e, "hipMalloc(plan)");
@@ -935,7 +949,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         sweep::LevelTable in{P.d_tab[a][0], time_in, P.d_tab[a][2], P.d_tab[a][3]};
         sweep::LevelOut o{P.d_tab[b][0], P.d_timen + (size_t)l * P.cap_events, P.d_tab[b][2], P.d_tab[b][3],
                           P.d_from + (size_t)l * P.cap_events, P.d_sibsrc + (size_t)l * P.cap_events,
-                          P.d_nodeb + (size_t)l * P.cap_events};
+                          P.d_nodeb + (size_t)l * P.cap_events, nullptr};
         launch::merge_level(s, in, o, (uint32_t)E);
     }
     c->prof_end(pf, s);
@@ -1071,5 +1085,191 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         c->prof_n[IMT_PROF_HOST] += 1;
     }
     if (!dev) IMT_HIP(c, hipStreamSynchronize(s));
+    return IMT_OK;
+}
+
+
+// ------------------------------------------------------------------------------------
+// e: one tree on several GPUs, sequential semantics (imt_itree_batch_*)
+// ------------------------------------------------------------------------------------
+extern "C" int imt_itree_batch_begin(imt_itree* t, const void* vals, size_t n, unsigned flags, uint32_t* events_out,
+                                     uint32_t* l0_out) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (!vals || n == 0) return c->fail(IMT_ERR_ARG, "null / empty batch");
+    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
+    if (t->pending.active) return c->fail(IMT_ERR_ARG, "a sharded batch is already open");
+    if (n > ((size_t)1 << 30)) return c->fail(IMT_ERR_RANGE, "batch too large");
+    int rc = c->set_device();
+    if (rc) return rc;
+    const uint64_t M = t->size;
+    if (M + n > t->cap) return c->fail(IMT_ERR_FULL, "tree capacity %llu exceeded", (unsigned long long)t->cap);
+    if ((rc = join_top(t))) return rc;
+    if ((rc = ensure_device_index(t))) return rc;
+    const bool dev = flags & IMT_DEVICE_PTRS;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    const size_t E = 2 * n;
+    const unsigned L0 = std::min(ceil_log2(M + n), t->depth);
+    PlanSet& P = t->plan[t->cur];
+    if (P.in_flight) {
+        IMT_HIP(c, hipEventSynchronize(P.done));
+        P.in_flight = false;
+    }
+    if ((rc = plan_reserve(c, P, E, t->depth, t->cap))) return rc;
+    hipStream_t s = c->stream;
+    size_t slot = 2;
+    const uint8_t* d_vals = (const uint8_t*)vals;
+    if (!dev) {
+        uint8_t* up = (uint8_t*)c->dev_scratch(slot++, n * 32);
+        if (!up) return IMT_ERR_HIP;
+        IMT_HIP(c, hipMemcpyAsync(up, vals, n * 32, hipMemcpyHostToDevice, s));
+        d_vals = up;
+    }
+    IMT_HIP(c, hipMemsetAsync(P.ws.err, 0, sizeof(int), s));
+    if (fmt != IMT_FMT_CANONICAL) {
+        uint8_t* can = (uint8_t*)c->dev_scratch(slot++, n * 32);
+        if (!can) return IMT_ERR_HIP;
+        launch::convert(s, d_vals, can, n, fmt, IMT_FMT_CANONICAL, P.ws.err);
+        d_vals = can;
+    }
+    IMT_HIP(c, hipStreamSynchronize(t->up_stream));
+    prep::run(s, P.ws, d_vals, t->d_val, t->d_sorted[t->sorted_cur], t->d_sorted[t->sorted_cur ^ 1], (uint32_t)M,
+              (uint32_t)n, P.d_pre, P.d_tab[0][0], P.d_tab[0][1], P.d_tab[0][2], P.d_tab[0][3], P.ws.o_low,
+              P.ws.o_largest, P.ws.o_lowleaf, P.ws.o_newleaf);
+    IMT_HIP(c, hipMemcpyAsync(t->h_err_pin, P.ws.err, sizeof(int), hipMemcpyDeviceToHost, s));
+    IMT_HIP(c, hipStreamSynchronize(s));
+    const int perr = *t->h_err_pin;
+    if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
+    if (perr & prep::ERR_ZERO) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
+    if (perr & prep::ERR_DUPLICATE) return c->fail(IMT_ERR_VALUE, "duplicate value (inside the batch or already in the tree)");
+    // index phase for every level, with the slot of every event per level
+    launch::slot0(s, P.d_tab[0][1], P.d_slot, (uint32_t)E);
+    for (unsigned l = 0; l < L0; l++) {
+        const int a = l & 1, b = a ^ 1;
+        const uint32_t* time_in = l == 0 ? P.d_tab[0][1] : P.d_timen + (size_t)(l - 1) * P.cap_events;
+        sweep::LevelTable in{P.d_tab[a][0], time_in, P.d_tab[a][2], P.d_tab[a][3]};
+        sweep::LevelOut o{P.d_tab[b][0], P.d_timen + (size_t)l * P.cap_events, P.d_tab[b][2], P.d_tab[b][3],
+                          P.d_from + (size_t)l * P.cap_events, P.d_sibsrc + (size_t)l * P.cap_events,
+                          P.d_nodeb + (size_t)l * P.cap_events, P.d_slot + (size_t)(l + 1) * P.cap_events};
+        launch::merge_level(s, in, o, (uint32_t)E);
+    }
+    t->pending.active = true;
+    t->pending.n = n;
+    t->pending.l0 = L0;
+    t->pending.set = t->cur;
+    if (events_out) *events_out = (uint32_t)E;
+    if (l0_out) *l0_out = L0;
+    return IMT_OK;
+}
+
+#define IMT_PENDING(t, c)                                                                   \
+    if (!(t)) return IMT_ERR_ARG;                                                           \
+    imt_ctx* c = (t)->ctx;                                                                  \
+    if (!(t)->pending.active) return c->fail(IMT_ERR_ARG, "no sharded batch is open");      \
+    { int rc__ = c->set_device(); if (rc__) return rc__; }                                  \
+    PlanSet& P = (t)->plan[(t)->pending.set];                                               \
+    const size_t E = 2 * (t)->pending.n;                                                    \
+    const unsigned L0 = (t)->pending.l0;                                                    \
+    (void)E; (void)L0; (void)P
+
+extern "C" int imt_itree_batch_leaves(imt_itree* t, void* val0, uint32_t k_begin, uint32_t k_count) {
+    IMT_PENDING(t, c);
+    if (!val0 || (size_t)k_begin + k_count > E) return c->fail(IMT_ERR_RANGE, "slot range outside the batch");
+    launch::sweep_leaves(c->stream, P.d_pre, P.d_tab[0][1], (uint8_t*)val0, k_begin, k_count, IMT_FMT_CANONICAL, c->d_err);
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_batch_level(imt_itree* t, unsigned level, const void* val_in, void* val_out, uint32_t k_begin,
+                                     uint32_t k_count) {
+    IMT_PENDING(t, c);
+    if (level >= L0) return c->fail(IMT_ERR_RANGE, "level %u >= l0 %u", level, L0);
+    if (!val_in || !val_out || (size_t)k_begin + k_count > E) return c->fail(IMT_ERR_RANGE, "slot range outside the batch");
+    const size_t o = (size_t)level * P.cap_events;
+    launch::sweep_level(c->stream, (const uint8_t*)val_in, (uint8_t*)val_out, P.d_from + o, P.d_sibsrc + o, P.d_nodeb + o,
+                        P.d_timen + o, t->d_nodes + t->h_off[level] * 32, t->h_len[level], c->d_zero + (size_t)level * 32,
+                        k_begin, k_count, nullptr, nullptr, launch::SibLayout{0, 0}, level, IMT_FMT_DEVICE);
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_batch_top(imt_itree* t, const void* val_l0, uint32_t e_begin, uint32_t e_count, void* roots,
+                                   void* top_path) {
+    IMT_PENDING(t, c);
+    if (!val_l0 || !roots || !top_path || (size_t)e_begin + e_count > E)
+        return c->fail(IMT_ERR_RANGE, "event range outside the batch");
+    launch::sweep_top(c->stream, (const uint8_t*)val_l0, L0, t->depth, c->d_zero, t->d_nodes, t->d_off, e_begin, e_count,
+                      (uint32_t)E, nullptr, nullptr, nullptr, nullptr, nullptr, launch::SibLayout{0, 0}, IMT_FMT_DEVICE,
+                      (uint8_t*)roots, (uint8_t*)top_path);
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_batch_extract(imt_itree* t, const void* const* val_levels, const void* roots, uint32_t ins_begin,
+                                       uint32_t ins_count, const imt_insert_out* out, unsigned flags) {
+    IMT_PENDING(t, c);
+    if (!val_levels || !roots || !out) return c->fail(IMT_ERR_ARG, "null argument");
+    if (!(flags & IMT_DEVICE_PTRS)) return c->fail(IMT_ERR_ARG, "imt_itree_batch_extract takes device pointers");
+    if ((size_t)ins_begin + ins_count > t->pending.n) return c->fail(IMT_ERR_RANGE, "insertion range outside the batch");
+    if (ins_count == 0) return IMT_OK;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    hipStream_t s = c->stream;
+    IMT_HIP(c, hipMemcpyAsync(P.d_valptr, val_levels, (size_t)(L0 + 1) * sizeof(void*), hipMemcpyHostToDevice, s));
+    launch::ExtractParams p{};
+    p.val = P.d_valptr;
+    p.slot = P.d_slot;
+    p.sibsrc = P.d_sibsrc;
+    p.node_below = P.d_nodeb;
+    p.stride = P.cap_events;
+    p.tree_nodes = t->d_nodes;
+    p.tree_off = t->d_off;
+    p.tree_len = t->d_len;
+    p.zero = c->d_zero;
+    p.roots = (const uint8_t*)roots;
+    p.l0 = L0;
+    p.depth = t->depth;
+    p.ins_begin = ins_begin;
+    p.ins_count = ins_count;
+    p.n_total = (uint32_t)t->pending.n;
+    p.old_root = (uint8_t*)out->old_root;
+    p.interim_root = (uint8_t*)out->interim_root;
+    p.new_root = (uint8_t*)out->new_root;
+    p.low_sib = (uint8_t*)out->low_sib;
+    p.new_sib = (uint8_t*)out->new_sib;
+    p.lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->depth} : launch::SibLayout{ins_count, 1};
+    p.fmt_out = fmt;
+    launch::extract(s, p);
+    if (out->low_index)
+        IMT_HIP(c, hipMemcpyAsync(out->low_index, P.ws.o_low + ins_begin, (size_t)ins_count * 8, hipMemcpyDeviceToDevice, s));
+    if (out->is_largest)
+        IMT_HIP(c, hipMemcpyAsync(out->is_largest, P.ws.o_largest + ins_begin, ins_count, hipMemcpyDeviceToDevice, s));
+    if (out->low_leaf)
+        launch::convert(s, P.ws.o_lowleaf + (size_t)ins_begin * 96, (uint8_t*)out->low_leaf, (size_t)ins_count * 3,
+                        IMT_FMT_CANONICAL, fmt, c->d_err);
+    if (out->new_leaf)
+        launch::convert(s, P.ws.o_newleaf + (size_t)ins_begin * 96, (uint8_t*)out->new_leaf, (size_t)ins_count * 3,
+                        IMT_FMT_CANONICAL, fmt, c->d_err);
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_batch_end(imt_itree* t, const void* const* val_levels, const void* top_path) {
+    IMT_PENDING(t, c);
+    if (!val_levels || !top_path) return c->fail(IMT_ERR_ARG, "null argument");
+    hipStream_t s = c->stream;
+    for (unsigned l = 0; l < L0; l++) {
+        const size_t o = (size_t)l * P.cap_events;
+        launch::writeback(s, (const uint8_t*)val_levels[l], P.d_from + o, P.d_nodeb + o, t->d_nodes + t->h_off[l] * 32,
+                          (uint32_t)E);
+    }
+    launch::store_top_path(s, (const uint8_t*)top_path, t->d_nodes, t->d_off, L0, t->depth);
+    IMT_HIP(c, hipMemcpyAsync(P.d_root, t->d_nodes + t->h_off[t->depth] * 32, 32, hipMemcpyDeviceToDevice, s));
+    P.has_root = true;
+    IMT_HIP(c, hipEventRecord(P.done, s));
+    P.in_flight = true;
+    P.pipelined = false;
+    P.l0 = L0;
+    t->sorted_cur ^= 1;
+    t->size += t->pending.n;
+    t->mirror_valid = false;
+    t->cur = (t->cur + 1) % imt_itree::NSETS;
+    t->batch_no++;
+    t->pending.active = false;
     return IMT_OK;
 }

@@ -439,14 +439,16 @@ k_sweep_top(const uint8_t* __restrict__ val, unsigned l0, unsigned depth, const 
             uint8_t* __restrict__ tree_nodes, const uint64_t* __restrict__ tree_off, uint32_t e_begin,
             uint32_t e_count, uint32_t total, uint8_t* __restrict__ old_root, uint8_t* __restrict__ interim_root,
             uint8_t* __restrict__ new_root, uint8_t* __restrict__ low_sib, uint8_t* __restrict__ new_sib,
-            launch::SibLayout lay, unsigned fmt_out) {
+            launch::SibLayout lay, unsigned fmt_out, uint8_t* __restrict__ roots_dev, uint8_t* __restrict__ top_path) {
+    // sharded mode (roots_dev != NULL): the root after every event goes to roots_dev[e] in device format
+    // and the last event's node at every level >= l0 to top_path instead of the stored tree
     const size_t t = gtid();
     if (t >= e_count) return;
     const uint32_t e = e_begin + (uint32_t)t;
     const bool last = e == total - 1;
     Fe cur;
     load_packed(cur, val + (size_t)e * 32);
-    if (last) store_packed(tree_nodes + tree_off[l0] * 32, cur);
+    if (last) store_packed(top_path ? top_path : tree_nodes + tree_off[l0] * 32, cur);
     uint8_t* dst = (e & 1u) ? new_sib : low_sib;
 #pragma unroll 1
     for (unsigned l = l0; l < depth; l++) {
@@ -455,8 +457,9 @@ k_sweep_top(const uint8_t* __restrict__ val, unsigned l0, unsigned depth, const 
         if (dst) store_fe(g_pc, dst + ((uint64_t)l * lay.level_stride + (uint64_t)(e >> 1) * lay.item_stride) * 32, z, fmt_out);
         hash23(g_pc, o, cur, z, cur, false);
         cur = o;
-        if (last) store_packed(tree_nodes + tree_off[l + 1] * 32, cur);
+        if (last) store_packed(top_path ? top_path + (size_t)(l + 1 - l0) * 32 : tree_nodes + tree_off[l + 1] * 32, cur);
     }
+    if (roots_dev) { store_packed(roots_dev + (size_t)e * 32, cur); return; }
     const uint32_t i = e >> 1;
     if (e & 1u) {
         if (new_root) store_fe(g_pc, new_root + (size_t)i * 32, cur, fmt_out);
@@ -464,6 +467,83 @@ k_sweep_top(const uint8_t* __restrict__ val, unsigned l0, unsigned depth, const 
     } else {
         if (interim_root) store_fe(g_pc, interim_root + (size_t)i * 32, cur, fmt_out);
     }
+}
+
+// ---- sharded single-list batch (imt_itree_batch_*): helpers ------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_slot0(const uint32_t* __restrict__ time0, uint32_t* __restrict__ slot0,
+                                                 uint32_t total) {
+    const size_t k = gtid();
+    if (k < total) slot0[time0[k]] = (uint32_t)k;
+}
+
+// Proof rows and roots of insertions [ins_begin, ins_begin + ins_count) from the gathered value arrays of
+// every level.  One thread per (event, level); the stored tree still holds the pre-batch nodes.
+struct ExtractArgs {
+    const uint8_t* const* val;          // [l0 + 1] device pointers, level l in level-l slot order
+    const uint32_t* slot;               // [l0 + 1][stride]: slot[l][event]
+    const int32_t* sibsrc;              // [l0][stride]
+    const uint32_t* node_below;         // [l0][stride]
+    size_t stride;
+    const uint8_t* tree_nodes;
+    const uint64_t* tree_off;
+    const uint64_t* tree_len;
+    const uint8_t* zero;
+    const uint8_t* roots;               // [events][32] device format: root after each event
+    unsigned l0, depth;
+    uint32_t ins_begin, ins_count, n_total;
+    uint8_t *old_root, *interim_root, *new_root, *low_sib, *new_sib;   // rows indexed from ins_begin
+    launch::SibLayout lay;
+    unsigned fmt_out;
+};
+__global__ void __launch_bounds__(BLOCK) k_extract(ExtractArgs a) {
+    const size_t t = gtid();
+    const size_t per = (size_t)a.depth + 1;      // depth proof levels + one "roots" task per event
+    if (t >= (size_t)a.ins_count * 2 * per) return;
+    const uint32_t ev_local = (uint32_t)(t % ((size_t)a.ins_count * 2));   // events fastest: coalesced rows
+    const unsigned task = (unsigned)(t / ((size_t)a.ins_count * 2));
+    const uint32_t i_local = ev_local >> 1, odd = ev_local & 1u;
+    const uint32_t e = (a.ins_begin + i_local) * 2 + odd;
+    Fe x;
+    if (task == a.depth) {                       // roots
+        load_packed(x, a.roots + (size_t)e * 32);
+        if (odd) {
+            if (a.new_root) store_fe(g_pc, a.new_root + (size_t)i_local * 32, x, a.fmt_out);
+        } else {
+            if (a.interim_root) store_fe(g_pc, a.interim_root + (size_t)i_local * 32, x, a.fmt_out);
+            if (a.old_root) {                    // root before insertion i = after event 2i-1, or the stored root
+                Fe o;
+                if (e > 0) load_packed(o, a.roots + (size_t)(e - 1) * 32);
+                else load_packed(o, a.tree_nodes + a.tree_off[a.depth] * 32);
+                store_fe(g_pc, a.old_root + (size_t)i_local * 32, o, a.fmt_out);
+            }
+        }
+        return;
+    }
+    uint8_t* dst = odd ? a.new_sib : a.low_sib;
+    if (!dst) return;
+    const unsigned l = task;
+    const uint8_t* sp;
+    if (l < a.l0) {
+        const uint32_t kp = a.slot[(size_t)(l + 1) * a.stride + e];
+        const int32_t ss = a.sibsrc[(size_t)l * a.stride + kp];
+        const uint64_t sn = (uint64_t)(a.node_below[(size_t)l * a.stride + kp] ^ 1u);
+        sp = ss >= 0 ? a.val[l] + (size_t)ss * 32
+                     : (sn < a.tree_len[l] ? a.tree_nodes + (a.tree_off[l] + sn) * 32 : a.zero + (size_t)l * 32);
+    } else {
+        sp = a.zero + (size_t)l * 32;
+    }
+    load_packed(x, sp);
+    store_fe(g_pc, dst + ((uint64_t)l * a.lay.level_stride + (uint64_t)i_local * a.lay.item_stride) * 32, x, a.fmt_out);
+}
+
+__global__ void k_store_top_path(const uint8_t* __restrict__ top_path, uint8_t* __restrict__ tree_nodes,
+                                 const uint64_t* __restrict__ tree_off, unsigned l0, unsigned depth) {
+    const unsigned l = l0 + threadIdx.x;
+    if (l > depth) return;
+    const Word4* s = reinterpret_cast<const Word4*>(top_path + (size_t)(l - l0) * 32);
+    Word4* d = reinterpret_cast<Word4*>(tree_nodes + tree_off[l] * 32);
+    d[0] = s[0];
+    d[1] = s[1];
 }
 
 inline unsigned nblk(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
@@ -572,10 +652,27 @@ void writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const 
 void sweep_top(hipStream_t s, const uint8_t* val, unsigned l0, unsigned depth, const uint8_t* zero, uint8_t* tree_nodes,
                const uint64_t* tree_off, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
                uint8_t* interim_root, uint8_t* new_root, uint8_t* low_sib, uint8_t* new_sib, SibLayout lay,
-               unsigned fmt_out) {
+               unsigned fmt_out, uint8_t* roots_dev, uint8_t* top_path) {
     if (!e_count) return;
     hipLaunchKernelGGL(k_sweep_top, dim3(nblk(e_count)), dim3(BLOCK), 0, s, val, l0, depth, zero, tree_nodes, tree_off,
-                       e_begin, e_count, total, old_root, interim_root, new_root, low_sib, new_sib, lay, fmt_out);
+                       e_begin, e_count, total, old_root, interim_root, new_root, low_sib, new_sib, lay, fmt_out, roots_dev,
+                       top_path);
+}
+void slot0(hipStream_t s, const uint32_t* time0, uint32_t* slot0_out, uint32_t total) {
+    if (!total) return;
+    hipLaunchKernelGGL(k_slot0, dim3(nblk(total)), dim3(BLOCK), 0, s, time0, slot0_out, total);
+}
+void extract(hipStream_t s, const ExtractParams& p) {
+    if (!p.ins_count) return;
+    ExtractArgs a{p.val, p.slot, p.sibsrc, p.node_below, p.stride, p.tree_nodes, p.tree_off, p.tree_len, p.zero, p.roots,
+                  p.l0, p.depth, p.ins_begin, p.ins_count, p.n_total, p.old_root, p.interim_root, p.new_root, p.low_sib,
+                  p.new_sib, p.lay, p.fmt_out};
+    const size_t threads = (size_t)p.ins_count * 2 * ((size_t)p.depth + 1);
+    hipLaunchKernelGGL(k_extract, dim3(nblk(threads)), dim3(BLOCK), 0, s, a);
+}
+void store_top_path(hipStream_t s, const uint8_t* top_path, uint8_t* tree_nodes, const uint64_t* tree_off, unsigned l0,
+                    unsigned depth) {
+    hipLaunchKernelGGL(k_store_top_path, dim3(1), dim3(64), 0, s, top_path, tree_nodes, tree_off, l0, depth);
 }
 
 }  // namespace launch

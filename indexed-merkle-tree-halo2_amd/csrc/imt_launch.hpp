@@ -83,7 +83,30 @@ void writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const 
 void sweep_top(hipStream_t s, const uint8_t* val, unsigned l0, unsigned depth, const uint8_t* zero, uint8_t* tree_nodes,
                const uint64_t* tree_off, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
                uint8_t* interim_root, uint8_t* new_root, uint8_t* low_sib, uint8_t* new_sib, SibLayout lay,
-               unsigned fmt_out);
+               unsigned fmt_out, uint8_t* roots_dev = nullptr, uint8_t* top_path = nullptr);
+
+// ---- sharded single-list batch (imt_itree_batch_*) ----
+void slot0(hipStream_t s, const uint32_t* time0, uint32_t* slot0_out, uint32_t total);
+struct ExtractParams {
+    const uint8_t* const* val;   // device array of l0 + 1 device pointers
+    const uint32_t* slot;
+    const int32_t* sibsrc;
+    const uint32_t* node_below;
+    size_t stride;
+    const uint8_t* tree_nodes;
+    const uint64_t* tree_off;
+    const uint64_t* tree_len;
+    const uint8_t* zero;
+    const uint8_t* roots;
+    unsigned l0, depth;
+    uint32_t ins_begin, ins_count, n_total;
+    uint8_t *old_root, *interim_root, *new_root, *low_sib, *new_sib;
+    SibLayout lay;
+    unsigned fmt_out;
+};
+void extract(hipStream_t s, const ExtractParams& p);
+void store_top_path(hipStream_t s, const uint8_t* top_path, uint8_t* tree_nodes, const uint64_t* tree_off, unsigned l0,
+                    unsigned depth);
 
 }  // namespace launch
 }  // namespace imt

@@ -35,6 +35,11 @@ struct Workspace {            // per plan set, sized for `cap_n` insertions
     void* tmp = nullptr;           // rocPRIM temporary storage
     size_t tmp_bytes = 0;
     int* err = nullptr;            // device word
+    // hash-free outputs kept for imt_itree_batch_extract (sharded mode)
+    uint64_t* o_low = nullptr;     // [n]
+    uint8_t* o_largest = nullptr;  // [n]
+    uint8_t* o_lowleaf = nullptr;  // [n][96]
+    uint8_t* o_newleaf = nullptr;  // [n][96]
 };
 
 size_t temp_bytes_needed(size_t n, size_t max_size);

@@ -44,6 +44,7 @@ struct LevelOut {
     uint32_t* from;         // slot of the same event one level down | (last-of-run << 31)
     int32_t* sibsrc;        // slot (one level down) of the sibling version, or -1 = stored tree
     uint32_t* node_below;   // node index one level down (its low bit = right child)
+    uint32_t* slot;         // optional: slot[event] = position of the event in the next level's order
 };
 
 constexpr uint32_t LAST_BIT = 0x80000000u;
@@ -78,6 +79,7 @@ IMT_SW_HD void merge_element(const LevelTable& in, const LevelOut& out, uint32_t
     out.from[kp] = k | ((k == b - 1) ? LAST_BIT : 0u);
     out.sibsrc[kp] = r > 0 ? (int32_t)(s0 + r - 1) : -1;
     out.node_below[kp] = n;
+    if (out.slot) out.slot[t] = kp;
 }
 
 }  // namespace sweep

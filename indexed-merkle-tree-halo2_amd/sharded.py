@@ -85,3 +85,94 @@ class ShardedIndexedTree:
                      for i in range(len(level) // 2)]
             idx >>= 1
         return sibs
+
+
+class ReplicatedIndexedTree:
+    """ONE indexed tree (the reference's single sorted list, bit-exact at any world size) on `world`
+    GPUs: every rank keeps a replica and runs the same hash-free preparation; the hashing of every
+    level is split by slot range, and the ranks all-gather the level's node versions (E x 32 bytes,
+    RCCL) before the next level.  Each rank returns the witnesses of its own share of the insertions.
+
+    Uses the imt_itree_batch_* entry points; `via_host=True` routes the collectives through host
+    memory (gloo rehearsal on a box without one GPU per rank)."""
+
+    def __init__(self, imt, ctx, tree, world=1, rank=0, dist=None, via_host=False):
+        import ctypes
+        self.imt, self.ctx, self.tree, self.world, self.rank, self.dist = imt, ctx, tree, world, rank, dist
+        self.via_host, self.ct = via_host, ctypes
+        self.lib = imt.lib
+        self.stream = torch.cuda.current_stream()
+        ctx.set_stream(self.stream.cuda_stream)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def _p(self, t):
+        return self.ct.c_void_p(t.data_ptr())
+
+    def _gather_rows(self, t, b, c):
+        """rows [b, b+c) of t were computed here; afterwards every rank has all rows"""
+        if self.world == 1:
+            return
+        if not self.via_host:
+            self.dist.all_gather_into_tensor(t.view(-1), t[b:b + c].reshape(-1))
+            return
+        mine = t[b:b + c].cpu()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        t.copy_(torch.cat(parts).to(t.device))
+
+    def _bcast(self, t, src):
+        if self.world == 1:
+            return
+        if not self.via_host:
+            self.dist.broadcast(t, src)
+            return
+        h = t.cpu()
+        self.dist.broadcast(h, src)
+        t.copy_(h.to(t.device))
+
+    def insert_batch(self, vals, proofs=True, fmt=0):
+        """vals: uint8 [n, 32] (numpy or torch), the same on every rank, n a multiple of world.
+        Returns a dict of torch tensors for this rank's insertions [rank*n/world, (rank+1)*n/world)."""
+        ct, lib, imt = self.ct, self.lib, self.imt
+        F = imt._ffi
+        if not torch.is_tensor(vals):
+            vals = torch.from_numpy(np.ascontiguousarray(vals))
+        vals = vals.to(self.device)
+        n = vals.shape[0]
+        if n % self.world:
+            raise ValueError("batch size must be a multiple of the world size")
+        ev, l0 = ct.c_uint32(), ct.c_uint32()
+        rc = lib.imt_itree_batch_begin(self.tree.h, self._p(vals), n, F.DEVICE_PTRS | fmt, ct.byref(ev), ct.byref(l0))
+        if rc == F.ERR["VALUE"]:
+            raise ValueError(lib.imt_last_error(self.ctx.h).decode())
+        self.ctx._check(rc)
+        E, L0, depth = ev.value, l0.value, self.tree.depth
+        u8 = dict(dtype=torch.uint8, device=self.device)
+        val = torch.empty((L0 + 1, E, 32), **u8)
+        kb, kc = self.rank * (E // self.world), E // self.world
+        self.ctx._check(lib.imt_itree_batch_leaves(self.tree.h, self._p(val[0]), kb, kc))
+        self._gather_rows(val[0], kb, kc)
+        for l in range(L0):
+            self.ctx._check(lib.imt_itree_batch_level(self.tree.h, l, self._p(val[l]), self._p(val[l + 1]), kb, kc))
+            self._gather_rows(val[l + 1], kb, kc)
+        roots = torch.empty((E, 32), **u8)
+        top_path = torch.zeros((depth - L0 + 1, 32), **u8)
+        self.ctx._check(lib.imt_itree_batch_top(self.tree.h, self._p(val[L0]), kb, kc, self._p(roots), self._p(top_path)))
+        self._gather_rows(roots, kb, kc)
+        self._bcast(top_path, self.world - 1)          # the last event lies in the last rank's range
+        ib, ic = self.rank * (n // self.world), n // self.world
+        out = dict(low_index=torch.empty(ic, dtype=torch.int64, device=self.device), is_largest=torch.empty(ic, **u8),
+                   low_leaf=torch.empty((ic, 3, 32), **u8), new_leaf=torch.empty((ic, 3, 32), **u8),
+                   old_root=torch.empty((ic, 32), **u8), interim_root=torch.empty((ic, 32), **u8),
+                   new_root=torch.empty((ic, 32), **u8))
+        if proofs:
+            out["low_sib"] = torch.empty((depth, ic, 32), **u8)
+            out["new_sib"] = torch.empty((depth, ic, 32), **u8)
+        st = F.InsertOut(**{k: v.data_ptr() for k, v in out.items()})
+        ptrs = (ct.c_void_p * (L0 + 1))(*[val[l].data_ptr() for l in range(L0 + 1)])
+        self.ctx._check(lib.imt_itree_batch_extract(self.tree.h, ptrs, self._p(roots), ib, ic, ct.byref(st),
+                                                    F.DEVICE_PTRS | fmt))
+        self.ctx._check(lib.imt_itree_batch_end(self.tree.h, ptrs, self._p(top_path)))
+        self.ctx.sync()
+        out["first_insertion"] = ib
+        return out

@@ -71,7 +71,7 @@ extern "C" void emul_merge_level(const uint32_t* node, const uint32_t* time, con
                                  uint32_t total, uint32_t* o_node, uint32_t* o_time, uint32_t* o_rs, uint32_t* o_re,
                                  uint32_t* o_from, int32_t* o_sibsrc, uint32_t* o_node_below) {
     sweep::LevelTable in{node, time, rs, re};
-    sweep::LevelOut out{o_node, o_time, o_rs, o_re, o_from, o_sibsrc, o_node_below};
+    sweep::LevelOut out{o_node, o_time, o_rs, o_re, o_from, o_sibsrc, o_node_below, nullptr};
     for (uint32_t k = 0; k < total; k++) sweep::merge_element(in, out, k, total);
 }
 

@@ -508,6 +508,97 @@ def test_snapshot_load_roundtrip(imt, ctx, oracle):
     oracle.sparse_free(oh)
 
 
+def _load_sharded_module():
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "indexed-merkle-tree-halo2_amd",
+                        "sharded.py")
+    spec = importlib.util.spec_from_file_location("imt_sharded", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_sharded_single_list_stepping_in_one_process(imt, ctx, oracle):
+    """imt_itree_batch_*: the sharded single-list batch driven by one process, first as one rank, then as
+    two and four 'ranks' taking their slot ranges in turn on the same arrays (what the all-gathers would
+    produce) -- every output equals imt_itree_insert_batch, which equals the sequential oracle."""
+    import ctypes
+    import torch
+    sharded = _load_sharded_module()
+    depth = 32
+    vals = oracle_lib.synth_values(1200, 0x494D5408)
+    ref = imt.IndexedTree(ctx, depth, 2048)
+    want = [ref.insert_batch(vals[a:a + 400]) for a in (0, 400, 800)]
+    dev = torch.device("cuda", 0)
+    F = imt._ffi
+    for parts in (1, 2, 4):
+        t = imt.IndexedTree(ctx, depth, 2048)
+        for bi, a in enumerate((0, 400, 800)):
+            chunk = torch.from_numpy(ints_to_arr(vals[a:a + 400])).to(dev)
+            n = 400
+            if parts == 1:
+                r = sharded.ReplicatedIndexedTree(imt, ctx, t).insert_batch(chunk)
+                got = {k: v.cpu().numpy() for k, v in r.items() if k != "first_insertion"}
+            else:
+                ev, l0 = ctypes.c_uint32(), ctypes.c_uint32()
+                P_ = lambda x: ctypes.c_void_p(x.data_ptr())
+                assert imt.lib.imt_itree_batch_begin(t.h, P_(chunk), n, F.DEVICE_PTRS, ctypes.byref(ev), ctypes.byref(l0)) == 0
+                E, L0 = ev.value, l0.value
+                val = torch.empty((L0 + 1, E, 32), dtype=torch.uint8, device=dev)
+                kc = E // parts
+                for q in reversed(range(parts)):        # any order: slots of one level are independent
+                    assert imt.lib.imt_itree_batch_leaves(t.h, P_(val[0]), q * kc, kc) == 0
+                for l in range(L0):
+                    for q in range(parts):
+                        assert imt.lib.imt_itree_batch_level(t.h, l, P_(val[l]), P_(val[l + 1]), q * kc, kc) == 0
+                roots = torch.empty((E, 32), dtype=torch.uint8, device=dev)
+                tops = [torch.zeros((depth - L0 + 1, 32), dtype=torch.uint8, device=dev) for _ in range(parts)]
+                for q in range(parts):
+                    assert imt.lib.imt_itree_batch_top(t.h, P_(val[L0]), q * kc, kc, P_(roots), P_(tops[q])) == 0
+                ptrs = (ctypes.c_void_p * (L0 + 1))(*[val[l].data_ptr() for l in range(L0 + 1)])
+                got = None
+                ic = n // parts
+                for q in range(parts):
+                    o = dict(low_index=torch.empty(ic, dtype=torch.int64, device=dev),
+                             is_largest=torch.empty(ic, dtype=torch.uint8, device=dev),
+                             low_leaf=torch.empty((ic, 3, 32), dtype=torch.uint8, device=dev),
+                             new_leaf=torch.empty((ic, 3, 32), dtype=torch.uint8, device=dev),
+                             old_root=torch.empty((ic, 32), dtype=torch.uint8, device=dev),
+                             interim_root=torch.empty((ic, 32), dtype=torch.uint8, device=dev),
+                             new_root=torch.empty((ic, 32), dtype=torch.uint8, device=dev),
+                             low_sib=torch.empty((depth, ic, 32), dtype=torch.uint8, device=dev),
+                             new_sib=torch.empty((depth, ic, 32), dtype=torch.uint8, device=dev))
+                    st = F.InsertOut(**{k: v.data_ptr() for k, v in o.items()})
+                    assert imt.lib.imt_itree_batch_extract(t.h, ptrs, P_(roots), q * ic, ic, ctypes.byref(st), F.DEVICE_PTRS) == 0
+                    ctx.sync()
+                    o = {k: v.cpu().numpy() for k, v in o.items()}
+                    if got is None:
+                        got = {k: [v] for k, v in o.items()}
+                    else:
+                        for k, v in o.items():
+                            got[k].append(v)
+                got = {k: np.concatenate(v, axis=1 if k.endswith("_sib") else 0) for k, v in got.items()}
+                assert imt.lib.imt_itree_batch_end(t.h, ptrs, P_(tops[parts - 1])) == 0
+                ctx.sync()
+            for k in ("low_index", "is_largest", "low_leaf", "new_leaf", "old_root", "interim_root", "new_root",
+                      "low_sib", "new_sib"):
+                assert (got[k].astype(want[bi][k].dtype) == want[bi][k]).all(), (parts, bi, k)
+            assert t.root() == imt.to_int(want[bi]["new_root"][-1])
+        assert t.root() == ref.root()
+        assert (t.snapshot() == ref.snapshot()).all()
+        r = t.insert_batch([3, 1, 2])                 # the ordinary path continues on the same tree
+        assert t.size == 1204
+    # a batch that must be refused leaves nothing open
+    t = imt.IndexedTree(ctx, depth, 64)
+    bad = torch.from_numpy(ints_to_arr([5, 5])).to(dev)
+    ev, l0 = ctypes.c_uint32(), ctypes.c_uint32()
+    assert imt.lib.imt_itree_batch_begin(t.h, ctypes.c_void_p(bad.data_ptr()), 2, F.DEVICE_PTRS, ctypes.byref(ev),
+                                         ctypes.byref(l0)) == F.ERR["VALUE"]
+    assert imt.lib.imt_itree_batch_leaves(t.h, ctypes.c_void_p(bad.data_ptr()), 0, 1) == F.ERR["ARG"]
+    t.insert_batch([7, 9])
+    assert t.size == 3
+
+
 def test_combine_subtree_roots(imt, ctx, oracle):
     rng = random.Random(41)
     leaves = ints_to_arr([rng.randrange(P) for _ in range(64)])
