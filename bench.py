@@ -87,6 +87,55 @@ def cpu_baseline(vals, budget_s=15.0):
             "sample": f"first {n} insertions of the same depth-32 workload, C oracle (oracle/sparse.c), {dt:.1f} s"}
 
 
+def bench_single_list(args, world, rank, local_rank, dist, backend, ctx, imt_amd):
+    """N > 1, IMT_BENCH_MODE=single-list: ONE depth-32 tree (the reference's single sorted list, bit-exact),
+    replicated on every rank; a step inserts world x 2^16 values, each rank hashes 1/world of every level and
+    the ranks all-gather the level's node versions (sharded.ReplicatedIndexedTree)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("imt_sharded", os.path.join(ROOT, "indexed-merkle-tree-halo2_amd",
+                                                                               "sharded.py"))
+    sharded = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharded)
+    steps_total = args.warmup + args.steps
+    gb = BATCH * world
+    tree = imt_amd.IndexedTree(ctx, DEPTH, 1 << (steps_total * gb).bit_length())
+    rep = sharded.ReplicatedIndexedTree(imt_amd, ctx, tree, world, rank, dist, via_host=(backend != "nccl"))
+    vals = torch.from_numpy(synth_values(steps_total * gb, 0, 1, 0x494D5402)).to(torch.device("cuda", local_rank))
+
+    def sync():
+        ctx.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    for i in range(args.warmup):
+        rep.insert_batch(vals[i * gb:(i + 1) * gb])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, steps_total):
+        rep.insert_batch(vals[i * gb:(i + 1) * gb])
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=("cuda" if backend == "nccl" else "cpu"))
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        value = args.steps * gb / dt
+        print(json.dumps({
+            "metric": "indexed-tree insertions/sec at depth=32 (bn256::Fr)", "value": value, "unit": "insertions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limbs (9 x 29-bit, Montgomery mod p), 64-bit accumulate", "data": "synthetic",
+            "config": {"workload": "depth=32, ONE indexed tree, world x 2^16 sequential-semantics insertions per step; "
+                                   "every rank returns roots + both proofs of its 2^16 insertions",
+                       "batch_per_gpu": BATCH, "depth": DEPTH,
+                       "parallelism": f"single sorted list replicated on {world} GPUs, per-level slot-range sharding + "
+                                      "all-gather of node versions"},
+            "roofline": None, "cpu_baseline": None,
+            "valu": {"whole_step_frac": value / world * 66 * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS}}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +175,9 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
+    mode = os.environ.get("IMT_BENCH_MODE", "subtrees")     # N > 1: "subtrees" (default) or "single-list"
+    if world > 1 and mode == "single-list":
+        return bench_single_list(args, world, rank, local_rank, dist, backend, ctx, imt_amd)
     k = world.bit_length() - 1
     depth = DEPTH - k
     steps_total = args.warmup + args.steps
