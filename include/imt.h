@@ -175,6 +175,12 @@ int imt_non_membership_batch(imt_ctx *ctx, const void *root, const void *low_lea
                              size_t n, uint8_t *fail_out /*[n]*/, void *root_out /*[n][32] or NULL*/,
                              unsigned flags);
 
+/* The 128-bit limb witnesses verify_non_inclusion loads for its comparisons
+ * (src/indexed_merkle_tree.rs:145-178, :206-224): q[i] = vals[i] >> 128, r[i] = vals[i] mod 2^128 as
+ * integers, returned as field elements in the format of `flags` (vals[i] = q[i] * 2^128 + r[i]). */
+int imt_split128_batch(imt_ctx *ctx, const void *vals /*[n][32]*/, void *q /*[n][32]*/, void *r /*[n][32]*/,
+                       size_t n, unsigned flags);
+
 /* ---- a14: batched insert_leaf witness ------------------------------------------ */
 /* insert_leaf (indexed_merkle_tree.rs:231-314): recomputes the 3 leaf hashes and 4 paths per
  * item and checks every constraint.  trace_out (optional) receives, level-major

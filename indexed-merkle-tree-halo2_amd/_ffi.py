@@ -55,6 +55,7 @@ SIGNATURES = {
                                        c_uint]),
     "imt_non_membership_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_void_p,
                                          c_void_p, c_size_t, c_void_p, c_void_p, c_uint]),
+    "imt_split128_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_uint]),
     "imt_insert_witness_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_size_t, c_void_p, c_void_p,
                                          c_uint]),

@@ -164,6 +164,14 @@ class Context:
                                                  _p(lg), n, _p(fail), _p(rout), flags))
         return (fail, rout) if want_root else fail
 
+    def split128(self, vals, fmt=0):
+        """(q, r) limb witnesses of verify_non_inclusion (src/indexed_merkle_tree.rs:145-178)."""
+        v = _arr(vals, (32,))
+        q = np.empty_like(v)
+        r = np.empty_like(v)
+        self._check(lib.imt_split128_batch(self.h, _p(v), _p(q), _p(r), v.shape[0], fmt))
+        return q, r
+
     # ---- a14 ----
     def insert_witness(self, old_root, low_leaf, low_index, low_sib, new_root, new_leaf, new_index, new_sib,
                        is_largest, depth, item_major=False, fmt=0, want_trace=False, new_path_index=None):

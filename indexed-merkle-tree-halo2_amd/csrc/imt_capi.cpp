@@ -474,6 +474,20 @@ extern "C" int imt_non_membership_batch(imt_ctx* c, const void* root, const void
     return io.finish();
 }
 
+extern "C" int imt_split128_batch(imt_ctx* c, const void* vals, void* q, void* r, size_t n, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    if (n == 0) return IMT_OK;
+    if (!vals || !q || !r) return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    const uint8_t* d_in = io.in(vals, n * 32);
+    uint8_t* d_q = io.out(q, n * 32);
+    uint8_t* d_r = io.out(r, n * 32);
+    if (io.rc) return io.rc;
+    launch::split128(c->stream, d_in, d_q, d_r, n, flags & IMT_FMT_MASK, c->d_err);
+    return io.finish();
+}
+
 // ------------------------------------------------------------------------------------
 // a14
 // ------------------------------------------------------------------------------------

@@ -197,6 +197,30 @@ k_non_membership(const uint8_t* __restrict__ root, unsigned root_stride, const u
     flag_err(err, ok);
 }
 
+// ---- a11: 128-bit limb split (src/indexed_merkle_tree.rs:145-178) ------------------
+__global__ void __launch_bounds__(BLOCK) k_split128(const uint8_t* __restrict__ vals, uint8_t* __restrict__ q,
+                                                    uint8_t* __restrict__ r, size_t n, unsigned fmt, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Fe x, xi;
+    bool ok = load_fe(g_pc, x, vals + i * 32, fmt);
+    to_int(xi, x);                                   // canonical integer, 29-bit limbs
+    uint32_t w[8];
+    pack(w, xi);
+    Fe lo, hi, t;
+    const uint32_t wl[8] = {w[0], w[1], w[2], w[3], 0, 0, 0, 0};
+    const uint32_t wh[8] = {w[4], w[5], w[6], w[7], 0, 0, 0, 0};
+    unpack(t, wl);
+    mont_mul(lo, t, g_pc.from_canon);
+    canonicalize(lo);
+    unpack(t, wh);
+    mont_mul(hi, t, g_pc.from_canon);
+    canonicalize(hi);
+    store_fe(g_pc, r + i * 32, lo, fmt);
+    store_fe(g_pc, q + i * 32, hi, fmt);
+    flag_err(err, ok);
+}
+
 // ---- a14: insert_leaf (src/indexed_merkle_tree.rs:231-314) ------------------------
 // blockIdx.y selects one of the four chains of an item, so leaf-hash selection is uniform.
 // trace rows (device format): 0 low_leaf_hash, 1 root_from_low, 2 new_low_leaf_hash,
@@ -571,6 +595,10 @@ void convert(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, unsigned 
              int* err) {
     if (!n) return;
     hipLaunchKernelGGL(k_convert, dim3(nblk(n)), dim3(BLOCK), 0, s, in, out, n, fmt_in, fmt_out, err);
+}
+void split128(hipStream_t s, const uint8_t* vals, uint8_t* q, uint8_t* r, size_t n, unsigned fmt, int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_split128, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, q, r, n, fmt, err);
 }
 void path_root(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index, bool is_helper,
                const uint8_t* sib, SibLayout lay, unsigned depth, size_t n, uint8_t* root_out,

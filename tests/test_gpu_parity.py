@@ -599,6 +599,16 @@ def test_sharded_single_list_stepping_in_one_process(imt, ctx, oracle):
     assert t.size == 3
 
 
+def test_split128_limb_witnesses(imt, ctx):
+    rng = random.Random(61)
+    vals = [0, 1, (1 << 128) - 1, 1 << 128, (1 << 128) + 1, P - 1] + [rng.randrange(P) for _ in range(500)]
+    q, r = ctx.split128(ints_to_arr(vals))
+    assert ints(q) == [v >> 128 for v in vals] and ints(r) == [v & ((1 << 128) - 1) for v in vals]
+    R = 1 << 256
+    q, r = ctx.split128(ints_to_arr([v * R % P for v in vals]), fmt=imt._ffi.FMT_MONT256)
+    assert ints(q) == [(v >> 128) * R % P for v in vals] and ints(r) == [(v & ((1 << 128) - 1)) * R % P for v in vals]
+
+
 def test_combine_subtree_roots(imt, ctx, oracle):
     rng = random.Random(41)
     leaves = ints_to_arr([rng.randrange(P) for _ in range(64)])
