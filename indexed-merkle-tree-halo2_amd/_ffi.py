@@ -83,6 +83,8 @@ SIGNATURES = {
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
+    if os.environ.get("IMT_LIB_PATH") and not hasattr(lib, _name):
+        continue                  # a tuning build of an older revision (explicit override only)
     _fn = getattr(lib, _name)     # AttributeError here = the library does not export the symbol
     _fn.restype = _res
     _fn.argtypes = _args

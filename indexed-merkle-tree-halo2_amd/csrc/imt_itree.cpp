@@ -681,66 +681,61 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
 // ------------------------------------------------------------------------------------
 // batch insertion
 // ------------------------------------------------------------------------------------
-extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, const imt_insert_out* out,
-                                      unsigned flags) {
-    if (!t) return IMT_ERR_ARG;
+namespace {
+
+const int64_t REF_NONE = INT64_MIN;   // "no successor" in the host path's neighbour references
+const U256 U256_ZERO = {0, 0, 0, 0};
+
+// Host prepare (IMT_HOST_PREP).  Neighbour references: >= 0 -> rank of a batch element in value order;
+// < 0 -> ~(leaf index of a stored leaf); REF_NONE.
+struct HostPlan {
+    std::vector<U256> v;                      // batch values in insertion order, canonical
+    std::vector<uint8_t> lowleaf, newleaf;    // hash-free outputs, if requested
+    uint64_t M = 0;
+};
+
+inline uint64_t ref_leaf(const imt_itree* t, const HostPlan& hp, int64_t ref) {
+    return ref >= 0 ? hp.M + t->w_ord[(size_t)ref] : (uint64_t)~ref;
+}
+inline const U256& ref_val(const imt_itree* t, const HostPlan& hp, int64_t ref) {
+    return ref >= 0 ? hp.v[t->w_ord[(size_t)ref]] : t->pre[(size_t)~ref].val;
+}
+
+// Sections of the host path: (1) values to the host, (2) low leaf of every insertion
+// (update_idx_leaf :639-658 as a predecessor search: sort the batch, locate each value between two
+// stored leaves, then unlink the batch from that list in reverse insertion order -- what is adjacent at
+// unlink time is exactly what had been inserted earlier), (4) event preimages and their (position,
+// time) order into the pinned staging of P, (5) upload on the side stream.
+int host_prepare(imt_itree* t, PlanSet& P, const void* vals, size_t n, unsigned flags, bool want_lowleaf,
+                 bool want_newleaf, HostPlan& hp) {
     imt_ctx* c = t->ctx;
-    if (n == 0) return IMT_OK;
-    if (!vals) return c->fail(IMT_ERR_ARG, "null vals");
-    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
-    if (n > ((size_t)1 << 30)) return c->fail(IMT_ERR_RANGE, "batch too large");
-    int rc = c->set_device();
-    if (rc) return rc;
     const bool dev = flags & IMT_DEVICE_PTRS;
-    const unsigned fmt = flags & IMT_FMT_MASK;
-    const uint64_t M = t->size;
-    if (M + n > t->cap) return c->fail(IMT_ERR_FULL, "tree capacity %llu exceeded", (unsigned long long)t->cap);
-
-    const auto host_t0 = std::chrono::steady_clock::now();
-    double host_wait_ms = 0;
-    static const bool trace = getenv("IMT_TRACE_HOST") != nullptr;
-    auto lap_t = host_t0;
-    double laps[10] = {0};
-    auto lap = [&](int k) {
-        if (!trace) return;
-        auto now = std::chrono::steady_clock::now();
-        laps[k] += std::chrono::duration<double, std::milli>(now - lap_t).count();
-        lap_t = now;
-    };
-    const bool gpu_prep = (flags & IMT_HOST_PREP) == 0;
-    std::vector<U256> v;
-    std::vector<uint32_t>& ord = t->w_ord;
-    const int64_t NONE = INT64_MIN;
-    std::vector<int64_t>&prv = t->w_prv, &nxt = t->w_nxt;
-    std::vector<uint32_t>& rank_of = t->w_rank;
-    std::vector<int64_t>&pred = t->w_pred, &succ = t->w_succ;   // by insertion time
-    if (!gpu_prep) {
-    // ---- 1. values, canonical, on the host.  With device pointers they are read on the side
-    //         stream, so the call does not wait for an earlier batch still running. ----
-    if ((rc = ensure_mirror(t))) return rc;
-    rc = fetch_canonical(c, dev ? t->up_stream : c->stream, vals, n, flags, v);
+    const uint64_t M = hp.M = t->size;
+    const size_t E = 2 * n;
+    int rc = ensure_mirror(t);
     if (rc) return rc;
+    // With device pointers the values are read on the side stream, so the call does not wait for an
+    // earlier batch that is still running.
+    std::vector<U256>& v = hp.v;
+    if ((rc = fetch_canonical(c, dev ? t->up_stream : c->stream, vals, n, flags, v))) return rc;
 
-    lap(0);
-    // ---- 2. low leaf of every insertion (update_idx_leaf :639-658, as a predecessor search):
-    //         sort the batch, locate each value between two stored leaves, then unlink the batch
-    //         from that list in reverse insertion order: what is adjacent at unlink time is
-    //         exactly what had been inserted earlier. ----
+    std::vector<uint32_t>& ord = t->w_ord;
     {
         std::vector<std::pair<uint64_t, uint32_t>>& sk = t->w_sortkey;   // (top limb, index): cheap compares
         sk.resize(n);
         for (size_t i = 0; i < n; i++) sk[i] = {v[i][3], (uint32_t)i};
-        std::sort(sk.begin(), sk.end(), [&](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) {
-            if (a.first != b.first) return a.first < b.first;
-            return lt256(v[a.second], v[b.second]);
-        });
+        std::sort(sk.begin(), sk.end(),
+                  [&](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) {
+                      if (a.first != b.first) return a.first < b.first;
+                      return lt256(v[a.second], v[b.second]);
+                  });
         ord.resize(n);
         for (size_t i = 0; i < n; i++) ord[i] = sk[i].second;
     }
     if (is_zero256(v[ord[0]])) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
     for (size_t r = 1; r < n; r++)
         if (v[ord[r]] == v[ord[r - 1]]) return c->fail(IMT_ERR_VALUE, "duplicate value inside the batch");
-    // neighbours: >= 0 -> rank of a batch element; < 0 -> ~(leaf index of a stored leaf); NONE
+    std::vector<int64_t>&prv = t->w_prv, &nxt = t->w_nxt;
     prv.resize(n);
     nxt.resize(n);
     {
@@ -754,11 +749,13 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
             const bool same_gap_prev = r > 0 && cmp_ent(t, t->sorted[q - 1], v[ord[r - 1]]) < 0;
             prv[r] = same_gap_prev ? (int64_t)(r - 1) : ~(int64_t)t->sorted[q - 1].idx;
             const bool next_in_gap = r + 1 < n && (q >= S || cmp_ent(t, t->sorted[q], v[ord[r + 1]]) > 0);
-            nxt[r] = next_in_gap ? (int64_t)(r + 1) : (q < S ? ~(int64_t)t->sorted[q].idx : NONE);
+            nxt[r] = next_in_gap ? (int64_t)(r + 1) : (q < S ? ~(int64_t)t->sorted[q].idx : REF_NONE);
         }
     }
+    std::vector<uint32_t>& rank_of = t->w_rank;
     rank_of.resize(n);
     for (size_t r = 0; r < n; r++) rank_of[ord[r]] = (uint32_t)r;
+    std::vector<int64_t>&pred = t->w_pred, &succ = t->w_succ;   // by insertion time
     pred.resize(n);
     succ.resize(n);
     for (size_t ii = n; ii-- > 0;) {
@@ -768,60 +765,35 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         if (prv[r] >= 0) nxt[prv[r]] = nxt[r];
         if (nxt[r] >= 0) prv[nxt[r]] = prv[r];
     }
-    }   // !gpu_prep
 
-    lap(1);
-    // ---- 3. plan buffers ----
-    const size_t E = 2 * n;
-    const unsigned L0 = std::min(ceil_log2(M + n), t->depth);
-    PlanSet& P = t->plan[t->cur];
-    if (P.in_flight) {   // back-pressure: at most NSETS batches in flight
-        const auto w0 = std::chrono::steady_clock::now();
-        IMT_HIP(c, hipEventSynchronize(P.done));
-        host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
-        P.in_flight = false;
-    }
-    rc = plan_reserve(c, P, E, t->depth, t->cap);   // all levels up front: growing later would stall the pipeline
-    if (rc) return rc;
+    // events: preimages at every time step + the hash-free outputs
     uint8_t* h_pre = P.h_pin;
     uint32_t* h_tab = reinterpret_cast<uint32_t*>(P.h_pin + P.cap_events * 96);
     uint32_t *h_node = h_tab, *h_time = h_tab + P.cap_events, *h_rs = h_tab + 2 * P.cap_events,
              *h_re = h_tab + 3 * P.cap_events;
-
-    lap(2);
-    // ---- 4. events: preimages at every time step + host-side outputs ----
     std::vector<uint64_t>& o_low = t->w_low;
     std::vector<uint8_t>& o_largest = t->w_largest;
-    std::vector<uint8_t> o_lowleaf(!gpu_prep && out && out->low_leaf ? n * 96 : 0),
-        o_newleaf(!gpu_prep && out && out->new_leaf ? n * 96 : 0);
-    // hash-free outputs of the GPU prepare path (device buffers: the user's, or scratch in host mode)
-    uint64_t* gp_low = nullptr;
-    uint8_t *gp_largest = nullptr, *gp_lowleaf = nullptr, *gp_newleaf = nullptr;
-    size_t slot = 2;
-    auto leaf_of = [&](int64_t ref) -> uint64_t { return ref >= 0 ? M + ord[ref] : (uint64_t)~ref; };
-    auto val_of = [&](int64_t ref) -> const U256& { return ref >= 0 ? v[ord[ref]] : t->pre[(size_t)~ref].val; };
-    static const U256 ZERO = {0, 0, 0, 0};
-    if (!gpu_prep) {
     o_low.resize(n);
     o_largest.resize(n);
+    hp.lowleaf.assign(want_lowleaf ? n * 96 : 0, 0);
+    hp.newleaf.assign(want_newleaf ? n * 96 : 0, 0);
     std::vector<uint64_t>& keys = t->w_keys;   // (pos << 32) | event
     keys.resize(E);
     for (size_t i = 0; i < n; i++) {
-        const uint64_t low = leaf_of(pred[i]);
-        const U256& lowval = val_of(pred[i]);
-        const bool has_succ = succ[i] != NONE;
-        const U256& sval = has_succ ? val_of(succ[i]) : ZERO;
-        const uint64_t sidx = has_succ ? leaf_of(succ[i]) : 0;
+        const uint64_t low = ref_leaf(t, hp, pred[i]);
+        const U256& lowval = ref_val(t, hp, pred[i]);
+        const bool has_succ = succ[i] != REF_NONE;
+        const U256& sval = has_succ ? ref_val(t, hp, succ[i]) : U256_ZERO;
+        const uint64_t sidx = has_succ ? ref_leaf(t, hp, succ[i]) : 0;
         o_low[i] = low;
         o_largest[i] = has_succ ? 0 : 1;                               // :737-742
-        if (!o_lowleaf.empty()) put_pre(&o_lowleaf[i * 96], lowval, sval, sidx);
+        if (want_lowleaf) put_pre(&hp.lowleaf[i * 96], lowval, sval, sidx);
         put_pre(h_pre + (2 * i) * 96, lowval, v[i], M + i);            // low leaf rewritten :655-656
         put_pre(h_pre + (2 * i + 1) * 96, v[i], sval, sidx);           // new leaf inherits :650-654
-        if (!o_newleaf.empty()) std::memcpy(&o_newleaf[i * 96], h_pre + (2 * i + 1) * 96, 96);
+        if (want_newleaf) std::memcpy(&hp.newleaf[i * 96], h_pre + (2 * i + 1) * 96, 96);
         keys[2 * i] = (low << 32) | (uint64_t)(2 * i);
         keys[2 * i + 1] = ((M + i) << 32) | (uint64_t)(2 * i + 1);
     }
-    lap(3);
     {   // stable LSD radix sort on the 32-bit position (two 16-bit passes); events are already in time order
         std::vector<uint64_t>& tmp = t->w_keys2;
         std::vector<uint32_t>& hist = t->w_hist;
@@ -850,62 +822,154 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         }
         k = j;
     }
-
-    lap(4);
-    // ---- 5. upload on the side stream; the compute stream waits for it ----
     IMT_HIP(c, hipMemcpyAsync(P.d_pre, h_pre, E * 96, hipMemcpyHostToDevice, t->up_stream));
     IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][0], h_node, E * 4, hipMemcpyHostToDevice, t->up_stream));
     IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][1], h_time, E * 4, hipMemcpyHostToDevice, t->up_stream));
     IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][2], h_rs, E * 4, hipMemcpyHostToDevice, t->up_stream));
     IMT_HIP(c, hipMemcpyAsync(P.d_tab[0][3], h_re, E * 4, hipMemcpyHostToDevice, t->up_stream));
-    } else {
-        // ---- 4'/5'. the same on the GPU (imt_prep.hip), on the side stream ----
-        if ((rc = ensure_device_index(t))) return rc;
-        hipStream_t ps = t->up_stream;
-        const uint8_t* d_vals = (const uint8_t*)vals;
-        if (!dev) {
-            uint8_t* up = (uint8_t*)c->dev_scratch(slot++, n * 32);
-            if (!up) return IMT_ERR_HIP;
-            IMT_HIP(c, hipMemcpyAsync(up, vals, n * 32, hipMemcpyHostToDevice, ps));
-            d_vals = up;
-        }
-        IMT_HIP(c, hipMemsetAsync(P.ws.err, 0, sizeof(int), ps));
-        if (fmt != IMT_FMT_CANONICAL) {
-            uint8_t* can = (uint8_t*)c->dev_scratch(slot++, n * 32);
-            if (!can) return IMT_ERR_HIP;
-            launch::convert(ps, d_vals, can, n, fmt, IMT_FMT_CANONICAL, P.ws.err);   // sets bit 0 = non-canonical
-            d_vals = can;
-        }
-        if (out) {
-            auto dev_out = [&](void* user, size_t bytes) -> void* {
-                if (!user) return nullptr;
-                return dev ? user : c->dev_scratch(slot++, bytes);
-            };
-            gp_low = (uint64_t*)dev_out(out->low_index, n * 8);
-            gp_largest = (uint8_t*)dev_out(out->is_largest, n);
-            gp_lowleaf = (uint8_t*)dev_out(out->low_leaf, n * 96);
-            gp_newleaf = (uint8_t*)dev_out(out->new_leaf, n * 96);
-        }
-        prep::run(ps, P.ws, d_vals, t->d_val, t->d_sorted[t->sorted_cur], t->d_sorted[t->sorted_cur ^ 1], (uint32_t)M,
-                  (uint32_t)n, P.d_pre, P.d_tab[0][0], P.d_tab[0][1], P.d_tab[0][2], P.d_tab[0][3], gp_low, gp_largest,
-                  gp_lowleaf, gp_newleaf);
-        IMT_HIP(c, hipMemcpyAsync(t->h_err_pin, P.ws.err, sizeof(int), hipMemcpyDeviceToHost, ps));
-        const auto w0 = std::chrono::steady_clock::now();
-        IMT_HIP(c, hipStreamSynchronize(ps));       // the batch is committed only if its values are acceptable
-        host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
-        const int perr = *t->h_err_pin;
-        if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
-        if (perr & prep::ERR_ZERO) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
-        if (perr & prep::ERR_DUPLICATE) return c->fail(IMT_ERR_VALUE, "duplicate value (inside the batch or already in the tree)");
-        t->sorted_cur ^= 1;
+    return IMT_OK;
+}
+
+// host mirror after a host-prepared batch: new preimages, rewritten low leaves, merged sorted index
+void host_commit(imt_itree* t, const HostPlan& hp, size_t n) {
+    const uint64_t M = hp.M;
+    const std::vector<U256>& v = hp.v;
+    t->dev_index_valid = false;
+    t->pre.resize(M + n);
+    for (size_t i = 0; i < n; i++) {
+        const bool has_succ = t->w_succ[i] != REF_NONE;
+        Pre& lowp = t->pre[t->w_low[i]];
+        Pre& np = t->pre[M + i];
+        np.val = v[i];
+        np.next_val = has_succ ? ref_val(t, hp, t->w_succ[i]) : U256_ZERO;
+        np.next_idx = has_succ ? ref_leaf(t, hp, t->w_succ[i]) : 0;
+        lowp.next_val = v[i];
+        lowp.next_idx = M + i;
     }
+    std::vector<SortedEnt>& merged = t->w_merged;
+    merged.clear();
+    merged.reserve(t->sorted.size() + n);
+    size_t q = 0;
+    for (size_t r = 0; r < n; r++) {
+        const U256& x = v[t->w_ord[r]];
+        while (q < t->sorted.size() && cmp_ent(t, t->sorted[q], x) < 0) merged.push_back(t->sorted[q++]);
+        merged.push_back(SortedEnt{x[3], M + t->w_ord[r]});
+    }
+    while (q < t->sorted.size()) merged.push_back(t->sorted[q++]);
+    t->sorted.swap(merged);
+    t->size = M + n;
+}
+
+// GPU prepare (default): the same on the device (imt_prep.hip), on the side stream.  The hash-free
+// outputs go straight to device buffers (the user's, or scratch in host-pointer mode).  The batch is
+// committed to the device index only if its values are acceptable.
+struct GpuOuts {
+    uint64_t* low = nullptr;
+    uint8_t *largest = nullptr, *lowleaf = nullptr, *newleaf = nullptr;
+};
+int gpu_prepare(imt_itree* t, PlanSet& P, const void* vals, size_t n, unsigned flags, const imt_insert_out* out,
+                size_t& slot, GpuOuts& go, double& wait_ms) {
+    imt_ctx* c = t->ctx;
+    const bool dev = flags & IMT_DEVICE_PTRS;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    int rc = ensure_device_index(t);
+    if (rc) return rc;
+    hipStream_t ps = t->up_stream;
+    const uint8_t* d_vals = (const uint8_t*)vals;
+    if (!dev) {
+        uint8_t* up = (uint8_t*)c->dev_scratch(slot++, n * 32);
+        if (!up) return IMT_ERR_HIP;
+        IMT_HIP(c, hipMemcpyAsync(up, vals, n * 32, hipMemcpyHostToDevice, ps));
+        d_vals = up;
+    }
+    IMT_HIP(c, hipMemsetAsync(P.ws.err, 0, sizeof(int), ps));
+    if (fmt != IMT_FMT_CANONICAL) {
+        uint8_t* can = (uint8_t*)c->dev_scratch(slot++, n * 32);
+        if (!can) return IMT_ERR_HIP;
+        launch::convert(ps, d_vals, can, n, fmt, IMT_FMT_CANONICAL, P.ws.err);   // sets bit 0 = non-canonical
+        d_vals = can;
+    }
+    if (out) {
+        auto dev_out = [&](void* user, size_t bytes) -> void* {
+            if (!user) return nullptr;
+            return dev ? user : c->dev_scratch(slot++, bytes);
+        };
+        go.low = (uint64_t*)dev_out(out->low_index, n * 8);
+        go.largest = (uint8_t*)dev_out(out->is_largest, n);
+        go.lowleaf = (uint8_t*)dev_out(out->low_leaf, n * 96);
+        go.newleaf = (uint8_t*)dev_out(out->new_leaf, n * 96);
+        if ((out->low_index && !go.low) || (out->is_largest && !go.largest) || (out->low_leaf && !go.lowleaf) ||
+            (out->new_leaf && !go.newleaf))
+            return IMT_ERR_HIP;
+    }
+    prep::run(ps, P.ws, d_vals, t->d_val, t->d_sorted[t->sorted_cur], t->d_sorted[t->sorted_cur ^ 1], (uint32_t)t->size,
+              (uint32_t)n, P.d_pre, P.d_tab[0][0], P.d_tab[0][1], P.d_tab[0][2], P.d_tab[0][3], go.low, go.largest,
+              go.lowleaf, go.newleaf);
+    IMT_HIP(c, hipMemcpyAsync(t->h_err_pin, P.ws.err, sizeof(int), hipMemcpyDeviceToHost, ps));
+    const auto w0 = std::chrono::steady_clock::now();
+    IMT_HIP(c, hipStreamSynchronize(ps));
+    wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    const int perr = *t->h_err_pin;
+    if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
+    if (perr & prep::ERR_ZERO) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
+    if (perr & prep::ERR_DUPLICATE)
+        return c->fail(IMT_ERR_VALUE, "duplicate value (inside the batch or already in the tree)");
+    t->sorted_cur ^= 1;
+    return IMT_OK;
+}
+
+}  // namespace
+
+extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, const imt_insert_out* out,
+                                      unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (n == 0) return IMT_OK;
+    if (!vals) return c->fail(IMT_ERR_ARG, "null vals");
+    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
+    if (n > ((size_t)1 << 30)) return c->fail(IMT_ERR_RANGE, "batch too large");
+    if (t->pending.active) return c->fail(IMT_ERR_ARG, "a sharded batch is open (imt_itree_batch_end first)");
+    int rc = c->set_device();
+    if (rc) return rc;
+    const bool dev = flags & IMT_DEVICE_PTRS;
+    const bool gpu_prep = (flags & IMT_HOST_PREP) == 0;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    const uint64_t M = t->size;
+    if (M + n > t->cap) return c->fail(IMT_ERR_FULL, "tree capacity %llu exceeded", (unsigned long long)t->cap);
+    const auto host_t0 = std::chrono::steady_clock::now();
+    double host_wait_ms = 0;
+
+    // ---- plan buffers ----
+    const size_t E = 2 * n;
+    const unsigned L0 = std::min(ceil_log2(M + n), t->depth);
+    PlanSet& P = t->plan[t->cur];
+    if (P.in_flight) {   // back-pressure: at most NSETS batches in flight
+        const auto w0 = std::chrono::steady_clock::now();
+        IMT_HIP(c, hipEventSynchronize(P.done));
+        host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        P.in_flight = false;
+    }
+    rc = plan_reserve(c, P, E, t->depth, t->cap);   // all levels up front: growing later would stall the pipeline
+    if (rc) return rc;
+
+    // ---- hash-free part: low leaves, event preimages, event order (side stream) ----
+    size_t slot = 2;
+    HostPlan hp;
+    GpuOuts go;
+    if (gpu_prep)
+        rc = gpu_prepare(t, P, vals, n, flags, out, slot, go, host_wait_ms);
+    else
+        rc = host_prepare(t, P, vals, n, flags, out && out->low_leaf, out && out->new_leaf, hp);
+    if (rc) return rc;
     IMT_HIP(c, hipEventRecord(t->up_done, t->up_stream));
+
+    // ---- compute stream: the context's, or one of the two pipeline streams ----
     const bool pipelined = dev && (flags & IMT_PIPELINE);
     hipStream_t s = c->stream;
     const PlanSet* prev = nullptr;      // the batch before this one, if it is still on a pipeline stream
     if (pipelined) {
         s = t->pipe_stream[t->batch_no & 1];
-        IMT_HIP(c, hipEventRecord(t->user_mark, c->stream));     // inputs produced on the user's stream
+        IMT_HIP(c, hipEventRecord(t->user_mark, c->stream));     // buffers last used on the user's stream
         IMT_HIP(c, hipStreamWaitEvent(s, t->user_mark, 0));
         const PlanSet& o = t->plan[(t->cur + imt_itree::NSETS - 1) % imt_itree::NSETS];
         if (o.in_flight && o.pipelined) prev = &o;
@@ -915,7 +979,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     }
     IMT_HIP(c, hipStreamWaitEvent(s, t->up_done, 0));
 
-    // ---- 6. GPU outputs ----
+    // ---- GPU outputs ----
     const size_t sib_bytes = (size_t)t->depth * n * 32;
     uint8_t *g_old = nullptr, *g_int = nullptr, *g_new = nullptr, *g_ls = nullptr, *g_ns = nullptr;
     auto gpu_out = [&](void* user, size_t bytes) -> uint8_t* {
@@ -935,9 +999,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     }
     launch::SibLayout lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->depth} : launch::SibLayout{n, 1};
 
-    lap(5);
-    // ---- 7. leaf hashes, index phase (no hashing), then the hash sweep ----
-    // (the leaf kernel reads the level-0 time table before the merges recycle that buffer)
+    // ---- leaf hashes, index phase (no hashing), then the hash sweep ----
     int pf = c->prof_begin(IMT_PROF_LEAVES, s);
     launch::sweep_leaves(s, P.d_pre, P.d_tab[0][1], P.d_val[0], 0, (uint32_t)E, IMT_FMT_CANONICAL, c->d_err);
     c->prof_end(pf, s);
@@ -986,46 +1048,31 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     t->cur = (t->cur + 1) % imt_itree::NSETS;
     t->batch_no++;
 
-    lap(6);
-    // ---- 8. host mirror ----
+    // ---- commit the hash-free state ----
     if (gpu_prep) {
         t->size = M + n;
         t->mirror_valid = false;     // rebuilt from the device index when a host-side call needs it
     } else {
-    t->dev_index_valid = false;
-    t->pre.resize(M + n);
-    for (size_t i = 0; i < n; i++) {
-        const bool has_succ = succ[i] != NONE;
-        Pre& lowp = t->pre[o_low[i]];
-        Pre& np = t->pre[M + i];
-        np.val = v[i];
-        np.next_val = has_succ ? val_of(succ[i]) : ZERO;
-        np.next_idx = has_succ ? leaf_of(succ[i]) : 0;
-        lowp.next_val = v[i];
-        lowp.next_idx = M + i;
+        host_commit(t, hp, n);
     }
-    {
-        std::vector<SortedEnt>& merged = t->w_merged;
-        merged.clear();
-        merged.reserve(t->sorted.size() + n);
-        size_t q = 0;
-        for (size_t r = 0; r < n; r++) {
-            const U256& x = v[ord[r]];
-            while (q < t->sorted.size() && cmp_ent(t, t->sorted[q], x) < 0) merged.push_back(t->sorted[q++]);
-            merged.push_back(SortedEnt{x[3], M + ord[r]});
-        }
-        while (q < t->sorted.size()) merged.push_back(t->sorted[q++]);
-        t->sorted.swap(merged);
-    }
-    t->size = M + n;
-    }   // !gpu_prep
 
-    lap(7);
-    // ---- 9. outputs ----
-    if (out) {
+    // ---- hash-free outputs ----
+    if (out && gpu_prep) {
+        // written by k_events in canonical form; other formats are converted in place behind up_done
+        if (fmt != IMT_FMT_CANONICAL) {
+            if (go.lowleaf) launch::convert(s, go.lowleaf, go.lowleaf, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+            if (go.newleaf) launch::convert(s, go.newleaf, go.newleaf, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+        }
+        if (!dev) {
+            if (go.low) IMT_HIP(c, hipMemcpyAsync(out->low_index, go.low, n * 8, hipMemcpyDeviceToHost, s));
+            if (go.largest) IMT_HIP(c, hipMemcpyAsync(out->is_largest, go.largest, n, hipMemcpyDeviceToHost, s));
+            if (go.lowleaf) IMT_HIP(c, hipMemcpyAsync(out->low_leaf, go.lowleaf, n * 96, hipMemcpyDeviceToHost, s));
+            if (go.newleaf) IMT_HIP(c, hipMemcpyAsync(out->new_leaf, go.newleaf, n * 96, hipMemcpyDeviceToHost, s));
+        }
+    } else if (out) {
         auto host_out = [&](void* user, const void* src, size_t bytes) -> int {
             if (!user) return IMT_OK;
-            if (dev) {   // side stream: does not wait for the sweep; src is a local vector
+            if (dev) {   // side stream: does not wait for the sweep; src is host memory of this call
                 IMT_HIP(c, hipMemcpyAsync(user, src, bytes, hipMemcpyHostToDevice, t->up_stream));
                 IMT_HIP(c, hipStreamSynchronize(t->up_stream));
             } else {
@@ -1033,29 +1080,16 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
             }
             return IMT_OK;
         };
-        if (gpu_prep) {
-            // written by k_events in canonical form; other formats are converted in place behind up_done
-            if (fmt != IMT_FMT_CANONICAL) {
-                if (gp_lowleaf) launch::convert(s, gp_lowleaf, gp_lowleaf, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
-                if (gp_newleaf) launch::convert(s, gp_newleaf, gp_newleaf, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
-            }
-            if (!dev) {
-                if (gp_low) IMT_HIP(c, hipMemcpyAsync(out->low_index, gp_low, n * 8, hipMemcpyDeviceToHost, s));
-                if (gp_largest) IMT_HIP(c, hipMemcpyAsync(out->is_largest, gp_largest, n, hipMemcpyDeviceToHost, s));
-                if (gp_lowleaf) IMT_HIP(c, hipMemcpyAsync(out->low_leaf, gp_lowleaf, n * 96, hipMemcpyDeviceToHost, s));
-                if (gp_newleaf) IMT_HIP(c, hipMemcpyAsync(out->new_leaf, gp_newleaf, n * 96, hipMemcpyDeviceToHost, s));
-            }
-        } else {
-        if ((rc = host_out(out->low_index, o_low.data(), n * 8))) return rc;
-        if ((rc = host_out(out->is_largest, o_largest.data(), n))) return rc;
+        if ((rc = host_out(out->low_index, t->w_low.data(), n * 8))) return rc;
+        if ((rc = host_out(out->is_largest, t->w_largest.data(), n))) return rc;
         if (fmt == IMT_FMT_CANONICAL) {
-            if ((rc = host_out(out->low_leaf, o_lowleaf.data(), n * 96))) return rc;
-            if ((rc = host_out(out->new_leaf, o_newleaf.data(), n * 96))) return rc;
+            if ((rc = host_out(out->low_leaf, hp.lowleaf.data(), n * 96))) return rc;
+            if ((rc = host_out(out->new_leaf, hp.newleaf.data(), n * 96))) return rc;
         } else {
             for (int w = 0; w < 2; w++) {
                 void* user = w ? out->new_leaf : out->low_leaf;
                 if (!user) continue;
-                const std::vector<uint8_t>& src = w ? o_newleaf : o_lowleaf;
+                const std::vector<uint8_t>& src = w ? hp.newleaf : hp.lowleaf;
                 uint8_t* d_in = (uint8_t*)c->dev_scratch(slot++, n * 96);
                 if (!d_in) return IMT_ERR_HIP;
                 IMT_HIP(c, hipMemcpyAsync(d_in, src.data(), n * 96, hipMemcpyHostToDevice, s));
@@ -1066,19 +1100,14 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
                 IMT_HIP(c, hipStreamSynchronize(s));
             }
         }
-        }   // !gpu_prep
-        if (!dev) {
-            if (out->old_root) IMT_HIP(c, hipMemcpyAsync(out->old_root, g_old, n * 32, hipMemcpyDeviceToHost, s));
-            if (out->interim_root) IMT_HIP(c, hipMemcpyAsync(out->interim_root, g_int, n * 32, hipMemcpyDeviceToHost, s));
-            if (out->new_root) IMT_HIP(c, hipMemcpyAsync(out->new_root, g_new, n * 32, hipMemcpyDeviceToHost, s));
-            if (out->low_sib) IMT_HIP(c, hipMemcpyAsync(out->low_sib, g_ls, sib_bytes, hipMemcpyDeviceToHost, s));
-            if (out->new_sib) IMT_HIP(c, hipMemcpyAsync(out->new_sib, g_ns, sib_bytes, hipMemcpyDeviceToHost, s));
-        }
     }
-    lap(8);
-    if (trace)
-        fprintf(stderr, "[imt host] fetch %.2f search %.2f plan(wait incl) %.2f events %.2f sort %.2f upload %.2f launch %.2f mirror %.2f outputs %.2f ms\n",
-                laps[0], laps[1], laps[2], laps[3], laps[4], laps[5], laps[6], laps[7], laps[8]);
+    if (out && !dev) {
+        if (out->old_root) IMT_HIP(c, hipMemcpyAsync(out->old_root, g_old, n * 32, hipMemcpyDeviceToHost, s));
+        if (out->interim_root) IMT_HIP(c, hipMemcpyAsync(out->interim_root, g_int, n * 32, hipMemcpyDeviceToHost, s));
+        if (out->new_root) IMT_HIP(c, hipMemcpyAsync(out->new_root, g_new, n * 32, hipMemcpyDeviceToHost, s));
+        if (out->low_sib) IMT_HIP(c, hipMemcpyAsync(out->low_sib, g_ls, sib_bytes, hipMemcpyDeviceToHost, s));
+        if (out->new_sib) IMT_HIP(c, hipMemcpyAsync(out->new_sib, g_ns, sib_bytes, hipMemcpyDeviceToHost, s));
+    }
     if (c->profiling) {
         c->prof_ms[IMT_PROF_HOST] +=
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count() - host_wait_ms;
@@ -1087,7 +1116,6 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     if (!dev) IMT_HIP(c, hipStreamSynchronize(s));
     return IMT_OK;
 }
-
 
 // ------------------------------------------------------------------------------------
 // e: one tree on several GPUs, sequential semantics (imt_itree_batch_*)

@@ -34,6 +34,22 @@ __device__ __forceinline__ void flag_err(int* err, bool ok) {
     if (!ok) atomicOr(err, 1);
 }
 
+// ONE copy of the hash in the code object, shared by every kernel.  Inlined per kernel, the 60 KB
+// permutation body exists once per kernel; when two different hash kernels of consecutive batches
+// share a CU (IMT_PIPELINE) they then evict each other from the 64 KB instruction cache.  A called
+// function is the same instructions for all of them.  g_pc is referenced directly so that the
+// constant loads stay scalar (function arguments would be treated as divergent).
+template <bool THREE>
+__device__ __noinline__ Fe hash_shared(Fe a, Fe b, Fe c) {
+    Fe o;
+    hash23(g_pc, o, a, b, c, THREE);
+    return o;
+}
+__device__ __forceinline__ void hash_call(Fe& o, const Fe& a, const Fe& b, const Fe& c, bool three) {
+    if (three) o = hash_shared<true>(a, b, c);
+    else o = hash_shared<false>(a, b, a);
+}
+
 // integer value (not Montgomery) of a device-form element, canonical limbs
 __device__ __forceinline__ void to_int(Fe& r, const Fe& a) {
     mont_mul(r, a, g_pc.int_one);
@@ -84,7 +100,7 @@ __device__ __forceinline__ void hash_chain(Fe& cur, bool has_leaf3, const Fe pre
             }
             c = a;
         }
-        hash23(g_pc, cur, a, b, c, three);
+        hash_call(cur, a, b, c, three);
         if (three && leaf_hash_out) store_packed(leaf_hash_out, cur);
     }
 }
@@ -101,7 +117,7 @@ __global__ void __launch_bounds__(BLOCK) IMT_HASH_KATTR k_hash_batch(const uint8
     ok &= load_fe(g_pc, b, p + 32, fmt_in);
     c = a;
     if (arity == 3) ok &= load_fe(g_pc, c, p + 64, fmt_in);
-    hash23(g_pc, o, a, b, c, arity == 3);
+    hash_call(o, a, b, c, arity == 3);
     store_fe(g_pc, out + i * 32, o, fmt_out);
     flag_err(err, ok);
 }
@@ -311,7 +327,7 @@ __global__ void __launch_bounds__(BLOCK) k_tree_level(const uint8_t* __restrict_
     Fe a, b, o;
     load_packed(a, prev + (2 * i) * 32);
     load_packed(b, prev + (2 * i + 1) * 32);
-    hash2(g_pc, o, a, b);
+    hash_call(o, a, b, a, false);
     store_packed(next + i * 32, o);
 }
 
@@ -330,7 +346,7 @@ __global__ void k_zero_chain(uint8_t* out, unsigned depth) {
 #pragma unroll 1
     for (unsigned l = 0; l < depth; l++) {
         Fe o;
-        hash2(g_pc, o, cur, cur);
+        hash_call(o, cur, cur, cur, false);
         cur = o;
         store_packed(out + (size_t)(l + 1) * 32, cur);
     }
@@ -345,7 +361,7 @@ __global__ void k_extend_root(uint8_t* cur_io, const uint8_t* zero, unsigned fro
     for (unsigned l = from; l < to; l++) {
         Fe z, o;
         load_packed(z, zero + (size_t)l * 32);
-        hash2(g_pc, o, cur, z);
+        hash_call(o, cur, z, cur, false);
         cur = o;
     }
     store_packed(cur_io, cur);
@@ -400,7 +416,7 @@ k_sweep_leaves(const uint8_t* __restrict__ pre, const uint32_t* __restrict__ tim
     bool ok = load_fe(g_pc, a, p, fmt_in);
     ok &= load_fe(g_pc, b, p + 32, fmt_in);
     ok &= load_fe(g_pc, c, p + 64, fmt_in);
-    hash23(g_pc, o, a, b, c, true);
+    hash_call(o, a, b, c, true);
     store_packed(val0 + (size_t)k * 32, o);
     flag_err(err, ok);
 }
@@ -435,7 +451,7 @@ k_sweep_level(const uint8_t* __restrict__ val_in, uint8_t* __restrict__ val_out,
         a.v[i] = right ? sv.v[i] : cur.v[i];
         b.v[i] = right ? cur.v[i] : sv.v[i];
     }
-    hash23(g_pc, o, a, b, a, false);
+    hash_call(o, a, b, a, false);
     store_packed(val_out + (size_t)kp * 32, o);
     const uint32_t e = time_next[kp];
     uint8_t* dst = (e & 1u) ? new_sib : low_sib;
@@ -479,7 +495,7 @@ k_sweep_top(const uint8_t* __restrict__ val, unsigned l0, unsigned depth, const 
         Fe z, o;
         load_packed(z, zero + (size_t)l * 32);
         if (dst) store_fe(g_pc, dst + ((uint64_t)l * lay.level_stride + (uint64_t)(e >> 1) * lay.item_stride) * 32, z, fmt_out);
-        hash23(g_pc, o, cur, z, cur, false);
+        hash_call(o, cur, z, cur, false);
         cur = o;
         if (last) store_packed(top_path ? top_path + (size_t)(l + 1 - l0) * 32 : tree_nodes + tree_off[l + 1] * 32, cur);
     }
