@@ -269,6 +269,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    mad_peak = ctypes.c_double(0.0)
+    if rank == 0:
+        lib.imt_measure_mad_peak(ctx.h, ctypes.byref(mad_peak))   # this device, this run (devices differ)
     if rank == 0:
         n_ins = args.steps * BATCH * world
         value = n_ins / dt
@@ -309,6 +312,9 @@ def main():
                              "what": "2 extra un-pipelined steps after the timed region: the kernel alone on the GPU"},
                          "note": "declared HBM per the contract; the kernel is integer-VALU bound, see valu"},
             "valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep_level",
+                     "peak_gmads_measured_now": mad_peak.value,
+                     "whole_step_frac_of_measured": (value / world * (2 + 2 * depth) * MADS_PER_HASH / 1e9 / mad_peak.value
+                                                     if mad_peak.value else None),
                      "achieved_gmads": hashes_per_s * MADS_PER_HASH / 1e9, "peak_gmads": VALU_PEAK_GMADS,
                      "frac": hashes_per_s * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS,
                      "hashes_per_s": hashes_per_s,

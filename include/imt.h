@@ -114,6 +114,9 @@ const char *imt_version(void);
 #define IMT_PROF_WRITEBACK 4   /* k_writeback */
 #define IMT_PROF_HOST 5        /* host side of imt_itree_insert_batch (wall time, waits excluded) */
 #define IMT_PROF_CLASSES 6
+/* Measures the device's v_mad_u64_u32 issue rate (8 independent chains per lane, 8 waves per SIMD): the
+ * ceiling of the VALU roofline bench.py reports.  *gmads = 10^9 lane multiply-adds per second. */
+int imt_measure_mad_peak(imt_ctx *ctx, double *gmads);
 int imt_profile_enable(imt_ctx *ctx, int on);
 int imt_profile_read(imt_ctx *ctx, double *out /*[2*IMT_PROF_CLASSES]*/);
 

@@ -35,6 +35,7 @@ SIGNATURES = {
     "imt_last_error": (ctypes.c_char_p, [c_void_p]),
     "imt_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "imt_ctx_sync": (c_int, [c_void_p]),
+    "imt_measure_mad_peak": (c_int, [c_void_p, P(ctypes.c_double)]),
     "imt_profile_enable": (c_int, [c_void_p, c_int]),
     "imt_profile_read": (c_int, [c_void_p, P(ctypes.c_double)]),
     "imt_hash2_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint]),

@@ -72,6 +72,31 @@ void imt_ctx::prof_end(int idx, hipStream_t on) {
     if (idx >= 0) (void)hipEventRecord(prof_pending[(size_t)idx].b, on ? on : stream);
 }
 
+extern "C" int imt_measure_mad_peak(imt_ctx* c, double* gmads) {
+    if (!c || !gmads) return IMT_ERR_ARG;
+    int rc = c->set_device();
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    IMT_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    const unsigned blocks = (unsigned)prop.multiProcessorCount * 8;    // 8 waves per SIMD
+    const int iters = 4096;
+    uint32_t* out = (uint32_t*)c->dev_scratch(0, (size_t)blocks * 256 * 4);
+    if (!out) return IMT_ERR_HIP;
+    hipEvent_t e0, e1;
+    IMT_HIP(c, hipEventCreate(&e0));
+    IMT_HIP(c, hipEventCreate(&e1));
+    launch::mad_peak(c->stream, out, blocks, iters);                    // warm-up
+    IMT_HIP(c, hipEventRecord(e0, c->stream));
+    for (int r = 0; r < 3; r++) launch::mad_peak(c->stream, out, blocks, iters);
+    IMT_HIP(c, hipEventRecord(e1, c->stream));
+    IMT_HIP(c, hipEventSynchronize(e1));
+    float ms = 0;
+    IMT_HIP(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *gmads = 3.0 * blocks * 256.0 * 8.0 * iters / (ms * 1e-3) / 1e9;
+    return IMT_OK;
+}
 extern "C" int imt_profile_enable(imt_ctx* c, int on) {
     if (!c) return IMT_ERR_ARG;
     c->profiling = on != 0;

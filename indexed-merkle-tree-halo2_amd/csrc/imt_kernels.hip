@@ -586,6 +586,23 @@ __global__ void k_store_top_path(const uint8_t* __restrict__ top_path, uint8_t* 
     d[1] = s[1];
 }
 
+// issue-rate probe for the VALU roofline: nothing but independent v_mad_u64_u32 chains
+__global__ void __launch_bounds__(256) k_mad_peak(uint32_t* out, uint32_t seed, int iters) {
+    uint64_t a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;
+    uint64_t a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;
+    const uint32_t b = (uint32_t)a0 | 1u, c = seed * 77u + 12345u;
+    for (int i = 0; i < iters; i++) {
+        asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n"
+                     "v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                     "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n"
+                     "v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(b), "v"(c) : "vcc");
+    }
+    const uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+}
+
 inline unsigned nblk(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
 }  // namespace
@@ -666,6 +683,9 @@ void write_helpers(hipStream_t s, uint64_t index, unsigned depth, uint8_t* out, 
 }
 
 
+void mad_peak(hipStream_t s, uint32_t* out, unsigned blocks, int iters) {
+    hipLaunchKernelGGL(k_mad_peak, dim3(blocks), dim3(256), 0, s, out, 1u, iters);
+}
 void fill_level(hipStream_t s, uint8_t* nodes, size_t n, const uint8_t* zero_l) {
     if (!n) return;
     hipLaunchKernelGGL(k_fill_level, dim3(nblk(n)), dim3(BLOCK), 0, s, nodes, n, zero_l);

@@ -34,6 +34,8 @@ void permute_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, uns
 void convert(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, unsigned fmt_in,
              unsigned fmt_out, int* err);
 
+// `blocks` x 256 threads, each 8 x `iters` multiply-adds
+void mad_peak(hipStream_t s, uint32_t* out, unsigned blocks, int iters);
 void split128(hipStream_t s, const uint8_t* vals, uint8_t* q, uint8_t* r, size_t n, unsigned fmt, int* err);
 
 // Path recompute.  leaf3 != NULL: the start value is hash3(leaf3[i]) ([n][3][32]);
