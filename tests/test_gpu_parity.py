@@ -609,6 +609,22 @@ def test_split128_limb_witnesses(imt, ctx):
     assert ints(q) == [(v >> 128) * R % P for v in vals] and ints(r) == [(v & ((1 << 128) - 1)) * R % P for v in vals]
 
 
+def test_c_example_runs(imt):
+    """examples/insert_demo.c: the C ABI from plain C, end to end on the GPU."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "insert_demo")
+    csrc = os.path.join(root, "indexed-merkle-tree-halo2_amd", "csrc")
+    r = subprocess.run(["gcc", "-std=c11", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "insert_demo.c"),
+                        "-L", csrc, "-limt_hip", "-Wl,-rpath," + csrc, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all satisfied" in r.stdout
+    want = int(GOLD["multi_round_depth3"][-1]["new_root"])
+    assert f"{want:064x}" in r.stdout          # the last root of test_insert_leaf_multiple_round
+
+
 def test_combine_subtree_roots(imt, ctx, oracle):
     rng = random.Random(41)
     leaves = ints_to_arr([rng.randrange(P) for _ in range(64)])

@@ -195,3 +195,19 @@ def test_prepare_logic_nearest_smaller_and_count_below(emul):
     for x in vals + [1, 77, (5 << 200) + 4, P - 2, 10 ** 6 + 1]:
         got = emul.emul_count_below(val.ctypes.data_as(ctypes.c_void_p), srt.ctypes.data_as(u32p), len(vals), b32(x))
         assert got == sum(1 for y in vals if y < x)
+
+
+def test_header_is_plain_c_and_example_links():
+    """include/imt.h must compile as C11 (it is the FFI contract) and the C example must link against
+    the library (no compute: there is no GPU here)."""
+    import subprocess
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                        os.path.join(ROOT, "include", "imt.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = os.path.join(ROOT, "examples", "insert_demo")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "insert_demo.c"), "-L",
+                        os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc"), "-limt_hip",
+                        "-Wl,-rpath," + os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc"), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
