@@ -47,6 +47,7 @@ namespace dev {
 #define IMT_P29_7 0x0e5c2634u
 #define IMT_P29_8 0x0030644eu
 constexpr uint32_t N0INV29 = 0x0fffffffu;   // -p^-1 mod 2^29
+constexpr uint32_t N0INV32 = 0xefffffffu;   // -p^-1 mod 2^32
 
 IMT_HD constexpr uint32_t p29(int i) {
     return i == 0 ? IMT_P29_0 : i == 1 ? IMT_P29_1 : i == 2 ? IMT_P29_2 : i == 3 ? IMT_P29_3 :
@@ -56,14 +57,27 @@ IMT_HD constexpr uint32_t p29(int i) {
 
 // ---------------------------------------------------------------------------------
 // Montgomery reduction of a sum of NT limb products plus (optionally) addend * R.
-//   r = (sum_t a[t]*b[t] + addend*R + m*p) / R,   r < sum/R + addend + p
-// Preconditions (column accumulators must stay below 2^64):
-//   NT*9*max(a limb)*max(b limb) + 9*2^58 + 2^35 < 2^64
-// which holds for NT<=4 with 29-bit limbs (45 * 2^58 < 2^64), and for NT=1 with 30-bit limbs on
-// both sides.
-// Output limbs are normalised (< 2^29; the top limb holds whatever is left).
+//   r = (sum_t a[t]*b[t] + addend*R + m*p) / R
+// The quotient digits m_k only have to clear the low 29 bits of their column.  With WIDE_M they
+// are taken as full 32-bit words, m_k = lo32(column) * (-p^-1 mod 2^32), which saves the mask per
+// digit; the column then has its low 32 bits clear and the result grows by up to 8p instead of p
+// (m < 2^264 = 8R):
+//   WIDE_M : r < sum/R + addend + 8p        !WIDE_M : r < sum/R + addend + p
+// Column accumulators must stay below 2^64.  A column holds each limb of p at most once, so its
+// m*p part is below 2^32 * (sum of the limbs of p) = 0.4251 * 2^64 (WIDE_M) or 9 * 2^58 (!WIDE_M);
+// the a*b part is at most NT * 9 * max(a limb) * max(b limb), and the carry-in is below 2^36:
+//   NT = 4, 29-bit limbs : 36 * 2^58 = 0.5625 * 2^64   -> 0.9876 * 2^64 with WIDE_M
+//   NT = 1, 30-bit limbs on both sides : 9 * 2^60 = 0.5625 * 2^64 -> the same
+// Output limbs are normalised (< 2^29; the top limb holds whatever is left, so values must stay
+// below 2^261 = 169p: every lane that is only ever ADDED to between multiplications -- the linear
+// lanes of the partial rounds -- uses !WIDE_M).
 // ---------------------------------------------------------------------------------
-template <int NT, bool ADD>
+template <bool WIDE_M>
+IMT_HD uint32_t mont_digit(uint64_t acc) {
+    return WIDE_M ? (uint32_t)acc * N0INV32 : (((uint32_t)acc * N0INV29) & MASK29);
+}
+
+template <int NT, bool ADD, bool WIDE_M = true>
 IMT_HD void mont_dot(Fe& r, const Fe* a, const Fe* b, const Fe& addend) {
     uint32_t m[NL];
     uint64_t acc = 0;
@@ -76,7 +90,7 @@ IMT_HD void mont_dot(Fe& r, const Fe* a, const Fe* b, const Fe& addend) {
         }
 #pragma unroll
         for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p29(k - i);
-        m[k] = ((uint32_t)acc * N0INV29) & MASK29;
+        m[k] = mont_digit<WIDE_M>(acc);
         acc += (uint64_t)m[k] * p29(0);
         acc >>= 29;
     }
@@ -101,8 +115,8 @@ IMT_HD void mont_mul(Fe& r, const Fe& a, const Fe& b) {
     mont_dot<1, false>(r, &a, &b, a);
 }
 
-// r = a^2 / R.  36 doubled cross products + 9 squares instead of 81 products.
-// Precondition: limbs of a < 2^30.
+// r = a^2 / R (+ up to 8p: wide quotient digits).  36 doubled cross products + 9 squares instead
+// of 81 products.  Precondition: limbs of a < 2^30 (column 8: 4 * 2^31 * 2^30 + 2^60 = 0.5625 * 2^64).
 IMT_HD void mont_sqr(Fe& r, const Fe& a) {
     uint32_t m[NL], a2[NL];
 #pragma unroll
@@ -115,7 +129,7 @@ IMT_HD void mont_sqr(Fe& r, const Fe& a) {
         if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
 #pragma unroll
         for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p29(k - i);
-        m[k] = ((uint32_t)acc * N0INV29) & MASK29;
+        m[k] = mont_digit<true>(acc);
         acc += (uint64_t)m[k] * p29(0);
         acc >>= 29;
     }
@@ -167,12 +181,39 @@ IMT_HD void sub_p(Fe& a) {
     }
 }
 
-// bring a normalised value < 4p into [0, p)
-IMT_HD void canonicalize(Fe& a) {
+// limb i of (p << SH), SH = 0..3
+template <int SH>
+IMT_HD constexpr uint32_t p29_shl(int i) {
+    return i == 0 ? ((p29(0) << SH) & MASK29)
+         : i < NL - 1 ? (((p29(i) << SH) | (p29(i - 1) >> (29 - SH))) & MASK29)
+                      : ((p29(i) << SH) | (p29(i - 1) >> (29 - SH)));
+}
+// a -= (p << SH) if a >= (p << SH)   (normalised limbs)
+template <int SH>
+IMT_HD void cond_sub_p_shl(Fe& a) {
+    bool ge = true;
 #pragma unroll
-    for (int it = 0; it < 3; it++) {
-        if (geq_p(a)) sub_p(a);
+    for (int i = 0; i < NL; i++) {
+        const uint32_t pi = p29_shl<SH>(i);
+        if (a.v[i] != pi) ge = a.v[i] > pi;
     }
+    if (ge) {
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            uint32_t d = a.v[i] - p29_shl<SH>(i) - borrow;
+            borrow = (i < NL - 1) ? (d >> 31) : 0;
+            a.v[i] = (i < NL - 1) ? (d & MASK29) : d;
+        }
+    }
+}
+
+// bring a normalised value < 16p into [0, p)
+IMT_HD void canonicalize(Fe& a) {
+    cond_sub_p_shl<3>(a);
+    cond_sub_p_shl<2>(a);
+    cond_sub_p_shl<1>(a);
+    cond_sub_p_shl<0>(a);
 }
 
 // 8 x u32 packed (value < 2^256) <-> 9 x 29-bit limbs
@@ -237,7 +278,7 @@ IMT_HD void sbox(Fe& x) {   // x <- x^5; limbs of x < 2^30
 // through the same code with y_second = 0.
 // One loop so that each body exists once in the instruction stream.
 // `first_rc` replaces the round-0 constants (sponge padding folded in by the caller).
-// Entry: limbs normalised.  Exit: limbs normalised, every lane < 2p.
+// Entry: limbs normalised, lanes < 16p.  Exit: limbs normalised, every lane < 9p.
 IMT_HD void permute(const PoseidonConsts& pc, Fe s[3], const Fe* first_rc) {
     constexpr int NSTEP = RF + (RP + 1) / 2;   // 4 full, 29 partial pairs, 4 full
 #pragma unroll 1
@@ -277,8 +318,8 @@ IMT_HD void permute(const PoseidonConsts& pc, Fe s[3], const Fe* first_rc) {
             const int q = second ? p + 1 : p;    // with y[1] = 0 the second column constant is unused
             const Fe c1[2] = {pc.sp_col[p][0], pc.sp_col[q][0]};
             const Fe c2[2] = {pc.sp_col[p][1], pc.sp_col[q][1]};
-            mont_dot<2, true>(s[1], c1, y, s[1]);
-            mont_dot<2, true>(s[2], c2, y, s[2]);
+            mont_dot<2, true, false>(s[1], c1, y, s[1]);   // narrow digits: these lanes only accumulate
+            mont_dot<2, true, false>(s[2], c2, y, s[2]);
             s[0] = n0;
         }
     }

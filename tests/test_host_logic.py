@@ -53,6 +53,76 @@ def test_device_field_arithmetic_on_host(emul):
         assert int.from_bytes(out.raw, "little") == x * x % P
 
 
+def test_column_accumulator_bounds():
+    """Worst-case proof of the no-carry column accumulation in csrc/imt_device.hpp (mont_dot /
+    mont_sqr): with 32-bit quotient digits every 64-bit column stays below 2^64, and with the value
+    growth of +8p per wide reduction (+p per narrow one) every lane of the permutation stays below
+    2^261 with a top limb below 2^29."""
+    NL, W = 9, 29
+    pl = [(P >> (W * i)) & ((1 << W) - 1) for i in range(NL)]
+    assert sum(pl[i] << (W * i) for i in range(NL)) == P
+    carry_in = 1 << 36
+
+    def worst_column(ab_terms, m_max):
+        # ab_terms(k) = bound of the a*b part of column k; the m*p part holds each limb of p at most once
+        worst = 0
+        for k in range(2 * NL - 1):
+            lo, hi = max(0, k - (NL - 1)), min(k, NL - 1)
+            mp = sum(m_max * pl[k - i] for i in range(lo, hi + 1))
+            worst = max(worst, ab_terms(k) + mp + carry_in)
+        return worst
+
+    def n_products(k):
+        return min(k, NL - 1) - max(0, k - (NL - 1)) + 1
+
+    wide, narrow = (1 << 32) - 1, (1 << 29) - 1
+    l29, l30, l31 = (1 << 29) - 1, (1 << 30) - 1, (1 << 31) - 1
+    # mont_dot<NT>: operands with 29-bit limbs (constants x state), wide digits, NT up to 4
+    for nt in (1, 2, 3, 4):
+        assert worst_column(lambda k: nt * n_products(k) * l29 * l29, wide) < 1 << 64
+    # mont_mul(x4, x): one side lazily added (30-bit limbs)
+    assert worst_column(lambda k: n_products(k) * l29 * l30, wide) < 1 << 64
+    # mont_sqr of a lazily added value: doubled operand 31 bits x 30 bits, plus the square term
+    def sqr_terms(k):
+        lo = max(0, k - (NL - 1))
+        cross = len([i for i in range(lo, NL) if 2 * i < k])
+        return cross * l31 * l30 + (l30 * l30 if k % 2 == 0 else 0)
+    assert worst_column(sqr_terms, wide) < 1 << 64
+    # the linear-lane update REDC(s R + c y + c' y') keeps 29-bit digits; the addend limb is < 2^32
+    assert worst_column(lambda k: 2 * n_products(k) * l29 * l29 + (1 << 32), narrow) < 1 << 64
+
+    # value growth through one permutation, in units of p (R / p > 169)
+    R_over_p = (1 << 261) / P
+    def red(t_over_p2, wide_m=True):          # bound of REDC(T) given T <= t_over_p2 * p^2
+        return t_over_p2 / R_over_p + (8 if wide_m else 1)
+    def sbox(x):                              # x in units of p, after the lazy add of a constant
+        x2 = red(x * x); x4 = red(x2 * x2); return red(x4 * x)
+    lanes = [16.0, 16.0, 16.0]                # entry bound
+    worst_lane = max(lanes)
+    for _ in range(4):
+        y = [sbox(v + 1) for v in lanes]
+        lanes = [red(sum(y))] * 3             # matrix entries < p
+        worst_lane = max(worst_lane, *lanes)
+    s0, s1, s2 = lanes
+    for _ in range(29):
+        y0 = sbox(s0 + 1)
+        n0 = red(y0 + s1 + s2)
+        y1 = sbox(n0 + 1)
+        n0 = red(y1 + s1 + s2 + y0)
+        s1 = s1 + (y0 + y1) / R_over_p + 1
+        s2 = s2 + (y0 + y1) / R_over_p + 1
+        s0 = n0
+        worst_lane = max(worst_lane, s0, s1, s2, y0 + 1, y1 + 1)
+    lanes = [s0, s1, s2]
+    for _ in range(4):
+        y = [sbox(v + 1) for v in lanes]
+        lanes = [red(sum(y))] * 3
+        worst_lane = max(worst_lane, *lanes)
+    assert worst_lane < 64                    # << 169: top limb < 64p >> 232 < 2^28
+    assert (64 * P) >> 232 < 1 << 28
+    assert max(lanes) < 9                     # what canonicalize (< 16p) and the next block's entry need
+
+
 def test_device_poseidon_on_host_matches_oracle(emul, oracle):
     rng = random.Random(2)
     cases = [[0, 0], [0, 0, 0], [1, 2], [1, 2, 3], [P - 1, P - 1], [P - 1, P - 1, P - 1]]
