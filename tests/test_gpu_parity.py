@@ -304,8 +304,14 @@ def test_insert_batch_rejects_bad_values(imt, ctx, host_prep):
     with pytest.raises(imt.ImtError) as ei:
         t.insert_batch([P], host_prep=host_prep)
     assert ei.value.code == imt._ffi.ERR["NONCANONICAL"]
+    root = t.root()
+    t.insert_batch([], host_prep=host_prep)                                 # empty batch: a no-op
+    assert t.root() == root and t.size == 3
     t.insert_batch(list(range(100, 113)), host_prep=host_prep)              # exactly full
     assert t.size == 16
+    with pytest.raises(imt.ImtError) as ei:
+        t.insert_batch([200], host_prep=host_prep)                          # one past full
+    assert ei.value.code == imt._ffi.ERR["FULL"]
 
 
 def test_reference_tests_through_the_mirror_api(imt, ctx, oracle):
