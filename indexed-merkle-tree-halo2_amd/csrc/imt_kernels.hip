@@ -27,6 +27,12 @@ using namespace dev;
 #ifndef IMT_HASH_KATTR
 #define IMT_HASH_KATTR
 #endif
+// Every kernel that calls the shared hash function asks for 4 waves per SIMD.  The attribute cannot
+// be put on a device function, but LLVM propagates it from the callers when ALL of them carry it;
+// without it the three-input instance is allocated 228 VGPRs (2 waves/SIMD).
+#ifndef IMT_HASH_WAVES
+#define IMT_HASH_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 constexpr int BLOCK = IMT_BLOCK;   // 256 = 4 waves = one per SIMD of a CU
 
 __device__ __forceinline__ size_t gtid() { return (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
@@ -106,7 +112,7 @@ __device__ __forceinline__ void hash_chain(Fe& cur, bool has_leaf3, const Fe pre
 }
 
 // ---- a1 / a10 --------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) IMT_HASH_KATTR k_hash_batch(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) IMT_HASH_KATTR k_hash_batch(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                       size_t n, int arity, unsigned fmt_in, unsigned fmt_out,
                                                       int* err) {
     const size_t i = gtid();
@@ -150,7 +156,7 @@ __global__ void __launch_bounds__(BLOCK) k_convert(const uint8_t* __restrict__ i
 }
 
 // ---- a5 / a8 / a9 ----------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK)
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
 k_path_root(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3, const uint64_t* __restrict__ index,
             int is_helper, const uint8_t* __restrict__ sib, launch::SibLayout lay, unsigned depth, size_t n,
             uint8_t* __restrict__ root_out, const uint8_t* __restrict__ expect, unsigned expect_stride,
@@ -180,7 +186,7 @@ k_path_root(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3,
 }
 
 // ---- a13: verify_non_inclusion (src/indexed_merkle_tree.rs:127-229) ---------------
-__global__ void __launch_bounds__(BLOCK)
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
 k_non_membership(const uint8_t* __restrict__ root, unsigned root_stride, const uint8_t* __restrict__ low_leaf,
                  const uint64_t* __restrict__ low_index, const uint8_t* __restrict__ sib, launch::SibLayout lay,
                  unsigned depth, const uint8_t* __restrict__ new_val, const uint8_t* __restrict__ is_largest,
@@ -241,7 +247,7 @@ __global__ void __launch_bounds__(BLOCK) k_split128(const uint8_t* __restrict__ 
 // blockIdx.y selects one of the four chains of an item, so leaf-hash selection is uniform.
 // trace rows (device format): 0 low_leaf_hash, 1 root_from_low, 2 new_low_leaf_hash,
 // 3 interim_root, 4 zero_slot_root, 5 new_leaf_hash, 6 new_root_recomputed.
-__global__ void __launch_bounds__(BLOCK)
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
 k_insert_chains(const uint8_t* __restrict__ low_leaf, const uint64_t* __restrict__ low_index,
                 const uint8_t* __restrict__ low_sib, const uint8_t* __restrict__ new_leaf,
                 const uint64_t* __restrict__ new_index, const uint64_t* __restrict__ new_path_index,
@@ -320,7 +326,7 @@ k_insert_check(const uint8_t* __restrict__ old_root, const uint8_t* __restrict__
 }
 
 // ---- a2: one level of the dense build (src/utils.rs:43-48) ------------------------
-__global__ void __launch_bounds__(BLOCK) k_tree_level(const uint8_t* __restrict__ prev, uint8_t* __restrict__ next,
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_tree_level(const uint8_t* __restrict__ prev, uint8_t* __restrict__ next,
                                                       size_t n_parents) {
     const size_t i = gtid();
     if (i >= n_parents) return;
@@ -338,7 +344,7 @@ __device__ __forceinline__ void force_vector(Fe& x) {
     for (int i = 0; i < NL; i++) asm volatile("" : "+v"(x.v[i]));
 }
 
-__global__ void k_zero_chain(uint8_t* out, unsigned depth) {
+__global__ IMT_HASH_WAVES void k_zero_chain(uint8_t* out, unsigned depth) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Fe cur = g_pc.zero_leaf;
     force_vector(cur);
@@ -352,7 +358,7 @@ __global__ void k_zero_chain(uint8_t* out, unsigned depth) {
     }
 }
 
-__global__ void k_extend_root(uint8_t* cur_io, const uint8_t* zero, unsigned from, unsigned to) {
+__global__ IMT_HASH_WAVES void k_extend_root(uint8_t* cur_io, const uint8_t* zero, unsigned from, unsigned to) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Fe cur;
     load_packed(cur, cur_io);
@@ -405,7 +411,7 @@ __global__ void __launch_bounds__(BLOCK) k_fill_level(uint8_t* __restrict__ node
 }
 
 // leaf versions: slot k of level 0 holds H(preimage of event time0[k])   (:662-671)
-__global__ void __launch_bounds__(BLOCK) IMT_HASH_KATTR
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) IMT_HASH_KATTR
 k_sweep_leaves(const uint8_t* __restrict__ pre, const uint32_t* __restrict__ time0, uint8_t* __restrict__ val0,
                uint32_t k_begin, uint32_t k_count, unsigned fmt_in, int* err) {
     const size_t t = gtid();
@@ -428,7 +434,7 @@ __global__ void __launch_bounds__(BLOCK) k_merge_level(sweep::LevelTable in, swe
 }
 
 // level l -> l+1: one hash per event version; the sibling read is the proof element
-__global__ void __launch_bounds__(BLOCK) IMT_HASH_KATTR
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) IMT_HASH_KATTR
 k_sweep_level(const uint8_t* __restrict__ val_in, uint8_t* __restrict__ val_out, const uint32_t* __restrict__ from,
               const int32_t* __restrict__ sibsrc, const uint32_t* __restrict__ node_below,
               const uint32_t* __restrict__ time_next, const uint8_t* __restrict__ tree_l, uint64_t len_l,
@@ -474,7 +480,7 @@ k_writeback(const uint8_t* __restrict__ val_l, const uint32_t* __restrict__ from
 
 // levels [l0, depth): every event is alone in node 0 and its sibling is the empty subtree.
 // val is indexed by event id (the level-l0 order is pure time order).
-__global__ void __launch_bounds__(BLOCK) IMT_HASH_KATTR
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) IMT_HASH_KATTR
 k_sweep_top(const uint8_t* __restrict__ val, unsigned l0, unsigned depth, const uint8_t* __restrict__ zero,
             uint8_t* __restrict__ tree_nodes, const uint64_t* __restrict__ tree_off, uint32_t e_begin,
             uint32_t e_count, uint32_t total, uint8_t* __restrict__ old_root, uint8_t* __restrict__ interim_root,
