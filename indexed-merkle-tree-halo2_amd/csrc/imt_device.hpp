@@ -77,6 +77,17 @@ IMT_HD uint32_t mont_digit(uint64_t acc) {
     return WIDE_M ? (uint32_t)acc * N0INV32 : (((uint32_t)acc * N0INV29) & MASK29);
 }
 
+}  // namespace dev
+}  // namespace imt
+// On the device the products below are replaced by hand-laid single-chain assembly with the same
+// values (generated; see tools/gen_mont_asm.py).  -DIMT_NO_MONT_ASM keeps the C++ forms.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(IMT_NO_MONT_ASM)
+#define IMT_MONT_ASM 1
+#include "imt_mont_asm.hpp"
+#endif
+namespace imt {
+namespace dev {
+
 template <int NT, bool ADD, bool WIDE_M = true>
 IMT_HD void mont_dot(Fe& r, const Fe* a, const Fe* b, const Fe& addend) {
     uint32_t m[NL];
@@ -112,12 +123,35 @@ IMT_HD void mont_dot(Fe& r, const Fe* a, const Fe* b, const Fe& addend) {
 }
 
 IMT_HD void mont_mul(Fe& r, const Fe& a, const Fe& b) {
+#ifdef IMT_MONT_ASM
+    masm::mul_vv(r, &a, &b);
+#else
     mont_dot<1, false>(r, &a, &b, a);
+#endif
+}
+
+// mont_dot whose first factors `c` are wave-uniform constants (entries of the __constant__ Poseidon
+// tables indexed by the round counter).  Only permute() may use it: see imt_mont_asm.hpp.
+template <int NT, bool ADD, bool WIDE_M = true>
+IMT_HD void mont_dot_uc(Fe& r, const Fe* c, const Fe* v, const Fe& addend) {
+#ifdef IMT_MONT_ASM
+    static_assert((NT == 3 && !ADD && WIDE_M) || (NT == 4 && !ADD && WIDE_M) || (NT == 2 && ADD && !WIDE_M),
+                  "no assembly form for this shape");
+    if constexpr (NT == 3) masm::dot3_uc(r, c, v);
+    else if constexpr (NT == 4) masm::dot4_uc(r, c, v);
+    else masm::dot2_add_uc_narrow(r, c, v, addend);
+#else
+    mont_dot<NT, ADD, WIDE_M>(r, c, v, addend);
+#endif
 }
 
 // r = a^2 / R (+ up to 8p: wide quotient digits).  36 doubled cross products + 9 squares instead
 // of 81 products.  Precondition: limbs of a < 2^30 (column 8: 4 * 2^31 * 2^30 + 2^60 = 0.5625 * 2^64).
 IMT_HD void mont_sqr(Fe& r, const Fe& a) {
+#ifdef IMT_MONT_ASM
+    masm::sqr_v(r, a);
+    return;
+#endif
     uint32_t m[NL], a2[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) a2[i] = a.v[i] << 1;
@@ -292,9 +326,9 @@ IMT_HD void permute(const PoseidonConsts& pc, Fe s[3], const Fe* first_rc) {
             sbox(s[0]); sbox(s[1]); sbox(s[2]);
             const Fe(*mat)[3] = (st == RF / 2 - 1) ? pc.pre : pc.mds;
             Fe n0, n1, n2;
-            mont_dot<3, false>(n0, mat[0], s, s[0]);
-            mont_dot<3, false>(n1, mat[1], s, s[0]);
-            mont_dot<3, false>(n2, mat[2], s, s[0]);
+            mont_dot_uc<3, false>(n0, mat[0], s, s[0]);
+            mont_dot_uc<3, false>(n1, mat[1], s, s[0]);
+            mont_dot_uc<3, false>(n2, mat[2], s, s[0]);
             s[0] = n0; s[1] = n1; s[2] = n2;
         } else {
             const int p = 2 * (st - RF / 2);
@@ -303,7 +337,7 @@ IMT_HD void permute(const PoseidonConsts& pc, Fe s[3], const Fe* first_rc) {
             add_lazy(v[0], s[0], pc.k_partial[p]);
             sbox(v[0]);
             v[1] = s[1]; v[2] = s[2];
-            mont_dot<3, false>(n0, pc.sp_row[p], v, v[0]);
+            mont_dot_uc<3, false>(n0, pc.sp_row[p], v, v[0]);
             y[0] = v[0];
 #pragma unroll
             for (int i = 0; i < NL; i++) y[1].v[i] = 0;
@@ -312,14 +346,14 @@ IMT_HD void permute(const PoseidonConsts& pc, Fe s[3], const Fe* first_rc) {
                 sbox(v[0]);
                 v[3] = y[0];
                 const Fe c4[4] = {pc.sp_row[p + 1][0], pc.sp_row[p + 1][1], pc.sp_row[p + 1][2], pc.sp_gamma[p + 1]};
-                mont_dot<4, false>(n0, c4, v, v[0]);
+                mont_dot_uc<4, false>(n0, c4, v, v[0]);
                 y[1] = v[0];
             }
             const int q = second ? p + 1 : p;    // with y[1] = 0 the second column constant is unused
             const Fe c1[2] = {pc.sp_col[p][0], pc.sp_col[q][0]};
             const Fe c2[2] = {pc.sp_col[p][1], pc.sp_col[q][1]};
-            mont_dot<2, true, false>(s[1], c1, y, s[1]);   // narrow digits: these lanes only accumulate
-            mont_dot<2, true, false>(s[2], c2, y, s[2]);
+            mont_dot_uc<2, true, false>(s[1], c1, y, s[1]);   // narrow digits: these lanes only accumulate
+            mont_dot_uc<2, true, false>(s[2], c2, y, s[2]);
             s[0] = n0;
         }
     }

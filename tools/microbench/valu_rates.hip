@@ -139,6 +139,54 @@ __global__ void __launch_bounds__(256) k_mix_mad64_add(unsigned* out, unsigned s
     out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)r ^ (unsigned)(r >> 32) ^ u0 ^ u1 ^ u2 ^ u3;
 }
 
+
+// dependent chains: how many waves per SIMD hide the latency of back-to-back v_mad_u64_u32 on ONE
+// accumulator (the single-chain column accumulation of csrc/imt_mont_asm.hpp)?
+__global__ void __launch_bounds__(256) k_mad_dep1(unsigned* out, unsigned seed) {
+    unsigned long long d0 = threadIdx.x;
+    unsigned b = (threadIdx.x + seed) | 1, c = seed + 99;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile(
+            "v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+            "v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+            "v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+            "v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+            : "+v"(d0) : "v"(b), "v"(c) : "vcc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)d0 ^ (unsigned)(d0 >> 32);
+}
+__global__ void __launch_bounds__(256) k_mad_dep2(unsigned* out, unsigned seed) {
+    unsigned long long d0 = threadIdx.x, d1 = d0 + 5;
+    unsigned b = (threadIdx.x + seed) | 1, c = seed + 99;
+    for (int i = 0; i < ITER; i++) {
+        asm volatile(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n"
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n"
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n"
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n"
+            : "+v"(d0), "+v"(d1) : "v"(b), "v"(c) : "vcc");
+    }
+    unsigned long long r = d0 ^ d1;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)r ^ (unsigned)(r >> 32);
+}
+// one column step of the single-chain form: 6 mads, mul_lo, mad, shift -- all dependent
+__global__ void __launch_bounds__(256) k_column_dep(unsigned* out, unsigned seed) {
+    unsigned b = (threadIdx.x + seed) | 1, c = seed + 99, m = 0, lo = threadIdx.x;
+    asm volatile("v_mov_b32 v60, %0\n v_mov_b32 v61, 0\n" : : "v"(lo) : "v60", "v61");
+    for (int i = 0; i < ITER; i++) {
+        asm volatile(
+            "v_mad_u64_u32 v[60:61], vcc, %1, %2, v[60:61]\n v_mad_u64_u32 v[60:61], vcc, %1, %2, v[60:61]\n"
+            "v_mad_u64_u32 v[60:61], vcc, %1, %2, v[60:61]\n v_mad_u64_u32 v[60:61], vcc, %1, %2, v[60:61]\n"
+            "v_mad_u64_u32 v[60:61], vcc, %1, %2, v[60:61]\n"
+            "v_mul_lo_u32 %0, v60, %2\n"
+            "v_mad_u64_u32 v[60:61], vcc, %0, %1, v[60:61]\n"
+            "v_lshrrev_b64 v[60:61], 29, v[60:61]\n"
+            : "+v"(m) : "v"(b), "v"(c) : "vcc", "v60", "v61");
+    }
+    asm volatile("v_mov_b32 %0, v60\n" : "=v"(lo) : : "v60", "v61");
+    out[blockIdx.x * blockDim.x + threadIdx.x] = lo ^ m;
+}
+
 typedef void (*kfn)(unsigned*, unsigned);
 struct Case { const char* name; kfn fn; int inst_per_iter; };
 
@@ -158,6 +206,8 @@ int main() {
         {"v_lshl_add_u64", k_lshl_add_u64, 8}, {"v_lshlrev_b64", k_lshlrev_b64, 8},
         {"v_fma_f64", k_fma_f64, 8}, {"v_add_f64", k_add_f64, 8}, {"v_mul_f64", k_mul_f64, 8},
         {"mix 4x(fma_f64+add_u32)", k_mix_fma64_int, 8}, {"mix 4x(mad_u64+addc)", k_mix_mad64_add, 8},
+        {"mad_u64 1 dependent chain", k_mad_dep1, 8}, {"mad_u64 2 dependent chains", k_mad_dep2, 8},
+        {"column step, dependent", k_column_dep, 8},
     };
     unsigned* out;
     const int wavesPerSimdList[] = {1, 2, 4, 8};
