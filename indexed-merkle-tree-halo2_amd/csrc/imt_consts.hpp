@@ -19,8 +19,8 @@ struct PoseidonConsts {
     Fe rc_full[RF][3];    // rounds 0..3 as generated; round 61 carries the partial rounds' leftover
     Fe rc_h2p2[3];        // rc_full[0] + (0,1,0): second permutation of a 2-input hash
     Fe k_partial[RP];     // lane-0 constants of the partial rounds
-    Fe mds[3][3];
-    Fe pre[3][3];         // matrix of full round 3 (M followed by the first N')
+    Fe mats[2][3][3];     // [0] = MDS; [1] = matrix of full round 3 (M followed by the first N').  One
+                          // array so that the round's matrix is an address, not a select over both.
     Fe sp_row[RP][3];     // sparse round: new s0 = row . (y, s1, s2)
     Fe sp_col[RP][2];     // sparse round: new s_i = s_i + col_i * y
     Fe sp_gamma[RP];      // row[p][1]*col[p-1][0] + row[p][2]*col[p-1][1]: lets round p use the linear

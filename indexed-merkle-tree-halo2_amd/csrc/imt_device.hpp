@@ -324,7 +324,7 @@ IMT_HD void permute(const PoseidonConsts& pc, Fe s[3], const Fe* first_rc) {
             add_lazy(s[1], s[1], rc[1]);
             add_lazy(s[2], s[2], rc[2]);
             sbox(s[0]); sbox(s[1]); sbox(s[2]);
-            const Fe(*mat)[3] = (st == RF / 2 - 1) ? pc.pre : pc.mds;
+            const Fe(*mat)[3] = pc.mats[st == RF / 2 - 1 ? 1 : 0];
             Fe n0, n1, n2;
             mont_dot_uc<3, false>(n0, mat[0], s, s[0]);
             mont_dot_uc<3, false>(n1, mat[1], s, s[0]);

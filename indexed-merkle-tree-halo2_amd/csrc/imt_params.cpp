@@ -247,8 +247,8 @@ void HostPoseidon::fill_consts(dev::PoseidonConsts& pc) const {
     }
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) {
-            pc.mds[i][j] = to_dev(mds[i][j]);
-            pc.pre[i][j] = to_dev(pre[i][j]);
+            pc.mats[0][i][j] = to_dev(mds[i][j]);
+            pc.mats[1][i][j] = to_dev(pre[i][j]);
         }
     pc.cap0 = to_dev(cap0);
     pc.one = to_dev(F.one());
