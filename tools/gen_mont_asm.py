@@ -23,6 +23,7 @@ a 64-bit operand.  m[j] and r[j] share a register (m[j] is last read in column j
 in column j+9).
 """
 import os
+import sys
 
 NL = 9
 ACC = "v[38:39]"       # caller-saved, even-aligned (64-bit operands must be on gfx950)
@@ -90,11 +91,12 @@ def gen(name, nt, a_kind, add, wide, sqr=False, doc=""):
         if add:
             mad("%%[e%d]" % (k - NL), "1")
         lines.append("v_and_b32_e32 %%[r%d], %s, %s" % (k - NL, MASK, ACC_LO))
-        lines.append("v_lshrrev_b64 %s, 29, %s" % (ACC, ACC))
+        if k < 2 * NL - 2 or add:
+            lines.append("v_lshrrev_b64 %s, 29, %s" % (ACC, ACC))
     if add:
         lines.append("v_add_u32_e32 %%[r%d], %s, %%[e%d]" % (NL - 1, ACC_LO, NL - 1))
-    else:
-        lines.append("v_mov_b32_e32 %%[r%d], %s" % (NL - 1, ACC_LO))
+    else:   # low word of (acc >> 29) straight into the top limb
+        lines.append("v_alignbit_b32 %%[r%d], %s, %s, 29" % (NL - 1, "v39", ACC_LO))
 
     n_mad = sum(1 for l in lines if l.startswith("v_mad_u64_u32"))
     if sqr:
@@ -157,6 +159,8 @@ def main():
     body.append(FOOTER)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "indexed-merkle-tree-halo2_amd", "csrc", "imt_mont_asm.hpp")
+    if len(sys.argv) > 1:          # tests regenerate into a scratch file and compare
+        path = sys.argv[1]
     with open(path, "w") as f:
         f.write("\n".join(body))
     print("wrote", path)
