@@ -27,11 +27,15 @@ using namespace dev;
 #ifndef IMT_HASH_KATTR
 #define IMT_HASH_KATTR
 #endif
-// Every kernel that calls the shared hash function asks for 4 waves per SIMD.  The attribute cannot
-// be put on a device function, but LLVM propagates it from the callers when ALL of them carry it;
-// without it the three-input instance is allocated 228 VGPRs (2 waves/SIMD).
+// Every kernel that calls the shared hash function asks for 5 waves per SIMD (96 VGPRs).  The
+// attribute cannot be put on a device function, but LLVM propagates it from the callers when ALL of
+// them carry it; without it the three-input instance is allocated 228 VGPRs (2 waves/SIMD).  With
+// the assembly multipliers the hash needs < 90 registers; measured on MI355X (bench.py, 16 steps,
+// same box): 4 waves 2.93 M insertions/s, 5 waves 3.05 M, 6 waves 3.02-3.07 M but the kernel alone
+// 2 % slower, 8 waves 2.93 M.  The fifth wave is what the small kernels of the other batch and the
+// scalar-load waits of the hash overlap with.
 #ifndef IMT_HASH_WAVES
-#define IMT_HASH_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+#define IMT_HASH_WAVES __attribute__((amdgpu_waves_per_eu(5, 5)))
 #endif
 constexpr int BLOCK = IMT_BLOCK;   // 256 = 4 waves = one per SIMD of a CU
 
