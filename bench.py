@@ -270,8 +270,22 @@ def main():
         dt = float(tmax.item())
 
     mad_peak = ctypes.c_double(0.0)
+    copy_gbps = None
     if rank == 0:
         lib.imt_measure_mad_peak(ctx.h, ctypes.byref(mad_peak))   # this device, this run (devices differ)
+        # the HBM ceiling of a plain copy on this box, printed beside the vendor peak
+        a = torch.empty(1 << 29, dtype=torch.uint8, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2 * a.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
     if rank == 0:
         n_ins = args.steps * BATCH * world
         value = n_ins / dt
@@ -301,6 +315,7 @@ def main():
                        "prepare": "gpu (imt_prep.hip)" if gpu_prep else "host"},
             "roofline": {"bound": "hbm", "kernel": "k_sweep_level", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": PMC_TRAFFIC_SWEEP_LEVEL,
+                         "peak_copy_measured": copy_gbps,
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.txt (separate --pmc passes; value arrays, "
                                            "index tables and the proof store are counted, the 35 B/hash algorithmic "
                                            "figure counts only path inputs)",
