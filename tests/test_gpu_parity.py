@@ -751,3 +751,69 @@ def test_config3_non_membership_2pow20_properties(imt, ctx):
     assert (rout == imt.to_bytes(root)[None]).all()
     fail = ctx.non_membership(imt.to_bytes(root), leaves, low, sib, depth, leaves[:, 0, :].copy(), largest)
     assert (fail & imt._ffi.F_LOW_LT_NEW).all()
+
+
+def test_config4_eight_shards_2pow22_properties(imt, ctx, oracle):
+    """BASELINE config 4 on one GPU: 2^22 insertions, 8 value-partitioned shards (v mod 8) of 2^19
+    insertions each into height-29 subtrees, run one after the other; the subtree roots are combined
+    into the depth-32 root exactly as the all-gather step does.  Per shard: every insert_leaf
+    constraint of every insertion holds (independent witness kernels), roots chain across batches,
+    the final root equals a bulk rebuild from the snapshot.  The top of the tree is checked against
+    the oracle (7 hashes)."""
+    import ctypes
+    import torch
+    shards, sub_depth, depth, per_shard, bs = 8, 29, 32, 1 << 19, 1 << 16
+    dev = torch.device("cuda", 0)
+    c2 = imt.Context(0)
+    c2.set_stream(torch.cuda.current_stream().cuda_stream)
+    P_ = lambda x: ctypes.c_void_p(x.data_ptr())
+    o = dict(low_index=torch.empty(bs, dtype=torch.int64, device=dev),
+             is_largest=torch.empty(bs, dtype=torch.uint8, device=dev),
+             low_leaf=torch.empty((bs, 3, 32), dtype=torch.uint8, device=dev),
+             new_leaf=torch.empty((bs, 3, 32), dtype=torch.uint8, device=dev),
+             old_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
+             interim_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
+             new_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
+             low_sib=torch.empty((sub_depth, bs, 32), dtype=torch.uint8, device=dev),
+             new_sib=torch.empty((sub_depth, bs, 32), dtype=torch.uint8, device=dev))
+    st = imt._ffi.InsertOut(**{k: v.data_ptr() for k, v in o.items()})
+    fail = torch.empty(bs, dtype=torch.uint8, device=dev)
+    roots = []
+    for s in range(shards):
+        rng = np.random.default_rng(400 + s)
+        raw = rng.integers(0, 256, size=(per_shard, 32), dtype=np.uint8)
+        raw[:, 31] &= 0x0f
+        raw[:, 0] = (raw[:, 0] & 0xf8) | s                 # this shard's residue class mod 8
+        raw[:, 1] |= 1                                      # non-zero
+        vals = torch.from_numpy(raw).to(dev)
+        t = imt.IndexedTree(c2, sub_depth, 1 << 20)
+        prev = None
+        for b in range(per_shard // bs):
+            rc = imt.lib.imt_itree_insert_batch(t.h, ctypes.c_void_p(vals.data_ptr() + b * bs * 32), bs,
+                                                ctypes.byref(st), imt._ffi.DEVICE_PTRS)
+            assert rc == 0, imt.lib.imt_last_error(c2.h)
+            new_index = torch.arange(1 + b * bs, 1 + (b + 1) * bs, dtype=torch.int64, device=dev)
+            rc = imt.lib.imt_insert_witness_batch(c2.h, P_(o["old_root"]), P_(o["low_leaf"]), P_(o["low_index"]),
+                                                  P_(o["low_sib"]), P_(o["new_root"]), P_(o["new_leaf"]), P_(new_index),
+                                                  None, P_(o["new_sib"]), P_(o["is_largest"]), sub_depth, bs, P_(fail),
+                                                  None, imt._ffi.DEVICE_PTRS)
+            assert rc == 0
+            c2.sync()
+            assert int(fail.max()) == 0, (s, b)
+            assert bool((o["old_root"][1:] == o["new_root"][:-1]).all())
+            if prev is not None:
+                assert bool((o["old_root"][0] == prev).all())
+            prev = o["new_root"][-1].clone()
+        assert t.size == per_shard + 1
+        assert ints(prev.cpu().numpy()) == [t.root()]
+        t2 = imt.IndexedTree(c2, sub_depth, 1 << 20)
+        t2.load(t.snapshot())
+        assert t2.root() == t.root()
+        roots.append(t.root())
+        t.close(); t2.close()
+    top = ints(c2.combine_subtree_roots(imt.to_bytes(roots), sub_depth, depth))[0]
+    lvl = roots
+    while len(lvl) > 1:
+        lvl = [oracle.hash([lvl[i], lvl[i + 1]]) for i in range(0, len(lvl), 2)]
+    assert top == lvl[0]
+    c2.close()
