@@ -44,7 +44,7 @@ __device__ __forceinline__ void flag_err(int* err, bool ok) {
     if (!ok) atomicOr(err, 1);
 }
 
-// ONE copy of the hash in the code object, shared by every kernel.  Inlined per kernel, the 60 KB
+// ONE copy of the hash in the code object, shared by every kernel.  Inlined per kernel, the 47 KB
 // permutation body exists once per kernel; when two different hash kernels of consecutive batches
 // share a CU (IMT_PIPELINE) they then evict each other from the 64 KB instruction cache.  A called
 // function is the same instructions for all of them.  g_pc is referenced directly so that the
