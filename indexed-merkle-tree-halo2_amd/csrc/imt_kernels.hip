@@ -24,9 +24,6 @@ using namespace dev;
 #ifndef IMT_BLOCK
 #define IMT_BLOCK 256
 #endif
-#ifndef IMT_HASH_KATTR
-#define IMT_HASH_KATTR
-#endif
 // Every kernel that calls the shared hash function asks for 5 waves per SIMD (96 VGPRs).  The
 // attribute cannot be put on a device function, but LLVM propagates it from the callers when ALL of
 // them carry it; without it the three-input instance is allocated 228 VGPRs (2 waves/SIMD).  With
@@ -116,7 +113,7 @@ __device__ __forceinline__ void hash_chain(Fe& cur, bool has_leaf3, const Fe pre
 }
 
 // ---- a1 / a10 --------------------------------------------------------------------
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) IMT_HASH_KATTR k_hash_batch(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_hash_batch(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                       size_t n, int arity, unsigned fmt_in, unsigned fmt_out,
                                                       int* err) {
     const size_t i = gtid();
@@ -415,7 +412,7 @@ __global__ void __launch_bounds__(BLOCK) k_fill_level(uint8_t* __restrict__ node
 }
 
 // leaf versions: slot k of level 0 holds H(preimage of event time0[k])   (:662-671)
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) IMT_HASH_KATTR
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
 k_sweep_leaves(const uint8_t* __restrict__ pre, const uint32_t* __restrict__ time0, uint8_t* __restrict__ val0,
                uint32_t k_begin, uint32_t k_count, unsigned fmt_in, int* err) {
     const size_t t = gtid();
@@ -438,7 +435,7 @@ __global__ void __launch_bounds__(BLOCK) k_merge_level(sweep::LevelTable in, swe
 }
 
 // level l -> l+1: one hash per event version; the sibling read is the proof element
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) IMT_HASH_KATTR
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
 k_sweep_level(const uint8_t* __restrict__ val_in, uint8_t* __restrict__ val_out, const uint32_t* __restrict__ from,
               const int32_t* __restrict__ sibsrc, const uint32_t* __restrict__ node_below,
               const uint32_t* __restrict__ time_next, const uint8_t* __restrict__ tree_l, uint64_t len_l,
@@ -484,7 +481,7 @@ k_writeback(const uint8_t* __restrict__ val_l, const uint32_t* __restrict__ from
 
 // levels [l0, depth): every event is alone in node 0 and its sibling is the empty subtree.
 // val is indexed by event id (the level-l0 order is pure time order).
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) IMT_HASH_KATTR
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
 k_sweep_top(const uint8_t* __restrict__ val, unsigned l0, unsigned depth, const uint8_t* __restrict__ zero,
             uint8_t* __restrict__ tree_nodes, const uint64_t* __restrict__ tree_off, uint32_t e_begin,
             uint32_t e_count, uint32_t total, uint8_t* __restrict__ old_root, uint8_t* __restrict__ interim_root,
