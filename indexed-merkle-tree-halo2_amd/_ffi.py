@@ -15,6 +15,31 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
         "(or __graft_entry__.build()); there is no fallback implementation")
 
+
+
+def _preload_torch_hip_runtime():
+    """A process can hold one HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so.N
+    (same soname as /opt/rocm's, which libimt_hip.so links against); whichever is loaded first serves
+    both.  If this library came first, a later `import torch` would run on a runtime it was not built
+    with and report "No HIP GPUs are available".  So when torch is installed, its runtime is loaded
+    first -- without importing torch itself -- and libimt_hip.so binds to it, which is the order
+    bench.py and the GPU tests have always run in."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libamdhip64.so",):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
+if not os.environ.get("IMT_NO_TORCH_RUNTIME_PRELOAD"):
+    _preload_torch_hip_runtime()
 lib = ctypes.CDLL(LIB_PATH)
 
 c_void_p, c_size_t, c_uint, c_int, c_u64 = (ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int,

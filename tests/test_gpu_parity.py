@@ -817,3 +817,27 @@ def test_config4_eight_shards_2pow22_properties(imt, ctx, oracle):
         lvl = [oracle.hash([lvl[i], lvl[i + 1]]) for i in range(0, len(lvl), 2)]
     assert top == lvl[0]
     c2.close()
+
+
+def test_library_loaded_before_torch_leaves_torch_usable():
+    """The mirror package loaded BEFORE torch touches the GPU (fresh process): both must then see the
+    device -- PyTorch-ROCm bundles its own HIP runtime with the same soname as the one libimt_hip.so
+    links against (see _ffi._preload_torch_hip_runtime)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, imt_amd\n"
+        "assert 'torch' not in sys.modules\n"
+        "c = imt_amd.Context(0)\n"
+        "h = c.hash2(np.zeros((4, 2, 32), np.uint8))\n"
+        "import torch\n"
+        "s = torch.cuda.current_stream().cuda_stream\n"
+        "x = torch.arange(8, device='cuda:0').sum().item()\n"
+        "assert x == 28\n"
+        "c.set_stream(s)\n"
+        "h2 = c.hash2(np.zeros((4, 2, 32), np.uint8))\n"
+        "assert (h == h2).all()\n"
+        "print('ok')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
