@@ -188,11 +188,20 @@ def main():
     vals = torch.from_numpy(vals_h).to(dev)
 
     u8 = dict(dtype=torch.uint8, device=dev)
-    bufs = dict(low_index=torch.empty(BATCH, dtype=torch.int64, device=dev),
-                low_leaf=torch.empty((BATCH, 3, 32), **u8), is_largest=torch.empty(BATCH, **u8),
-                old_root=torch.empty((BATCH, 32), **u8), interim_root=torch.empty((BATCH, 32), **u8),
-                new_root=torch.empty((BATCH, 32), **u8), new_leaf=torch.empty((BATCH, 3, 32), **u8),
-                low_sib=torch.empty((depth, BATCH, 32), **u8), new_sib=torch.empty((depth, BATCH, 32), **u8))
+    out_pinned = os.environ.get("IMT_BENCH_OUT") == "pinned"
+    if out_pinned:
+        # secondary measurement (PCIe note): every per-insertion output lands in pinned HOST
+        # memory, written by the kernels over PCIe (hipHostMalloc memory is device-addressable), which
+        # is what a host-language caller that wants the witnesses in its own memory would do.
+        u8o = dict(dtype=torch.uint8, device="cpu", pin_memory=True)
+        i64o = dict(dtype=torch.int64, device="cpu", pin_memory=True)
+    else:
+        u8o, i64o = u8, dict(dtype=torch.int64, device=dev)
+    bufs = dict(low_index=torch.empty(BATCH, **i64o),
+                low_leaf=torch.empty((BATCH, 3, 32), **u8o), is_largest=torch.empty(BATCH, **u8o),
+                old_root=torch.empty((BATCH, 32), **u8o), interim_root=torch.empty((BATCH, 32), **u8o),
+                new_root=torch.empty((BATCH, 32), **u8o), new_leaf=torch.empty((BATCH, 3, 32), **u8o),
+                low_sib=torch.empty((depth, BATCH, 32), **u8o), new_sib=torch.empty((depth, BATCH, 32), **u8o))
     out = _ffi.InsertOut(**{name: t.data_ptr() for name, t in bufs.items()})
     flags = _ffi.DEVICE_PTRS | _ffi.FMT_CANONICAL
     ins_flags = flags | (0 if os.environ.get("IMT_NO_PIPELINE") else _ffi.PIPELINE)
@@ -312,7 +321,8 @@ def main():
                        "parallelism": "single tree" if world == 1 else
                        f"{world} value-partitioned subtrees by leaf-index range + RCCL all-gather of subtree roots per step",
                        "hashes_per_insertion": 2 + 2 * depth,
-                       "prepare": "gpu (imt_prep.hip)" if gpu_prep else "host"},
+                       "prepare": "gpu (imt_prep.hip)" if gpu_prep else "host",
+                       "outputs": "pinned host memory, written by the kernels over PCIe" if out_pinned else "HBM"},
             "roofline": {"bound": "hbm", "kernel": "k_sweep_level", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": PMC_TRAFFIC_SWEEP_LEVEL,
                          "peak_copy_measured": copy_gbps,

@@ -100,6 +100,15 @@ const char *imt_last_error(const imt_ctx *ctx);
 int imt_ctx_set_stream(imt_ctx *ctx, void *hip_stream);
 /* Wait for the stream and report deferred input errors (IMT_ERR_NONCANONICAL, ...). */
 int imt_ctx_sync(imt_ctx *ctx);
+/* Page-locked host memory that the device can address (hipHostMalloc).  A pointer from here may be
+ * passed wherever IMT_DEVICE_PTRS expects a device pointer: the kernels then read the values and
+ * write the roots and proofs straight into the caller's memory over PCIe, asynchronously and
+ * pipelined like any device-pointer call, and the data is valid on the host after imt_ctx_sync().
+ * This is how a host-language caller (the Rust shim of INTEGRATION.md) gets its witnesses without a
+ * staging copy: measured at the same insertion rate as HBM-resident outputs.
+ * Plain host pointers (no IMT_DEVICE_PTRS) stay supported and are synchronous. */
+int imt_host_alloc(imt_ctx *ctx, size_t bytes, void **out);
+int imt_host_free(imt_ctx *ctx, void *ptr);
 /* ABI / build identification, e.g. "imt-hip gfx950 r1" */
 const char *imt_version(void);
 /* Per-kernel timing with HIP events recorded on the context's stream around the launches of

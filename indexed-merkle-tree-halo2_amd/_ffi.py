@@ -59,6 +59,8 @@ SIGNATURES = {
     "imt_ctx_destroy": (None, [c_void_p]),
     "imt_last_error": (ctypes.c_char_p, [c_void_p]),
     "imt_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "imt_host_alloc": (c_int, [c_void_p, c_size_t, P(c_void_p)]),
+    "imt_host_free": (c_int, [c_void_p, c_void_p]),
     "imt_ctx_sync": (c_int, [c_void_p]),
     "imt_measure_mad_peak": (c_int, [c_void_p, P(ctypes.c_double)]),
     "imt_profile_enable": (c_int, [c_void_p, c_int]),

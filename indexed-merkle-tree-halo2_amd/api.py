@@ -91,6 +91,24 @@ class Context:
     def sync(self):
         self._check(lib.imt_ctx_sync(self.h))
 
+    def host_alloc(self, shape, dtype=np.uint8):
+        """numpy array over page-locked, device-addressable host memory (imt_host_alloc); pass its
+        `.ctypes.data` wherever IMT_DEVICE_PTRS expects a device pointer.  Free with host_free(arr)."""
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        self._check(lib.imt_host_alloc(self.h, max(nbytes, 1), ctypes.byref(p)))
+        buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._check(lib.imt_host_free(self.h, ctypes.c_void_p(p)))
+
     # ---- a1 / a10 ----
     def hash2(self, pairs, fmt=0):
         a = _arr(pairs, (2, 32))

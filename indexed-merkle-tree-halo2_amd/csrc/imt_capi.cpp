@@ -72,6 +72,23 @@ void imt_ctx::prof_end(int idx, hipStream_t on) {
     if (idx >= 0) (void)hipEventRecord(prof_pending[(size_t)idx].b, on ? on : stream);
 }
 
+extern "C" int imt_host_alloc(imt_ctx* c, size_t bytes, void** out) {
+    if (!c || !out || bytes == 0) return c ? c->fail(IMT_ERR_ARG, "null / empty host allocation") : IMT_ERR_ARG;
+    int rc = c->set_device();
+    if (rc) return rc;
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return c->fail(IMT_ERR_ALLOC, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    *out = p;
+    return IMT_OK;
+}
+extern "C" int imt_host_free(imt_ctx* c, void* ptr) {
+    if (!c) return IMT_ERR_ARG;
+    if (!ptr) return IMT_OK;
+    IMT_HIP(c, hipHostFree(ptr));
+    return IMT_OK;
+}
+
 extern "C" int imt_measure_mad_peak(imt_ctx* c, double* gmads) {
     if (!c || !gmads) return IMT_ERR_ARG;
     int rc = c->set_device();

@@ -841,3 +841,44 @@ def test_library_loaded_before_torch_leaves_torch_usable():
         "print('ok')\n" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_pinned_host_buffers_as_device_pointers(imt, ctx, oracle):
+    """imt_host_alloc: values read from and witnesses written to page-locked HOST memory by the kernels
+    (IMT_DEVICE_PTRS | IMT_PIPELINE, three batches in flight), equal to the synchronous host-pointer
+    call and to the oracle."""
+    import ctypes
+    depth, n, nb = 32, 1024, 3
+    vals = oracle_lib.synth_values(nb * n, 0x494D5407)
+    c2 = imt.Context(0)
+    t_ref = imt.IndexedTree(c2, depth, 8192)
+    want = [t_ref.insert_batch(vals[i * n:(i + 1) * n]) for i in range(nb)]
+    t = imt.IndexedTree(c2, depth, 8192)
+    pv = c2.host_alloc((nb * n, 32))
+    pv[:] = imt.to_bytes(vals)
+    outs = []
+    for b in range(nb):
+        o = dict(low_index=c2.host_alloc(n, np.uint64), is_largest=c2.host_alloc(n),
+                 low_leaf=c2.host_alloc((n, 3, 32)), new_leaf=c2.host_alloc((n, 3, 32)),
+                 old_root=c2.host_alloc((n, 32)), interim_root=c2.host_alloc((n, 32)), new_root=c2.host_alloc((n, 32)),
+                 low_sib=c2.host_alloc((depth, n, 32)), new_sib=c2.host_alloc((depth, n, 32)))
+        for a in o.values():
+            a[...] = 0xee
+        st = imt._ffi.InsertOut(**{k: v.ctypes.data for k, v in o.items()})
+        rc = imt.lib.imt_itree_insert_batch(t.h, ctypes.c_void_p(pv.ctypes.data + b * n * 32), n, ctypes.byref(st),
+                                            imt._ffi.DEVICE_PTRS | imt._ffi.PIPELINE)
+        assert rc == 0, imt.lib.imt_last_error(c2.h)
+        outs.append(o)
+    c2.sync()
+    for b, o in enumerate(outs):
+        for k in o:
+            assert (np.asarray(o[k]) == want[b][k]).all(), (b, k)
+    assert t.root() == t_ref.root()
+    oh, rows, _ = _oracle_run(oracle, depth, 8192, vals[:64])
+    assert ints(outs[0]["new_root"][:64]) == [r["new_root"] for r in rows]
+    oracle.sparse_free(oh)
+    for o in outs:
+        for a in o.values():
+            c2.host_free(a)
+    c2.host_free(pv)
+    t.close(); t_ref.close(); c2.close()
