@@ -264,6 +264,8 @@ def main():
     # region two hash kernels of consecutive batches share the SIMDs and stretch each other.
     b2b = (ctypes.c_double * 12)()
     extra = 2 if steps_total + 2 <= vals.shape[0] // BATCH else 0
+    if os.environ.get("IMT_BENCH_NO_ATTRIBUTION"):
+        extra = 0       # profiler runs: every k_sweep_level launch of the process is then a pipelined one
     if extra:
         saved = ins_flags
         ins_flags = flags | (0 if gpu_prep else _ffi.HOST_PREP)
