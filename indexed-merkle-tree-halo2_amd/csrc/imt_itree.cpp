@@ -53,6 +53,12 @@ unsigned ceil_log2(uint64_t x) {
 }
 
 // one set of plan buffers (device + pinned host staging)
+// Batches in flight on the GPU under IMT_PIPELINE.  3 was measured (with 5 and 6 waves/SIMD): no gain
+// over 2 -- two batches already keep two hash kernels resident 80 % of the time.
+#ifndef IMT_NPIPE
+#define IMT_NPIPE 2
+#endif
+
 struct PlanSet {
     size_t cap_events = 0;       // capacity in events
     unsigned cap_levels = 0;
@@ -97,7 +103,8 @@ struct imt_itree {
     int* h_err_pin = nullptr;        // pinned word for the prepare kernels' error bits
     // a sharded batch between imt_itree_batch_begin and _end
     struct Pending { bool active = false; size_t n = 0; unsigned l0 = 0; int set = 0; } pending;
-    static constexpr int NSETS = 3;      // host work may run two batches ahead of the GPU
+    static constexpr int NPIPE = IMT_NPIPE;     // batches in flight on the GPU under IMT_PIPELINE
+    static constexpr int NSETS = NPIPE + 1;     // host work may run one batch further ahead
     PlanSet plan[NSETS];
     int cur = 0;
     uint64_t batch_no = 0;
@@ -106,7 +113,7 @@ struct imt_itree {
     // IMT_PIPELINE: consecutive batches alternate between two internal streams and run one level
     // apart (batch k+1 sweeps level l once batch k has written level l back), so two hash kernels
     // share the GPU and the SIMDs see twice the waves of a single 2^16 batch.
-    hipStream_t pipe_stream[2] = {nullptr, nullptr};
+    hipStream_t pipe_stream[NPIPE] = {};
     hipEvent_t user_mark = nullptr;  // position of the context's stream when a pipelined call starts
     bool pipe_pending = false;       // pipelined work the context's stream has not been ordered behind
     // reusable host work arrays of insert_batch
@@ -263,14 +270,27 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
         (e = hipEventCreateWithFlags(&t->up_done, hipEventDisableTiming)) != hipSuccess ||
         // different priorities: the runtime may otherwise map both streams to one hardware queue, which
         // serialises them (seen with rocprofv3: same Queue_Id, zero overlap)
-        (e = hipStreamCreateWithPriority(&t->pipe_stream[0], hipStreamNonBlocking, 0)) != hipSuccess ||
-        (e = hipStreamCreateWithPriority(&t->pipe_stream[1], hipStreamNonBlocking, -1)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&t->user_mark, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&t->plan[0].done, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&t->plan[1].done, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&t->plan[2].done, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&t->user_mark, hipEventDisableTiming)) != hipSuccess) {
         imt_itree_free(t);
         return c->hip_fail(e, "imt_itree_new allocation");
+    }
+    {
+        // different priorities: the runtime may otherwise map the streams to one hardware queue, which
+        // serialises them (seen with rocprofv3: same Queue_Id, zero overlap)
+        int least = 0, greatest = 0;
+        hipDeviceGetStreamPriorityRange(&least, &greatest);      // numerically: least >= greatest
+        for (int i = 0; i < imt_itree::NPIPE; i++) {
+            const int prio = std::max(greatest, std::min(least, 0 - i));
+            if ((e = hipStreamCreateWithPriority(&t->pipe_stream[i], hipStreamNonBlocking, prio)) != hipSuccess) {
+                imt_itree_free(t);
+                return c->hip_fail(e, "hipStreamCreateWithPriority");
+            }
+        }
+        for (auto& pl : t->plan)
+            if ((e = hipEventCreateWithFlags(&pl.done, hipEventDisableTiming)) != hipSuccess) {
+                imt_itree_free(t);
+                return c->hip_fail(e, "hipEventCreate");
+            }
     }
     for (auto& pl : t->plan)
         for (unsigned l = 0; l <= depth; l++)
@@ -292,8 +312,7 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
     t->pre.push_back(Pre{{0, 0, 0, 0}, {0, 0, 0, 0}, 0});
     t->sorted.push_back(SortedEnt{0, 0});
     t->size = 1;
-    c->side_streams.push_back(t->pipe_stream[0]);
-    c->side_streams.push_back(t->pipe_stream[1]);
+    for (auto ps : t->pipe_stream) c->side_streams.push_back(ps);
     *out = t;
     return IMT_OK;
 }
@@ -968,7 +987,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     hipStream_t s = c->stream;
     const PlanSet* prev = nullptr;      // the batch before this one, if it is still on a pipeline stream
     if (pipelined) {
-        s = t->pipe_stream[t->batch_no & 1];
+        s = t->pipe_stream[t->batch_no % imt_itree::NPIPE];
         IMT_HIP(c, hipEventRecord(t->user_mark, c->stream));     // buffers last used on the user's stream
         IMT_HIP(c, hipStreamWaitEvent(s, t->user_mark, 0));
         const PlanSet& o = t->plan[(t->cur + imt_itree::NSETS - 1) % imt_itree::NSETS];
