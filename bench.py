@@ -43,7 +43,7 @@ VALU_PEAK_GMADS = 36443.0           # measured v_mad_u64_u32 lane-ops/ns (profil
 # HBM bytes of one k_sweep_level launch at E = 2^17 events from the PMC passes in
 # profiles/r01_pmc_hbm_traffic.txt: 2 x FETCH_SIZE (gfx950 reports half of 16-B/lane reads,
 # MI355X_MICROARCH.md "HBM") + WRITE_SIZE, counter unit KB
-PMC_TRAFFIC_SWEEP_LEVEL = int((2 * 3835.9 + 8192.7) * 1024)
+PMC_TRAFFIC_SWEEP_LEVEL = int((2 * 4096.2 + 13312.5) * 1024)   # profiles/r01_pmc_hbm_traffic.txt (final build)
 
 
 def synth_values(total, residue, modulus, seed):
@@ -329,8 +329,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": PMC_TRAFFIC_SWEEP_LEVEL,
                          "peak_copy_measured": copy_gbps,
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.txt (separate --pmc passes; value arrays, "
-                                           "index tables and the proof store are counted, the 35 B/hash algorithmic "
-                                           "figure counts only path inputs)",
+                                           "index tables, the proof store and 36 B/hash of call-ABI stack are counted, "
+                                           "the 35 B/hash algorithmic figure counts only path inputs)",
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "back_to_back": None if not b2b_avg_ms else {
                              "avg_launch_ms": b2b_avg_ms, "achieved": alg_bytes / (b2b_avg_ms * 1e-3) / 1e9,

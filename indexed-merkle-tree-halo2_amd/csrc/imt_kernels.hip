@@ -46,6 +46,10 @@ __device__ __forceinline__ void flag_err(int* err, bool ok) {
 // share a CU (IMT_PIPELINE) they then evict each other from the 64 KB instruction cache.  A called
 // function is the same instructions for all of them.  g_pc is referenced directly so that the
 // constant loads stay scalar (function arguments would be treated as divergent).
+// (Passing the inputs as vectors instead of structs would keep all of them in registers, but the
+// function then allocates 19-35 callee-saved VGPRs and saves them to scratch on every call; with
+// struct arguments only the first travels in registers, the others through 36 B of the caller's
+// stack each, and the function stays inside the caller-saved set.  The second costs less.)
 template <bool THREE>
 __device__ __noinline__ Fe hash_shared(Fe a, Fe b, Fe c) {
     Fe o;
@@ -458,11 +462,12 @@ k_sweep_level(const uint8_t* __restrict__ val_in, uint8_t* __restrict__ val_out,
         a.v[i] = right ? sv.v[i] : cur.v[i];
         b.v[i] = right ? cur.v[i] : sv.v[i];
     }
-    hash_call(o, a, b, a, false);
-    store_packed(val_out + (size_t)kp * 32, o);
+    // the sibling IS the proof element: stored before the call so that it need not survive it
     const uint32_t e = time_next[kp];
     uint8_t* dst = (e & 1u) ? new_sib : low_sib;
     if (dst) store_fe(g_pc, dst + ((uint64_t)level * lay.level_stride + (uint64_t)(e >> 1) * lay.item_stride) * 32, sv, fmt_out);
+    hash_call(o, a, b, a, false);
+    store_packed(val_out + (size_t)kp * 32, o);
 }
 
 // final version of every touched node of level l goes back to the stored tree
