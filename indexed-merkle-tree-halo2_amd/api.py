@@ -35,6 +35,9 @@ def to_bytes(x):
     """int or iterable of ints (any nesting) -> uint8 array [..., 32] little-endian."""
     if isinstance(x, (int, np.integer)):
         return np.frombuffer(int(x).to_bytes(32, "little"), dtype=np.uint8).copy()
+    x = list(x)
+    if x and all(isinstance(v, (int, np.integer)) for v in x):      # flat list: one join instead of n arrays
+        return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in x), dtype=np.uint8).reshape(len(x), 32).copy()
     a = [to_bytes(v) for v in x]
     return np.stack(a) if a else np.zeros((0, 32), dtype=np.uint8)
 
