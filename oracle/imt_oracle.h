@@ -14,7 +14,10 @@
  * halo2-base @ aerius-labs/halo2-lib branch feat/secp256k1-hash2curve,
  * Cargo.toml:14-16, no lockfile); their published algorithm is restated here.
  * Everything except that one KAT (hash2 values, roots, depth > 3) is
- * "derived, KAT-anchored": unpinned by the reference itself.
+ * "derived, KAT-anchored": unpinned by the reference itself.  The permutation alone
+ * is additionally pinned by two public known answers of circomlib's Poseidon (same
+ * t=3 constants): lane 0 of the permutation of [0,1,2] and of [0,0,0]
+ * (selftest.c, tests/golden/vectors.json "public-circomlib").
  *
  * Field elements cross this API as 32-byte little-endian canonical integers
  * (what halo2curves' Fr::to_repr() yields).

@@ -35,6 +35,20 @@ int main(void) {
     dec_to_le32(KAT_ZERO, KAT_ZERO_DEC);
     orc_hash3(z, zero, zero, zero);
     if (memcmp(z, KAT_ZERO, 32)) { printf("FAIL: H(0,0,0) != reference KAT\n"); bad = 1; }
+    {   /* public circomlib known answers: lane 0 of the permutation of [0,1,2] and of [0,0,0] */
+        static const char P12[] = "7853200120776062878684798364095072458815029376092732009249414926327459813530";
+        static const char P00[] = "14744269619966411208579211824598458697587494354926760081771325075741142829156";
+        uint8_t st[3][32], want[32];
+        memset(st, 0, sizeof st);
+        st[1][0] = 1; st[2][0] = 2;
+        orc_permute_bytes(st);
+        dec_to_le32(want, P12);
+        if (memcmp(st[0], want, 32)) { printf("FAIL: permutation([0,1,2])[0] != circomlib poseidon([1,2])\n"); bad = 1; }
+        memset(st, 0, sizeof st);
+        orc_permute_bytes(st);
+        dec_to_le32(want, P00);
+        if (memcmp(st[0], want, 32)) { printf("FAIL: permutation([0,0,0])[0] != circomlib poseidon([0,0])\n"); bad = 1; }
+    }
     /* test_insert_leaf_multiple_round: depth 3, values 30,10,20,5,50,35 */
     static const uint64_t vals[6] = {30, 10, 20, 5, 50, 35};
     uint8_t pre[8][3][32], leaves[8][32], old_root[32];

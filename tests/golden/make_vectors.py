@@ -5,6 +5,11 @@ cannot run here, so the fixture has three provenance classes, recorded per entry
   "reference"      the zero-leaf hash literal at /root/reference/src/indexed_merkle_tree.rs:248
   "survey-script"  values SURVEY.md sec. B lists, computed there by an independent big-int script
   "oracle"         values produced by oracle/ (KAT-anchored, unpinned by the reference itself)
+  "public-circomlib"  the widely published known answers of circomlib's Poseidon for two inputs,
+                   poseidon([1,2]) and poseidon([0,0]): lane 0 of THIS permutation (same Grain
+                   constants and MDS, t=3, R_F=8, R_P=57) applied to [0,a,b].  They pin the
+                   permutation independently of the reference's own known answer, which in turn pins
+                   the sponge around it (capacity 2^64, padding, output lane 1).
 Run from the repo root:  python tests/golden/make_vectors.py
 """
 import json
@@ -24,6 +29,10 @@ def add(kind, inputs, out, prov):
 
 
 add("hash3", [0, 0, 0], oracle_lib.KAT_ZERO, "reference")
+add("permute_lane0", [0, 1, 2], 7853200120776062878684798364095072458815029376092732009249414926327459813530,
+    "public-circomlib")      # 0x115cc0f5e7d690413df64c6b9662e9cf2a3617f2743245519e19607a4417189a
+add("permute_lane0", [0, 0, 0], 14744269619966411208579211824598458697587494354926760081771325075741142829156,
+    "public-circomlib")      # 0x2098f5fb9e239eab3ceac3f27b81e481dc3124d55ffed523a839ee8446b64864
 z = oracle_lib.KAT_ZERO
 add("hash2", [z, z], 4631070890700890603680124140378602853676871767725085684580160391942752072668, "survey-script")
 add("hash2", [1, 2], 21877010470986031768387685515622483058891036836834541740519926154448980606803, "survey-script")

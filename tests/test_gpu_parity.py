@@ -32,6 +32,10 @@ def test_kat_and_golden_vectors(imt, ctx):
     assert ints(out3) == [int(e["out"]) for e in h3]
     outp = ctx.permute(ints_to_arr([int(x) for e in pm for x in e["in"]]).reshape(-1, 3, 32))
     assert ints(outp) == [int(x) for e in pm for x in e["out"]]
+    pub = [e for e in GOLD["entries"] if e["kind"] == "permute_lane0"]     # public circomlib known answers
+    assert len(pub) == 2
+    outq = ctx.permute(ints_to_arr([int(x) for e in pub for x in e["in"]]).reshape(-1, 3, 32))
+    assert ints(outq[:, 0]) == [int(e["out"]) for e in pub]
     z = ctx.zero_hashes(32)
     for e in GOLD["entries"]:
         if e["kind"] == "empty_root":
