@@ -87,6 +87,42 @@ def cpu_baseline(vals, budget_s=15.0):
             "sample": f"first {n} insertions of the same depth-32 workload, C oracle (oracle/sparse.c), {dt:.1f} s"}
 
 
+def cpu_baseline_all_cores(vals, budget_s=8.0):
+    """The same oracle on every host core: T independent depth-32 trees, thread k inserting the values
+    k, k+T, ... (the value-partitioned form the multi-GPU bench uses).  Extra information beside the
+    one-thread `cpu_baseline` the contract asks for; ctypes releases the GIL during the C call."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    orc = oracle_lib.load()
+    lib = orc.lib
+    T = max(1, min(os.cpu_count() or 1, 64))
+    counts = [0] * T
+    t0 = time.perf_counter()
+
+    def work(k):
+        h = orc.sparse_new(DEPTH, 1 << 14)
+        low = ctypes.c_uint64()
+        i = k
+        while i < vals.shape[0] and time.perf_counter() - t0 < budget_s:
+            rc = lib.orc_sparse_insert(h, vals[i].ctypes.data_as(ctypes.c_void_p), ctypes.byref(low), None, None,
+                                       None, None, None, None)
+            assert rc == 0
+            counts[k] += 1
+            i += T
+        orc.sparse_free(h)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    n = sum(counts)
+    return {"value": n / dt, "unit": "insertions/s", "cores": T, "kind": "port",
+            "sample": f"{n} insertions over {T} threads, one depth-32 tree per thread, C oracle, {dt:.1f} s"}
+
+
 def bench_single_list(args, world, rank, local_rank, dist, backend, ctx, imt_amd):
     """N > 1, IMT_BENCH_MODE=single-list: ONE depth-32 tree (the reference's single sorted list, bit-exact),
     replicated on every rank; a step inserts world x 2^16 values, each rank hashes 1/world of every level and
@@ -355,6 +391,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(vals_h)
+            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(vals_h)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
