@@ -75,6 +75,12 @@ extern "C" {
                                      imt_itree_root / get_proof / non-pipelined call on the tree), not by
                                      the context's stream. */
 
+#define IMT_INPUTS_READY 0x200u   /* imt_itree_insert_batch with IMT_DEVICE_PTRS: `vals` and the hash-free output buffers
+                                     (low_index, is_largest, low_leaf, new_leaf) are idle -- nothing enqueued on the
+                                     context's stream still writes `vals` or reads those outputs.  Without it the
+                                     batch's preparation is ordered behind the context's stream first, which costs
+                                     nothing unless that stream holds long-running work. */
+
 /* failure bits written per item by the relation checkers; each is one constraint or
  * assert of the reference (src/indexed_merkle_tree.rs) */
 #define IMT_F_RANGE_PRED 0x01   /* select(is_largest, next_val==0, new<next_val) == 1   :182-191 */
@@ -235,6 +241,9 @@ typedef struct imt_insert_out {
     void *low_sib;           /* [depth][n][32] low-leaf proof against old_root (layout per flags) */
     void *new_sib;           /* [depth][n][32] new-slot proof against interim_root / new_root */
 } imt_insert_out;
+/* Every 32-byte row a device pointer refers to (values, preimages, roots, sibling rows) must be 16-byte
+ * aligned: the kernels move field elements as two 16-byte words.  hipMalloc, imt_host_alloc and torch
+ * allocations are; an offset into them must be a multiple of 16 bytes. */
 
 /* n sequential insertions with the semantics of update_idx_leaf + rebuild (:632-660,
  * :715-735): insertion i finds the low leaf among everything inserted before it, rewrites
@@ -270,6 +279,35 @@ int imt_itree_non_membership_witness(imt_itree *t, const void *vals /*[n][32]*/,
                                      uint8_t *is_largest /*[n]*/, void *low_sib /*[depth][n][32]*/,
                                      unsigned flags);
 
+/* ---- e: the tree as ONE SUBTREE of a deeper tree (sharding by leaf-index range) -----------------
+ * north_star's multi-GPU layout: GPU g owns leaf indices [g << depth, (g + 1) << depth) of a tree of depth
+ * global_depth as an indexed tree of its own (own {0,0,0} sentinel at its first leaf, own sorted list; the
+ * value space is partitioned between the subtrees by the caller).
+ * After imt_itree_set_placement (on an empty tree) every LEAF INDEX that crosses the API is global,
+ * (subtree_index << depth) + local: low_index outputs, index arguments, and the next_idx field of leaf
+ * preimages -- hence what is hashed into the leaves (new_val_idx, src/indexed_merkle_tree.rs:655,:715).
+ * Sibling arrays passed to imt_itree_insert_batch are dimensioned for global_depth levels ([global_depth][n]
+ * or, item-major, [n][global_depth]); the batch writes levels [0, depth). */
+int imt_itree_set_placement(imt_itree *t, unsigned global_depth, uint64_t subtree_index);
+/* The value partition between subtrees: from now on imt_itree_insert_batch / imt_itree_batch_begin accept only
+ * values with v mod modulus == residue (checked for every value, on the GPU with the default prepare) and
+ * fail with IMT_ERR_VALUE otherwise, the tree unchanged.  modulus 0 or 1 = accept everything. */
+int imt_itree_set_value_partition(imt_itree *t, uint32_t modulus, uint32_t residue);
+/* Lifts the outputs of ONE imt_itree_insert_batch on a placed tree to witnesses of the enclosing tree, so
+ * that they are what insert_leaf takes (src/indexed_merkle_tree.rs:231-245: depth-d proofs, depth-d roots):
+ * old_root / interim_root / new_root (given as subtree roots, replaced in place) climb the global_depth - depth
+ * upper levels, and rows [depth, global_depth) of low_sib / new_sib receive the siblings of that climb.
+ * Order of a step across subtrees: subtree 0's insertions, then subtree 1's, ...; so the siblings left of
+ * this subtree are taken from roots_after (every subtree's root after the step) and those right of it from
+ * roots_before.  Both are [n_subtrees][32] in the format of `flags` (what an all-gather of imt_itree_root /
+ * imt_itree_root_lagged returns); levels above depth + log2(n_subtrees) meet empty subtrees.
+ * 2 * (global_depth - depth) hashes per insertion: with the batch's 2 + 2 * depth that is the 2 + 2 * 32 of an
+ * unsharded depth-32 insertion.  Host or device pointers per flags; enqueued on the context's stream, which
+ * the caller must have ordered behind the batch (imt_itree_root_lagged for that batch, or imt_ctx_sync). */
+int imt_itree_lift_batch(imt_itree *t, const void *roots_before /*[n_subtrees][32]*/,
+                         const void *roots_after /*[n_subtrees][32]*/, size_t n_subtrees, size_t n,
+                         const imt_insert_out *out, unsigned flags);
+
 /* ---- e: one tree on several GPUs, sequential semantics (single sorted list) ------------------
  * Every rank holds a replica of the tree and calls the same sequence with the same values; the hashing
  * of each step is split by slot range between the ranks, and the caller all-gathers the value arrays in
@@ -298,6 +336,8 @@ int imt_itree_batch_extract(imt_itree *t, const void *const *val_levels /*host a
                             const void *roots, uint32_t ins_begin, uint32_t ins_count,
                             const imt_insert_out *out, unsigned flags);
 int imt_itree_batch_end(imt_itree *t, const void *const *val_levels, const void *top_path);
+/* gives up an open batch (after a failed collective, say): the tree is as it was before imt_itree_batch_begin */
+int imt_itree_batch_abort(imt_itree *t);
 
 /* ---- e: multi-GPU helpers ------------------------------------------------------ */
 /* Root of a depth-`depth` tree whose 2^k subtrees of height `sub_height` have the given

@@ -106,6 +106,10 @@ SIGNATURES = {
     "imt_itree_batch_extract": (c_int, [c_void_p, P(c_void_p), c_void_p, ctypes.c_uint32, ctypes.c_uint32, P(InsertOut),
                                         c_uint]),
     "imt_itree_batch_end": (c_int, [c_void_p, P(c_void_p), c_void_p]),
+    "imt_itree_batch_abort": (c_int, [c_void_p]),
+    "imt_itree_set_placement": (c_int, [c_void_p, c_uint, c_u64]),
+    "imt_itree_set_value_partition": (c_int, [c_void_p, ctypes.c_uint32, ctypes.c_uint32]),
+    "imt_itree_lift_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, P(InsertOut), c_uint]),
     "imt_combine_subtree_roots": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, c_uint, c_void_p, c_uint]),
     "imt_zero_hashes": (c_int, [c_void_p, c_uint, c_void_p, c_uint]),
 }
@@ -122,6 +126,6 @@ IMT_OK = 0
 ERR = dict(NO_LEAVES=-1, ODD_LEAVES=-2, NOT_POW2=-3, RANGE=-4, NONCANONICAL=-5, ALLOC=-6, NO_DEVICE=-7, HIP=-8,
            ARG=-9, VALUE=-10, FULL=-11, INTERNAL=-12)
 FMT_CANONICAL, FMT_MONT256, FMT_DEVICE = 0, 1, 2
-DEVICE_PTRS, SIB_ITEM_MAJOR, ROOT_PER_ITEM, PIPELINE, HOST_PREP = 0x10, 0x20, 0x40, 0x80, 0x100
+DEVICE_PTRS, SIB_ITEM_MAJOR, ROOT_PER_ITEM, PIPELINE, HOST_PREP, INPUTS_READY = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 F_RANGE_PRED, F_LOW_IN_ROOT, F_LOW_LT_NEW, F_ZERO_SLOT, F_NEXT_VAL, F_NEXT_IDX, F_NEW_ROOT, F_BAD_BIT = (
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80)

@@ -343,9 +343,29 @@ class IndexedTree:
 
     def __init__(self, ctx, depth, capacity):
         self.ctx, self.depth, self.capacity = ctx, depth, capacity
+        self.global_depth, self.index_base = depth, 0
         h = ctypes.c_void_p()
         ctx._check(lib.imt_itree_new(ctx.h, depth, capacity, ctypes.byref(h)))
         self.h = h
+
+    def set_placement(self, global_depth, subtree_index):
+        """Make this (empty) tree subtree `subtree_index` at height `depth` of a tree of depth `global_depth`:
+        leaf indices crossing the API, including the hashed next_idx fields, become global
+        (imt_itree_set_placement); sibling arrays get global_depth rows, filled up by lift_batch()."""
+        self.ctx._check(lib.imt_itree_set_placement(self.h, global_depth, subtree_index))
+        self.global_depth, self.index_base = global_depth, subtree_index << self.depth
+
+    def lift_batch(self, res, roots_before, roots_after, item_major=False):
+        """In place: the dict insert_batch() returned becomes depth-`global_depth` witnesses
+        (imt_itree_lift_batch).  roots_before / roots_after: uint8 [n_subtrees, 32], every subtree's root
+        before / after the step."""
+        rb, ra = _arr(roots_before, (32,)), _arr(roots_after, (32,))
+        n = res["new_root"].shape[0]
+        out = _ffi.InsertOut(**{k: res[k].ctypes.data for k in ("old_root", "interim_root", "new_root", "low_sib",
+                                                               "new_sib") if k in res})
+        self.ctx._check(lib.imt_itree_lift_batch(self.h, _p(rb), _p(ra), rb.shape[0], n, ctypes.byref(out),
+                                                 _ffi.SIB_ITEM_MAJOR if item_major else 0))
+        return res
 
     def close(self):
         if getattr(self, "h", None):
@@ -370,7 +390,7 @@ class IndexedTree:
     def insert_batch(self, vals, proofs=True, item_major=False, host_prep=False):
         """n sequential insertions (update_idx_leaf semantics); returns a dict of numpy arrays."""
         v = to_bytes(vals) if not isinstance(vals, np.ndarray) else _arr(vals, (32,))
-        n, d = v.shape[0], self.depth
+        n, d = v.shape[0], self.global_depth      # a placed tree fills rows [0, depth); lift_batch() the rest
         res = dict(low_index=np.empty(n, np.uint64), low_leaf=np.empty((n, 3, 32), np.uint8),
                    is_largest=np.empty(n, np.uint8), old_root=np.empty((n, 32), np.uint8),
                    interim_root=np.empty((n, 32), np.uint8), new_root=np.empty((n, 32), np.uint8),
@@ -385,7 +405,7 @@ class IndexedTree:
         if rc == _ffi.ERR["VALUE"]:
             raise ValueError(lib.imt_last_error(self.ctx.h).decode())
         self.ctx._check(rc)
-        res["new_index"] = np.arange(self.size - n, self.size, dtype=np.uint64)
+        res["new_index"] = np.arange(self.size - n, self.size, dtype=np.uint64) + np.uint64(self.index_base)
         return res
 
     def get_proof_batch(self, index, item_major=False):
@@ -403,7 +423,7 @@ class IndexedTree:
 
     def snapshot(self):
         """Leaf preimages [size, 3, 32] in index order: the checkpoint of the tree."""
-        return self.get_leaves(np.arange(self.size, dtype=np.uint64))
+        return self.get_leaves(np.arange(self.size, dtype=np.uint64) + np.uint64(self.index_base))
 
     def load(self, preimages):
         """Replace the contents with a snapshot (bulk rebuild on the GPU)."""

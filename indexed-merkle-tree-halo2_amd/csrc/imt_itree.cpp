@@ -9,6 +9,7 @@
 // IMT_DEVICE_PTRS | IMT_PIPELINE consecutive batches overlap on two compute streams.
 #include "imt_ctx.hpp"
 #include "imt_prep.hpp"
+#include "imt_prep_logic.hpp"
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -88,6 +89,12 @@ struct imt_itree {
     imt_ctx* ctx = nullptr;
     unsigned depth = 0;
     uint64_t cap = 0, size = 0;
+    // placement as a subtree of a deeper tree (imt_itree_set_placement); the defaults are "not placed"
+    unsigned global_depth = 0;       // = depth when not placed
+    uint64_t sub_index = 0;          // which subtree of height `depth`
+    uint64_t index_base = 0;         // sub_index << depth: added to every leaf index that crosses the API
+    uint32_t part_mod = 0, part_res = 0;   // value partition between the subtrees (imt_itree_set_value_partition)
+    hipEvent_t in_mark = nullptr;    // position of the context's stream when a device-pointer call starts
     std::vector<uint64_t> h_off, h_len;
     uint8_t* d_nodes = nullptr;
     uint64_t* d_off = nullptr;
@@ -226,6 +233,7 @@ extern "C" void imt_itree_free(imt_itree* t) {
         hipStreamDestroy(ps);
     }
     if (t->user_mark) hipEventDestroy(t->user_mark);
+    if (t->in_mark) hipEventDestroy(t->in_mark);
     if (t->d_nodes) hipFree(t->d_nodes);
     if (t->d_off) hipFree(t->d_off);
     if (t->d_len) hipFree(t->d_len);
@@ -249,6 +257,7 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
     if (!t) return c->fail(IMT_ERR_ALLOC, "out of host memory");
     t->ctx = c;
     t->depth = depth;
+    t->global_depth = depth;
     t->cap = capacity;
     uint64_t off = 0;
     for (unsigned l = 0; l <= depth; l++) {
@@ -268,8 +277,7 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
         (e = hipMalloc((void**)&t->d_len, (depth + 1) * 8)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&t->up_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&t->up_done, hipEventDisableTiming)) != hipSuccess ||
-        // different priorities: the runtime may otherwise map both streams to one hardware queue, which
-        // serialises them (seen with rocprofv3: same Queue_Id, zero overlap)
+        (e = hipEventCreateWithFlags(&t->in_mark, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&t->user_mark, hipEventDisableTiming)) != hipSuccess) {
         imt_itree_free(t);
         return c->hip_fail(e, "imt_itree_new allocation");
@@ -478,7 +486,7 @@ extern "C" int imt_itree_find_low_batch(imt_itree* t, const void* vals, size_t n
     for (size_t i = 0; i < n; i++) {
         size_t pos;
         if (find_pred(t, v[i], pos)) return c->fail(IMT_ERR_VALUE, "value %zu is zero or already in the tree", i);
-        res[i] = t->sorted[pos].idx;
+        res[i] = t->index_base + t->sorted[pos].idx;
     }
     if (flags & IMT_DEVICE_PTRS) {
         IMT_HIP(c, hipMemcpy(low_index, res.data(), n * 8, hipMemcpyHostToDevice));
@@ -499,10 +507,11 @@ extern "C" int imt_itree_get_leaves(imt_itree* t, const uint64_t* index, size_t 
     if ((rc = ensure_mirror(t))) return rc;
     std::vector<uint8_t> buf(n * 96);
     for (size_t i = 0; i < n; i++) {
-        if (index[i] >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
-        if (index[i] < t->size) {
-            const Pre& p = t->pre[index[i]];
-            put_pre(&buf[i * 96], p.val, p.next_val, p.next_idx);
+        const uint64_t li = index[i] - t->index_base;      // wraps for an index below the base: caught below
+        if (li >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
+        if (li < t->size) {
+            const Pre& p = t->pre[li];                      // the mirror holds local indices; 0 = "no successor"
+            put_pre(&buf[i * 96], p.val, p.next_val, is_zero256(p.next_val) ? 0 : t->index_base + p.next_idx);
         } else {
             std::memset(&buf[i * 96], 0, 96);
         }
@@ -532,7 +541,7 @@ extern "C" int imt_itree_get_proof_batch(imt_itree* t, const uint64_t* index, si
     const bool dev = flags & IMT_DEVICE_PTRS;
     if (!dev)
         for (size_t i = 0; i < n; i++)
-            if (index[i] >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
+            if (index[i] - t->index_base >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
     if ((rc = join_top(t))) return rc;
     const unsigned depth = t->depth;
     const uint64_t* d_idx = index;
@@ -543,7 +552,7 @@ extern "C" int imt_itree_get_proof_batch(imt_itree* t, const uint64_t* index, si
         if (!d_idx || !d_out) return IMT_ERR_HIP;
         IMT_HIP(c, hipMemcpyAsync((void*)d_idx, index, n * 8, hipMemcpyHostToDevice, c->stream));
     }
-    launch::TreeView tv{t->d_nodes, t->d_off, t->d_len, c->d_zero};
+    launch::TreeView tv{t->d_nodes, t->d_off, t->d_len, c->d_zero, t->index_base};
     launch::SibLayout lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, depth} : launch::SibLayout{n, 1};
     launch::gather_proof(c->stream, tv, d_idx, n, depth, d_out, lay, flags & IMT_FMT_MASK);
     if (!dev) {
@@ -601,11 +610,11 @@ extern "C" int imt_itree_non_membership_witness(imt_itree* t, const void* vals, 
     const size_t sib_bytes = (size_t)t->depth * n * 32;
     uint8_t* g_sib = outbuf(low_sib, sib_bytes);
     if (!g_low || (low_leaf && !g_leaf) || (is_largest && !g_lg) || (low_sib && !g_sib)) return IMT_ERR_HIP;
-    prep::nm_witness(s, d_vals, t->d_val, t->d_sorted[t->sorted_cur], (uint32_t)t->size, (uint32_t)n, g_low, g_leaf, g_lg,
-                     d_perr);
+    prep::nm_witness(s, d_vals, t->d_val, t->d_sorted[t->sorted_cur], (uint32_t)t->size, (uint32_t)n, t->index_base,
+                     g_low, g_leaf, g_lg, d_perr);
     if (g_leaf && fmt != IMT_FMT_CANONICAL) launch::convert(s, g_leaf, g_leaf, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
     if (g_sib) {
-        launch::TreeView tv{t->d_nodes, t->d_off, t->d_len, c->d_zero};
+        launch::TreeView tv{t->d_nodes, t->d_off, t->d_len, c->d_zero, t->index_base};
         launch::SibLayout lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->depth} : launch::SibLayout{n, 1};
         launch::gather_proof(s, tv, g_low, n, t->depth, g_sib, lay, fmt);
     }
@@ -643,9 +652,17 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
     rc = fetch_canonical(c, c->stream, preimages, (size_t)n * 3, flags, flat);
     if (rc) return rc;
     // ---- list check: sorted by val, next pointers = successor in that order, last points to 0 ----
-    for (uint64_t i = 0; i < n; i++)
-        if (flat[3 * i + 2][1] | flat[3 * i + 2][2] | flat[3 * i + 2][3] || flat[3 * i + 2][0] >= n)
+    // next_idx fields are global indices (index_base + local) except the "no successor" 0; make them local
+    for (uint64_t i = 0; i < n; i++) {
+        U256& nx = flat[3 * i + 2];
+        if (!is_zero256(flat[3 * i + 1])) {
+            if (nx[1] | nx[2] | nx[3] || nx[0] < t->index_base)
+                return c->fail(IMT_ERR_VALUE, "leaf %llu: next_idx out of range", (unsigned long long)i);
+            nx[0] -= t->index_base;
+        }
+        if (nx[1] | nx[2] | nx[3] || nx[0] >= n)
             return c->fail(IMT_ERR_VALUE, "leaf %llu: next_idx out of range", (unsigned long long)i);
+    }
     if (!is_zero256(flat[0])) return c->fail(IMT_ERR_VALUE, "leaf 0 must be the {0,..} sentinel");
     std::vector<uint64_t> order(n);
     std::iota(order.begin(), order.end(), (uint64_t)0);
@@ -667,6 +684,9 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
     if ((rc = c->clear_err())) return rc;
     uint8_t* d_pre = (uint8_t*)c->dev_scratch(2, (size_t)n * 96);
     if (!d_pre) return IMT_ERR_HIP;
+    if (t->index_base)      // what is hashed is the global index
+        for (uint64_t i = 0; i < n; i++)
+            if (!is_zero256(flat[3 * i + 1])) flat[3 * i + 2][0] += t->index_base;
     IMT_HIP(c, hipMemcpyAsync(d_pre, flat.data(), (size_t)n * 96, hipMemcpyHostToDevice, s));
     for (unsigned l = 0; l <= t->depth; l++)
         launch::fill_level(s, t->d_nodes + t->h_off[l] * 32, t->h_len[l], c->d_zero + (size_t)l * 32);
@@ -688,11 +708,14 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
     // ---- host mirror ----
     t->pre.resize(n);
     t->sorted.resize(n);
-    for (uint64_t i = 0; i < n; i++) t->pre[i] = Pre{flat[3 * i], flat[3 * i + 1], flat[3 * i + 2][0]};
+    for (uint64_t i = 0; i < n; i++)
+        t->pre[i] = Pre{flat[3 * i], flat[3 * i + 1],
+                        is_zero256(flat[3 * i + 1]) ? 0 : flat[3 * i + 2][0] - t->index_base};
     for (uint64_t r = 0; r < n; r++) t->sorted[r] = SortedEnt{flat[3 * order[r]][3], order[r]};
     t->size = n;
     t->mirror_valid = true;
     t->dev_index_valid = false;
+    t->pending.active = false;
     for (auto& pl : t->plan) pl.has_root = false;
     return IMT_OK;
 }
@@ -752,6 +775,10 @@ int host_prepare(imt_itree* t, PlanSet& P, const void* vals, size_t n, unsigned 
         for (size_t i = 0; i < n; i++) ord[i] = sk[i].second;
     }
     if (is_zero256(v[ord[0]])) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
+    if (t->part_mod > 1)
+        for (size_t i = 0; i < n; i++)
+            if (prep::mod_small(reinterpret_cast<const uint8_t*>(v[i].data()), t->part_mod) != t->part_res)
+                return c->fail(IMT_ERR_VALUE, "a value belongs to another subtree (v %% %u != %u)", t->part_mod, t->part_res);
     for (size_t r = 1; r < n; r++)
         if (v[ord[r]] == v[ord[r - 1]]) return c->fail(IMT_ERR_VALUE, "duplicate value inside the batch");
     std::vector<int64_t>&prv = t->w_prv, &nxt = t->w_nxt;
@@ -803,11 +830,11 @@ int host_prepare(imt_itree* t, PlanSet& P, const void* vals, size_t n, unsigned 
         const U256& lowval = ref_val(t, hp, pred[i]);
         const bool has_succ = succ[i] != REF_NONE;
         const U256& sval = has_succ ? ref_val(t, hp, succ[i]) : U256_ZERO;
-        const uint64_t sidx = has_succ ? ref_leaf(t, hp, succ[i]) : 0;
+        const uint64_t sidx = has_succ ? t->index_base + ref_leaf(t, hp, succ[i]) : 0;
         o_low[i] = low;
         o_largest[i] = has_succ ? 0 : 1;                               // :737-742
         if (want_lowleaf) put_pre(&hp.lowleaf[i * 96], lowval, sval, sidx);
-        put_pre(h_pre + (2 * i) * 96, lowval, v[i], M + i);            // low leaf rewritten :655-656
+        put_pre(h_pre + (2 * i) * 96, lowval, v[i], t->index_base + M + i);   // low leaf rewritten :655-656
         put_pre(h_pre + (2 * i + 1) * 96, v[i], sval, sidx);           // new leaf inherits :650-654
         if (want_newleaf) std::memcpy(&hp.newleaf[i * 96], h_pre + (2 * i + 1) * 96, 96);
         keys[2 * i] = (low << 32) | (uint64_t)(2 * i);
@@ -921,9 +948,11 @@ int gpu_prepare(imt_itree* t, PlanSet& P, const void* vals, size_t n, unsigned f
             (out->new_leaf && !go.newleaf))
             return IMT_ERR_HIP;
     }
-    prep::run(ps, P.ws, d_vals, t->d_val, t->d_sorted[t->sorted_cur], t->d_sorted[t->sorted_cur ^ 1], (uint32_t)t->size,
-              (uint32_t)n, P.d_pre, P.d_tab[0][0], P.d_tab[0][1], P.d_tab[0][2], P.d_tab[0][3], go.low, go.largest,
-              go.lowleaf, go.newleaf);
+    P.ws.part_mod = t->part_mod;
+    P.ws.part_res = t->part_res;
+    IMT_HIP(c, prep::run(ps, P.ws, d_vals, t->d_val, t->d_sorted[t->sorted_cur], t->d_sorted[t->sorted_cur ^ 1],
+                         (uint32_t)t->size, (uint32_t)n, t->index_base, P.d_pre, P.d_tab[0][0], P.d_tab[0][1], P.d_tab[0][2],
+                         P.d_tab[0][3], go.low, go.largest, go.lowleaf, go.newleaf));
     IMT_HIP(c, hipMemcpyAsync(t->h_err_pin, P.ws.err, sizeof(int), hipMemcpyDeviceToHost, ps));
     const auto w0 = std::chrono::steady_clock::now();
     IMT_HIP(c, hipStreamSynchronize(ps));
@@ -931,10 +960,11 @@ int gpu_prepare(imt_itree* t, PlanSet& P, const void* vals, size_t n, unsigned f
     const int perr = *t->h_err_pin;
     if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
     if (perr & prep::ERR_ZERO) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
+    if (perr & prep::ERR_FOREIGN)
+        return c->fail(IMT_ERR_VALUE, "a value belongs to another subtree (v %% %u != %u)", t->part_mod, t->part_res);
     if (perr & prep::ERR_DUPLICATE)
         return c->fail(IMT_ERR_VALUE, "duplicate value (inside the batch or already in the tree)");
-    t->sorted_cur ^= 1;
-    return IMT_OK;
+    return IMT_OK;     // the merged index sits in d_sorted[sorted_cur ^ 1]; the caller flips when it commits
 }
 
 }  // namespace
@@ -972,6 +1002,16 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     if (rc) return rc;
 
     // ---- hash-free part: low leaves, event preimages, event order (side stream) ----
+    // The side stream reads the caller's `vals` and writes the caller's hash-free outputs (low_index,
+    // is_largest, low_leaf, new_leaf), so with device pointers it is first ordered behind everything the
+    // caller has enqueued on the context's stream (imt.h: "work is enqueued on the context's stream").
+    // IMT_INPUTS_READY waives that: the caller guarantees those buffers are idle.
+    // (Host-pointer calls are ordered too: their staging scratch may still be read by an asynchronous
+    // device-pointer call, e.g. imt_itree_lift_batch, enqueued earlier on the context's stream.)
+    if (!(dev && (flags & IMT_INPUTS_READY))) {
+        IMT_HIP(c, hipEventRecord(t->in_mark, c->stream));
+        IMT_HIP(c, hipStreamWaitEvent(t->up_stream, t->in_mark, 0));
+    }
     size_t slot = 2;
     HostPlan hp;
     GpuOuts go;
@@ -999,13 +1039,13 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     IMT_HIP(c, hipStreamWaitEvent(s, t->up_done, 0));
 
     // ---- GPU outputs ----
-    const size_t sib_bytes = (size_t)t->depth * n * 32;
     uint8_t *g_old = nullptr, *g_int = nullptr, *g_new = nullptr, *g_ls = nullptr, *g_ns = nullptr;
     auto gpu_out = [&](void* user, size_t bytes) -> uint8_t* {
         if (!user) return nullptr;
         if (dev) return (uint8_t*)user;
         return (uint8_t*)c->dev_scratch(slot++, bytes);
     };
+    const size_t sib_bytes = (size_t)t->global_depth * n * 32;
     if (out) {
         g_old = gpu_out(out->old_root, n * 32);
         g_int = gpu_out(out->interim_root, n * 32);
@@ -1016,7 +1056,8 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
             (out->low_sib && !g_ls) || (out->new_sib && !g_ns))
             return IMT_ERR_HIP;
     }
-    launch::SibLayout lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->depth} : launch::SibLayout{n, 1};
+    // a placed tree writes rows [0, depth) of sibling arrays dimensioned for global_depth levels
+    launch::SibLayout lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->global_depth} : launch::SibLayout{n, 1};
 
     // ---- leaf hashes, index phase (no hashing), then the hash sweep ----
     int pf = c->prof_begin(IMT_PROF_LEAVES, s);
@@ -1069,6 +1110,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
 
     // ---- commit the hash-free state ----
     if (gpu_prep) {
+        t->sorted_cur ^= 1;          // the merged index becomes current together with the size
         t->size = M + n;
         t->mirror_valid = false;     // rebuilt from the device index when a host-side call needs it
     } else {
@@ -1099,7 +1141,11 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
             }
             return IMT_OK;
         };
-        if ((rc = host_out(out->low_index, t->w_low.data(), n * 8))) return rc;
+        if (t->index_base && out->low_index) {
+            std::vector<uint64_t> glob(t->w_low);
+            for (auto& x : glob) x += t->index_base;
+            if ((rc = host_out(out->low_index, glob.data(), n * 8))) return rc;
+        } else if ((rc = host_out(out->low_index, t->w_low.data(), n * 8))) return rc;
         if ((rc = host_out(out->is_largest, t->w_largest.data(), n))) return rc;
         if (fmt == IMT_FMT_CANONICAL) {
             if ((rc = host_out(out->low_leaf, hp.lowleaf.data(), n * 96))) return rc;
@@ -1124,8 +1170,10 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         if (out->old_root) IMT_HIP(c, hipMemcpyAsync(out->old_root, g_old, n * 32, hipMemcpyDeviceToHost, s));
         if (out->interim_root) IMT_HIP(c, hipMemcpyAsync(out->interim_root, g_int, n * 32, hipMemcpyDeviceToHost, s));
         if (out->new_root) IMT_HIP(c, hipMemcpyAsync(out->new_root, g_new, n * 32, hipMemcpyDeviceToHost, s));
-        if (out->low_sib) IMT_HIP(c, hipMemcpyAsync(out->low_sib, g_ls, sib_bytes, hipMemcpyDeviceToHost, s));
-        if (out->new_sib) IMT_HIP(c, hipMemcpyAsync(out->new_sib, g_ns, sib_bytes, hipMemcpyDeviceToHost, s));
+        // level-major: only rows [0, depth) were written (a placed tree's upper rows come from imt_itree_lift_batch)
+        const size_t sib_copy = (flags & IMT_SIB_ITEM_MAJOR) ? sib_bytes : (size_t)t->depth * n * 32;
+        if (out->low_sib) IMT_HIP(c, hipMemcpyAsync(out->low_sib, g_ls, sib_copy, hipMemcpyDeviceToHost, s));
+        if (out->new_sib) IMT_HIP(c, hipMemcpyAsync(out->new_sib, g_ns, sib_copy, hipMemcpyDeviceToHost, s));
     }
     if (c->profiling) {
         c->prof_ms[IMT_PROF_HOST] +=
@@ -1180,14 +1228,18 @@ extern "C" int imt_itree_batch_begin(imt_itree* t, const void* vals, size_t n, u
         d_vals = can;
     }
     IMT_HIP(c, hipStreamSynchronize(t->up_stream));
-    prep::run(s, P.ws, d_vals, t->d_val, t->d_sorted[t->sorted_cur], t->d_sorted[t->sorted_cur ^ 1], (uint32_t)M,
-              (uint32_t)n, P.d_pre, P.d_tab[0][0], P.d_tab[0][1], P.d_tab[0][2], P.d_tab[0][3], P.ws.o_low,
-              P.ws.o_largest, P.ws.o_lowleaf, P.ws.o_newleaf);
+    P.ws.part_mod = t->part_mod;
+    P.ws.part_res = t->part_res;
+    IMT_HIP(c, prep::run(s, P.ws, d_vals, t->d_val, t->d_sorted[t->sorted_cur], t->d_sorted[t->sorted_cur ^ 1], (uint32_t)M,
+                         (uint32_t)n, t->index_base, P.d_pre, P.d_tab[0][0], P.d_tab[0][1], P.d_tab[0][2], P.d_tab[0][3],
+                         P.ws.o_low, P.ws.o_largest, P.ws.o_lowleaf, P.ws.o_newleaf));
     IMT_HIP(c, hipMemcpyAsync(t->h_err_pin, P.ws.err, sizeof(int), hipMemcpyDeviceToHost, s));
     IMT_HIP(c, hipStreamSynchronize(s));
     const int perr = *t->h_err_pin;
     if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
     if (perr & prep::ERR_ZERO) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
+    if (perr & prep::ERR_FOREIGN)
+        return c->fail(IMT_ERR_VALUE, "a value belongs to another subtree (v %% %u != %u)", t->part_mod, t->part_res);
     if (perr & prep::ERR_DUPLICATE) return c->fail(IMT_ERR_VALUE, "duplicate value (inside the batch or already in the tree)");
     // index phase for every level, with the slot of every event per level
     launch::slot0(s, P.d_tab[0][1], P.d_slot, (uint32_t)E);
@@ -1280,7 +1332,7 @@ extern "C" int imt_itree_batch_extract(imt_itree* t, const void* const* val_leve
     p.new_root = (uint8_t*)out->new_root;
     p.low_sib = (uint8_t*)out->low_sib;
     p.new_sib = (uint8_t*)out->new_sib;
-    p.lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->depth} : launch::SibLayout{ins_count, 1};
+    p.lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->global_depth} : launch::SibLayout{ins_count, 1};
     p.fmt_out = fmt;
     launch::extract(s, p);
     if (out->low_index)
@@ -1293,6 +1345,14 @@ extern "C" int imt_itree_batch_extract(imt_itree* t, const void* const* val_leve
     if (out->new_leaf)
         launch::convert(s, P.ws.o_newleaf + (size_t)ins_begin * 96, (uint8_t*)out->new_leaf, (size_t)ins_count * 3,
                         IMT_FMT_CANONICAL, fmt, c->d_err);
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_batch_abort(imt_itree* t) {
+    if (!t) return IMT_ERR_ARG;
+    // nothing of an open batch has touched the stored tree, the committed index or the size: rows
+    // [size, size + n) of the value array and the spare sorted index are simply overwritten next time
+    t->pending.active = false;
     return IMT_OK;
 }
 
@@ -1318,5 +1378,121 @@ extern "C" int imt_itree_batch_end(imt_itree* t, const void* const* val_levels, 
     t->cur = (t->cur + 1) % imt_itree::NSETS;
     t->batch_no++;
     t->pending.active = false;
+    return IMT_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// e: the tree as one subtree of a deeper tree (leaf-index-range sharding)
+// ------------------------------------------------------------------------------------
+extern "C" int imt_itree_set_placement(imt_itree* t, unsigned global_depth, uint64_t subtree_index) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (t->size != 1 || t->batch_no != 0) return c->fail(IMT_ERR_ARG, "placement must be set on an empty tree");
+    if (global_depth < t->depth || global_depth > IMT_MAX_DEPTH)
+        return c->fail(IMT_ERR_RANGE, "global depth %u outside [%u, %d]", global_depth, t->depth, IMT_MAX_DEPTH);
+    const unsigned up = global_depth - t->depth;
+    if (up < 64 && (subtree_index >> up) != 0) return c->fail(IMT_ERR_RANGE, "subtree index does not fit the global tree");
+    if (global_depth > 63 && subtree_index != 0) return c->fail(IMT_ERR_RANGE, "leaf indices must fit 64 bits");
+    t->global_depth = global_depth;
+    t->sub_index = subtree_index;
+    t->index_base = t->depth < 64 ? subtree_index << t->depth : 0;
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_set_value_partition(imt_itree* t, uint32_t modulus, uint32_t residue) {
+    if (!t) return IMT_ERR_ARG;
+    if (modulus > 1 && residue >= modulus) return t->ctx->fail(IMT_ERR_ARG, "residue %u >= modulus %u", residue, modulus);
+    t->part_mod = modulus;
+    t->part_res = residue;
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_lift_batch(imt_itree* t, const void* roots_before, const void* roots_after, size_t n_subtrees,
+                                    size_t n, const imt_insert_out* out, unsigned flags) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (!out) return c->fail(IMT_ERR_ARG, "null outputs");
+    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
+    if (n_subtrees == 0 || (n_subtrees & (n_subtrees - 1)) || n_subtrees > 65536)
+        return c->fail(IMT_ERR_ARG, "n_subtrees must be a power of two (<= 65536)");
+    unsigned k = 0;
+    while (((size_t)1 << k) < n_subtrees) k++;
+    const unsigned levels = t->global_depth - t->depth;
+    if (k > levels) return c->fail(IMT_ERR_RANGE, "depth + log2(n_subtrees) exceeds the global depth");
+    if (t->sub_index >= n_subtrees) return c->fail(IMT_ERR_RANGE, "this tree is subtree %llu of %zu",
+                                                   (unsigned long long)t->sub_index, n_subtrees);
+    if (n_subtrees > 1 && (!roots_before || !roots_after)) return c->fail(IMT_ERR_ARG, "null subtree roots");
+    if (n == 0 || levels == 0) return IMT_OK;
+    if (n > ((size_t)1 << 30)) return c->fail(IMT_ERR_RANGE, "batch too large");
+    int rc = c->set_device();
+    if (rc) return rc;
+    const bool dev = flags & IMT_DEVICE_PTRS;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    hipStream_t s = c->stream;
+    if (!dev && (rc = c->clear_err())) return rc;
+    size_t slot = 2;
+    auto scratch = [&](size_t bytes) { return (uint8_t*)c->dev_scratch(slot++, bytes); };
+    // ---- the `levels` siblings above this subtree's root: constant for the whole batch ----
+    uint8_t* tree_buf = scratch(2 * n_subtrees * 32);       // dense tree over the mixed roots
+    uint8_t* top = scratch((size_t)levels * 32);            // device format
+    if (!tree_buf || !top) return IMT_ERR_HIP;
+    if (n_subtrees > 1) {
+        const uint8_t *d_b = (const uint8_t*)roots_before, *d_a = (const uint8_t*)roots_after;
+        if (!dev) {
+            uint8_t* up = scratch(2 * n_subtrees * 32);
+            if (!up) return IMT_ERR_HIP;
+            IMT_HIP(c, hipMemcpyAsync(up, roots_before, n_subtrees * 32, hipMemcpyHostToDevice, s));
+            IMT_HIP(c, hipMemcpyAsync(up + n_subtrees * 32, roots_after, n_subtrees * 32, hipMemcpyHostToDevice, s));
+            d_b = up;
+            d_a = up + n_subtrees * 32;
+        }
+        // subtrees left of this one (lower leaf indices) are taken AFTER the step, those right of it BEFORE:
+        // within a step the insertions of subtree 0 come first, then subtree 1's, ...
+        launch::mix_roots(s, d_b, d_a, tree_buf, (uint32_t)n_subtrees, (uint32_t)t->sub_index, fmt, c->d_err);
+        size_t off = 0;
+        for (size_t m = n_subtrees; m > 1; m >>= 1) {
+            launch::tree_level(s, tree_buf + off * 32, tree_buf + (off + m) * 32, m / 2);
+            off += m;
+        }
+    }
+    launch::pick_top(s, tree_buf, (uint32_t)n_subtrees, (uint32_t)t->sub_index, k, levels, c->d_zero, t->depth, top);
+    const uint64_t pos_bits = t->sub_index;                 // bit j: the ancestor at height depth + j is a right child
+    // ---- roots, in place ----
+    uint8_t* d_roots[3] = {(uint8_t*)out->old_root, (uint8_t*)out->interim_root, (uint8_t*)out->new_root};
+    void* h_roots[3] = {out->old_root, out->interim_root, out->new_root};
+    if (!dev)
+        for (int j = 0; j < 3; j++)
+            if (h_roots[j]) {
+                d_roots[j] = scratch(n * 32);
+                if (!d_roots[j]) return IMT_ERR_HIP;
+                IMT_HIP(c, hipMemcpyAsync(d_roots[j], h_roots[j], n * 32, hipMemcpyHostToDevice, s));
+            }
+    launch::lift_roots(s, d_roots[0], d_roots[1], d_roots[2], (uint32_t)n, top, pos_bits, levels, fmt, c->d_err);
+    // ---- sibling rows [depth, global_depth) ----
+    const bool item_major = flags & IMT_SIB_ITEM_MAJOR;
+    launch::SibLayout lay = item_major ? launch::SibLayout{1, t->global_depth} : launch::SibLayout{n, 1};
+    if (dev) {
+        launch::fill_sib_rows(s, (uint8_t*)out->low_sib, lay, t->depth, levels, (uint32_t)n, top, fmt);
+        launch::fill_sib_rows(s, (uint8_t*)out->new_sib, lay, t->depth, levels, (uint32_t)n, top, fmt);
+        return IMT_OK;
+    }
+    for (int j = 0; j < 3; j++)
+        if (h_roots[j]) IMT_HIP(c, hipMemcpyAsync(h_roots[j], d_roots[j], n * 32, hipMemcpyDeviceToHost, s));
+    std::vector<uint8_t> h_top((size_t)levels * 32);
+    if (out->low_sib || out->new_sib) {
+        uint8_t* top_fmt = scratch((size_t)levels * 32);
+        if (!top_fmt) return IMT_ERR_HIP;
+        launch::convert(s, top, top_fmt, levels, IMT_FMT_DEVICE, fmt, c->d_err);
+        IMT_HIP(c, hipMemcpyAsync(h_top.data(), top_fmt, (size_t)levels * 32, hipMemcpyDeviceToHost, s));
+    }
+    if ((rc = c->sync_and_check())) return rc;
+    for (void* sibv : {out->low_sib, out->new_sib}) {
+        uint8_t* sib = (uint8_t*)sibv;
+        if (!sib) continue;
+        for (unsigned j = 0; j < levels; j++)
+            for (size_t i = 0; i < n; i++)
+                std::memcpy(sib + ((uint64_t)(t->depth + j) * lay.level_stride + i * lay.item_stride) * 32,
+                            &h_top[(size_t)j * 32], 32);
+    }
     return IMT_OK;
 }

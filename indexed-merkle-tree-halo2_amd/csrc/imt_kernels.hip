@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(BLOCK) k_gather_proof(launch::TreeView tv, con
     if (t >= n * depth) return;
     const size_t i = t % n;            // items fastest: coalesced level-major stores
     const unsigned l = (unsigned)(t / n);
-    const uint64_t s = (index[i] >> l) ^ 1;
+    const uint64_t s = ((index[i] - tv.index_base) >> l) ^ 1;
     const uint8_t* src = s < tv.len[l] ? tv.nodes + (tv.off[l] + s) * 32 : tv.zero + (size_t)l * 32;
     Fe x;
     load_packed(x, src);
@@ -519,6 +519,90 @@ k_sweep_top(const uint8_t* __restrict__ val, unsigned l0, unsigned depth, const 
     } else {
         if (interim_root) store_fe(g_pc, interim_root + (size_t)i * 32, cur, fmt_out);
     }
+}
+
+// ---- subtree placement (imt_itree_lift_batch) ---------------------------------------------------
+// A tree placed as subtree g of a deeper tree produces subtree-level roots; the enclosing tree's root
+// after the same event is `levels` more hash2 up a path whose siblings are the same for the whole batch.
+// Jobs: [0, n) interim_root, [n, 2n) new_root (+ old_root[i+1]), then old_root (1 row, or n when new_root
+// is absent).
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
+k_lift_roots(uint8_t* __restrict__ old_root, uint8_t* __restrict__ interim_root, uint8_t* __restrict__ new_root,
+             uint32_t n, const uint8_t* __restrict__ top, uint64_t pos_bits, unsigned levels, unsigned fmt, int* err) {
+    const size_t t = gtid();
+    const uint32_t n_int = interim_root ? n : 0, n_new = new_root ? n : 0;
+    const uint32_t n_old = old_root ? (new_root ? 1u : n) : 0;
+    if (t >= (size_t)n_int + n_new + n_old) return;
+    uint8_t* row;
+    uint8_t* also = nullptr;
+    if (t < n_int) {
+        row = interim_root + t * 32;
+    } else if (t < (size_t)n_int + n_new) {
+        const size_t i = t - n_int;
+        row = new_root + i * 32;
+        if (old_root && i + 1 < n) also = old_root + (i + 1) * 32;
+    } else {
+        row = old_root + (t - n_int - n_new) * 32;
+    }
+    Fe cur;
+    bool ok = load_fe(g_pc, cur, row, fmt);
+#pragma unroll 1
+    for (unsigned j = 0; j < levels; j++) {
+        Fe sv, a, b, o;
+        load_packed(sv, top + (size_t)j * 32);
+        const bool right = (pos_bits >> j) & 1;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            a.v[i] = right ? sv.v[i] : cur.v[i];
+            b.v[i] = right ? cur.v[i] : sv.v[i];
+        }
+        hash_call(o, a, b, a, false);
+        cur = o;
+    }
+    store_fe(g_pc, row, cur, fmt);
+    if (also) store_fe(g_pc, also, cur, fmt);
+    flag_err(err, ok);
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_fill_sib_rows(uint8_t* __restrict__ sib, launch::SibLayout lay, unsigned first_level, unsigned levels, uint32_t n,
+                const uint8_t* __restrict__ top, unsigned fmt_out) {
+    const size_t t = gtid();
+    if (t >= (size_t)n * levels) return;
+    const uint32_t i = (uint32_t)(t % n);          // items fastest: coalesced level-major stores
+    const unsigned j = (unsigned)(t / n);
+    Fe x;
+    load_packed(x, top + (size_t)j * 32);
+    store_fe(g_pc, sib + ((uint64_t)(first_level + j) * lay.level_stride + (uint64_t)i * lay.item_stride) * 32, x, fmt_out);
+}
+
+__global__ void k_mix_roots(const uint8_t* __restrict__ before, const uint8_t* __restrict__ after,
+                            uint8_t* __restrict__ mixed, uint32_t n_sub, uint32_t self, unsigned fmt_in, int* err) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_sub) return;
+    Fe x;
+    const bool ok = load_fe(g_pc, x, (r < self ? after : before) + (size_t)r * 32, fmt_in);
+    store_packed(mixed + (size_t)r * 32, x);
+    flag_err(err, ok);
+}
+
+// levels_buf: the dense tree over the mixed roots, level j at offset (2 n_sub - (2 n_sub >> j)) rows
+__global__ void k_pick_top(const uint8_t* __restrict__ levels_buf, uint32_t n_sub, uint32_t self, unsigned k,
+                           unsigned levels, const uint8_t* __restrict__ zero, unsigned sub_depth,
+                           uint8_t* __restrict__ top) {
+    const unsigned j = threadIdx.x;
+    if (j >= levels) return;
+    const uint8_t* src;
+    if (j < k) {
+        const size_t off = 2 * (size_t)n_sub - ((2 * (size_t)n_sub) >> j);
+        src = levels_buf + (off + ((self >> j) ^ 1u)) * 32;
+    } else {
+        src = zero + (size_t)(sub_depth + j) * 32;
+    }
+    const Word4* s4 = reinterpret_cast<const Word4*>(src);
+    Word4* d4 = reinterpret_cast<Word4*>(top + (size_t)j * 32);
+    d4[0] = s4[0];
+    d4[1] = s4[1];
 }
 
 // ---- sharded single-list batch (imt_itree_batch_*): helpers ------------------------------------
@@ -733,6 +817,28 @@ void sweep_top(hipStream_t s, const uint8_t* val, unsigned l0, unsigned depth, c
     hipLaunchKernelGGL(k_sweep_top, dim3(nblk(e_count)), dim3(BLOCK), 0, s, val, l0, depth, zero, tree_nodes, tree_off,
                        e_begin, e_count, total, old_root, interim_root, new_root, low_sib, new_sib, lay, fmt_out, roots_dev,
                        top_path);
+}
+void lift_roots(hipStream_t s, uint8_t* old_root, uint8_t* interim_root, uint8_t* new_root, uint32_t n,
+                const uint8_t* top, uint64_t pos_bits, unsigned levels, unsigned fmt, int* err) {
+    const size_t jobs = (interim_root ? n : 0) + (size_t)(new_root ? n : 0) + (old_root ? (new_root ? 1u : n) : 0);
+    if (!jobs) return;
+    hipLaunchKernelGGL(k_lift_roots, dim3(nblk(jobs)), dim3(BLOCK), 0, s, old_root, interim_root, new_root, n, top,
+                       pos_bits, levels, fmt, err);
+}
+void fill_sib_rows(hipStream_t s, uint8_t* sib, SibLayout lay, unsigned first_level, unsigned levels, uint32_t n,
+                   const uint8_t* top, unsigned fmt_out) {
+    if (!sib || !n || !levels) return;
+    hipLaunchKernelGGL(k_fill_sib_rows, dim3(nblk((size_t)n * levels)), dim3(BLOCK), 0, s, sib, lay, first_level, levels,
+                       n, top, fmt_out);
+}
+void mix_roots(hipStream_t s, const uint8_t* before, const uint8_t* after, uint8_t* mixed, uint32_t n_sub, uint32_t self,
+               unsigned fmt_in, int* err) {
+    hipLaunchKernelGGL(k_mix_roots, dim3((n_sub + 63) / 64), dim3(64), 0, s, before, after, mixed, n_sub, self, fmt_in,
+                       err);
+}
+void pick_top(hipStream_t s, const uint8_t* levels_buf, uint32_t n_sub, uint32_t self, unsigned k, unsigned levels,
+              const uint8_t* zero, unsigned sub_depth, uint8_t* top) {
+    hipLaunchKernelGGL(k_pick_top, dim3(1), dim3(64), 0, s, levels_buf, n_sub, self, k, levels, zero, sub_depth, top);
 }
 void slot0(hipStream_t s, const uint32_t* time0, uint32_t* slot0_out, uint32_t total) {
     if (!total) return;

@@ -23,6 +23,7 @@ struct TreeView {
     const uint64_t* off;         // [depth+1] device array
     const uint64_t* len;         // [depth+1] device array
     const uint8_t* zero;         // [depth+1][32] device format, may be NULL when never needed
+    uint64_t index_base = 0;     // leaf indices handed to gather_proof are global: local = index - index_base
 };
 
 hipError_t upload_consts(const dev::PoseidonConsts& pc);
@@ -88,6 +89,23 @@ void sweep_top(hipStream_t s, const uint8_t* val, unsigned l0, unsigned depth, c
                const uint64_t* tree_off, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
                uint8_t* interim_root, uint8_t* new_root, uint8_t* low_sib, uint8_t* new_sib, SibLayout lay,
                unsigned fmt_out, uint8_t* roots_dev = nullptr, uint8_t* top_path = nullptr);
+
+// ---- subtree placement: lift subtree-level witnesses to the depth of the enclosing tree ----
+// top[j] (device format, j < levels) = sibling of this subtree's ancestor at height sub_depth + j;
+// bit j of pos_bits = that ancestor is a RIGHT child.  Roots are lifted in place (format fmt):
+// interim_root[i], new_root[i] and old_root[i] climb `levels` hashes each; with new_root and old_root
+// both given, old_root[i + 1] is written from new_root[i] and only old_root[0] climbs on its own.
+void lift_roots(hipStream_t s, uint8_t* old_root, uint8_t* interim_root, uint8_t* new_root, uint32_t n,
+                const uint8_t* top, uint64_t pos_bits, unsigned levels, unsigned fmt, int* err);
+// rows [first_level, first_level + levels) of a sibling array = top[j], for all n items
+void fill_sib_rows(hipStream_t s, uint8_t* sib, SibLayout lay, unsigned first_level, unsigned levels, uint32_t n,
+                   const uint8_t* top, unsigned fmt_out);
+// mixed[r] = r < self ? after[r] : before[r]   (device format out, fmt_in in)
+void mix_roots(hipStream_t s, const uint8_t* before, const uint8_t* after, uint8_t* mixed, uint32_t n_sub, uint32_t self,
+               unsigned fmt_in, int* err);
+// top[j] = node (j, (self >> j) ^ 1) of the tree over `mixed` for j < k, then zero[sub_depth + j] for j >= k
+void pick_top(hipStream_t s, const uint8_t* levels_buf, uint32_t n_sub, uint32_t self, unsigned k, unsigned levels,
+              const uint8_t* zero, unsigned sub_depth, uint8_t* top);
 
 // ---- sharded single-list batch (imt_itree_batch_*) ----
 void slot0(hipStream_t s, const uint32_t* time0, uint32_t* slot0_out, uint32_t total);

@@ -49,13 +49,15 @@ __device__ __forceinline__ bool geq_p(const uint8_t* v) {
 }
 
 __global__ void __launch_bounds__(BLOCK) k_scatter(const uint8_t* __restrict__ vals, uint8_t* __restrict__ d_val,
-                                                   uint32_t M, uint32_t n, uint32_t* __restrict__ iota, int* err) {
+                                                   uint32_t M, uint32_t n, uint32_t part_mod, uint32_t part_res,
+                                                   uint32_t* __restrict__ iota, int* err) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint8_t* v = vals + (uint64_t)i * 32;
     const uint64_t* x = reinterpret_cast<const uint64_t*>(v);
     if (geq_p(v)) atomicOr(err, ERR_NONCANONICAL);
     if ((x[0] | x[1] | x[2] | x[3]) == 0) atomicOr(err, ERR_ZERO);
+    if (part_mod > 1 && mod_small(v, part_mod) != part_res) atomicOr(err, ERR_FOREIGN);
     copy32(d_val + (uint64_t)(M + i) * 32, v);
     iota[i] = M + i;
 }
@@ -101,7 +103,7 @@ __global__ void __launch_bounds__(BLOCK) k_neighbours(const uint32_t* __restrict
 
 // preimages at every time step (:650-656), event keys, and the hash-free outputs
 __global__ void __launch_bounds__(BLOCK)
-k_events(const uint8_t* __restrict__ d_val, uint32_t M, uint32_t n, const uint32_t* __restrict__ low,
+k_events(const uint8_t* __restrict__ d_val, uint32_t M, uint32_t n, uint64_t base, const uint32_t* __restrict__ low,
          const uint32_t* __restrict__ succ, uint8_t* __restrict__ pre, uint64_t* __restrict__ keys,
          uint64_t* __restrict__ o_low_index, uint8_t* __restrict__ o_is_largest, uint8_t* __restrict__ o_low_leaf,
          uint8_t* __restrict__ o_new_leaf) {
@@ -112,15 +114,15 @@ k_events(const uint8_t* __restrict__ d_val, uint32_t M, uint32_t n, const uint32
     const uint8_t* lv = d_val + (uint64_t)lo * 32;
     uint8_t* e0 = pre + (uint64_t)(2 * i) * 96;
     uint8_t* e1 = e0 + 96;
-    copy32(e0, lv);                      // low leaf rewritten: {low.val, v, M+i}
+    copy32(e0, lv);                      // low leaf rewritten: {low.val, v, base+M+i}
     copy32(e0 + 32, v);
-    put_u64(e0 + 64, (uint64_t)M + i);
+    put_u64(e0 + 64, base + M + i);      // `base`: the tree is a subtree of a deeper one (imt_itree_set_placement)
     copy32(e1, v);                       // new leaf inherits the low leaf's old pointers
-    if (su != NONE) { copy32(e1 + 32, d_val + (uint64_t)su * 32); put_u64(e1 + 64, su); }
+    if (su != NONE) { copy32(e1 + 32, d_val + (uint64_t)su * 32); put_u64(e1 + 64, base + su); }
     else { zero32(e1 + 32); zero32(e1 + 64); }
     keys[2 * i] = ((uint64_t)lo << 32) | (uint64_t)(2 * i);
     keys[2 * i + 1] = ((uint64_t)(M + i) << 32) | (uint64_t)(2 * i + 1);
-    if (o_low_index) o_low_index[i] = lo;
+    if (o_low_index) o_low_index[i] = base + lo;
     if (o_is_largest) o_is_largest[i] = su == NONE ? 1 : 0;
     if (o_low_leaf) {                    // the low leaf BEFORE this insertion: {low.val, succ.val, succ.idx}
         uint8_t* o = o_low_leaf + (uint64_t)i * 96;
@@ -157,20 +159,20 @@ __global__ void __launch_bounds__(BLOCK) k_runs(const uint64_t* __restrict__ key
 
 __global__ void __launch_bounds__(BLOCK) k_find_low(const uint8_t* __restrict__ vals, const uint8_t* __restrict__ d_val,
                                                     const uint32_t* __restrict__ sorted, uint32_t M, uint32_t n,
-                                                    uint64_t* __restrict__ low_index, int* err) {
+                                                    uint64_t base, uint64_t* __restrict__ low_index, int* err) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint8_t* x = vals + (uint64_t)i * 32;
     if (geq_p(x)) atomicOr(err, ERR_NONCANONICAL);
     const uint32_t g = count_below(d_val, sorted, M, x);
-    if (g == 0) { atomicOr(err, ERR_ZERO); low_index[i] = 0; return; }
+    if (g == 0) { atomicOr(err, ERR_ZERO); low_index[i] = base; return; }
     if (g < M && eq256(d_val + (uint64_t)sorted[g] * 32, x)) atomicOr(err, ERR_DUPLICATE);
-    low_index[i] = sorted[g - 1];
+    low_index[i] = base + sorted[g - 1];
 }
 
 __global__ void __launch_bounds__(BLOCK)
 k_nm_witness(const uint8_t* __restrict__ vals, const uint8_t* __restrict__ d_val, const uint32_t* __restrict__ sorted,
-             uint32_t M, uint32_t n, uint64_t* __restrict__ low_index, uint8_t* __restrict__ low_leaf,
+             uint32_t M, uint32_t n, uint64_t base, uint64_t* __restrict__ low_index, uint8_t* __restrict__ low_leaf,
              uint8_t* __restrict__ is_largest, int* err) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -180,12 +182,12 @@ k_nm_witness(const uint8_t* __restrict__ vals, const uint8_t* __restrict__ d_val
     if (g == 0) { atomicOr(err, ERR_ZERO); g = 1; }
     if (g < M && eq256(d_val + (uint64_t)sorted[g] * 32, x)) atomicOr(err, ERR_DUPLICATE);
     const uint32_t lo = sorted[g - 1];
-    if (low_index) low_index[i] = lo;
+    if (low_index) low_index[i] = base + lo;
     if (is_largest) is_largest[i] = g == M ? 1 : 0;
     if (low_leaf) {        // the stored list: a leaf points at its successor in value order
         uint8_t* o = low_leaf + (uint64_t)i * 96;
         copy32(o, d_val + (uint64_t)lo * 32);
-        if (g < M) { copy32(o + 32, d_val + (uint64_t)sorted[g] * 32); put_u64(o + 64, sorted[g]); }
+        if (g < M) { copy32(o + 32, d_val + (uint64_t)sorted[g] * 32); put_u64(o + 64, base + sorted[g]); }
         else { zero32(o + 32); zero32(o + 64); }
     }
 }
@@ -208,39 +210,48 @@ size_t temp_bytes_needed(size_t n, size_t max_size) {
     return (m > c ? m : c) + 256;
 }
 
-void run(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val, const uint32_t* sorted_old,
-         uint32_t* sorted_new, uint32_t M, uint32_t n, uint8_t* pre, uint32_t* node, uint32_t* time, uint32_t* rs,
-         uint32_t* re, uint64_t* o_low_index, uint8_t* o_is_largest, uint8_t* o_low_leaf, uint8_t* o_new_leaf) {
+hipError_t run(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val, const uint32_t* sorted_old,
+               uint32_t* sorted_new, uint32_t M, uint32_t n, uint64_t base, uint8_t* pre, uint32_t* node, uint32_t* time,
+               uint32_t* rs, uint32_t* re, uint64_t* o_low_index, uint8_t* o_is_largest, uint8_t* o_low_leaf,
+               uint8_t* o_new_leaf) {
     const int levels = levels_for(n);
-    hipLaunchKernelGGL(k_scatter, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, M, n, ws.iota, ws.err);
+    hipError_t e;
+    // the workspace was sized for (cap_n, tree capacity); a larger request must not run into it
+    if (n > ws.cap_n || temp_bytes_needed(n, (size_t)M) > ws.tmp_bytes) return hipErrorInvalidValue;
+    (void)hipGetLastError();       // the thread's sticky error may be a stale one from an unrelated earlier call
+    hipLaunchKernelGGL(k_scatter, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, M, n, ws.part_mod, ws.part_res, ws.iota,
+                       ws.err);
     size_t tb = ws.tmp_bytes;
-    (void)rocprim::merge_sort(ws.tmp, tb, ws.iota, ws.bsorted, (size_t)n, ValLess{d_val}, s);
+    if ((e = rocprim::merge_sort(ws.tmp, tb, ws.iota, ws.bsorted, (size_t)n, ValLess{d_val}, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_gap, dim3(nblk(n)), dim3(BLOCK), 0, s, d_val, sorted_old, M, ws.bsorted, n, ws.gap, ws.st,
                        ws.err);
     for (int k = 1; k < levels; k++)
         hipLaunchKernelGGL(k_sparse_level, dim3(nblk(n)), dim3(BLOCK), 0, s, ws.st, n, k);
     hipLaunchKernelGGL(k_neighbours, dim3(nblk(n)), dim3(BLOCK), 0, s, ws.st, levels, ws.bsorted, ws.gap, sorted_old, M,
                        n, ws.low, ws.succ);
-    hipLaunchKernelGGL(k_events, dim3(nblk(n)), dim3(BLOCK), 0, s, d_val, M, n, ws.low, ws.succ, pre, ws.keys,
+    hipLaunchKernelGGL(k_events, dim3(nblk(n)), dim3(BLOCK), 0, s, d_val, M, n, base, ws.low, ws.succ, pre, ws.keys,
                        o_low_index, o_is_largest, o_low_leaf, o_new_leaf);
     tb = ws.tmp_bytes;
-    (void)rocprim::radix_sort_keys(ws.tmp, tb, ws.keys, ws.keys_sorted, (size_t)2 * n, 0, 64, s);
+    if ((e = rocprim::radix_sort_keys(ws.tmp, tb, ws.keys, ws.keys_sorted, (size_t)2 * n, 0, 64, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_runs, dim3(nblk(2 * (size_t)n)), dim3(BLOCK), 0, s, ws.keys_sorted, 2 * n, node, time, rs, re);
     tb = ws.tmp_bytes;
-    (void)rocprim::merge(ws.tmp, tb, sorted_old, ws.bsorted, sorted_new, (size_t)M, (size_t)n, ValLess{d_val}, s);
+    if ((e = rocprim::merge(ws.tmp, tb, sorted_old, ws.bsorted, sorted_new, (size_t)M, (size_t)n, ValLess{d_val}, s)) !=
+        hipSuccess)
+        return e;
+    return hipGetLastError();      // a failed launch anywhere in the sequence
 }
 
 void nm_witness(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
-                uint64_t* low_index, uint8_t* low_leaf, uint8_t* is_largest, int* err) {
+                uint64_t base, uint64_t* low_index, uint8_t* low_leaf, uint8_t* is_largest, int* err) {
     if (!n) return;
-    hipLaunchKernelGGL(k_nm_witness, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, sorted, M, n, low_index, low_leaf,
-                       is_largest, err);
+    hipLaunchKernelGGL(k_nm_witness, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, sorted, M, n, base, low_index,
+                       low_leaf, is_largest, err);
 }
 
 void find_low(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
-              uint64_t* low_index, int* err) {
+              uint64_t base, uint64_t* low_index, int* err) {
     if (!n) return;
-    hipLaunchKernelGGL(k_find_low, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, sorted, M, n, low_index, err);
+    hipLaunchKernelGGL(k_find_low, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, sorted, M, n, base, low_index, err);
 }
 
 }  // namespace prep

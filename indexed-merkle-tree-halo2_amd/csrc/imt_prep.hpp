@@ -20,10 +20,11 @@ namespace prep {
 
 constexpr uint32_t NONE = 0xffffffffu;
 // error bits written by the kernels
-constexpr int ERR_NONCANONICAL = 1, ERR_ZERO = 2, ERR_DUPLICATE = 4;
+constexpr int ERR_NONCANONICAL = 1, ERR_ZERO = 2, ERR_DUPLICATE = 4, ERR_FOREIGN = 8;
 
 struct Workspace {            // per plan set, sized for `cap_n` insertions
     size_t cap_n = 0;
+    uint32_t part_mod = 0, part_res = 0;   // value partition: accept only v % part_mod == part_res (0/1 = everything)
     uint32_t* iota = nullptr;      // [n]   M+i
     uint32_t* bsorted = nullptr;   // [n]   new leaf indices in value order
     uint32_t* gap = nullptr;       // [n]   stored values below each new value
@@ -52,20 +53,25 @@ size_t temp_bytes_needed(size_t n, size_t max_size);
 //   node/time/rs/re  level-0 tables [2n]
 //   o_* user outputs (device pointers, any may be NULL): low_index u64[n], is_largest u8[n],
 //        low_leaf / new_leaf [n][3][32] canonical
+//   base      added to every leaf index that leaves the tree: the next_idx fields of the preimages and
+//             o_low_index (a tree placed as a subtree of a deeper one, imt_itree_set_placement)
 // Errors are OR-ed into ws.err (ERR_*); nothing outside rows [M, M+n) of d_val, sorted_new and the
-// workspace is written, so a failed batch leaves the tree untouched.
-void run(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val, const uint32_t* sorted_old,
-         uint32_t* sorted_new, uint32_t M, uint32_t n, uint8_t* pre, uint32_t* node, uint32_t* time, uint32_t* rs,
-         uint32_t* re, uint64_t* o_low_index, uint8_t* o_is_largest, uint8_t* o_low_leaf, uint8_t* o_new_leaf);
+// workspace is written, so a failed batch leaves the tree untouched.  Returns the first failure of a
+// rocPRIM call or kernel launch (hipErrorInvalidValue if the workspace is too small for (n, M)).
+// All 32-byte rows (vals, d_val, pre, o_*_leaf) must be 16-byte aligned: they move as two 16-byte words.
+hipError_t run(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val, const uint32_t* sorted_old,
+               uint32_t* sorted_new, uint32_t M, uint32_t n, uint64_t base, uint8_t* pre, uint32_t* node, uint32_t* time,
+               uint32_t* rs, uint32_t* re, uint64_t* o_low_index, uint8_t* o_is_largest, uint8_t* o_low_leaf,
+               uint8_t* o_new_leaf);
 
 // non-membership witness: low leaf index, its preimage {val, next_val, next_idx} (canonical) and the
 // is_largest flag of every candidate; any output may be NULL
 void nm_witness(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
-                uint64_t* low_index, uint8_t* low_leaf, uint8_t* is_largest, int* err);
+                uint64_t base, uint64_t* low_index, uint8_t* low_leaf, uint8_t* is_largest, int* err);
 
 // predecessor search only (imt_itree_find_low_batch): low[i] = leaf index of the greatest value < vals[i]
 void find_low(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
-              uint64_t* low_index, int* err);
+              uint64_t base, uint64_t* low_index, int* err);
 
 }  // namespace prep
 }  // namespace imt

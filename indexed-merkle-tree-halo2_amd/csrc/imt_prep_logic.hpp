@@ -26,6 +26,14 @@ IMT_PL_HD bool eq256(const uint8_t* a, const uint8_t* b) {
     return x[0] == y[0] && x[1] == y[1] && x[2] == y[2] && x[3] == y[3];
 }
 
+// (256-bit little-endian integer) mod m, m < 2^32
+IMT_PL_HD uint32_t mod_small(const uint8_t* a, uint32_t m) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(a);
+    uint64_t r = 0;
+    for (int i = 7; i >= 0; i--) r = ((r << 32) | w[i]) % m;
+    return (uint32_t)r;
+}
+
 // number of stored values (sorted[0..M) indexes val) strictly below x
 IMT_PL_HD uint32_t count_below(const uint8_t* val, const uint32_t* sorted, uint32_t M, const uint8_t* x) {
     uint32_t lo = 0, hi = M;

@@ -1,50 +1,140 @@
-"""Multi-GPU: one depth-D tree as `world` value-partitioned indexed subtrees, one per GPU.
+"""Multi-GPU: one depth-D tree as `world` indexed subtrees, one per GPU (north_star's sharding by
+leaf-index range).
 
-Rank g owns the values with v % world == g and the leaf-index range
-[g * 2^(D-k), (g+1) * 2^(D-k)) of the depth-D tree (k = log2 world) as an indexed subtree of
-height D-k with its own {0,0,0} sentinel.  Insertions never cross ranks; the only exchange
-is an all-gather of the `world` subtree roots (32 bytes each; RCCL over xGMI with the "nccl"
-backend), after which every rank hashes the top k levels itself.  Non-membership of v is
-decided by the one subtree v belongs to, so the partition keeps the indexed tree's guarantee.
+Rank g owns the values with v % world == g and the leaf-index range [g << (D-k), (g+1) << (D-k)) of the
+depth-D tree (k = log2 world) as an indexed subtree of height D-k with its own {0,0,0} sentinel at its
+first leaf.  Insertions never cross ranks.  Every step the ranks all-gather their `world` subtree roots
+(32 bytes each; RCCL over xGMI with the "nccl" backend) -- the one collective of the path -- and every
+rank then LIFTS the witnesses of its own insertions to the full depth D (imt_itree_lift_batch): k more
+hashes per root and the k upper siblings per proof, so that what comes out is exactly what the
+reference's insert_leaf takes (src/indexed_merkle_tree.rs:231-245: depth-D proofs, depth-D roots, 2 + 2 D
+hashes per insertion) with global leaf indices.  Order of a step across ranks: rank 0's insertions, then
+rank 1's, ...; a rank's upper siblings therefore mix the other ranks' roots after the step (ranks below
+it) and before the step (ranks above it).  The exchange runs one step behind the insertions so that it
+waits for a finished batch while two more are in flight.
 
-With world == 1 this is exactly the reference's single tree (src/indexed_merkle_tree.rs
-:632-671, :715-735).  For world > 1 the root commits to `world` sorted lists instead of one;
-the reference has no multi-device form to compare with, so parity for it is defined against the
-CPU oracle building the same subtrees and combining their roots (tests/test_sharded_gloo.py).
+With world == 1 this is the reference's single tree (:632-671, :715-735).  For world > 1 the root
+commits to `world` sorted lists instead of one (non-membership of v is decided by the subtree that owns
+v); the reference has no multi-device form, so parity is defined against the CPU oracle building the same
+subtrees and, at small depth, a dense rebuild of the whole tree after every event
+(tests/test_sharded_gloo.py on CPU with gloo; tests/test_gpu_parity.py through GpuBackend).
 
-The compute backend is pluggable so the collective logic can be exercised on CPU with gloo:
-`GpuBackend` (the product: libimt_hip.so) or, in tests only, an oracle-backed stand-in.
+The compute backend is pluggable so that the collective logic runs on CPU with gloo: `GpuBackend` (the
+product: libimt_hip.so) or, in tests only, an oracle-backed stand-in with the same methods.
 """
+import ctypes
+
 import numpy as np
 import torch
 
 
 class GpuBackend:
-    """The product path: one imt context + one imt_itree on this rank's GPU."""
+    """The product path: one imt context and one placed imt_itree on this rank's GPU.  Witnesses stay in
+    HBM (torch tensors), in `nbuf` rotating buffer sets so that the set of a batch is not rewritten
+    before its lift has run."""
 
-    def __init__(self, imt, device_index, sub_height, capacity):
-        self.imt = imt
-        self.ctx = imt.Context(device_index)
-        self.tree = imt.IndexedTree(self.ctx, sub_height, capacity)
+    FIELDS = ("low_index", "low_leaf", "is_largest", "old_root", "interim_root", "new_root", "new_leaf", "low_sib",
+              "new_sib")
+
+    def __init__(self, imt, device_index, depth, world, rank, capacity, batch, pipeline=True, inputs_ready=False,
+                 nbuf=2, fmt=0, host_prep=False, pinned_outputs=False):
+        self.imt, self.F = imt, imt._ffi
+        self.depth, self.world, self.rank, self.batch, self.fmt = depth, world, rank, batch, fmt
+        self.sub_height = depth - (world.bit_length() - 1)
         self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(device_index)
+        self.ctx = imt.Context(device_index)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.tree = imt.IndexedTree(self.ctx, self.sub_height, capacity)
+        self.tree.set_placement(depth, rank)
+        self.ctx._check(imt.lib.imt_itree_set_value_partition(self.tree.h, world, rank))
+        u8 = dict(dtype=torch.uint8, device=self.device)
+        # pinned_outputs: the witnesses land in page-locked HOST memory, written by the kernels over PCIe
+        # (device-addressable, so they are still passed as IMT_DEVICE_PTRS): what a host-language caller wants
+        o8 = dict(dtype=torch.uint8, device="cpu", pin_memory=True) if pinned_outputs else u8
+        o64 = dict(dtype=torch.int64, device="cpu", pin_memory=True) if pinned_outputs else dict(dtype=torch.int64,
+                                                                                                 device=self.device)
+        self.sets = [dict(low_index=torch.empty(batch, **o64),
+                          low_leaf=torch.empty((batch, 3, 32), **o8), is_largest=torch.empty(batch, **o8),
+                          old_root=torch.empty((batch, 32), **o8), interim_root=torch.empty((batch, 32), **o8),
+                          new_root=torch.empty((batch, 32), **o8), new_leaf=torch.empty((batch, 3, 32), **o8),
+                          low_sib=torch.empty((depth, batch, 32), **o8), new_sib=torch.empty((depth, batch, 32), **o8))
+                     for _ in range(nbuf)]
+        self.structs = [self.F.InsertOut(**{k: t.data_ptr() for k, t in b.items()}) for b in self.sets]
+        self.flags = self.F.DEVICE_PTRS | fmt
+        self.ins_flags = (self.flags | (self.F.PIPELINE if pipeline else 0) | (self.F.INPUTS_READY if inputs_ready else 0)
+                          | (self.F.HOST_PREP if host_prep else 0))
+        self.next_slot = 0
+        self.first_index = [0] * nbuf
+        self._root = torch.empty(32, **u8)
 
-    def insert_batch(self, vals, proofs=True):
-        return self.tree.insert_batch(vals, proofs=proofs)
+    def initial_root(self):
+        """root of a subtree that holds only its sentinel = the empty subtree of that height"""
+        return torch.from_numpy(self.ctx.zero_hashes(self.sub_height, self.fmt)[self.sub_height].copy())
 
-    def root_bytes(self):
-        return self.imt.to_bytes(self.tree.root())
+    def insert(self, vals, flags=None):
+        """vals: uint8 [batch, 32] (torch on this device, or numpy).  Enqueues the batch; returns its slot."""
+        if not torch.is_tensor(vals):
+            vals = torch.from_numpy(np.ascontiguousarray(vals))
+        vals = vals.to(self.device)
+        if vals.shape != (self.batch, 32):
+            raise ValueError(f"expected [{self.batch}, 32] values")
+        slot = self.next_slot
+        self.next_slot = (slot + 1) % len(self.sets)
+        self.first_index[slot] = self.tree.index_base + self.tree.size
+        rc = self.imt.lib.imt_itree_insert_batch(self.tree.h, ctypes.c_void_p(vals.data_ptr()), self.batch,
+                                                 ctypes.byref(self.structs[slot]),
+                                                 self.ins_flags if flags is None else flags)
+        if rc == self.F.ERR["VALUE"]:
+            raise ValueError(self.imt.lib.imt_last_error(self.ctx.h).decode())
+        self.ctx._check(rc)
+        return slot
 
-    def combine(self, roots, sub_height, depth):
-        return self.ctx.combine_subtree_roots(roots, sub_height, depth)
+    def root_after(self, lag):
+        """this subtree's root after the batch inserted `lag` calls ago; orders the stream behind that batch"""
+        self.ctx._check(self.imt.lib.imt_itree_root_lagged(self.tree.h, lag, ctypes.c_void_p(self._root.data_ptr()),
+                                                           self.flags))
+        return self._root
+
+    def lift(self, slot, roots_before, roots_after):
+        rb, ra = (r.to(self.device).contiguous() for r in (roots_before, roots_after))
+        self.ctx._check(self.imt.lib.imt_itree_lift_batch(self.tree.h, ctypes.c_void_p(rb.data_ptr()),
+                                                          ctypes.c_void_p(ra.data_ptr()), self.world, self.batch,
+                                                          ctypes.byref(self.structs[slot]), self.flags))
+
+    def combine(self, roots):
+        out = torch.empty(32, dtype=torch.uint8, device=self.device)
+        r = roots.to(self.device).contiguous()
+        self.ctx._check(self.imt.lib.imt_combine_subtree_roots(self.ctx.h, ctypes.c_void_p(r.data_ptr()), self.world,
+                                                               self.sub_height, self.depth,
+                                                               ctypes.c_void_p(out.data_ptr()), self.flags))
+        return out
+
+    def outputs(self, slot):
+        """the slot's witness tensors (valid on the host after sync()) + the global index of its first new leaf"""
+        d = dict(self.sets[slot])
+        d["first_new_index"] = self.first_index[slot]
+        return d
+
+    def sync(self):
+        self.ctx.sync()
+        torch.cuda.synchronize()
 
 
 class ShardedIndexedTree:
-    def __init__(self, backend, depth, world=1, rank=0, dist=None):
+    """step(vals) inserts this rank's batch and finishes -- root exchange + lift -- the PREVIOUS step,
+    whose depth-D witnesses it returns; flush() finishes the last one."""
+
+    def __init__(self, backend, depth, world=1, rank=0, dist=None, via_host=False):
         if world & (world - 1):
             raise ValueError("world size must be a power of two")
         self.backend, self.depth, self.world, self.rank, self.dist = backend, depth, world, rank, dist
+        self.via_host = via_host
         self.k = world.bit_length() - 1
         self.sub_height = depth - self.k
+        self.pending = None
+        self.roots_prev = None if backend is None else torch.stack([backend.initial_root()] * world)
+        self.global_root = None
 
     def owner(self, value):
         return int(value) % self.world
@@ -53,38 +143,38 @@ class ShardedIndexedTree:
         """first global leaf index of this rank's subtree"""
         return self.rank << self.sub_height
 
-    def insert_batch(self, vals, proofs=True):
-        """vals: ints owned by this rank (v % world == rank).  Returns the backend's witness dict;
-        indices in it are local to the subtree (add leaf_base() for global positions)."""
-        for v in vals[:16]:
-            if self.owner(v) != self.rank:
-                raise ValueError(f"value {v} belongs to rank {self.owner(v)}, not {self.rank}")
-        return self.backend.insert_batch(vals, proofs=proofs)
+    def step(self, vals):
+        slot = self.backend.insert(vals)        # the backend refuses values of another rank (all of them checked)
+        done = self._finish(1) if self.pending is not None else None
+        self.pending = slot
+        return done
 
-    def gather_roots(self):
-        """[world, 32] uint8: every rank's subtree root (the one collective of the path)."""
-        mine = torch.from_numpy(np.ascontiguousarray(self.backend.root_bytes()))
+    def flush(self):
+        if self.pending is None:
+            return None
+        done = self._finish(0)
+        self.pending = None
+        return done
+
+    def gather_roots(self, mine):
+        """[world, 32]: every rank's subtree root -- the one collective of the path"""
         if self.world == 1:
-            return mine.reshape(1, 32).numpy()
-        mine = mine.to(self.backend.device)
-        parts = [torch.empty(32, dtype=torch.uint8, device=self.backend.device) for _ in range(self.world)]
-        self.dist.all_gather(parts, mine)
-        return torch.stack(parts).cpu().numpy()
+            return mine.reshape(1, 32).clone()
+        if self.via_host:       # gloo rehearsal: through host memory
+            m = mine.cpu()
+            parts = [torch.empty_like(m) for _ in range(self.world)]
+            self.dist.all_gather(parts, m)
+            return torch.stack(parts)
+        out = torch.empty((self.world, 32), dtype=torch.uint8, device=mine.device)
+        self.dist.all_gather_into_tensor(out.view(-1), mine.contiguous().view(-1))
+        return out
 
-    def global_root(self):
-        roots = self.gather_roots()
-        return self.backend.combine(roots, self.sub_height, self.depth)
-
-    def top_proof(self, roots):
-        """the k siblings that extend a subtree-root proof to the global root, for this rank"""
-        level = [r for r in roots]
-        sibs, idx = [], self.rank
-        while len(level) > 1:
-            sibs.append(level[idx ^ 1])
-            level = [self.backend.combine(np.stack([level[2 * i], level[2 * i + 1]]), 0, 1)
-                     for i in range(len(level) // 2)]
-            idx >>= 1
-        return sibs
+    def _finish(self, lag):
+        roots_after = self.gather_roots(self.backend.root_after(lag))
+        self.backend.lift(self.pending, self.roots_prev, roots_after)
+        self.global_root = self.backend.combine(roots_after)
+        self.roots_prev = roots_after
+        return self.backend.outputs(self.pending)
 
 
 class ReplicatedIndexedTree:

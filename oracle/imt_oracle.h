@@ -142,6 +142,8 @@ int orc_hash_preimages(uint8_t *leaves_out, const uint8_t *preimages, size_t n);
 typedef struct orc_sparse orc_sparse;
 int orc_sparse_new(orc_sparse **out, unsigned depth, uint64_t capacity);
 void orc_sparse_free(orc_sparse *t);
+/* subtree of a deeper tree: next_idx fields hold base + local index (positions in this API stay local) */
+void orc_sparse_set_index_base(orc_sparse *t, uint64_t base);
 void orc_sparse_root(const orc_sparse *t, uint8_t root[32]);
 uint64_t orc_sparse_size(const orc_sparse *t);
 int orc_sparse_proof(const orc_sparse *t, uint64_t index, uint8_t *proof /*[d][32]*/);

@@ -21,6 +21,7 @@ struct orc_sparse {
     ofr_t *zero;          /* Z[0..depth] */
     uint8_t *pre;         /* [cap][3][32] canonical preimages */
     uint64_t *sorted;     /* leaf indices ordered by val */
+    uint64_t index_base;  /* added to every next_idx that is hashed into a leaf (subtree of a deeper tree) */
 };
 
 static void zero_table(ofr_t *z, unsigned depth) {
@@ -72,6 +73,11 @@ int orc_sparse_new(orc_sparse **out, unsigned depth, uint64_t cap) {
     *out = t;
     return ORC_OK;
 }
+
+/* The tree is subtree number (base >> depth) of a deeper tree: leaf j of it is leaf base + j there, and
+ * that global index is what a leaf's next_idx field holds (new_val_idx at :655, :715).  Positions passed
+ * to / returned by this API stay local. */
+void orc_sparse_set_index_base(orc_sparse *t, uint64_t base) { t->index_base = base; }
 
 void orc_sparse_root(const orc_sparse *t, uint8_t root[32]) { ofr_to_bytes(root, &t->lvl[t->depth][0]); }
 uint64_t orc_sparse_size(const orc_sparse *t) { return t->size; }
@@ -160,7 +166,7 @@ int orc_sparse_insert(orc_sparse *t, const uint8_t val[32], uint64_t *low_idx,
     memcpy(np, val, 32);
     memcpy(np + 32, lp + 32, 64);
     memcpy(lp + 32, val, 32);
-    put_u64(lp + 64, idx);
+    put_u64(lp + 64, t->index_base + idx);
     ofr_from_bytes(&a, lp); ofr_from_bytes(&b, lp + 32); ofr_from_bytes(&c, lp + 64);
     orc_hash3_fr(&h, &a, &b, &c);
     set_leaf(t, low, &h);

@@ -165,6 +165,9 @@ class Oracle:
     def sparse_free(self, h):
         self.lib.orc_sparse_free(h)
 
+    def sparse_set_index_base(self, h, base):
+        self.lib.orc_sparse_set_index_base(h, ctypes.c_uint64(base))
+
     def sparse_root(self, h):
         out = ctypes.create_string_buffer(32)
         self.lib.orc_sparse_root(h, out)

@@ -757,70 +757,180 @@ def test_config3_non_membership_2pow20_properties(imt, ctx):
     assert (fail & imt._ffi.F_LOW_LT_NEW).all()
 
 
-def test_config4_eight_shards_2pow22_properties(imt, ctx, oracle):
-    """BASELINE config 4 on one GPU: 2^22 insertions, 8 value-partitioned shards (v mod 8) of 2^19
-    insertions each into height-29 subtrees, run one after the other; the subtree roots are combined
-    into the depth-32 root exactly as the all-gather step does.  Per shard: every insert_leaf
-    constraint of every insertion holds (independent witness kernels), roots chain across batches,
-    the final root equals a bulk rebuild from the snapshot.  The top of the tree is checked against
-    the oracle (7 hashes)."""
+def _load_sharded():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("imt_sharded", os.path.join(root, "indexed-merkle-tree-halo2_amd",
+                                                                               "sharded.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _witness_fail(imt, be, o, depth):
+    """imt_insert_witness_batch at the FULL depth on a lifted output set of GpuBackend, global indices"""
     import ctypes
     import torch
-    shards, sub_depth, depth, per_shard, bs = 8, 29, 32, 1 << 19, 1 << 16
-    dev = torch.device("cuda", 0)
-    c2 = imt.Context(0)
-    c2.set_stream(torch.cuda.current_stream().cuda_stream)
     P_ = lambda x: ctypes.c_void_p(x.data_ptr())
-    o = dict(low_index=torch.empty(bs, dtype=torch.int64, device=dev),
-             is_largest=torch.empty(bs, dtype=torch.uint8, device=dev),
-             low_leaf=torch.empty((bs, 3, 32), dtype=torch.uint8, device=dev),
-             new_leaf=torch.empty((bs, 3, 32), dtype=torch.uint8, device=dev),
-             old_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
-             interim_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
-             new_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
-             low_sib=torch.empty((sub_depth, bs, 32), dtype=torch.uint8, device=dev),
-             new_sib=torch.empty((sub_depth, bs, 32), dtype=torch.uint8, device=dev))
-    st = imt._ffi.InsertOut(**{k: v.data_ptr() for k, v in o.items()})
-    fail = torch.empty(bs, dtype=torch.uint8, device=dev)
-    roots = []
+    n = o["new_root"].shape[0]
+    fail = torch.empty(n, dtype=torch.uint8, device=o["new_root"].device)
+    new_index = torch.arange(o["first_new_index"], o["first_new_index"] + n, dtype=torch.int64, device=fail.device)
+    rc = imt.lib.imt_insert_witness_batch(be.ctx.h, P_(o["old_root"]), P_(o["low_leaf"]), P_(o["low_index"]),
+                                          P_(o["low_sib"]), P_(o["new_root"]), P_(o["new_leaf"]), P_(new_index), None,
+                                          P_(o["new_sib"]), P_(o["is_largest"]), depth, n, P_(fail), None,
+                                          imt._ffi.DEVICE_PTRS)
+    assert rc == 0, imt.lib.imt_last_error(be.ctx.h)
+    be.sync()
+    return fail
+
+
+@pytest.mark.parametrize("world,depth", [(4, 8), (2, 6), (8, 8)])
+def test_subtree_lift_matches_dense_replay(imt, ctx, oracle, world, depth):
+    """Subtree sharding end to end through sharded.GpuBackend, `world` shards one after the other on one GPU:
+    every lifted witness (global indices, depth-`depth` roots and proofs) equals a dense rebuild of the WHOLE
+    tree (the oracle's IndexedMerkleTree::new) after every single event of the global order, and passes
+    imt_insert_witness_batch at the full depth."""
+    import torch
+    from sharded_ref import dense_global_replay
+    sharded = _load_sharded()
+    n_step, steps_n = 5, 3
+    k = world.bit_length() - 1
+    raw = oracle_lib.synth_values(n_step * steps_n * world * 6, 0x494D5440 + world)
+    vals = [[v for v in raw if v % world == g][:n_step * steps_n] for g in range(world)]
+    steps = [[vals[g][st * n_step:(st + 1) * n_step] for g in range(world)] for st in range(steps_n)]
+    want, final_root = dense_global_replay(oracle, depth, world, steps)
+    be = [sharded.GpuBackend(imt, 0, depth, world, g, 1 << (depth - k), n_step, pipeline=(g % 2 == 0)) for g in range(world)]
+    roots_prev = torch.stack([be[0].initial_root()] * world)
+    for st in range(steps_n):
+        slots = [be[g].insert(imt.to_bytes(steps[st][g])) for g in range(world)]
+        roots_after = torch.stack([be[g].root_after(0).clone() for g in range(world)])
+        for g in range(world):
+            be[g].lift(slots[g], roots_prev, roots_after)
+            o = be[g].outputs(slots[g])
+            assert int(_witness_fail(imt, be[g], o, depth).max()) == 0
+            h = {key: (v.cpu().numpy() if torch.is_tensor(v) else v) for key, v in o.items()}
+            for i, exp in enumerate(want[st][g]):
+                assert int(h["low_index"][i]) == exp["low"] and h["first_new_index"] + i == exp["new_index"]
+                assert ints(h["low_leaf"][i]) == exp["low_leaf"] and ints(h["new_leaf"][i]) == exp["new_leaf"]
+                assert int(h["is_largest"][i]) == exp["largest"]
+                for key in ("old_root", "interim_root", "new_root"):
+                    assert ints(h[key][i]) == [exp[key]], (st, g, i, key)
+                assert (h["low_sib"][:, i] == exp["low_proof"]).all(), (st, g, i)
+                assert (h["new_sib"][:, i] == exp["new_proof"]).all(), (st, g, i)
+        roots_prev = roots_after
+    assert ints(be[0].combine(roots_prev).cpu().numpy()) == [final_root]
+    # snapshot of a placed tree: global next_idx fields; reload reproduces the subtree root
+    g = world - 1
+    snap = be[g].tree.snapshot()
+    nxt = [x for x in ints(snap[:, 2]) if x]
+    assert nxt and all((g << (depth - k)) < x < ((g + 1) << (depth - k)) for x in nxt)
+    t2 = imt.IndexedTree(be[g].ctx, depth - k, 1 << (depth - k))
+    t2.set_placement(depth, g)
+    t2.load(snap)
+    assert t2.root() == be[g].tree.root()
+    # the value partition is enforced for EVERY value of a batch, on the GPU (k_scatter)
+    fresh = [vals[0][j] + world for j in range(n_step - 1)]
+    size0 = be[0].tree.size
+    with pytest.raises(ValueError, match="another subtree"):
+        be[0].insert(imt.to_bytes(fresh + [vals[1][1]]))           # only the last one is misrouted
+    assert be[0].tree.size == size0
+    be[0].insert(imt.to_bytes(fresh + [vals[0][0] + 2 * world]))   # the tree is still usable afterwards
+    be[0].sync()
+    assert be[0].tree.size == size0 + n_step
+    for b in be:
+        b.tree.close(); b.ctx.close()
+
+
+def test_lift_batch_host_pointers_and_item_major(imt, ctx, oracle):
+    """imt_itree_lift_batch with host pointers, both sibling layouts, equal to the device-pointer path; a
+    placed tree's low-leaf queries speak global indices."""
+    depth, world, g, n = 10, 4, 2, 7
+    sub = depth - 2
+    vals = [v for v in oracle_lib.synth_values(200, 0x494D5441) if v % world == g][:2 * n]
+    rng = random.Random(5)
+    before = ints_to_arr([rng.randrange(P) for _ in range(world)])
+    after = ints_to_arr([rng.randrange(P) for _ in range(world)])
+    res = {}
+    for item_major in (False, True):
+        t = imt.IndexedTree(ctx, sub, 64)
+        t.set_placement(depth, g)
+        t.insert_batch(vals[:n], item_major=item_major)
+        r = t.insert_batch(vals[n:], item_major=item_major)
+        assert r["low_sib"].shape == ((n, depth, 32) if item_major else (depth, n, 32))
+        sub_new_root = r["new_root"].copy()
+        t.lift_batch(r, before, after, item_major=item_major)
+        res[item_major] = r
+        # the climb, restated with the oracle: ranks below g after the step, ranks above before it
+        mixed = [ints(after)[q] if q < g else ints(before)[q] for q in range(world)]
+        s0, s1 = mixed[g ^ 1], oracle.hash([mixed[0], mixed[1]])
+        for i in range(n):
+            x = oracle.hash([ints(sub_new_root[i])[0], s0])          # g = 2: left child, then right child
+            assert ints(r["new_root"][i]) == [oracle.hash([s1, x])]
+        sib = r["new_sib"] if not item_major else r["new_sib"].transpose(1, 0, 2)
+        assert ints(sib[sub, 0]) == [s0] and ints(sib[sub + 1, n - 1]) == [s1]
+        low = t.find_low([vals[0] + world])                         # global index of the low leaf
+        assert (g << sub) <= int(low[0]) < ((g + 1) << sub)
+        assert (t.get_leaves(low)[0, 0] == imt.to_bytes(vals[0])).all()
+        lw, leaves, sibs, largest = t.non_membership_witness([vals[0] + world])
+        assert int(lw[0]) == int(low[0]) and sibs.shape == (sub, 1, 32)
+        t.close()
+    assert (res[True]["low_sib"].transpose(1, 0, 2) == res[False]["low_sib"]).all()
+    assert (res[True]["old_root"] == res[False]["old_root"]).all()
+
+
+def test_config4_eight_shards_2pow22_properties(imt, ctx, oracle):
+    """BASELINE config 4 on one GPU: 2^22 insertions as 8 value-partitioned shards (v mod 8) x 8 steps x 2^16,
+    height-29 subtrees through sharded.GpuBackend (pipelined device-pointer batches), the roots exchanged per
+    step as the all-gather does and every batch lifted to depth 32.  Every insert_leaf constraint of every
+    insertion holds AT DEPTH 32 with global leaf indices (independent witness kernels: 131 hashes each); the
+    global root sequence is continuous inside a batch, from rank to rank inside a step and from step to step;
+    the final root equals the combination of the subtree roots (checked against the oracle, 7 hashes) and every
+    subtree equals a bulk rebuild from its snapshot."""
+    import torch
+    sharded = _load_sharded()
+    shards, depth, steps_n, bs = 8, 32, 8, 1 << 16
+    sub_depth = depth - 3
+    dev = torch.device("cuda", 0)
+    be = [sharded.GpuBackend(imt, 0, depth, shards, g, 1 << 20, bs, pipeline=True) for g in range(shards)]
+    vals = []
     for s in range(shards):
         rng = np.random.default_rng(400 + s)
-        raw = rng.integers(0, 256, size=(per_shard, 32), dtype=np.uint8)
+        raw = rng.integers(0, 256, size=(steps_n * bs, 32), dtype=np.uint8)
         raw[:, 31] &= 0x0f
         raw[:, 0] = (raw[:, 0] & 0xf8) | s                 # this shard's residue class mod 8
         raw[:, 1] |= 1                                      # non-zero
-        vals = torch.from_numpy(raw).to(dev)
-        t = imt.IndexedTree(c2, sub_depth, 1 << 20)
-        prev = None
-        for b in range(per_shard // bs):
-            rc = imt.lib.imt_itree_insert_batch(t.h, ctypes.c_void_p(vals.data_ptr() + b * bs * 32), bs,
-                                                ctypes.byref(st), imt._ffi.DEVICE_PTRS)
-            assert rc == 0, imt.lib.imt_last_error(c2.h)
-            new_index = torch.arange(1 + b * bs, 1 + (b + 1) * bs, dtype=torch.int64, device=dev)
-            rc = imt.lib.imt_insert_witness_batch(c2.h, P_(o["old_root"]), P_(o["low_leaf"]), P_(o["low_index"]),
-                                                  P_(o["low_sib"]), P_(o["new_root"]), P_(o["new_leaf"]), P_(new_index),
-                                                  None, P_(o["new_sib"]), P_(o["is_largest"]), sub_depth, bs, P_(fail),
-                                                  None, imt._ffi.DEVICE_PTRS)
-            assert rc == 0
-            c2.sync()
-            assert int(fail.max()) == 0, (s, b)
+        vals.append(torch.from_numpy(raw).to(dev))
+    roots_prev = torch.stack([be[0].initial_root()] * shards).to(dev)
+    last_root = None
+    for st in range(steps_n):
+        slots = [be[g].insert(vals[g][st * bs:(st + 1) * bs]) for g in range(shards)]
+        roots_after = torch.stack([be[g].root_after(0).clone() for g in range(shards)])
+        for g in range(shards):
+            be[g].lift(slots[g], roots_prev, roots_after)
+            o = be[g].outputs(slots[g])
+            assert o["first_new_index"] == (g << sub_depth) + 1 + st * bs
+            assert int(_witness_fail(imt, be[g], o, depth).max()) == 0, (st, g)
             assert bool((o["old_root"][1:] == o["new_root"][:-1]).all())
-            if prev is not None:
-                assert bool((o["old_root"][0] == prev).all())
-            prev = o["new_root"][-1].clone()
-        assert t.size == per_shard + 1
-        assert ints(prev.cpu().numpy()) == [t.root()]
-        t2 = imt.IndexedTree(c2, sub_depth, 1 << 20)
-        t2.load(t.snapshot())
-        assert t2.root() == t.root()
-        roots.append(t.root())
-        t.close(); t2.close()
-    top = ints(c2.combine_subtree_roots(imt.to_bytes(roots), sub_depth, depth))[0]
+            if last_root is not None:
+                assert bool((o["old_root"][0] == last_root).all()), (st, g)      # rank to rank, step to step
+            last_root = o["new_root"][-1].clone()
+        roots_prev = roots_after
+    top = ints(be[0].combine(roots_prev).cpu().numpy())[0]
+    assert ints(last_root.cpu().numpy()) == [top]
+    roots = ints(roots_prev.cpu().numpy())
     lvl = roots
     while len(lvl) > 1:
         lvl = [oracle.hash([lvl[i], lvl[i + 1]]) for i in range(0, len(lvl), 2)]
     assert top == lvl[0]
-    c2.close()
+    for g in (0, 5):
+        assert be[g].tree.size == steps_n * bs + 1 and be[g].tree.root() == roots[g]
+        t2 = imt.IndexedTree(be[g].ctx, sub_depth, 1 << 20)
+        t2.set_placement(depth, g)
+        t2.load(be[g].tree.snapshot())
+        assert t2.root() == roots[g]
+        t2.close()
+    for b in be:
+        b.tree.close(); b.ctx.close()
 
 
 def test_library_loaded_before_torch_leaves_torch_usable():

@@ -1,6 +1,10 @@
-"""GPU, two processes on one MI355X (gloo collectives through host memory): the single-list
-multi-GPU mode, ReplicatedIndexedTree, end to end.  Each rank returns the witnesses of its half of
-every batch; together they must equal the one-process imt_itree_insert_batch results."""
+"""GPU, two processes on one MI355X (gloo collectives through host memory).
+
+* the subtree mode (bench.py's N > 1 path): sharded.ShardedIndexedTree over sharded.GpuBackend -- lagged
+  root exchange, lift to depth 32 -- against the CPU oracle building the same two subtrees, and at depth 8
+  against a dense rebuild of the whole tree after every event;
+* the single-list mode, ReplicatedIndexedTree: each rank returns the witnesses of its half of every batch;
+  together they must equal the one-process imt_itree_insert_batch results."""
 import os
 import sys
 
@@ -80,3 +84,137 @@ def test_single_list_on_two_ranks(imt, ctx):
                 assert (r[k] == want[k][:, sl]).all(), (b, rank, k)
     for rank, _, root, size in got:                      # both replicas hold the same, reference-equal tree
         assert root == ref.root() and size == ref.size
+
+
+# ------------------------------------------------------------------------------------------------
+# subtree mode through ShardedIndexedTree + GpuBackend
+# ------------------------------------------------------------------------------------------------
+SUB_N, SUB_STEPS = 6, 3
+
+
+def _sub_vals(rank, world, seed):
+    import oracle_lib
+    raw = oracle_lib.synth_values(SUB_N * SUB_STEPS * world * 4, seed)
+    return [v for v in raw if v % world == rank][:SUB_N * SUB_STEPS]
+
+
+def _sub_worker(rank, world, port, depth, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import imt_amd
+    sharded = _load_sharded()
+    k = world.bit_length() - 1
+    be = sharded.GpuBackend(imt_amd, 0, depth, world, rank, 64, SUB_N, pipeline=True, nbuf=2)
+    tree = sharded.ShardedIndexedTree(be, depth, world, rank, dist, via_host=True)
+    vals = _sub_vals(rank, world, 0x494D5450 + depth)
+    finished, roots, fails = [], [], []
+
+    def take(done):
+        be.sync()
+        n = SUB_N
+        fail = torch.empty(n, dtype=torch.uint8, device=be.device)
+        new_index = torch.arange(done["first_new_index"], done["first_new_index"] + n, dtype=torch.int64, device=be.device)
+        import ctypes
+        P_ = lambda x: ctypes.c_void_p(x.data_ptr())
+        rc = imt_amd.lib.imt_insert_witness_batch(be.ctx.h, P_(done["old_root"]), P_(done["low_leaf"]), P_(done["low_index"]),
+                                                  P_(done["low_sib"]), P_(done["new_root"]), P_(done["new_leaf"]),
+                                                  P_(new_index), None, P_(done["new_sib"]), P_(done["is_largest"]), depth,
+                                                  n, P_(fail), None, imt_amd._ffi.DEVICE_PTRS)
+        assert rc == 0
+        be.sync()
+        fails.append(int(fail.max()))
+        finished.append({key: (v.cpu().numpy().copy() if torch.is_tensor(v) else v) for key, v in done.items()})
+        roots.append(tree.global_root.cpu().numpy().tobytes())
+
+    for st in range(SUB_STEPS):
+        done = tree.step(imt_amd.to_bytes(vals[st * SUB_N:(st + 1) * SUB_N]))
+        if done is not None:
+            take(done)
+    take(tree.flush())
+    q.put((rank, finished, roots, fails))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("depth", [8, 32])
+def test_subtree_mode_on_two_ranks(imt, ctx, oracle, depth):
+    world = 2
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = 29800 + (os.getpid() % 1000) + depth
+    procs = [mpctx.Process(target=_sub_worker, args=(r, world, port, depth, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    vals = [_sub_vals(r, world, 0x494D5450 + depth) for r in range(world)]
+    steps = [[vals[r][st * SUB_N:(st + 1) * SUB_N] for r in range(world)] for st in range(SUB_STEPS)]
+    ints = lambda a: [int.from_bytes(x.tobytes(), "little") for x in np.asarray(a, np.uint8).reshape(-1, 32)]
+    for rank, finished, roots, fails in got:
+        assert fails == [0] * SUB_STEPS and len(finished) == SUB_STEPS       # insert_leaf relations at full depth
+    if depth <= 8:
+        from sharded_ref import dense_global_replay
+        want, final_root = dense_global_replay(oracle, depth, world, steps)
+        for rank, finished, roots, _ in got:
+            for st in range(SUB_STEPS):
+                h = finished[st]
+                for i, exp in enumerate(want[st][rank]):
+                    assert int(h["low_index"][i]) == exp["low"] and h["first_new_index"] + i == exp["new_index"]
+                    for key in ("old_root", "interim_root", "new_root"):
+                        assert ints(h[key][i]) == [exp[key]], (st, rank, i, key)
+                    assert (h["low_sib"][:, i] == exp["low_proof"]).all() and (h["new_sib"][:, i] == exp["new_proof"]).all()
+                assert roots[st] == want[st][world - 1][-1]["new_root"].to_bytes(32, "little")
+        assert got[0][2][-1] == final_root.to_bytes(32, "little")
+    else:
+        # depth 32: the oracle builds the same two height-31 subtrees; top level restated with oracle.hash
+        sub = depth - 1
+        hs = [oracle.sparse_new(sub, 64) for _ in range(world)]
+        for r in range(world):
+            oracle.sparse_set_index_base(hs[r], r << sub)
+        sub_roots = [oracle.sparse_root(h) for h in hs]
+        for st in range(SUB_STEPS):
+            for r in range(world):
+                h = got[r][1][st]
+                for i, v in enumerate(steps[st][r]):
+                    o = oracle.sparse_insert(hs[r], sub, v)
+                    assert o["rc"] == 0
+                    other = sub_roots[r ^ 1]          # rank 0 sees rank 1 before the step, rank 1 sees rank 0 after it
+                    up = (lambda x: oracle.hash([x, other])) if r == 0 else (lambda x: oracle.hash([other, x]))
+                    assert ints(h["interim_root"][i]) == [up(o["interim_root"])], (st, r, i)
+                    assert ints(h["new_root"][i]) == [up(o["new_root"])]
+                    assert int(h["low_index"][i]) == (r << sub) + o["low"]
+                    assert (h["low_sib"][:sub, i] == o["low_proof"]).all() and (h["new_sib"][:sub, i] == o["new_proof"]).all()
+                    assert ints(h["low_sib"][sub, i]) == [other] and ints(h["new_sib"][sub, i]) == [other]
+                    assert (h["low_leaf"][i] == o["low_leaf"]).all()
+                sub_roots[r] = oracle.sparse_root(hs[r])
+            assert got[0][2][st] == oracle.hash(sub_roots).to_bytes(32, "little")
+        for h in hs:
+            oracle.sparse_free(h)
+
+
+def test_bench_gpus2_as_typed_rehearsal():
+    """`python3 bench.py --gpus 2 --steps 2 --warmup 1` exactly as the driver would type it (no torchrun around
+    it): the process launches its two ranks as children, rank 0's JSON line comes back on stdout.  Rehearsal
+    switches for the one-GPU box: both ranks on device 0, root exchange through gloo."""
+    import json
+    import subprocess
+    env = dict(os.environ, IMT_BENCH_DEVICE="0", IMT_BENCH_COLLECTIVE="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["collective_backend"] == "gloo"
+    assert res["verified"] is True
+    assert res["config"]["hashes_per_insertion"] == 66 and res["config"]["subtree_height_per_gpu"] == 31
+    assert res["value"] > 0 and res["steps"] == 2 and res["scaling"] == "weak"
+    # --gpus that contradicts the launcher's world size is an error, not silently ignored
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                        capture_output=True, text=True, timeout=300, env=env2, cwd=ROOT)
+    assert r2.returncode != 0 and "does not match WORLD_SIZE" in (r2.stdout + r2.stderr)
