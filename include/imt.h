@@ -115,7 +115,7 @@ int imt_ctx_sync(imt_ctx *ctx);
  * Plain host pointers (no IMT_DEVICE_PTRS) stay supported and are synchronous. */
 int imt_host_alloc(imt_ctx *ctx, size_t bytes, void **out);
 int imt_host_free(imt_ctx *ctx, void *ptr);
-/* ABI / build identification, e.g. "imt-hip gfx950 r1" */
+/* ABI / build identification, e.g. "imt-hip gfx950 r2" */
 const char *imt_version(void);
 /* Per-kernel timing with HIP events recorded on the context's stream around the launches of
  * imt_itree_insert_batch (used by bench.py for the roofline line; off by default).
@@ -146,6 +146,47 @@ int imt_hash3_batch(imt_ctx *ctx, const void *in /*[n][3][32]*/, void *out /*[n]
 /* the bare permutation on [n][3] states (test hook for the round schedule) */
 int imt_permute_batch(imt_ctx *ctx, const void *in /*[n][3][32]*/, void *out /*[n][3][32]*/, size_t n,
                       unsigned flags);
+
+/* ---- f1: the witness trace of PoseidonHasher::hash_fix_len_array ---------------- */
+/* The circuit recomputes every Poseidon on the CPU while it assigns (hasher.hash_fix_len_array at
+ * src/indexed_merkle_tree.rs:92, :194, :271-275, :299-303).  These calls produce, on the GPU, every NEW advice value
+ * the gadget assigns for a hash -- both permutations' absorb cells, S-box intermediates x^2, x^4, x^5 + c and the
+ * running sums of every MDS row -- in assignment order ("trace rows"), so a chip can assign instead of recompute.
+ * Order and cell structure follow the published halo2-lib v0.4.x gadget (poseidon/hasher/state.rs over GateChip's
+ * vertical gate); halo2-base is not vendored in the reference, so this order is UNPINNED BY THE REFERENCE.  What pins
+ * it: the output row is the hash (reference KAT), every gate of the reconstructed column holds, and the CPU oracle
+ * restates it independently (oracle/trace.c).
+ *   rows: 1208 for 2 inputs, 1209 for 3 (imt_hash_trace_rows); the hash itself is row rows - 4.
+ *   trace layout: [rows][n][32] (row-major, coalesced on the device) or, with IMT_TRACE_ITEM_MAJOR, [n][rows][32]
+ *   (one hash's rows contiguous).  With IMT_FMT_MONT256 a row is the in-memory [u64;4] of a halo2curves Fr:
+ *   Witness(unsafe { transmute(row) }) needs no arithmetic on the host. */
+#define IMT_TRACE_ITEM_MAJOR IMT_SIB_ITEM_MAJOR
+size_t imt_hash_trace_rows(int arity);
+int imt_hash_trace_batch(imt_ctx *ctx, const void *in /*[n][arity][32]*/, int arity, size_t n,
+                         void *trace /*[rows][n][32]*/, unsigned flags);
+/* The traces of ALL hashes of compute_merkle_root (src/indexed_merkle_tree.rs:78-96) for n paths: the leaf hash
+ * (3 inputs; only when leaf3 is given instead of leaf) followed by the `depth` path hashes bottom-up, each with the
+ * (left, right) inputs dual_mux selects.  trace = the blocks one after the other, [1209][n] (if leaf3) then depth x
+ * [1208][n]; item-major: [n][1209 + depth * 1208].  root_out (optional) = the recomputed roots. */
+int imt_path_trace_batch(imt_ctx *ctx, const void *leaf /*[n][32] or NULL*/, const void *leaf3 /*[n][3][32] or NULL*/,
+                         const uint64_t *index /*[n]*/, const void *sib, unsigned depth, size_t n, void *trace,
+                         void *root_out /*[n][32] or NULL*/, unsigned flags);
+/* The advice column of ONE hash, cell by cell, in assignment order: where each cell's value comes from and where
+ * the vertical gates a + b*c = d start (gate = 1 on cell a).  Static per arity; host pointers only. */
+#define IMT_CELL_CONST 0     /* constants[index] */
+#define IMT_CELL_INPUT 1     /* copy (Existing) of hash input `index` */
+#define IMT_CELL_INIT 2      /* copy of the hasher's initial-state cell `index`: 0 = 2^64, 1 and 2 = 0 */
+#define IMT_CELL_WITNESS 3   /* NEW value: trace row `index` (rows appear in increasing order) */
+#define IMT_CELL_COPY 4      /* copy (Existing) of trace row `index` */
+typedef struct imt_trace_cell {
+    uint8_t kind;            /* IMT_CELL_* */
+    uint8_t gate;            /* 1: q_enable here, the gate covers this cell and the next three */
+    uint16_t reserved;
+    uint32_t index;
+} imt_trace_cell;
+/* cells / constants may be NULL (sizes only).  constants[n_constants][32] in the format of `flags`. */
+int imt_hash_trace_layout(imt_ctx *ctx, int arity, imt_trace_cell *cells, size_t cells_cap, size_t *n_cells,
+                          void *constants, size_t const_cap, size_t *n_constants, uint32_t *out_row, unsigned flags);
 
 /* ---- a2 / a3 / a4: dense native tree ------------------------------------------- */
 /* IndexedMerkleTree::new (src/utils.rs:20-57): level-by-level build on the device.

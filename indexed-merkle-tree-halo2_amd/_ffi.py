@@ -47,6 +47,10 @@ c_void_p, c_size_t, c_uint, c_int, c_u64 = (ctypes.c_void_p, ctypes.c_size_t, ct
 P = ctypes.POINTER
 
 
+class TraceCell(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint8), ("gate", ctypes.c_uint8), ("reserved", ctypes.c_uint16), ("index", ctypes.c_uint32)]
+
+
 class InsertOut(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("low_index", "low_leaf", "is_largest", "old_root", "interim_root",
                                         "new_root", "new_leaf", "low_sib", "new_sib")]
@@ -68,6 +72,12 @@ SIGNATURES = {
     "imt_hash2_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint]),
     "imt_hash3_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint]),
     "imt_permute_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint]),
+    "imt_hash_trace_rows": (c_size_t, [c_int]),
+    "imt_hash_trace_batch": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_uint]),
+    "imt_path_trace_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_size_t, c_void_p, c_void_p,
+                                     c_uint]),
+    "imt_hash_trace_layout": (c_int, [c_void_p, c_int, P(TraceCell), c_size_t, P(c_size_t), c_void_p, c_size_t,
+                                      P(c_size_t), P(ctypes.c_uint32), c_uint]),
     "imt_tree_new": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, P(c_void_p)]),
     "imt_tree_free": (None, [c_void_p]),
     "imt_tree_num_levels": (c_size_t, [c_void_p]),
@@ -129,3 +139,5 @@ FMT_CANONICAL, FMT_MONT256, FMT_DEVICE = 0, 1, 2
 DEVICE_PTRS, SIB_ITEM_MAJOR, ROOT_PER_ITEM, PIPELINE, HOST_PREP, INPUTS_READY = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 F_RANGE_PRED, F_LOW_IN_ROOT, F_LOW_LT_NEW, F_ZERO_SLOT, F_NEXT_VAL, F_NEXT_IDX, F_NEW_ROOT, F_BAD_BIT = (
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80)
+CELL_CONST, CELL_INPUT, CELL_INIT, CELL_WITNESS, CELL_COPY = 0, 1, 2, 3, 4
+TRACE_ITEM_MAJOR = SIB_ITEM_MAJOR

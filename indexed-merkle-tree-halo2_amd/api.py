@@ -133,6 +133,40 @@ class Context:
         self._check(lib.imt_permute_batch(self.h, _p(a), _p(out), a.shape[0], fmt))
         return out
 
+    # ---- f1: witness trace of hash_fix_len_array ----
+    def hash_trace(self, inputs, fmt=0, item_major=False):
+        """inputs uint8 [n, 2 or 3, 32] -> every new advice value of halo2-base's hash_fix_len_array per hash,
+        in assignment order: uint8 [rows, n, 32] (item_major: [n, rows, 32]); rows = 1208 / 1209."""
+        a = np.ascontiguousarray(inputs, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[1] not in (2, 3) or a.shape[2] != 32:
+            raise ValueError(f"expected [n, 2|3, 32], got {a.shape}")
+        n, arity = a.shape[0], a.shape[1]
+        rows = lib.imt_hash_trace_rows(arity)
+        out = np.empty((n, rows, 32) if item_major else (rows, n, 32), dtype=np.uint8)
+        self._check(lib.imt_hash_trace_batch(self.h, _p(a), arity, n, _p(out),
+                                             fmt | (_ffi.TRACE_ITEM_MAJOR if item_major else 0)))
+        return out
+
+    def path_trace(self, index, sib, depth, leaf=None, leaf3=None, fmt=0, item_major=False):
+        """Traces of every hash of compute_merkle_root for n paths (imt_path_trace_batch); returns (trace, roots).
+        trace: uint8 [total_rows, n, 32] (blocks: leaf hash if leaf3, then the levels) or item-major [n, total_rows, 32]."""
+        src = _arr(leaf3, (3, 32)) if leaf3 is not None else _arr(leaf, (32,))
+        n = src.shape[0]
+        idx = np.ascontiguousarray(index, dtype=np.uint64)
+        sb = _arr(sib, (32,)) if depth else np.zeros((0, 32), np.uint8)
+        total = (lib.imt_hash_trace_rows(3) if leaf3 is not None else 0) + depth * lib.imt_hash_trace_rows(2)
+        out = np.empty((n, total, 32) if item_major else (total, n, 32), dtype=np.uint8)
+        roots = np.empty((n, 32), dtype=np.uint8)
+        self._check(lib.imt_path_trace_batch(self.h, _p(src) if leaf3 is None else None, _p(src) if leaf3 is not None else None,
+                                             _p(idx), _p(sb), depth, n, _p(out), _p(roots),
+                                             fmt | (_ffi.TRACE_ITEM_MAJOR if item_major else 0)))
+        return out, roots
+
+    def hash_trace_layout(self, arity, fmt=0):
+        """(cells, constants, out_row): the advice column of one hash, cell by cell (imt_hash_trace_layout).
+        cells: structured array with fields kind (_ffi.CELL_*), gate, index; constants: uint8 [k, 32]."""
+        return trace_layout(lambda *a: lib.imt_hash_trace_layout(self.h, *a), arity, fmt, self._check)
+
     # ---- a5 / a8 / a9 ----
     def path_root(self, leaf, index, sib, depth, item_major=False, fmt=0):
         leaf = _arr(leaf, (32,))
@@ -220,6 +254,45 @@ class Context:
         out = np.empty(32, dtype=np.uint8)
         self._check(lib.imt_combine_subtree_roots(self.h, _p(r), r.shape[0], sub_height, depth, _p(out), fmt))
         return out
+
+
+CELL_DTYPE = np.dtype([("kind", "u1"), ("gate", "u1"), ("reserved", "<u2"), ("index", "<u4")])
+
+
+def trace_layout(call, arity, fmt, check):
+    """shared by Context.hash_trace_layout and the CPU tests (which call the same C function on a GPU-less build)"""
+    nc, nk, row = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_uint32()
+    check(call(arity, None, 0, ctypes.byref(nc), None, 0, ctypes.byref(nk), ctypes.byref(row), fmt))
+    cells = np.zeros(nc.value, dtype=CELL_DTYPE)
+    consts = np.empty((nk.value, 32), dtype=np.uint8)
+    check(call(arity, cells.ctypes.data_as(ctypes.POINTER(_ffi.TraceCell)), nc.value, ctypes.byref(nc),
+               consts.ctypes.data_as(ctypes.c_void_p), nk.value, ctypes.byref(nk), ctypes.byref(row), fmt))
+    return cells, consts, row.value
+
+
+def rebuild_advice_column(cells, consts, inputs, trace_rows):
+    """The full advice column of one hash as Python ints from its layout, the constants (canonical), the hash inputs
+    and the trace rows (canonical): what a chip assigns.  INIT cells are the hasher's initial state [2^64, 0, 0]."""
+    init = [1 << 64, 0, 0]
+    k = [int.from_bytes(c.tobytes(), "little") for c in consts]
+    w = [int.from_bytes(r.tobytes(), "little") for r in np.asarray(trace_rows, dtype=np.uint8).reshape(-1, 32)]
+    col = []
+    for c in cells:
+        kind, idx = int(c["kind"]), int(c["index"])
+        col.append(k[idx] if kind == _ffi.CELL_CONST else inputs[idx] if kind == _ffi.CELL_INPUT
+                   else init[idx] if kind == _ffi.CELL_INIT else w[idx])
+    return col
+
+
+def check_vertical_gates(cells, col):
+    """halo2-base's only custom gate: q * (a + b * c - d) = 0 over four consecutive cells; returns the gate count"""
+    n = 0
+    for i in np.nonzero(cells["gate"])[0]:
+        a, b, c, d = col[i:i + 4]
+        if (a + b * c - d) % P_MODULUS:
+            raise AssertionError(f"gate at cell {i} does not hold")
+        n += 1
+    return n
 
 
 class IndexedMerkleTree:

@@ -143,7 +143,7 @@ extern "C" int imt_profile_read(imt_ctx* c, double* out) {
     return IMT_OK;
 }
 
-extern "C" const char* imt_version(void) { return "imt-hip gfx950 r1"; }
+extern "C" const char* imt_version(void) { return "imt-hip gfx950 r2"; }
 
 extern "C" int imt_ctx_create(int device, imt_ctx** out) {
     if (!out) return IMT_ERR_ARG;
@@ -158,9 +158,11 @@ extern "C" int imt_ctx_create(int device, imt_ctx** out) {
     if (!c->hp.init(err)) { delete c; return IMT_ERR_INTERNAL; }
     dev::PoseidonConsts pc;
     c->hp.fill_consts(pc);
+    dev::TraceConsts tc;
+    c->hp.fill_trace_consts(tc);
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->own_stream)) != hipSuccess ||
-        (e = launch::upload_consts(pc)) != hipSuccess || (e = hipMalloc((void**)&c->d_err, sizeof(int))) != hipSuccess ||
+        (e = launch::upload_consts(pc)) != hipSuccess || (e = launch::upload_trace_consts(tc)) != hipSuccess || (e = hipMalloc((void**)&c->d_err, sizeof(int))) != hipSuccess ||
         (e = hipMalloc((void**)&c->d_zero, (IMT_MAX_DEPTH + 1) * 32)) != hipSuccess) {
         if (c->own_stream) hipStreamDestroy(c->own_stream);
         if (c->d_err) hipFree(c->d_err);
@@ -311,6 +313,64 @@ extern "C" int imt_permute_batch(imt_ctx* c, const void* in, void* out, size_t n
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     launch::permute_batch(c->stream, d_in, d_out, n, fmt, fmt, c->d_err);
+    return io.finish();
+}
+
+// ------------------------------------------------------------------------------------
+// f1: witness trace of hash_fix_len_array
+// ------------------------------------------------------------------------------------
+extern "C" int imt_hash_trace_batch(imt_ctx* c, const void* in, int arity, size_t n, void* trace, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    const size_t rows = imt_hash_trace_rows(arity);
+    if (!rows) return c->fail(IMT_ERR_ARG, "arity must be 2 or 3");
+    if (n == 0) return IMT_OK;
+    if (!in || !trace) return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    const uint8_t* d_in = io.in(in, n * 32 * (size_t)arity);
+    uint8_t* d_tr = io.out(trace, n * rows * 32);
+    if (io.rc) return io.rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    const bool item_major = flags & IMT_TRACE_ITEM_MAJOR;
+    launch::hash_trace(c->stream, d_in, n, arity, d_tr, item_major ? 1 : n, item_major ? rows : 1, fmt, fmt, c->d_err);
+    return io.finish();
+}
+
+extern "C" int imt_path_trace_batch(imt_ctx* c, const void* leaf, const void* leaf3, const uint64_t* index,
+                                    const void* sib, unsigned depth, size_t n, void* trace, void* root_out,
+                                    unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    if (depth > IMT_MAX_DEPTH) return c->fail(IMT_ERR_RANGE, "depth %u > %d", depth, IMT_MAX_DEPTH);
+    if (n == 0) return IMT_OK;
+    if ((!leaf) == (!leaf3)) return c->fail(IMT_ERR_ARG, "exactly one of leaf / leaf3 must be given");
+    if (!index || !trace || (depth && !sib)) return c->fail(IMT_ERR_ARG, "null buffer");
+    const size_t r2 = dev::TRACE_ROWS_H2, r3 = dev::TRACE_ROWS_H3;
+    const size_t rows_total = (leaf3 ? r3 : 0) + (size_t)depth * r2;
+    Io io(c, flags);
+    const uint8_t* d_leaf = leaf ? io.in(leaf, n * 32) : nullptr;
+    const uint8_t* d_leaf3 = leaf3 ? io.in(leaf3, n * 96) : nullptr;
+    const uint64_t* d_idx = (const uint64_t*)io.in(index, n * 8);
+    const uint8_t* d_sib = io.in(sib, (size_t)depth * n * 32);
+    uint8_t* d_tr = io.out(trace, n * rows_total * 32);
+    uint8_t* d_root = io.out(root_out, n * 32);
+    uint8_t* pairs = io.temp((size_t)depth * n * 64);
+    if (io.rc) return io.rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    const bool item_major = flags & IMT_TRACE_ITEM_MAJOR;
+    // the chain first (one fast hash per level), which yields the two inputs of every hash on the path ...
+    launch::path_pairs(c->stream, d_leaf, d_leaf3, d_idx, false, d_sib, sib_layout(flags & ~IMT_TRACE_ITEM_MAJOR, depth, n),
+                       depth, n, pairs, d_root, fmt, fmt, c->d_err);
+    // ... then every hash of every path is an independent trace
+    size_t row0 = 0;
+    auto block = [&](const uint8_t* in_l, int arity, unsigned fmt_in, size_t rows) {
+        uint8_t* base = d_tr + (item_major ? row0 : row0 * n) * 32;
+        launch::hash_trace(c->stream, in_l, n, arity, base, item_major ? 1 : n, item_major ? rows_total : 1, fmt_in, fmt,
+                           c->d_err);
+        row0 += rows;
+    };
+    if (leaf3) block(d_leaf3, 3, fmt, r3);
+    for (unsigned l = 0; l < depth; l++) block(pairs + (size_t)l * n * 64, 2, IMT_FMT_DEVICE, r2);
     return io.finish();
 }
 

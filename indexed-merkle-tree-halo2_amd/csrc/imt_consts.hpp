@@ -34,5 +34,21 @@ struct PoseidonConsts {
     Fe zero_leaf;         // H(0,0,0) in device form
 };
 
+// ---- f1: tables of the witness-trace kernel (imt_trace_device.hpp) -------------------------------
+// halo2-base's OptimizedPoseidonSpec (= pse-poseidon's Spec): constants are added AFTER the S-box, the
+// full-round matrix is M except for the last round of the first half (pre_sparse_mds), every partial round
+// has its own sparse matrix {row, col_hat}.  Eight full rounds as one table: round f adds full_c[f] after
+// its S-boxes and multiplies by mats[f == RF/2 - 1].
+struct TraceConsts {
+    Fe absorb[3][3];      // constants of absorb_with_pre_constants for 2 / 1 / 0 inputs: start[0] with the
+                          // padding 1 folded into the first free lane ([0] = start[0] itself)
+    Fe full_c[RF][3];     // start[1..4], end[0..2], 0
+    Fe partial[RP];
+    Fe mats[2][3][3];     // [0] = mds, [1] = pre_sparse_mds
+    Fe row[RP][3];
+    Fe col_hat[RP][2];
+};
+constexpr int TRACE_ROWS_H2 = 1208, TRACE_ROWS_H3 = 1209;   // witnesses per 2- / 3-input hash
+
 }  // namespace dev
 }  // namespace imt

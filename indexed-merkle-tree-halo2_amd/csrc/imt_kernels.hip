@@ -11,12 +11,14 @@
 // a5/a8/a9 path_root, a13 non_membership, a14 insert_witness, a15 sweep_* (index logic in imt_sweep.hpp;
 // the hash-free batch preparation is a separate translation unit, imt_prep.hip).
 #include "imt_device.hpp"
+#include "imt_trace_device.hpp"
 #include "imt_launch.hpp"
 #include "imt_sweep.hpp"
 
 namespace imt {
 
 __constant__ dev::PoseidonConsts g_pc;
+__constant__ dev::TraceConsts g_tc;      // halo2-base form of the same permutation (witness trace, f1)
 
 namespace {
 using namespace dev;
@@ -157,6 +159,66 @@ __global__ void __launch_bounds__(BLOCK) k_convert(const uint8_t* __restrict__ i
     Fe x;
     bool ok = load_fe(g_pc, x, in + i * 32, fmt_in);
     store_fe(g_pc, out + i * 32, x, fmt_out);
+    flag_err(err, ok);
+}
+
+// ---- f1: witness trace of hash_fix_len_array (imt_trace_device.hpp) -----------------
+// One thread = one hash = 1208 / 1209 rows of 32 bytes.  Row j of item i goes to
+// trace + (j * row_stride + i * item_stride) * 32: row-major ([rows][n], row_stride = n) makes a wave's 64
+// stores of one row 2 KiB contiguous; item-major ([n][rows]) is the order a per-hash consumer reads.
+__global__ void __launch_bounds__(BLOCK)
+k_hash_trace(const uint8_t* __restrict__ in, size_t n, int arity, uint8_t* __restrict__ trace, uint64_t row_stride,
+             uint64_t item_stride, unsigned fmt_in, unsigned fmt_out, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    const uint8_t* p = in + i * 32 * (size_t)arity;
+    Fe a, b, c;
+    bool ok = load_fe(g_pc, a, p, fmt_in);
+    ok &= load_fe(g_pc, b, p + 32, fmt_in);
+    c = a;
+    if (arity == 3) ok &= load_fe(g_pc, c, p + 64, fmt_in);
+    TraceSink o{trace + i * item_stride * 32, row_stride * 32, fmt_out};
+    hash_trace(g_pc, g_tc, o, a, b, c, arity == 3);
+    flag_err(err, ok);
+}
+
+// (left, right) inputs of every hash2 along n paths, for the trace of a whole path: pairs[l][i][2] in device
+// format, + the leaf hash's output as the level-0 start.  Same walk as k_path_root.
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
+k_path_pairs(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3, const uint64_t* __restrict__ index,
+             int is_helper, const uint8_t* __restrict__ sib, launch::SibLayout lay, unsigned depth, size_t n,
+             uint8_t* __restrict__ pairs, uint8_t* __restrict__ root_out, unsigned fmt_in, unsigned fmt_out, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    bool ok = true;
+    Fe cur;
+    if (leaf3) {
+        Fe pre[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, pre[j], leaf3 + (i * 3 + j) * 32, fmt_in);
+        hash_call(cur, pre[0], pre[1], pre[2], true);
+    } else {
+        ok &= load_fe(g_pc, cur, leaf + i * 32, fmt_in);
+    }
+    uint64_t idx = index[i];
+    if (is_helper) idx = ~idx;
+#pragma unroll 1
+    for (unsigned l = 0; l < depth; l++) {
+        Fe sv, a, b, o;
+        ok &= load_fe(g_pc, sv, sib + ((uint64_t)l * lay.level_stride + i * lay.item_stride) * 32, fmt_in);
+        const bool right = (idx >> l) & 1;
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+            a.v[q] = right ? sv.v[q] : cur.v[q];
+            b.v[q] = right ? cur.v[q] : sv.v[q];
+        }
+        uint8_t* dst = pairs + ((size_t)l * n + i) * 64;
+        store_packed(dst, a);
+        store_packed(dst + 32, b);
+        hash_call(o, a, b, a, false);
+        cur = o;
+    }
+    if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
     flag_err(err, ok);
 }
 
@@ -708,6 +770,22 @@ namespace launch {
 
 hipError_t upload_consts(const dev::PoseidonConsts& pc) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_pc), &pc, sizeof(pc), 0, hipMemcpyHostToDevice);
+}
+hipError_t upload_trace_consts(const dev::TraceConsts& tc) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tc), &tc, sizeof(tc), 0, hipMemcpyHostToDevice);
+}
+void hash_trace(hipStream_t s, const uint8_t* in, size_t n, int arity, uint8_t* trace, uint64_t row_stride,
+                uint64_t item_stride, unsigned fmt_in, unsigned fmt_out, int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_hash_trace, dim3(nblk(n)), dim3(BLOCK), 0, s, in, n, arity, trace, row_stride, item_stride,
+                       fmt_in, fmt_out, err);
+}
+void path_pairs(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index, bool is_helper,
+                const uint8_t* sib, SibLayout lay, unsigned depth, size_t n, uint8_t* pairs, uint8_t* root_out,
+                unsigned fmt_in, unsigned fmt_out, int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_path_pairs, dim3(nblk(n)), dim3(BLOCK), 0, s, leaf, leaf3, index, is_helper ? 1 : 0, sib, lay,
+                       depth, n, pairs, root_out, fmt_in, fmt_out, err);
 }
 
 void hash_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, int arity, unsigned fmt_in,

@@ -27,6 +27,16 @@ struct TreeView {
 };
 
 hipError_t upload_consts(const dev::PoseidonConsts& pc);
+hipError_t upload_trace_consts(const dev::TraceConsts& tc);
+
+// f1: every witness of hash_fix_len_array for n hashes of `arity` inputs; row j of item i at
+// trace + (j * row_stride + i * item_stride) * 32
+void hash_trace(hipStream_t s, const uint8_t* in, size_t n, int arity, uint8_t* trace, uint64_t row_stride,
+                uint64_t item_stride, unsigned fmt_in, unsigned fmt_out, int* err);
+// the (left, right) inputs of every hash2 along n paths: pairs[depth][n][2][32], device format
+void path_pairs(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index, bool is_helper,
+                const uint8_t* sib, SibLayout lay, unsigned depth, size_t n, uint8_t* pairs, uint8_t* root_out,
+                unsigned fmt_in, unsigned fmt_out, int* err);
 
 void hash_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, int arity, unsigned fmt_in,
                 unsigned fmt_out, int* err);

@@ -91,6 +91,43 @@ void HostPoseidon::permute_opt(HFr s[3]) const {
     }
 }
 
+// The permutation as halo2-base's PoseidonState::permutation / pse-poseidon's Spec::permute run it (no
+// absorption here: the caller has added its inputs): s += start[0]; three rounds {x^5 + c, M}; one round
+// {x^5 + c, PRE}; 57 rounds {lane 0: x^5 + c; sparse}; three rounds {x^5 + c, M}; one round {x^5, M}.
+void HostPoseidon::permute_spec(HFr s[3]) const {
+    auto x5c = [&](HFr& x, const HFr& c) {
+        HFr x2 = F.mul(x, x), x4 = F.mul(x2, x2);
+        x = F.add(F.mul(x4, x), c);
+    };
+    auto dense = [&](const HFr m[3][3]) {
+        HFr n[3];
+        for (int i = 0; i < 3; i++) {
+            n[i] = F.mul(m[i][0], s[0]);
+            n[i] = F.add(n[i], F.mul(m[i][1], s[1]));
+            n[i] = F.add(n[i], F.mul(m[i][2], s[2]));
+        }
+        s[0] = n[0]; s[1] = n[1]; s[2] = n[2];
+    };
+    for (int i = 0; i < 3; i++) s[i] = F.add(s[i], tr_start[0][i]);
+    for (int r = 1; r <= 4; r++) {
+        for (int i = 0; i < 3; i++) x5c(s[i], tr_start[r][i]);
+        dense(r == 4 ? tr_pre : mds);
+    }
+    for (int p = 0; p < 57; p++) {
+        x5c(s[0], tr_partial[p]);
+        HFr n0 = F.mul(tr_row[p][0], s[0]);
+        n0 = F.add(n0, F.mul(tr_row[p][1], s[1]));
+        n0 = F.add(n0, F.mul(tr_row[p][2], s[2]));
+        s[1] = F.add(F.mul(tr_col_hat[p][0], s[0]), s[1]);
+        s[2] = F.add(F.mul(tr_col_hat[p][1], s[0]), s[2]);
+        s[0] = n0;
+    }
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 3; i++) x5c(s[i], r < 3 ? tr_end[r][i] : F.zero());
+        dense(mds);
+    }
+}
+
 // Poseidon::update + squeeze_and_reset for 2 / 3 inputs
 HFr HostPoseidon::hash2(const HFr& a, const HFr& b) const {
     HFr s[3] = {cap0, a, b};
@@ -194,6 +231,76 @@ bool HostPoseidon::init(std::string& err) {
     }
     std::memcpy(pre, cur, sizeof pre);
 
+    // ---- the halo2-base / pse-poseidon spec (Spec::new): needed value by value by the witness trace ----
+    {
+        typedef HFr M3[3][3];
+        auto mat_mul = [&](const M3 a, const M3 b, M3 o) {
+            HFr r[3][3];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    r[i][j] = F.mul(a[i][0], b[0][j]);
+                    r[i][j] = F.add(r[i][j], F.mul(a[i][1], b[1][j]));
+                    r[i][j] = F.add(r[i][j], F.mul(a[i][2], b[2][j]));
+                }
+            std::memcpy(o, r, sizeof r);
+        };
+        // M^-1 by the adjugate
+        HFr minv[3][3];
+        {
+            auto cof = [&](int r0, int r1, int c0, int c1) {
+                return F.sub(F.mul(mds[r0][c0], mds[r1][c1]), F.mul(mds[r0][c1], mds[r1][c0]));
+            };
+            HFr adj[3][3];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    const int r0 = (j + 1) % 3, r1 = (j + 2) % 3, c0 = (i + 1) % 3, c1 = (i + 2) % 3;
+                    adj[i][j] = cof(r0, r1, c0, c1);       // cyclic indices carry the sign
+                }
+            HFr det = F.add(F.add(F.mul(mds[0][0], adj[0][0]), F.mul(mds[0][1], adj[1][0])), F.mul(mds[0][2], adj[2][0]));
+            if (F.is_zero(det)) { err = "singular MDS"; return false; }
+            HFr di = F.inverse(det);
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) minv[i][j] = F.mul(adj[i][j], di);
+        }
+        // calculate_optimized_constants: start[0] = c_0; start[r] = M^-1 c_r; the partial rounds' constants are
+        // folded back to front from c_61 (lane 0 stays, lanes 1..2 travel on through M^-1); end[r] = M^-1 c_{62+r}
+        for (int i = 0; i < 3; i++) tr_start[0][i] = rc[0][i];
+        for (int r = 1; r < 4; r++) matvec(minv, rc[r], tr_start[r]);
+        HFr acc[3] = {rc[61][0], rc[61][1], rc[61][2]};
+        for (int p = 56; p >= 0; p--) {
+            HFr tmp[3];
+            matvec(minv, acc, tmp);
+            tr_partial[p] = tmp[0];
+            acc[0] = rc[4 + p][0];
+            acc[1] = F.add(tmp[1], rc[4 + p][1]);
+            acc[2] = F.add(tmp[2], rc[4 + p][2]);
+        }
+        matvec(minv, acc, tr_start[4]);
+        for (int r = 0; r < 3; r++) matvec(minv, rc[62 + r], tr_end[r]);
+        // calculate_sparse_matrices: A = M^T; 57 x { A = M' M'' (M' = diag(1, hat(A)), M'' = [[A00, A0*],[w_hat, I]],
+        // w_hat = hat(A)^-1 (A10, A20)^T); sparse = M''^T; A = M^T M' }, reversed; pre_sparse = A^T
+        HFr mt[3][3], a[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) mt[i][j] = a[i][j] = mds[j][i];
+        for (int k = 0; k < 57; k++) {
+            const int p = 56 - k;
+            HFr det = F.sub(F.mul(a[1][1], a[2][2]), F.mul(a[1][2], a[2][1]));
+            if (F.is_zero(det)) { err = "singular MDS minor"; return false; }
+            HFr di = F.inverse(det);
+            HFr hi[2][2] = {{F.mul(a[2][2], di), F.mul(F.sub(F.zero(), a[1][2]), di)},
+                            {F.mul(F.sub(F.zero(), a[2][1]), di), F.mul(a[1][1], di)}};
+            tr_row[p][0] = a[0][0];
+            tr_row[p][1] = F.add(F.mul(hi[0][0], a[1][0]), F.mul(hi[0][1], a[2][0]));
+            tr_row[p][2] = F.add(F.mul(hi[1][0], a[1][0]), F.mul(hi[1][1], a[2][0]));
+            tr_col_hat[p][0] = a[0][1];
+            tr_col_hat[p][1] = a[0][2];
+            HFr prime[3][3] = {{F.one(), F.zero(), F.zero()}, {F.zero(), a[1][1], a[1][2]}, {F.zero(), a[2][1], a[2][2]}};
+            mat_mul(mt, prime, a);
+        }
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) tr_pre[i][j] = a[j][i];
+    }
+
     // ---- self-check: optimised == plain ----
     for (uint64_t t = 0; t < 4; t++) {
         HFr a[3] = {F.from_u64(t * 7919), F.from_u64(t * t + 1), F.mul(cap0, F.from_u64(t + 3))};
@@ -204,8 +311,37 @@ bool HostPoseidon::init(std::string& err) {
             err = "optimised Poseidon schedule disagrees with the plain form";
             return false;
         }
+        HFr c3[3] = {F.from_u64(t * 7919), F.from_u64(t * t + 1), F.mul(cap0, F.from_u64(t + 3))};
+        // permute_spec adds start[0] itself (absorb_with_pre_constants does it in the gadget); the plain form adds
+        // c_0 in round 0, and start[0] == c_0
+        permute_spec(c3);
+        if (!(a[0] == c3[0] && a[1] == c3[1] && a[2] == c3[2])) {
+            err = "halo2-base form of the Poseidon schedule disagrees with the plain form";
+            return false;
+        }
     }
     return true;
+}
+
+void HostPoseidon::fill_trace_consts(dev::TraceConsts& tc) const {
+    for (int i = 0; i < 3; i++) {
+        tc.absorb[0][i] = to_dev(tr_start[0][i]);                                        // two inputs: no padding lane
+        tc.absorb[1][i] = to_dev(i == 2 ? F.add(tr_start[0][i], F.one()) : tr_start[0][i]);   // one input: 1 on lane 2
+        tc.absorb[2][i] = to_dev(i == 1 ? F.add(tr_start[0][i], F.one()) : tr_start[0][i]);   // no input: 1 on lane 1
+    }
+    for (int f = 0; f < 8; f++)
+        for (int i = 0; i < 3; i++)
+            tc.full_c[f][i] = to_dev(f < 4 ? tr_start[f + 1][i] : f < 7 ? tr_end[f - 4][i] : F.zero());
+    for (int p = 0; p < 57; p++) {
+        tc.partial[p] = to_dev(tr_partial[p]);
+        for (int i = 0; i < 3; i++) tc.row[p][i] = to_dev(tr_row[p][i]);
+        for (int i = 0; i < 2; i++) tc.col_hat[p][i] = to_dev(tr_col_hat[p][i]);
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            tc.mats[0][i][j] = to_dev(mds[i][j]);
+            tc.mats[1][i][j] = to_dev(tr_pre[i][j]);
+        }
 }
 
 dev::Fe HostPoseidon::int_to_dev_limbs(const uint8_t le[32]) const {

@@ -18,6 +18,11 @@ struct HostPoseidon {
     HFr sp_row[57][3];
     HFr sp_col[57][2];
     HFr cap0;           // 2^64
+    // halo2-base / pse-poseidon optimised spec, for the witness trace (f1): derived in init() from rc / mds by
+    // the published Spec::new algorithm (calculate_optimized_constants, calculate_sparse_matrices)
+    HFr tr_start[5][3], tr_partial[57], tr_end[3][3];
+    HFr tr_pre[3][3];
+    HFr tr_row[57][3], tr_col_hat[57][2];
 
     // Generates everything and cross-checks the optimised schedule against the plain
     // 65-round form on fixed states; returns false (with a message) on mismatch.
@@ -25,6 +30,8 @@ struct HostPoseidon {
 
     void permute_plain(HFr s[3]) const;
     void permute_opt(HFr s[3]) const;
+    void permute_spec(HFr s[3]) const;      // the same permutation in the tr_* (halo2-base) convention
+    void fill_trace_consts(dev::TraceConsts& tc) const;
     HFr hash2(const HFr& a, const HFr& b) const;
     HFr hash3(const HFr& a, const HFr& b, const HFr& c) const;
 

@@ -1,0 +1,206 @@
+// imt_trace_device.hpp -- f1: the witness trace of halo2-base's
+// PoseidonHasher::hash_fix_len_array, every NEW advice value in assignment order, so that a chip can assign
+// precomputed cells where the reference recomputes each Poseidon on the CPU:
+//   hasher.hash_fix_len_array(ctx, gate, &inp)   /root/reference/src/indexed_merkle_tree.rs:92 (path loop),
+//                                                :194, :271-275, :299-303 (leaf hashes)
+// halo2-base is un-vendored (aerius-labs/halo2-lib, branch feat/secp256k1-hash2curve, Cargo.toml:14); the order
+// restated here is the published halo2-lib v0.4.x gadget (poseidon/hasher/state.rs over gates/flex_gate.rs):
+//
+//   permutation(inputs):
+//     absorb   s0 + c                                    -> 1 row
+//              per input lane: s + in, (s + in) + c      -> 2 rows          (gate.sum of three)
+//              per free lane: s + c (the first one carries the padding 1)   -> 1 row
+//     4 x      per lane x^2, x^4, x * x^4 + c            -> 9 rows          (sbox_full)
+//              per output lane m0 s0, + m1 s1, + m2 s2   -> 9 rows          (apply_mds: gate.inner_product)
+//     57 x     lane 0: x^2, x^4, x * x^4 + c             -> 3 rows          (sbox_part)
+//              r0 s0, + r1 s1, + r2 s2                   -> 3 rows          (apply_sparse_mds, lane 0)
+//              c1 s0 + s1 ; c2 s0 + s2                   -> 2 rows          (lanes 1, 2: gate.mul_add)
+//     4 x      as the first four
+//   hash2 = permutation([a, b]), permutation([])      : 5 + 600 + 3 + 600 = 1208 rows
+//   hash3 = permutation([a, b]), permutation([c])     : 5 + 600 + 4 + 600 = 1209 rows
+//   result = lane 1 of the last apply_mds = row (rows - 4).
+//
+// Parity status: UNPINNED BY THE REFERENCE (no trace vector exists in it, halo2-base cannot be built here).
+// Pinned instead by: the last row equals the hash (reference KAT); every vertical gate a + b c = d of the
+// reconstructed advice column holds (tests); equality with the oracle's independent restatement (oracle/trace.c).
+//
+// Arithmetic: same radix-2^29 / R = 2^261 domain as the hash kernels, but every intermediate is an output, so the
+// lazy tricks of permute() do not apply.  All products use 29-bit quotient digits: for factors below 4p the result
+// is below 16 p^2 / R + p = 1.125 p (+ the addend of the fused forms); sums are brought below ~2.1 p by one
+// conditional subtraction of 2p (red2), so every operand stays below 4p and every stored limb below 2^29.
+// The kernel is bound by its HBM writes (38.7 KB per hash) about as much as by the VALU: DESIGN.md section 6.
+#pragma once
+#include "imt_device.hpp"
+
+namespace imt {
+namespace dev {
+
+// r = a * b / R + addend   (addend may be a wave-uniform constant)
+IMT_HD void t_mul_add(Fe& r, const Fe& a, const Fe& b, const Fe& addend_uniform) {
+#ifdef IMT_MONT_ASM
+    masm::mul_vv_adds_narrow(r, &a, &b, addend_uniform);
+#else
+    mont_dot<1, true, false>(r, &a, &b, addend_uniform);
+#endif
+}
+IMT_HD void t_sqr(Fe& r, const Fe& a) {
+#ifdef IMT_MONT_ASM
+    masm::sqr_v_narrow(r, a);
+#else
+    mont_dot<1, false, false>(r, &a, &a, a);
+#endif
+}
+// c wave-uniform (a __constant__ table entry indexed by the round counter)
+IMT_HD void t_mulc(Fe& r, const Fe& c_uniform, const Fe& v) {
+#ifdef IMT_MONT_ASM
+    masm::mul_uc_narrow(r, &c_uniform, &v);
+#else
+    mont_dot<1, false, false>(r, &c_uniform, &v, v);
+#endif
+}
+IMT_HD void t_mulc_add(Fe& r, const Fe& c_uniform, const Fe& v, const Fe& addend) {
+#ifdef IMT_MONT_ASM
+    masm::mul_uc_add_narrow(r, &c_uniform, &v, addend);
+#else
+    mont_dot<1, true, false>(r, &c_uniform, &v, addend);
+#endif
+}
+
+// a -= 2p if a >= 2p   (normalised limbs, a < 6p)
+IMT_HD void red2(Fe& a) { cond_sub_p_shl<1>(a); }
+
+// x * 2^261 (limbs normalised, value < 4p)  ->  canonical x * 2^256: what halo2curves keeps in memory.
+// Dividing by 2^5 is one 5-bit Montgomery step: p = 1 mod 32, so m = -a mod 32 clears the low five bits.
+IMT_HD void to_mont256_canonical(Fe& y, const Fe& a) {
+    const uint32_t m = (0u - a.v[0]) & 31u;
+    uint32_t t[NL];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        acc += (uint64_t)a.v[i] + (uint64_t)m * p29(i);
+        t[i] = (i < NL - 1) ? ((uint32_t)acc & MASK29) : (uint32_t)acc;
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) y.v[i] = (t[i] >> 5) | ((t[i + 1] & 31u) << 24);
+    y.v[NL - 1] = t[NL - 1] >> 5;
+    cond_sub_p_shl<0>(y);          // (4p + 31p) / 32 < 1.1 p
+}
+
+struct TraceSink {
+    uint8_t* p;              // next row of this hash
+    uint64_t stride;         // bytes from one row to the next
+    unsigned fmt;
+};
+// v: normalised limbs, value < 4p
+IMT_HD void t_emit(const PoseidonConsts& pc, TraceSink& o, const Fe& v) {
+    Fe y;
+    if (o.fmt == FMT_MONT256) {
+        to_mont256_canonical(y, v);
+    } else if (o.fmt == FMT_DEVICE) {
+        y = v;
+        cond_sub_p_shl<1>(y);
+        cond_sub_p_shl<0>(y);
+    } else {
+        mont_dot<1, false, false>(y, &v, &pc.int_one, v);      // v / R + p
+        cond_sub_p_shl<0>(y);
+    }
+    store_packed(o.p, y);
+    o.p += o.stride;
+}
+
+// a + b (both < ~2.1p), normalised and below ~2.2p
+IMT_HD void t_add(Fe& r, const Fe& a, const Fe& b) {
+    add_lazy(r, a, b);
+    normalize(r);
+    red2(r);
+}
+
+// x^5 + c with its three rows
+IMT_HD void t_x5c(const PoseidonConsts& pc, TraceSink& o, Fe& x, const Fe& c_uniform) {
+    Fe x2, x4;
+    t_sqr(x2, x);
+    t_emit(pc, o, x2);
+    t_sqr(x4, x2);
+    t_emit(pc, o, x4);
+    t_mul_add(x, x, x4, c_uniform);      // < 0.04p + p + p
+    red2(x);
+    t_emit(pc, o, x);
+}
+
+// gate.inner_product(s, row): the three running sums are rows
+IMT_HD void t_inner(const PoseidonConsts& pc, TraceSink& o, Fe& r, const Fe* row_uniform, const Fe s[3]) {
+    Fe acc;
+    t_mulc(acc, row_uniform[0], s[0]);
+    t_emit(pc, o, acc);
+    t_mulc_add(acc, row_uniform[1], s[1], acc);      // < 0.04p + 1.2p + p
+    red2(acc);
+    t_emit(pc, o, acc);
+    t_mulc_add(r, row_uniform[2], s[2], acc);
+    red2(r);
+    t_emit(pc, o, r);
+}
+
+// One permutation.  `absorb` = tc.absorb[2 - n_in]; in0 / in1 are read only for n_in >= 1 / 2.
+// Entry: lanes normalised, < 4p.
+IMT_HD void permute_trace(const PoseidonConsts& pc, const TraceConsts& tc, TraceSink& o, Fe s[3], int n_in,
+                          const Fe& in0, const Fe& in1) {
+    const Fe* ab = tc.absorb[2 - n_in];
+    t_add(s[0], s[0], ab[0]);
+    t_emit(pc, o, s[0]);
+    if (n_in >= 1) {
+        t_add(s[1], s[1], in0);
+        t_emit(pc, o, s[1]);
+    }
+    t_add(s[1], s[1], ab[1]);
+    t_emit(pc, o, s[1]);
+    if (n_in >= 2) {
+        t_add(s[2], s[2], in1);
+        t_emit(pc, o, s[2]);
+    }
+    t_add(s[2], s[2], ab[2]);
+    t_emit(pc, o, s[2]);
+#pragma unroll 1
+    for (int st = 0; st < RF + RP; st++) {
+        if (st < RF / 2 || st >= RF / 2 + RP) {
+            const int f = st < RF / 2 ? st : st - RP;
+            t_x5c(pc, o, s[0], tc.full_c[f][0]);
+            t_x5c(pc, o, s[1], tc.full_c[f][1]);
+            t_x5c(pc, o, s[2], tc.full_c[f][2]);
+            const Fe(*mat)[3] = tc.mats[f == RF / 2 - 1 ? 1 : 0];
+            Fe n0, n1, n2;
+            t_inner(pc, o, n0, mat[0], s);
+            t_inner(pc, o, n1, mat[1], s);
+            t_inner(pc, o, n2, mat[2], s);
+            s[0] = n0; s[1] = n1; s[2] = n2;
+        } else {
+            const int p = st - RF / 2;
+            t_x5c(pc, o, s[0], tc.partial[p]);
+            Fe n0;
+            t_inner(pc, o, n0, tc.row[p], s);
+            t_mulc_add(s[1], tc.col_hat[p][0], s[0], s[1]);   // gate.mul_add(s0, col_hat, s_i)
+            red2(s[1]);
+            t_emit(pc, o, s[1]);
+            t_mulc_add(s[2], tc.col_hat[p][1], s[0], s[2]);
+            red2(s[2]);
+            t_emit(pc, o, s[2]);
+            s[0] = n0;
+        }
+    }
+}
+
+// a, b, c: canonical device-form inputs (c only for three).  `three` must be wave-uniform.
+IMT_HD void hash_trace(const PoseidonConsts& pc, const TraceConsts& tc, TraceSink& o, const Fe& a, const Fe& b,
+                       const Fe& c, bool three) {
+    Fe s[3] = {pc.cap0, a, b};
+#pragma unroll
+    for (int i = 0; i < NL; i++) s[1].v[i] = s[2].v[i] = 0;     // PoseidonState::default: [2^64, 0, 0]
+#pragma unroll 1
+    for (int blk = 0; blk < 2; blk++) {
+        const int n_in = blk == 0 ? 2 : (three ? 1 : 0);
+        permute_trace(pc, tc, o, s, n_in, blk == 0 ? a : c, b);
+    }
+}
+
+}  // namespace dev
+}  // namespace imt

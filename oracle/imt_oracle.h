@@ -130,6 +130,24 @@ int orc_insert_leaf(const uint8_t old_root[32], const uint8_t low_leaf[3][32],
                     uint64_t new_leaf_index, const uint8_t *new_proof, const uint8_t *new_helper,
                     int is_new_leaf_largest, size_t depth, orc_insert_trace *trace);
 
+/* ---- f1: cell-by-cell witness trace of halo2-base's PoseidonHasher::hash_fix_len_array (trace.c) ----
+ * The advice column the gadget appends for one hash of `arity` inputs, in assignment order.  A cell is a
+ * constant, a copy of a hash input / of the initial state [2^64, 0, 0] / of an earlier witness, or a NEW witness
+ * (numbered in order: the "trace rows").  gate = 1 where a vertical gate a + b*c = d starts. */
+#define ORC_CELL_CONST 0
+#define ORC_CELL_INPUT 1
+#define ORC_CELL_INIT 2
+#define ORC_CELL_WITNESS 3
+#define ORC_CELL_COPY 4
+typedef struct { uint8_t kind, gate; uint16_t pad; uint32_t index; } orc_trace_cell;
+/* cells [cap][32] / desc [cap] / witness [wcap][32]: any may be NULL; counts are always returned.
+ * out_row = the trace row that is the hash (state[1] after the last permutation). */
+int orc_hash_trace(const uint8_t *in /*[arity][32]*/, int arity, uint8_t *cells, orc_trace_cell *desc, size_t cap,
+                   size_t *n_cells, uint8_t *witness, size_t wcap, size_t *n_witness, uint32_t *out_row);
+/* the optimised spec this file derives (for comparison with the product's own derivation) */
+void orc_trace_spec(uint8_t *start /*[5][3][32]*/, uint8_t *partial /*[57][32]*/, uint8_t *end /*[3][3][32]*/,
+                    uint8_t *pre_sparse /*[9][32]*/, uint8_t *sp_row /*[57][3][32]*/, uint8_t *sp_col_hat /*[57][2][32]*/);
+
 /* ---- indexed-list insertion of the test module (:632-671) */
 /* update_idx_leaf: linear scan, in place on preimages[n][3][32]; returns low idx in *low */
 int orc_update_idx_leaf(uint8_t *preimages, size_t n, const uint8_t new_val[32],

@@ -89,5 +89,33 @@ int main(void) {
     orc_tree_free(tree);
     orc_sparse_free(sp);
     printf(bad ? "SELFTEST FAILED\n" : "SELFTEST OK\n");
+        {   /* f1: every gate of the emitted advice column holds and the output cell is the sponge's hash */
+        static uint8_t cells[6000][32], wit[2000][32];
+        static orc_trace_cell desc[6000];
+        for (int arity = 2; arity <= 3; arity++) {
+            uint8_t in[3][32], want[32];
+            for (int j = 0; j < 3; j++) u64le(in[j], 0x1234567ULL * (uint64_t)(j + 1) + (uint64_t)arity);
+            size_t nc = 0, nw = 0;
+            uint32_t out_row = 0;
+            if (orc_hash_trace(&in[0][0], arity, &cells[0][0], desc, 6000, &nc, &wit[0][0], 2000, &nw, &out_row)) {
+                printf("FAIL: orc_hash_trace\n"); bad = 1; continue;
+            }
+            orc_hash_var(want, &in[0][0], (size_t)arity);
+            if (memcmp(wit[out_row], want, 32)) { printf("FAIL: trace output != sponge (arity %d)\n", arity); bad = 1; }
+            size_t gates = 0;
+            for (size_t i = 0; i + 3 < nc; i++) {
+                if (!desc[i].gate) continue;
+                ofr_t a, b, c, d, t;
+                ofr_from_bytes(&a, cells[i]); ofr_from_bytes(&b, cells[i + 1]);
+                ofr_from_bytes(&c, cells[i + 2]); ofr_from_bytes(&d, cells[i + 3]);
+                ofr_mul(&t, &b, &c);
+                ofr_add(&t, &t, &a);
+                if (!ofr_eq(&t, &d)) { printf("FAIL: gate at cell %zu (arity %d)\n", i, arity); bad = 1; break; }
+                gates++;
+            }
+            printf("trace arity %d: %zu cells, %zu witnesses, %zu gates, out row %u\n", arity, nc, nw, gates, out_row);
+            if (nw != (arity == 2 ? 1208u : 1209u) || nc != (arity == 2 ? 4506u : 4509u)) { printf("FAIL: trace size\n"); bad = 1; }
+        }
+    }
     return bad;
 }

@@ -32,11 +32,16 @@ def emul():
     import ctypes
     so = os.path.join(ROOT, "tests", "native", "libemul.so")
     csrc = os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc")
-    srcs = [os.path.join(ROOT, "tests", "native", "emul_device.cpp"), os.path.join(csrc, "imt_params.cpp")]
+    srcs = [os.path.join(ROOT, "tests", "native", "emul_device.cpp"), os.path.join(csrc, "imt_params.cpp"),
+            os.path.join(csrc, "imt_trace_layout.cpp")]
     deps = srcs + [os.path.join(csrc, f) for f in ("imt_device.hpp", "imt_consts.hpp", "imt_sweep.hpp",
-                                                    "imt_params.hpp", "imt_fr_host.hpp", "imt_prep_logic.hpp")]
+                                                    "imt_params.hpp", "imt_fr_host.hpp", "imt_prep_logic.hpp",
+                                                    "imt_trace_device.hpp", "imt_ctx.hpp")] + [
+        os.path.join(ROOT, "include", "imt.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", csrc, "-o", so] + srcs, ROOT)
+        # imt_trace_layout.cpp sees the context struct, hence the HIP *headers* (types only; nothing of HIP is linked)
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", csrc, "-I", "/opt/rocm/include",
+              "-D__HIP_PLATFORM_AMD__", "-o", so] + srcs, ROOT)
     lib = ctypes.CDLL(so)
     assert lib.emul_init() == 0
     return lib

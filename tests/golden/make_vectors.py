@@ -10,6 +10,9 @@ cannot run here, so the fixture has three provenance classes, recorded per entry
                    constants and MDS, t=3, R_F=8, R_P=57) applied to [0,a,b].  They pin the
                    permutation independently of the reference's own known answer, which in turn pins
                    the sponge around it (capacity 2^64, padding, output lane 1).
+  "oracle-trace"   f1: digests and checkpoints of the witness trace of hash_fix_len_array as oracle/trace.c
+                   restates halo2-base's gadget -- UNPINNED by the reference (its output row is pinned: it is the
+                   hash); kept so that a change of the trace order or of the spec derivation is noticed
 Run from the repo root:  python tests/golden/make_vectors.py
 """
 import json
@@ -70,6 +73,18 @@ for i in range(0, 24, 3):
 for i in range(24, 36, 3):
     add("permute", vals[i:i + 3], 0, "oracle")
     vec["entries"][-1]["out"] = [str(x) for x in O.permute(vals[i:i + 3])]
+# f1: witness traces (sha256 over the rows as canonical 32-byte little-endian, plus a few rows verbatim)
+import hashlib  # noqa: E402
+vec["hash_trace"] = []
+for xs in ([0, 0, 0], [1, 2], [1, 2, 3], vals[36:38], vals[38:41]):
+    t = O.hash_trace(xs)
+    w = t["witness"]
+    rows = [0, 1, 4, 5, 23, 604, 605, 608, len(w) - 9, t["out_row"], len(w) - 1]
+    vec["hash_trace"].append(dict(**{"in": [str(x) for x in xs]}, n_cells=int(len(t["cells"])), n_rows=int(len(w)),
+                                  out_row=int(t["out_row"]), sha256_rows=hashlib.sha256(w.tobytes()).hexdigest(),
+                                  sha256_cells=hashlib.sha256(t["cells"].tobytes()).hexdigest(),
+                                  rows={str(r): str(int.from_bytes(w[r].tobytes(), "little")) for r in rows},
+                                  provenance="oracle-trace"))
 h = O.sparse_new(32, 64)
 run = []
 for v in oracle_lib.synth_values(40, 0x494D5402):

@@ -3,6 +3,7 @@
 // Montgomery code, the optimised Poseidon schedule and the index kernels' per-element
 // logic with the oracle on a machine without a GPU.  Not part of the shipped library.
 #include "imt_device.hpp"
+#include "imt_trace_device.hpp"
 #include "imt_params.hpp"
 #include <cstring>
 #include <string>
@@ -10,6 +11,7 @@
 using namespace imt;
 static HostPoseidon* g_hp;
 static dev::PoseidonConsts g_consts;
+static dev::TraceConsts g_tconsts;
 
 extern "C" int emul_init(void) {
     if (g_hp) return 0;
@@ -17,6 +19,7 @@ extern "C" int emul_init(void) {
     std::string err;
     if (!g_hp->init(err)) return -1;
     g_hp->fill_consts(g_consts);
+    g_hp->fill_trace_consts(g_tconsts);
     return 0;
 }
 extern "C" int emul_consts_size(void) { return (int)sizeof(dev::PoseidonConsts); }
@@ -92,4 +95,28 @@ extern "C" uint32_t emul_nsr(const uint32_t* st, uint32_t n, int levels, uint32_
 }
 extern "C" uint32_t emul_count_below(const uint8_t* val, const uint32_t* sorted, uint32_t M, const uint8_t* x) {
     return imt::prep::count_below(val, sorted, M, x);
+}
+
+// ---- f1: the witness-trace device code (imt_trace_device.hpp) on the host: rows [n_rows][32] in fmt_out ----
+extern "C" int emul_hash_trace(const uint8_t* in, int arity, uint8_t* rows, unsigned fmt_in, unsigned fmt_out) {
+    dev::Fe a, b, c;
+    bool ok = dev::load_fe(g_consts, a, in, fmt_in);
+    ok &= dev::load_fe(g_consts, b, in + 32, fmt_in);
+    c = a;
+    if (arity == 3) ok &= dev::load_fe(g_consts, c, in + 64, fmt_in);
+    dev::TraceSink o{rows, 32, fmt_out};
+    dev::hash_trace(g_consts, g_tconsts, o, a, b, c, arity == 3);
+    return ok ? (int)((o.p - rows) / 32) : -5;
+}
+// the product's cell layout (imt_trace_layout.cpp) without a GPU: a context that only carries the tables
+#include "imt_ctx.hpp"
+extern "C" int emul_trace_layout(int arity, imt_trace_cell* cells, size_t cells_cap, size_t* n_cells, void* constants,
+                                 size_t const_cap, size_t* n_constants, uint32_t* out_row, unsigned flags) {
+    static imt_ctx* fake = nullptr;
+    if (!fake) {
+        fake = new imt_ctx();
+        std::string err;
+        if (!fake->hp.init(err)) return -12;
+    }
+    return imt_hash_trace_layout(fake, arity, cells, cells_cap, n_cells, constants, const_cap, n_constants, out_row, flags);
 }

@@ -25,6 +25,10 @@ class InsertTrace(ctypes.Structure):
                                                    "interim_root", "zero_slot_root", "new_leaf_hash", "new_root")]
 
 
+class TraceCell(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint8), ("gate", ctypes.c_uint8), ("pad", ctypes.c_uint16), ("index", ctypes.c_uint32)]
+
+
 class Oracle:
     def __init__(self, lib):
         self.lib = lib
@@ -66,6 +70,23 @@ class Oracle:
         out = np.empty((depth + 1, 32), dtype=np.uint8)
         self.lib.orc_zero_hashes(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(depth))
         return out
+
+    # ---- f1: cell-by-cell witness trace of hash_fix_len_array (oracle/trace.c) ----
+    def hash_trace(self, xs):
+        """dict(cells uint8 [nc,32], kind/gate/index uint arrays [nc], witness uint8 [nw,32], out_row)"""
+        cap, wcap = 6000, 2000
+        cells = np.empty((cap, 32), np.uint8)
+        desc = (TraceCell * cap)()
+        wit = np.empty((wcap, 32), np.uint8)
+        nc, nw, row = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_uint32()
+        rc = self.lib.orc_hash_trace(b"".join(b32(x) for x in xs), len(xs), cells.ctypes.data_as(ctypes.c_void_p), desc,
+                                     ctypes.c_size_t(cap), ctypes.byref(nc), wit.ctypes.data_as(ctypes.c_void_p),
+                                     ctypes.c_size_t(wcap), ctypes.byref(nw), ctypes.byref(row))
+        assert rc == 0, rc
+        d = np.frombuffer(bytes(desc), dtype=np.dtype([("kind", "u1"), ("gate", "u1"), ("pad", "<u2"), ("index", "<u4")]))
+        d = d[:nc.value]
+        return dict(cells=cells[:nc.value].copy(), kind=d["kind"].copy(), gate=d["gate"].copy(), index=d["index"].copy(),
+                    witness=wit[:nw.value].copy(), out_row=row.value)
 
     # ---- dense tree (src/utils.rs) ----
     def tree_new(self, leaves_arr):
@@ -207,7 +228,8 @@ def load():
     if _cached is not None:
         return _cached
     so = os.path.join(ODIR, "liboracle.so")
-    srcs = [os.path.join(ODIR, f) for f in ("fr.c", "poseidon.c", "tree.c", "indexed.c", "sparse.c", "imt_oracle.h")]
+    srcs = [os.path.join(ODIR, f) for f in ("fr.c", "poseidon.c", "tree.c", "indexed.c", "sparse.c", "trace.c",
+                                            "imt_oracle.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         r = subprocess.run(["make", "-C", ODIR, "liboracle.so"], capture_output=True, text=True)
         if r.returncode != 0:

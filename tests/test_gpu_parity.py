@@ -649,6 +649,95 @@ def test_combine_subtree_roots(imt, ctx, oracle):
     oracle.tree_free(ot)
 
 
+# ---------------------------------------------------------------- f1: witness trace
+def test_hash_trace_vs_oracle_formats_and_layouts(imt, ctx, oracle):
+    """imt_hash_trace_batch against oracle/trace.c on the golden inputs and random ones: every row, all three
+    formats, both layouts, ragged batch sizes; the output row equals imt_hash2/3_batch; the column rebuilt from the
+    product's own layout satisfies every vertical gate."""
+    R256, R261 = (1 << 256) % P, (1 << 261) % P
+    for arity in (2, 3):
+        gold = [[int(x) for x in g["in"]] for g in GOLD["hash_trace"] if len(g["in"]) == arity]
+        rnd = oracle_lib.synth_values(3 * 70, 0x494D5460 + arity)
+        items = gold + [[0] * arity, [P - 1] * arity] + [rnd[i * arity:(i + 1) * arity] for i in range(70)]
+        inp = np.stack([imt.to_bytes(x) for x in items])
+        want = [ints(oracle.hash_trace(x)["witness"]) for x in items]
+        rows = 1208 if arity == 2 else 1209
+        tr = ctx.hash_trace(inp)
+        assert tr.shape == (rows, len(items), 32)
+        for i in range(len(items)):
+            assert ints(tr[:, i]) == want[i], (arity, i)
+        hashes = ctx.hash2(inp) if arity == 2 else ctx.hash3(inp)
+        assert (tr[rows - 4] == hashes).all()
+        for n in (1, 63, 65):                                   # ragged: partial waves
+            assert (ctx.hash_trace(inp[:n]) == tr[:, :n]).all()
+        tim = ctx.hash_trace(inp, item_major=True)
+        assert tim.shape == (len(items), rows, 32) and (tim.transpose(1, 0, 2) == tr).all()
+        # the format applies to inputs and rows alike: MONT256 = halo2curves' in-memory x * 2^256, DEVICE = x * 2^261
+        for fmt, r in ((1, R256), (2, R261)):
+            inp_f = imt.to_bytes([[(v * r) % P for v in x] for x in items[:6]])
+            got = ctx.hash_trace(inp_f, fmt=fmt)
+            for i in range(6):
+                assert ints(got[:, i]) == [(v * r) % P for v in want[i]], (arity, fmt, i)
+        cells, consts, out_row = ctx.hash_trace_layout(arity)
+        assert out_row == rows - 4
+        for i in (0, len(items) - 1):
+            col = imt.rebuild_advice_column(cells, consts, items[i], tr[:, i])
+            assert imt.check_vertical_gates(cells, col) == rows
+            assert col == ints(oracle.hash_trace(items[i])["cells"])
+    for g in GOLD["hash_trace"]:                                # the committed digests, through the GPU
+        import hashlib
+        xs = [int(x) for x in g["in"]]
+        t = ctx.hash_trace(np.stack([imt.to_bytes(xs)]))[:, 0]
+        assert hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest() == g["sha256_rows"]
+    bad = imt.to_bytes([[1, 2]]).copy()
+    bad[0, 1] = 0xff                                            # >= p
+    with pytest.raises(imt.ImtError):
+        ctx.hash_trace(bad)
+
+
+def test_path_trace_is_the_trace_of_every_hash_on_the_path(imt, ctx, oracle):
+    """imt_path_trace_batch = leaf-hash trace + one hash2 trace per level with the (left, right) inputs dual_mux
+    selects (src/indexed_merkle_tree.rs:47-63,78-96); checked against the oracle hash by hash."""
+    depth, n = 5, 9
+    rng = random.Random(11)
+    leaf3 = [[rng.randrange(P) for _ in range(3)] for _ in range(n)]
+    sib = [[rng.randrange(P) for _ in range(n)] for _ in range(depth)]
+    index = [rng.randrange(1 << depth) for _ in range(n)]
+    tr, roots = ctx.path_trace(index, imt.to_bytes(sib), depth, leaf3=imt.to_bytes(leaf3))
+    assert tr.shape == (1209 + depth * 1208, n, 32)
+    for i in range(n):
+        t = oracle.hash_trace(leaf3[i])
+        assert ints(tr[:1209, i]) == ints(t["witness"])
+        cur, off = oracle.hash(leaf3[i]), 1209
+        for l in range(depth):
+            pair = [sib[l][i], cur] if (index[i] >> l) & 1 else [cur, sib[l][i]]
+            assert ints(tr[off:off + 1208, i]) == ints(oracle.hash_trace(pair)["witness"]), (i, l)
+            cur = oracle.hash(pair)
+            off += 1208
+        assert ints(roots[i]) == [cur]
+    tim, _ = ctx.path_trace(index, imt.to_bytes(sib), depth, leaf3=imt.to_bytes(leaf3), item_major=True)
+    assert (tim.transpose(1, 0, 2) == tr).all()
+    leaf = [rng.randrange(P) for _ in range(n)]
+    tr2, roots2 = ctx.path_trace(index, imt.to_bytes(sib), depth, leaf=imt.to_bytes(leaf))
+    assert tr2.shape == (depth * 1208, n, 32)
+    assert ints(roots2) == [oracle.path_root(leaf[i], index[i], imt.to_bytes([sib[l][i] for l in range(depth)])) for i in range(n)]
+
+
+def test_hash_trace_2pow14_properties(imt, ctx):
+    """2^14 traces in one launch (634 MB of rows): the output row of every item equals imt_hash2_batch, and sampled
+    items satisfy every gate of the rebuilt column."""
+    n = 1 << 14
+    rng = np.random.default_rng(5)
+    inp = rng.integers(0, 256, size=(n, 2, 32), dtype=np.uint8)
+    inp[:, :, 31] &= 0x0f
+    tr = ctx.hash_trace(inp)
+    assert (tr[1204] == ctx.hash2(inp)).all()
+    cells, consts, _ = ctx.hash_trace_layout(2)
+    for i in (0, 4097, n - 1):
+        col = imt.rebuild_advice_column(cells, consts, ints(inp[i]), tr[:, i])
+        assert imt.check_vertical_gates(cells, col) == 1208
+
+
 # ---------------------------------------------------------------- BASELINE-size properties
 def test_config2_full_size_properties(imt, ctx, oracle):
     """depth 32, 2^16 insertions (BASELINE config 2), checked through size-independent properties:

@@ -134,7 +134,10 @@ def test_generated_assembly_header_is_current(tmp_path):
     assert out.read_text() == committed
     blocks = committed.split("__device__ __forceinline__ void ")[1:]
     want = {"mul_vv": 81 + 81, "sqr_v": 45 + 81, "dot3_uc": 243 + 81, "dot4_uc": 324 + 81,
-            "dot2_add_uc_narrow": 162 + 81 + 8}
+            "dot2_add_uc_narrow": 162 + 81 + 8,
+            # the witness-trace kernel's one-product forms; "+ 8": the addend limbs enter as mad(e, 1)
+            "sqr_v_narrow": 45 + 81, "mul_vv_adds_narrow": 81 + 81 + 8, "mul_uc_narrow": 81 + 81,
+            "mul_uc_add_narrow": 81 + 81 + 8}
     for b in blocks:
         name = b.split("(")[0]
         assert b.count('"v_mad_u64_u32') == want[name]

@@ -1,0 +1,112 @@
+"""CPU: f1, the witness trace of halo2-base's PoseidonHasher::hash_fix_len_array
+(/root/reference/src/indexed_merkle_tree.rs:92,194,271-275,299-303 call it; the gadget is un-vendored).
+
+Three restatements are compared with each other and with what little the reference pins:
+  oracle/trace.c             C, derives the optimised spec from the plain Grain constants itself, emits the whole column
+  csrc/imt_trace_device.hpp  the product's device code (host build, tests/native), emits the new values only
+  csrc/imt_trace_layout.cpp  the product's cell map
+Pins: the output row is the hash (reference KAT for [0,0,0]); every vertical gate of every column holds."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from oracle_lib import P, KAT_ZERO
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "vectors.json")))
+R256 = (1 << 256) % P
+R261 = (1 << 261) % P
+CASES = [[0, 0, 0], [1, 2], [1, 2, 3], [P - 1, P - 2], [P - 1, 0, P - 1], [1 << 64, 0]]
+
+
+def _ints(a):
+    return [int.from_bytes(x.tobytes(), "little") for x in np.asarray(a, np.uint8).reshape(-1, 32)]
+
+
+def _api():
+    """the Python helpers of the product package without loading libimt_hip.so's GPU side: pure functions only"""
+    import imt_amd
+    return imt_amd
+
+
+def test_oracle_trace_output_is_the_hash_and_every_gate_holds(oracle):
+    cases = CASES + [oracle_lib.synth_values(3, 77)[:k] for k in (2, 3)]
+    for xs in cases:
+        t = oracle.hash_trace(xs)
+        w = _ints(t["witness"])
+        assert len(w) == (1208 if len(xs) == 2 else 1209) and len(t["cells"]) == (4506 if len(xs) == 2 else 4509)
+        assert t["out_row"] == len(w) - 4
+        assert w[t["out_row"]] == oracle.hash(xs)                       # = the plain 65-round sponge
+        col = _ints(t["cells"])
+        gates = 0
+        for i in np.nonzero(t["gate"])[0]:
+            assert (col[i] + col[i + 1] * col[i + 2] - col[i + 3]) % P == 0, (xs, i)
+            gates += 1
+        assert gates == len(w)                                           # every new value is the d of exactly one gate
+        # witness cells appear in order and carry the trace rows; copies repeat an EARLIER row
+        wi = [int(j) for k, j in zip(t["kind"], t["index"]) if k == 3]
+        assert wi == list(range(len(w)))
+        seen = -1
+        for k, j, v in zip(t["kind"], t["index"], col):
+            if k == 3:
+                seen = int(j)
+            if k == 4:
+                assert int(j) <= seen and v == w[int(j)]
+    assert _ints(oracle.hash_trace([0, 0, 0])["witness"])[1205] == KAT_ZERO      # reference :247-250
+
+
+def test_trace_golden_digests(oracle):
+    for g in GOLD["hash_trace"]:
+        xs = [int(x) for x in g["in"]]
+        t = oracle.hash_trace(xs)
+        assert hashlib.sha256(t["witness"].tobytes()).hexdigest() == g["sha256_rows"]
+        assert hashlib.sha256(t["cells"].tobytes()).hexdigest() == g["sha256_cells"]
+        w = _ints(t["witness"])
+        for r, v in g["rows"].items():
+            assert w[int(r)] == int(v)
+
+
+def _emul_trace(emul, xs, fmt_out):
+    rows = 1208 if len(xs) == 2 else 1209
+    out = np.zeros((rows + 2, 32), np.uint8)
+    n = emul.emul_hash_trace(b"".join(oracle_lib.b32(x) for x in xs), len(xs), out.ctypes.data_as(ctypes.c_void_p), 0, fmt_out)
+    assert n == rows
+    return out[:rows]
+
+
+def test_product_trace_code_equals_oracle_in_every_format(oracle, emul):
+    """imt_trace_device.hpp (host build of the same source the kernel compiles) against oracle/trace.c.  Format 1 is
+    what a Rust chip transmutes into Fr: x * 2^256 mod p; format 2 the library's own x * 2^261 mod p."""
+    for xs in CASES + [oracle_lib.synth_values(3, 78)[:k] for k in (2, 3)] + [[int(x) for x in g["in"]] for g in GOLD["hash_trace"]]:
+        want = _ints(oracle.hash_trace(xs)["witness"])
+        assert _ints(_emul_trace(emul, xs, 0)) == want
+        assert _ints(_emul_trace(emul, xs, 1)) == [(v * R256) % P for v in want]
+        assert _ints(_emul_trace(emul, xs, 2)) == [(v * R261) % P for v in want]
+
+
+@pytest.mark.parametrize("arity", [2, 3])
+def test_product_cell_layout_equals_oracle_and_rebuilds_a_satisfied_column(oracle, emul, arity):
+    imt = _api()
+    emul.emul_trace_layout.restype = ctypes.c_int
+    cells, consts, out_row = imt.trace_layout(lambda *a: emul.emul_trace_layout(*a), arity, 0,
+                                              lambda rc: (_ for _ in ()).throw(AssertionError(rc)) if rc else None)
+    xs = oracle_lib.synth_values(3, 79)[:arity]
+    t = oracle.hash_trace(xs)
+    assert out_row == t["out_row"] and len(cells) == len(t["cells"])
+    assert (cells["gate"] == t["gate"]).all() and (cells["kind"] == t["kind"]).all()
+    nonconst = cells["kind"] != imt._ffi.CELL_CONST
+    assert (cells["index"][nonconst] == t["index"][nonconst]).all()
+    # the column a chip would assign from the product's own trace + layout + constants equals the oracle's, cell by cell
+    col = imt.rebuild_advice_column(cells, consts, xs, _emul_trace(emul, xs, 0))
+    assert col == _ints(t["cells"])
+    assert imt.check_vertical_gates(cells, col) == (1208 if arity == 2 else 1209)
+    assert col[[i for i, c in enumerate(cells) if c["kind"] == 3 and c["index"] == out_row][0]] == oracle.hash(xs)
+    # the constants in Rust's in-memory form
+    _, consts_m, _ = imt.trace_layout(lambda *a: emul.emul_trace_layout(*a), arity, 1, lambda rc: None)
+    assert _ints(consts_m) == [(v * R256) % P for v in _ints(consts)]
+    assert len(set(_ints(consts))) == len(consts) < 420          # de-duplicated table

@@ -31,9 +31,9 @@ ACC_LO = "v38"
 MASK = "0x1fffffff"
 
 
-def gen(name, nt, a_kind, add, wide, sqr=False, doc=""):
+def gen(name, nt, a_kind, add, wide, sqr=False, doc="", add_kind="v"):
     """a_kind: 's' = the first factor of every term is a wave-uniform constant held in SGPRs,
-    'v' = per-lane values.  The second factor is always per-lane."""
+    'v' = per-lane values.  The second factor is always per-lane.  add_kind: the same for the addend."""
     lines = []
     ops_out = ["[r%d] \"=&v\"(r%d)" % (j, j) for j in range(NL)]
     ops_in = []
@@ -50,7 +50,7 @@ def gen(name, nt, a_kind, add, wide, sqr=False, doc=""):
                 ops_in.append("[b%d_%d] \"v\"(b[%d].v[%d])" % (t, i, t, i))
     if add:
         for i in range(NL):
-            ops_in.append("[e%d] \"v\"(addend.v[%d])" % (i, i))
+            ops_in.append("[e%d] \"%s\"(addend.v[%d])" % (i, add_kind, i))
     for i in range(NL):
         ops_in.append("[p%d] \"s\"(p29(%d))" % (i, i))
     ops_in.append("[n0] \"s\"(N0INV32)")
@@ -94,7 +94,8 @@ def gen(name, nt, a_kind, add, wide, sqr=False, doc=""):
         if k < 2 * NL - 2 or add:
             lines.append("v_lshrrev_b64 %s, 29, %s" % (ACC, ACC))
     if add:
-        lines.append("v_add_u32_e32 %%[r%d], %s, %%[e%d]" % (NL - 1, ACC_LO, NL - 1))
+        # the addend first: src0 of a VOP2 may be an SGPR (uniform addend), src1 must be a VGPR
+        lines.append("v_add_u32_e32 %%[r%d], %%[e%d], %s" % (NL - 1, NL - 1, ACC_LO))
     else:   # low word of (acc >> 29) straight into the top limb
         lines.append("v_alignbit_b32 %%[r%d], %s, %s, 29" % (NL - 1, "v39", ACC_LO))
 
@@ -156,6 +157,13 @@ def main():
     body.append(gen("dot4_uc", 4, "s", False, True, doc="r = sum_{t<4} a[t]*b[t] / R, a uniform constants, wide digits"))
     body.append(gen("dot2_add_uc_narrow", 2, "s", True, False,
                     doc="r = (sum_{t<2} a[t]*b[t] + addend*R) / R, a uniform constants, 29-bit digits: r < .../R + addend + p"))
+    # the witness-trace kernel (imt_trace_device.hpp): one product per emitted value, 29-bit digits throughout
+    body.append(gen("sqr_v_narrow", 1, "v", False, False, sqr=True, doc="r = a^2 / R, 29-bit digits: r < a^2/R + p"))
+    body.append(gen("mul_vv_adds_narrow", 1, "v", True, False, add_kind="s",
+                    doc="r = (a[0]*b[0] + addend*R) / R, addend a uniform constant, 29-bit digits"))
+    body.append(gen("mul_uc_narrow", 1, "s", False, False, doc="r = a[0]*b[0] / R, a a uniform constant, 29-bit digits"))
+    body.append(gen("mul_uc_add_narrow", 1, "s", True, False,
+                    doc="r = (a[0]*b[0] + addend*R) / R, a a uniform constant, addend per lane, 29-bit digits"))
     body.append(FOOTER)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "indexed-merkle-tree-halo2_amd", "csrc", "imt_mont_asm.hpp")
