@@ -1,0 +1,206 @@
+//! Circuit side.
+//!
+//! The reference's gadget recomputes every Poseidon on the CPU while it assigns:
+//! `hasher.hash_fix_len_array(ctx, gate, &inp)` at `src/indexed_merkle_tree.rs:92` (inside the path loop `:90-93`),
+//! `:194`, `:271-275`, `:299-303` -- 3 + 4 d hashes per `insert_leaf`.  [`TracedPoseidonHasher`] has the same method
+//! and lays down the SAME cells (same gates, same copy constraints, same constants), but takes every new value
+//! from a witness trace the GPU produced (`imt_path_trace_batch` / `imt_hash_trace_batch`) instead of computing it.
+//! To use it, the reference's private helpers only change the TYPE of their `hasher` parameter (or become generic
+//! over [`FixLenHasher`], which both hashers implement) -- see INTEGRATION.md.
+//!
+//! [`IndexedMerkleTreeChip`] is the optional sugar `north_star` names: the reference has no chip struct, only the
+//! free functions `insert_leaf` (`:231`) and `verify_non_inclusion` (`:127`).
+
+use crate::ffi::{imt_trace_cell, IMT_CELL_CONST, IMT_CELL_COPY, IMT_CELL_INIT, IMT_CELL_INPUT, IMT_CELL_WITNESS};
+use crate::gpu::{self, InsertWitness};
+use halo2_base::gates::GateInstructions;
+use halo2_base::poseidon::hasher::PoseidonHasher;
+use halo2_base::utils::BigPrimeField;
+use halo2_base::QuantumCell::{Constant, Existing, Witness};
+use halo2_base::{AssignedValue, Context};
+use std::cell::RefCell;
+use std::collections::VecDeque;
+
+/// What `compute_merkle_root` & co. need from a hasher (`PoseidonHasher::hash_fix_len_array`'s signature).
+pub trait FixLenHasher<F: BigPrimeField> {
+    fn hash_fix_len_array(
+        &self,
+        ctx: &mut Context<F>,
+        gate: &impl GateInstructions<F>,
+        inputs: &[AssignedValue<F>],
+    ) -> AssignedValue<F>;
+}
+
+impl<F: BigPrimeField, const T: usize, const RATE: usize> FixLenHasher<F> for PoseidonHasher<F, T, RATE> {
+    fn hash_fix_len_array(&self, ctx: &mut Context<F>, gate: &impl GateInstructions<F>, inputs: &[AssignedValue<F>]) -> AssignedValue<F> {
+        PoseidonHasher::hash_fix_len_array(self, ctx, gate, inputs)
+    }
+}
+
+/// One arity's static cell map.
+pub struct TraceLayout<F> {
+    pub cells: Vec<imt_trace_cell>,
+    pub constants: Vec<F>,
+    pub out_row: usize,
+    pub rows: usize,
+}
+
+/// Assigns precomputed traces.  Traces are queued in the order the circuit will ask for them (one `Vec<F>` of 1208 /
+/// 1209 rows per hash); `init_state` are the hasher's three initial-state cells ([2^64, 0, 0], loaded once with
+/// `ctx.load_constant`, exactly what `PoseidonHasher::initialize_consts` does at `:442`).
+pub struct TracedPoseidonHasher<F: BigPrimeField> {
+    layout2: TraceLayout<F>,
+    layout3: TraceLayout<F>,
+    init_state: [AssignedValue<F>; 3],
+    queue: RefCell<VecDeque<Vec<F>>>,
+}
+
+impl<F: BigPrimeField> TracedPoseidonHasher<F> {
+    pub fn new(ctx: &mut Context<F>) -> Self {
+        let mk = |arity: usize| {
+            let (cells, constants, out_row) = gpu::trace_layout::<F>(arity).expect("imt_hash_trace_layout");
+            let rows = cells.iter().filter(|c| c.kind == IMT_CELL_WITNESS).count();
+            TraceLayout { cells, constants, out_row, rows }
+        };
+        let init_state = [
+            ctx.load_constant(F::from_u128(1u128 << 64)),
+            ctx.load_constant(F::ZERO),
+            ctx.load_constant(F::ZERO),
+        ];
+        TracedPoseidonHasher { layout2: mk(2), layout3: mk(3), init_state, queue: RefCell::new(VecDeque::new()) }
+    }
+
+    /// Queue traces in call order.  `rows` may hold several hashes back to back (what `gpu::path_traces` returns
+    /// per item): it is split by the row counts of `arities`.
+    pub fn push_traces(&self, rows: &[F], arities: &[usize]) {
+        let mut off = 0;
+        let mut q = self.queue.borrow_mut();
+        for &a in arities {
+            let n = if a == 3 { self.layout3.rows } else { self.layout2.rows };
+            q.push_back(rows[off..off + n].to_vec());
+            off += n;
+        }
+        assert_eq!(off, rows.len(), "trace length does not match the hash sequence");
+    }
+
+    pub fn pending(&self) -> usize {
+        self.queue.borrow().len()
+    }
+}
+
+impl<F: BigPrimeField> FixLenHasher<F> for TracedPoseidonHasher<F> {
+    /// Cell for cell what `PoseidonHasher::hash_fix_len_array` assigns, region by region (a region = one
+    /// `ctx.assign_region` call of the original gadget: a `gate.add` / `sum` / `mul` / `mul_add` / `inner_product`).
+    fn hash_fix_len_array(&self, ctx: &mut Context<F>, _gate: &impl GateInstructions<F>, inputs: &[AssignedValue<F>]) -> AssignedValue<F> {
+        let layout = match inputs.len() {
+            2 => &self.layout2,
+            3 => &self.layout3,
+            n => panic!("no trace layout for {n} inputs"),
+        };
+        let rows = self.queue.borrow_mut().pop_front().expect("no precomputed trace queued for this hash");
+        assert_eq!(rows.len(), layout.rows);
+        let mut assigned: Vec<Option<AssignedValue<F>>> = vec![None; layout.rows];
+        let cells = &layout.cells;
+        let mut a = 0usize;
+        while a < cells.len() {
+            let mut b = a + 1;
+            while b < cells.len() && cells[b].region == 0 {
+                b += 1;
+            }
+            let region = &cells[a..b];
+            let quantum = region.iter().map(|c| match c.kind {
+                IMT_CELL_CONST => Constant(layout.constants[c.index as usize]),
+                IMT_CELL_INPUT => Existing(inputs[c.index as usize]),
+                IMT_CELL_INIT => Existing(self.init_state[c.index as usize]),
+                IMT_CELL_WITNESS => Witness(rows[c.index as usize]),
+                IMT_CELL_COPY => Existing(assigned[c.index as usize].expect("copy of a row that is not assigned yet")),
+                k => panic!("unknown cell kind {k}"),
+            });
+            let gates = region.iter().enumerate().filter(|(_, c)| c.gate == 1).map(|(i, _)| i as isize);
+            let start = ctx.advice.len();
+            ctx.assign_region(quantum.collect::<Vec<_>>(), gates.collect::<Vec<_>>());
+            for (i, c) in region.iter().enumerate() {
+                if c.kind == IMT_CELL_WITNESS {
+                    assigned[c.index as usize] = Some(ctx.get((start + i) as isize));
+                }
+            }
+            a = b;
+        }
+        assigned[layout.out_row].unwrap()
+    }
+}
+
+/// insert / update / non-membership in one object (the names `north_star` uses).  `assign_insert` loads one
+/// [`InsertWitness`] into the circuit and calls the reference's own `insert_leaf` through the closure the caller
+/// passes (the function is private to the reference's module, `src/indexed_merkle_tree.rs:231`), with a
+/// [`TracedPoseidonHasher`] primed with the 3 + 4 d traces of that insertion.
+pub struct IndexedMerkleTreeChip {
+    pub tree: gpu::IndexedTree,
+}
+
+/// the assigned cells `insert_leaf` takes, in its argument order (`:235-244`)
+pub struct AssignedInsert<F: BigPrimeField> {
+    pub old_root: AssignedValue<F>,
+    pub low_leaf: [AssignedValue<F>; 3],
+    pub low_leaf_proof: Vec<AssignedValue<F>>,
+    pub low_leaf_proof_helper: Vec<AssignedValue<F>>,
+    pub new_root: AssignedValue<F>,
+    pub new_leaf: [AssignedValue<F>; 3],
+    pub new_leaf_index: AssignedValue<F>,
+    pub new_leaf_proof: Vec<AssignedValue<F>>,
+    pub new_leaf_proof_helper: Vec<AssignedValue<F>>,
+    pub is_new_leaf_largest: AssignedValue<F>,
+}
+
+impl IndexedMerkleTreeChip {
+    pub fn new(depth: usize, capacity: u64) -> Self {
+        IndexedMerkleTreeChip { tree: gpu::IndexedTree::new(depth, capacity).expect("imt_itree_new") }
+    }
+
+    /// n insertions on the GPU: the witnesses `insert_leaf` takes, one per value
+    pub fn insert<F: BigPrimeField>(&mut self, vals: &[F]) -> Vec<InsertWitness<F>> {
+        self.tree.insert_batch(vals).expect("imt_itree_insert_batch")
+    }
+
+    /// The four `compute_merkle_root` calls of `insert_leaf`, in its order: low leaf (`:193-204`), rewritten low leaf
+    /// (`:271-284`), the zero leaf at the new slot (`:286-294`, no leaf hash: the zero-leaf hash is a constant), the
+    /// new leaf (`:299-312`) -- 3 + 4 d traces, queued on `hasher`.
+    pub fn prime_insert_traces<F: BigPrimeField>(&self, hasher: &TracedPoseidonHasher<F>, w: &InsertWitness<F>, zero_leaf_hash: F) {
+        let d = self.tree.depth;
+        let low_idx = helper_to_index(&w.low_leaf_proof_helper);
+        let new_idx = helper_to_index(&w.new_leaf_proof_helper);
+        let new_low = [w.low_leaf[0], w.new_leaf[0], F::from(w.new_leaf_index)];
+        let with_leaf: Vec<usize> = std::iter::once(3).chain(std::iter::repeat(2).take(d)).collect();
+        let t = gpu::path_traces(None, Some(&[w.low_leaf]), &[low_idx], &w.low_leaf_proof, d).expect("trace");
+        hasher.push_traces(&t[0], &with_leaf);
+        let t = gpu::path_traces(None, Some(&[new_low]), &[low_idx], &w.low_leaf_proof, d).expect("trace");
+        hasher.push_traces(&t[0], &with_leaf);
+        let t = gpu::path_traces(Some(&[zero_leaf_hash]), None, &[new_idx], &w.new_leaf_proof, d).expect("trace");
+        hasher.push_traces(&t[0], &vec![2; d]);
+        let t = gpu::path_traces(None, Some(&[w.new_leaf]), &[new_idx], &w.new_leaf_proof, d).expect("trace");
+        hasher.push_traces(&t[0], &with_leaf);
+    }
+
+    /// loads one witness as `insert_leaf`'s arguments (`ctx.load_witness` per value, as the reference's tests do at
+    /// `:444-474`)
+    pub fn assign_insert<F: BigPrimeField>(&self, ctx: &mut Context<F>, w: &InsertWitness<F>) -> AssignedInsert<F> {
+        let mut lw = |v: F| ctx.load_witness(v);
+        AssignedInsert {
+            old_root: lw(w.old_root),
+            low_leaf: [lw(w.low_leaf[0]), lw(w.low_leaf[1]), lw(w.low_leaf[2])],
+            low_leaf_proof: w.low_leaf_proof.iter().map(|v| lw(*v)).collect(),
+            low_leaf_proof_helper: w.low_leaf_proof_helper.iter().map(|v| lw(*v)).collect(),
+            new_root: lw(w.new_root),
+            new_leaf: [lw(w.new_leaf[0]), lw(w.new_leaf[1]), lw(w.new_leaf[2])],
+            new_leaf_index: lw(F::from(w.new_leaf_index)),
+            new_leaf_proof: w.new_leaf_proof.iter().map(|v| lw(*v)).collect(),
+            new_leaf_proof_helper: w.new_leaf_proof_helper.iter().map(|v| lw(*v)).collect(),
+            is_new_leaf_largest: lw(F::from(w.is_new_leaf_largest)),
+        }
+    }
+}
+
+/// helper = 1 iff left child (`src/utils.rs:79`) -> bit l of the index is 0
+fn helper_to_index<F: BigPrimeField>(helper: &[F]) -> u64 {
+    helper.iter().enumerate().fold(0u64, |acc, (l, h)| if *h == F::ZERO { acc | (1u64 << l) } else { acc })
+}

@@ -181,7 +181,9 @@ int imt_path_trace_batch(imt_ctx *ctx, const void *leaf /*[n][32] or NULL*/, con
 typedef struct imt_trace_cell {
     uint8_t kind;            /* IMT_CELL_* */
     uint8_t gate;            /* 1: q_enable here, the gate covers this cell and the next three */
-    uint16_t reserved;
+    uint16_t region;         /* 1: first cell of one ctx.assign_region call of the gadget (a gate.add / sum / mul /
+                                mul_add / inner_product): copies inside a region only refer to EARLIER regions, so a
+                                chip can assign region by region with Existing(..) handles it already holds */
     uint32_t index;
 } imt_trace_cell;
 /* cells / constants may be NULL (sizes only).  constants[n_constants][32] in the format of `flags`. */

@@ -48,7 +48,7 @@ P = ctypes.POINTER
 
 
 class TraceCell(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_uint8), ("gate", ctypes.c_uint8), ("reserved", ctypes.c_uint16), ("index", ctypes.c_uint32)]
+    _fields_ = [("kind", ctypes.c_uint8), ("gate", ctypes.c_uint8), ("region", ctypes.c_uint16), ("index", ctypes.c_uint32)]
 
 
 class InsertOut(ctypes.Structure):

@@ -256,7 +256,7 @@ class Context:
         return out
 
 
-CELL_DTYPE = np.dtype([("kind", "u1"), ("gate", "u1"), ("reserved", "<u2"), ("index", "<u4")])
+CELL_DTYPE = np.dtype([("kind", "u1"), ("gate", "u1"), ("region", "<u2"), ("index", "<u4")])
 
 
 def trace_layout(call, arity, fmt, check):

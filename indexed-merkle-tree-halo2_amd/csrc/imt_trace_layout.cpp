@@ -29,7 +29,12 @@ struct Walker {
         consts.push_back(v);
         return (uint32_t)consts.size() - 1;
     }
-    void push(uint8_t kind, uint32_t index, bool gate) { cells.push_back(imt_trace_cell{kind, (uint8_t)(gate ? 1 : 0), 0, index}); }
+    bool region_open = false;       // the next cell pushed starts a new assign_region call
+    void begin_region() { region_open = true; }
+    void push(uint8_t kind, uint32_t index, bool gate) {
+        cells.push_back(imt_trace_cell{kind, (uint8_t)(gate ? 1 : 0), (uint16_t)(region_open ? 1 : 0), index});
+        region_open = false;
+    }
     void constant(const HFr& v, bool gate = false) { push(IMT_CELL_CONST, cst(v), gate); }
     void existing(Ref r, bool gate = false) { push(r.kind == IMT_CELL_WITNESS ? IMT_CELL_COPY : r.kind, r.index, gate); }
     Ref witness() {
@@ -37,18 +42,20 @@ struct Walker {
         return Ref{IMT_CELL_WITNESS, n_witness++};
     }
     // GateChip (gates/flex_gate.rs)
-    Ref add_const(Ref a, const HFr& k) { existing(a, true); constant(k); constant(hp.F.one()); return witness(); }
+    Ref add_const(Ref a, const HFr& k) { begin_region(); existing(a, true); constant(k); constant(hp.F.one()); return witness(); }
     Ref sum3(Ref x, Ref in, const HFr& k) {          // gate.sum([x, in, Constant(k)]): two chained gates
+        begin_region();
         existing(x, true); existing(in); constant(hp.F.one());
         witness();
         cells.back().gate = 1;
         constant(k); constant(hp.F.one());
         return witness();
     }
-    Ref mul(Ref a, Ref b) { constant(hp.F.zero(), true); existing(a); existing(b); return witness(); }
-    Ref mul_add_const(Ref a, Ref b, const HFr& k) { constant(k, true); existing(a); existing(b); return witness(); }
-    Ref mul_const_add(Ref a, const HFr& k, Ref c) { existing(c, true); existing(a); constant(k); return witness(); }
+    Ref mul(Ref a, Ref b) { begin_region(); constant(hp.F.zero(), true); existing(a); existing(b); return witness(); }
+    Ref mul_add_const(Ref a, Ref b, const HFr& k) { begin_region(); constant(k, true); existing(a); existing(b); return witness(); }
+    Ref mul_const_add(Ref a, const HFr& k, Ref c) { begin_region(); existing(c, true); existing(a); constant(k); return witness(); }
     Ref inner(const Ref s[3], const HFr row[3]) {    // gate.inner_product(s, Constant(row)): three chained gates
+        begin_region();
         constant(hp.F.zero(), true);
         Ref w{};
         for (int i = 0; i < 3; i++) {

@@ -139,7 +139,7 @@ int orc_insert_leaf(const uint8_t old_root[32], const uint8_t low_leaf[3][32],
 #define ORC_CELL_INIT 2
 #define ORC_CELL_WITNESS 3
 #define ORC_CELL_COPY 4
-typedef struct { uint8_t kind, gate; uint16_t pad; uint32_t index; } orc_trace_cell;
+typedef struct { uint8_t kind, gate; uint16_t region; uint32_t index; } orc_trace_cell;   /* region = 1: first cell of an assign_region call */
 /* cells [cap][32] / desc [cap] / witness [wcap][32]: any may be NULL; counts are always returned.
  * out_row = the trace row that is the hash (state[1] after the last permutation). */
 int orc_hash_trace(const uint8_t *in /*[arity][32]*/, int arity, uint8_t *cells, orc_trace_cell *desc, size_t cap,

@@ -173,12 +173,14 @@ typedef struct {
     uint8_t *wit;              /* [wcap][32], may be NULL */
     size_t wcap, nw;
     int overflow;
+    int region_open;           /* the next cell starts a new ctx.assign_region call */
 } col_t;
 
 static void put(col_t *c, const ofr_t *v, uint8_t kind, uint32_t index, int gate) {
-    if (c->n >= c->cap && (c->cells || c->desc)) { c->overflow = 1; c->n++; return; }
+    if (c->n >= c->cap && (c->cells || c->desc)) { c->overflow = 1; c->region_open = 0; c->n++; return; }
     if (c->cells) ofr_to_bytes(c->cells + 32 * c->n, v);
-    if (c->desc) { c->desc[c->n].kind = kind; c->desc[c->n].gate = (uint8_t)gate; c->desc[c->n].pad = 0; c->desc[c->n].index = index; }
+    if (c->desc) { c->desc[c->n].kind = kind; c->desc[c->n].gate = (uint8_t)gate; c->desc[c->n].region = (uint16_t)c->region_open; c->desc[c->n].index = index; }
+    c->region_open = 0;
     c->n++;
 }
 static void put_const(col_t *c, const ofr_t *v, int gate) { put(c, v, ORC_CELL_CONST, 0, gate); }
@@ -204,6 +206,7 @@ static void mark_gate_last(col_t *c) {
 static aval g_add_const(col_t *c, const aval *a, const ofr_t *k) {
     ofr_t o;
     ofr_add(&o, &a->v, k);
+    c->region_open = 1;
     put_existing(c, a, 1); put_const(c, k, 0); put_const(c, &ONE, 0);
     return put_witness(c, &o);
 }
@@ -212,6 +215,7 @@ static aval g_sum3(col_t *c, const aval *x, const aval *in, const ofr_t *k) {
     ofr_t s1, s2;
     ofr_add(&s1, &x->v, &in->v);
     ofr_add(&s2, &s1, k);
+    c->region_open = 1;
     put_existing(c, x, 1); put_existing(c, in, 0); put_const(c, &ONE, 0);
     put_witness(c, &s1);
     mark_gate_last(c);                               /* the running sum opens the second gate */
@@ -221,6 +225,7 @@ static aval g_sum3(col_t *c, const aval *x, const aval *in, const ofr_t *k) {
 static aval g_mul(col_t *c, const aval *a, const aval *b) {
     ofr_t o;
     ofr_mul(&o, &a->v, &b->v);
+    c->region_open = 1;
     put_const(c, &ZERO, 1); put_existing(c, a, 0); put_existing(c, b, 0);
     return put_witness(c, &o);
 }
@@ -229,6 +234,7 @@ static aval g_mul_add_const(col_t *c, const aval *a, const aval *b, const ofr_t 
     ofr_t o;
     ofr_mul(&o, &a->v, &b->v);
     ofr_add(&o, &o, k);
+    c->region_open = 1;
     put_const(c, k, 1); put_existing(c, a, 0); put_existing(c, b, 0);
     return put_witness(c, &o);
 }
@@ -237,6 +243,7 @@ static aval g_mul_const_add(col_t *c, const aval *a, const ofr_t *k, const aval 
     ofr_t o;
     ofr_mul(&o, &a->v, k);
     ofr_add(&o, &o, &cc->v);
+    c->region_open = 1;
     put_existing(c, cc, 1); put_existing(c, a, 0); put_const(c, k, 0);
     return put_witness(c, &o);
 }
@@ -244,6 +251,7 @@ static aval g_mul_const_add(col_t *c, const aval *a, const ofr_t *k, const aval 
 static aval g_inner(col_t *c, const aval *s, const ofr_t *row) {
     ofr_t sum = ZERO, t;
     aval last;
+    c->region_open = 1;
     put_const(c, &ZERO, 1);
     for (int i = 0; i < T; i++) {
         ofr_mul(&t, &s[i].v, &row[i]);

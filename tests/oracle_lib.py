@@ -26,7 +26,7 @@ class InsertTrace(ctypes.Structure):
 
 
 class TraceCell(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_uint8), ("gate", ctypes.c_uint8), ("pad", ctypes.c_uint16), ("index", ctypes.c_uint32)]
+    _fields_ = [("kind", ctypes.c_uint8), ("gate", ctypes.c_uint8), ("region", ctypes.c_uint16), ("index", ctypes.c_uint32)]
 
 
 class Oracle:
@@ -83,9 +83,10 @@ class Oracle:
                                      ctypes.c_size_t(cap), ctypes.byref(nc), wit.ctypes.data_as(ctypes.c_void_p),
                                      ctypes.c_size_t(wcap), ctypes.byref(nw), ctypes.byref(row))
         assert rc == 0, rc
-        d = np.frombuffer(bytes(desc), dtype=np.dtype([("kind", "u1"), ("gate", "u1"), ("pad", "<u2"), ("index", "<u4")]))
+        d = np.frombuffer(bytes(desc), dtype=np.dtype([("kind", "u1"), ("gate", "u1"), ("region", "<u2"), ("index", "<u4")]))
         d = d[:nc.value]
         return dict(cells=cells[:nc.value].copy(), kind=d["kind"].copy(), gate=d["gate"].copy(), index=d["index"].copy(),
+                    region=d["region"].copy(),
                     witness=wit[:nw.value].copy(), out_row=row.value)
 
     # ---- dense tree (src/utils.rs) ----

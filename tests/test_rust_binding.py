@@ -1,0 +1,115 @@
+"""CPU: the Rust binding (bindings/rust, source only -- this image has no rustc) against include/imt.h.
+
+The FFI block is compared with the C prototypes mechanically: every export present on both sides, same number of
+arguments, each argument of the same class (pointer / 32-bit / 64-bit / size_t / double), same return class, and every
+#define that has a `pub const` twin carries the same value.  lib.rs must keep the reference's signatures
+(/root/reference/src/utils.rs:19-108) -- restated here as text, the reference is not read at test time."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = open(os.path.join(ROOT, "include", "imt.h")).read()
+FFI = open(os.path.join(ROOT, "bindings", "rust", "src", "ffi.rs")).read()
+LIB = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+
+
+def c_class(t):
+    t = re.sub(r"/\*.*?\*/", "", t).strip()
+    t = re.sub(r"\s+", " ", t)
+    if "*" in t:
+        return "ptr"
+    base = t.rsplit(" ", 1)[0] if " " in t else t           # drop the parameter name
+    base = base.replace("const ", "").strip()
+    return {"int": "i32", "unsigned": "u32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64",
+            "void": "void", "uint8_t": "u8"}[base]
+
+
+def rust_class(t):
+    t = t.strip()
+    if t.startswith("*"):
+        return "ptr"
+    return {"c_int": "i32", "c_uint": "u32", "u32": "u32", "u64": "u64", "usize": "usize", "c_double": "f64", "u8": "u8",
+            "i32": "i32"}[t]
+
+
+def c_prototypes():
+    src = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
+    out = {}
+    for m in re.finditer(r"^\s*((?:const\s+)?[A-Za-z_0-9]+\s*\*?)\s*(imt_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.M | re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        arglist = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        out[name] = ("ptr" if "*" in ret else c_class(ret + " x"), [c_class(a) for a in arglist])
+    return out
+
+
+def rust_prototypes():
+    block = FFI[FFI.index('extern "C" {'):]
+    out = {}
+    for m in re.finditer(r"pub fn (imt_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block):
+        name, args, ret = m.group(1), m.group(2).strip(), (m.group(3) or "").strip()
+        arglist = [a.split(":", 1)[1] for a in args.split(",") if a.strip()]
+        out[name] = ("void" if not ret else rust_class(ret), [rust_class(a) for a in arglist])
+    return out
+
+
+def test_every_export_is_bound_with_matching_shape():
+    c, r = c_prototypes(), rust_prototypes()
+    assert len(c) >= 55, sorted(c)                       # the parser sees the whole header
+    assert sorted(set(c) - set(r)) == [], "exports missing from ffi.rs"
+    assert sorted(set(r) - set(c)) == [], "ffi.rs declares functions imt.h does not have"
+    for name in c:
+        assert c[name] == r[name], (name, c[name], r[name])
+
+
+def test_the_library_exports_what_the_header_declares():
+    """(also covered by _ffi.SIGNATURES at import time) every prototype is a dynamic symbol of libimt_hip.so"""
+    import subprocess
+    so = os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc", "libimt_hip.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    have = set(re.findall(r"\b(imt_[a-z0-9_]+)\b", syms))
+    assert sorted(set(c_prototypes()) - have) == []
+
+
+def test_constants_agree():
+    defs = {}
+    for m in re.finditer(r"^#define\s+(IMT_[A-Z0-9_]+)\s+\(?(-?(?:0x)?[0-9a-fA-F]+)u?\)?\s*(?:/\*|$)", HDR, flags=re.M):
+        defs[m.group(1)] = int(m.group(2), 0)
+    defs["IMT_TRACE_ITEM_MAJOR"] = defs["IMT_SIB_ITEM_MAJOR"]          # defined as an alias in the header
+    consts = {m.group(1): int(m.group(2), 0) for m in
+              re.finditer(r"pub const (IMT_[A-Z0-9_]+): [a-z_0-9]+ = (-?(?:0x)?[0-9a-fA-F]+);", FFI)}
+    assert len(consts) >= 40
+    for k, v in consts.items():
+        assert k in defs and defs[k] == v, (k, v, defs.get(k))
+    for k in defs:
+        if k not in ("IMT_H",):
+            assert k in consts, f"{k} has no pub const in ffi.rs"
+
+
+def test_struct_layouts_agree():
+    m = re.search(r"typedef struct imt_insert_out \{(.*?)\} imt_insert_out;", HDR, flags=re.S)
+    c_fields = re.findall(r"\*\s*([a-z_]+);", re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S))
+    r = re.search(r"pub struct imt_insert_out \{(.*?)\}", FFI, flags=re.S)
+    assert c_fields == re.findall(r"pub ([a-z_]+):", r.group(1)) and len(c_fields) == 9
+    m = re.search(r"typedef struct imt_trace_cell \{(.*?)\} imt_trace_cell;", HDR, flags=re.S)
+    c_cell = re.findall(r"(uint8_t|uint16_t|uint32_t)\s+([a-z_]+);", re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S))
+    r = re.search(r"pub struct imt_trace_cell \{(.*?)\}", FFI, flags=re.S)
+    r_cell = re.findall(r"pub ([a-z_]+): (u8|u16|u32)", r.group(1))
+    assert [(n, {"uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32"}[t]) for t, n in c_cell] == r_cell
+
+
+def test_lib_rs_keeps_the_reference_signatures():
+    """src/utils.rs:5-10, :12-17, :20-23, :59, :63, :87 of the reference, as text"""
+    flat = re.sub(r"\s+", " ", LIB)
+    for sig in (
+        "pub struct IndexedMerkleTree<'a, F: ScalarField, const T: usize, const RATE: usize> { hash: &'a mut Poseidon<F, T, RATE>, tree: Vec<Vec<F>>, root: F, }",
+        "pub struct IndexedMerkleTreeLeaf<F: ScalarField> { pub val: F, pub next_val: F, pub next_idx: F, }",
+        "pub fn new( hash: &'a mut Poseidon<F, T, RATE>, leaves: Vec<F>, ) -> Result<IndexedMerkleTree<'a, F, T, RATE>, &'static str>",
+        "pub fn get_root(&self) -> F",
+        "pub fn get_proof(&self, index: usize) -> (Vec<F>, Vec<F>)",
+        "pub fn verify_proof(&mut self, leaf: &F, index: usize, root: &F, proof: &[F]) -> bool",
+        'Err("Cannot create Merkle Tree with no leaves")',
+        'Err("Leaves must be even")',
+    ):
+        assert sig in flat, sig
+    # no Drop on the borrowed-hasher type: the reference's tests re-borrow the hasher before they reassign the tree
+    assert "impl<'a, F: ScalarField, const T: usize, const RATE: usize> Drop for IndexedMerkleTree" not in flat

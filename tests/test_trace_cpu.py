@@ -99,6 +99,13 @@ def test_product_cell_layout_equals_oracle_and_rebuilds_a_satisfied_column(oracl
     t = oracle.hash_trace(xs)
     assert out_row == t["out_row"] and len(cells) == len(t["cells"])
     assert (cells["gate"] == t["gate"]).all() and (cells["kind"] == t["kind"]).all()
+    assert (cells["region"] == t["region"]).all()
+    # a chip assigns region by region: a copy inside a region never refers to a row of the same region
+    starts = list(np.nonzero(cells["region"])[0]) + [len(cells)]
+    assert starts[0] == 0 and set(np.diff(starts)) <= {4, 7, 10}          # add / mul / mul_add, sum, inner_product
+    for a, b in zip(starts, starts[1:]):
+        own = {int(c["index"]) for c in cells[a:b] if c["kind"] == imt._ffi.CELL_WITNESS}
+        assert not own & {int(c["index"]) for c in cells[a:b] if c["kind"] == imt._ffi.CELL_COPY}
     nonconst = cells["kind"] != imt._ffi.CELL_CONST
     assert (cells["index"][nonconst] == t["index"][nonconst]).all()
     # the column a chip would assign from the product's own trace + layout + constants equals the oracle's, cell by cell
