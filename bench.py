@@ -46,11 +46,14 @@ BYTES_PER_PATH_LEVEL = 1160.0 / 33  # one event, one level: a path's 1160 B spre
 MADS_PER_HASH = 2 * 76140           # v_mad_u64_u32 per 2-permutation hash
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GMADS = 36443.0           # measured v_mad_u64_u32 lane-ops/ns (profiles/r01_valu_rates.txt, 8 waves/SIMD)
-# HBM bytes of one k_sweep_level launch at E = 2^17 events from separate rocprofv3 --pmc passes: 2 x FETCH_SIZE
-# (gfx950 reports half of 16-B/lane reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, counter unit KB.  bench.py
-# cannot read PMC counters itself, so this is a STATIC figure, reported as roofline.traffic_static with its source.
-PMC_TRAFFIC_SWEEP_LEVEL = {"bytes": int((2 * 4096.2 + 13312.5) * 1024), "source": "profiles/r01_pmc_hbm_traffic.txt",
-                           "measured_at_commit": "2af0a05"}
+# HBM bytes of one k_sweep launch at E = 2^17 events from separate rocprofv3 --pmc passes: 2 x FETCH_SIZE (gfx950
+# reports half of 16-B/lane reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, counter unit KB, mean over the 99 k_sweep
+# dispatches of the run (3 leaf launches, 51 levels below l0, 45 at and above).  bench.py cannot read PMC counters
+# itself, so this is a STATIC figure, reported as roofline.traffic_static with its source.  (Round 1, three kernels
+# calling a shared hash function: 22.0 MB, of which 4.6 MB call-ABI scratch; profiles/r01_pmc_hbm_traffic.txt.)
+PMC_TRAFFIC_SWEEP_LEVEL = {"bytes": int((2 * 3580.1 + 8067.9) * 1024), "fetch_size_kb": 3580.1, "write_size_kb": 8067.9,
+                           "source": "profiles/r02_pmc_hbm_traffic.txt", "measured_at_commit": "round-2 k_sweep build"}
+TRACE_ROWS = 1208                   # witnesses per 2-input hash (imt_hash_trace_batch)
 
 
 def synth_values(total, residue, modulus, seed):
@@ -365,16 +368,46 @@ def main():
         torch.cuda.synchronize()
         copy_gbps = 2 * a.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
+    trace_line = None
+    if rank == 0 and not os.environ.get("IMT_BENCH_NO_TRACE"):
+        # f1, secondary line: the witness-trace kernel (every new advice value of hash_fix_len_array, 38.7 KB per hash)
+        # is the one kernel of this library with a meaningful HBM roofline.  2^18 hashes, rows in halo2curves' in-memory
+        # form, row-major; algorithmic bytes = the rows it must deliver (PMC WRITE_SIZE equals them: profiles/).
+        nt = 1 << 18
+        tin = torch.randint(0, 256, (nt, 2, 32), dtype=torch.uint8, device=dev)
+        tin[:, :, 31] &= 0x0f
+        tout = torch.empty((TRACE_ROWS, nt, 32), dtype=torch.uint8, device=dev)
+        tcall = lambda: ctx._check(lib.imt_hash_trace_batch(ctx.h, ctypes.c_void_p(tin.data_ptr()), 2, nt,
+                                                            ctypes.c_void_p(tout.data_ptr()),
+                                                            _ffi.DEVICE_PTRS | _ffi.FMT_MONT256))
+        tcall()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            tcall()
+        e1.record()
+        torch.cuda.synchronize()
+        tms = e0.elapsed_time(e1) / 3
+        tgbps = nt * TRACE_ROWS * 32 / (tms * 1e-3) / 1e9
+        trace_line = {"kernel": "k_hash_trace", "bound": "hbm", "hashes_per_launch": nt, "avg_launch_ms": tms,
+                      "hashes_per_s": nt / (tms * 1e-3), "achieved": tgbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": tgbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": nt * TRACE_ROWS * 32,
+                      "traffic_static": {"write_bytes": 10135000000, "source": "profiles/r02_pmc_trace_traffic.txt"}}
+        del tin, tout
     if rank == 0:
         n_ins = args.steps * BATCH * world
         value = n_ins / dt
-        names = ["k_sweep_leaves", "index(k_merge_level)", "k_sweep_level", "k_sweep_top", "k_writeback", "host_prepare"]
+        # one hash kernel, k_sweep, in three launch classes (HIP events per class): leaf hashes, the levels below l0
+        # (table-driven) and the levels from l0 to the root (every event against the empty subtree)
+        names = ["k_sweep[leaves]", "index(k_merge_level)", "k_sweep[level<l0]", "k_sweep[level>=l0]", "k_writeback",
+                 "host_prepare"]
         kern = {names[c]: {"ms_total": prof[2 * c], "launches": int(prof[2 * c + 1])} for c in range(6)}
         gpu_ms = sum(v["ms_total"] for n_, v in kern.items() if n_ != "host_prepare")
-        # dominant kernel by time: one k_sweep_level launch hashes 2*BATCH events up one level
-        lv = kern["k_sweep_level"]
-        pipe_ms = lv["ms_total"] / max(lv["launches"], 1)
-        alone_ms = b2b[4] / b2b[5] if b2b[5] else None
+        # dominant kernel by time: k_sweep; every one of its level launches hashes 2*BATCH events up one level
+        sweep = [2, 3]                       # profile classes of the level launches
+        pipe_ms = sum(prof[2 * c] for c in sweep) / max(sum(prof[2 * c + 1] for c in sweep), 1)
+        alone_ms = (sum(b2b[2 * c] for c in sweep) / sum(b2b[2 * c + 1] for c in sweep)) if b2b[5] else None
         alg_bytes = 2 * BATCH * BYTES_PER_PATH_LEVEL
 
         def line(ms):
@@ -407,7 +440,7 @@ def main():
                        "outputs": "pinned host memory, written by the kernels over PCIe" if out_pinned else "HBM",
                        "verified_how": "last timed step's outputs through imt_insert_witness_batch(depth=32, global "
                                        "indices) + root chain + tree root, after the timed region"},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep_level", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "k_sweep (level launches)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "traffic_static": PMC_TRAFFIC_SWEEP_LEVEL,
                          "peak_copy_measured": copy_gbps,
@@ -418,7 +451,7 @@ def main():
                                        "what": "the same kernel inside the timed region, sharing the SIMDs with a hash "
                                                "kernel of the neighbouring batch"},
                          "note": "declared HBM per the contract; the kernel is integer-VALU bound, see valu"},
-            "valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep_level",
+            "valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep (level launches)",
                      "peak_gmads_measured_now": mad_peak.value,
                      "whole_step_frac_of_measured": (value / world * hashes_per_insertion * MADS_PER_HASH / 1e9 /
                                                      mad_peak.value if mad_peak.value else None),
@@ -428,6 +461,7 @@ def main():
                      "whole_step_frac": value / world * hashes_per_insertion * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS,
                      "note": "kernel figures from the attribution pass (kernel alone); whole_step_frac = all hashes of "
                              "the step / wall time of the timed region"},
+            "trace_roofline": trace_line,
             "kernels": kern, "gpu_kernel_ms_per_step": gpu_ms / args.steps,
             "host_call_ms_per_step": host_s[0] / args.steps * 1e3,
             "host_prepare_ms_per_step": kern["host_prepare"]["ms_total"] / args.steps,

@@ -20,6 +20,7 @@
 // Value domain: Montgomery with R = 2^261.  Stored field elements (HBM, API buffers in
 // device format) are fully reduced (< p) and packed as 8 x u32 little-endian.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include "imt_consts.hpp"
 
@@ -368,6 +369,33 @@ IMT_HD void hash23(const PoseidonConsts& pc, Fe& out, const Fe& a, const Fe& b, 
         const Fe* rc0 = pc.rc_full[0];
         if (blk == 1) {
             if (three) {               // absorb [c, 1] into lanes 1, 2
+                add_lazy(s[1], s[1], c);
+                add_lazy(s[2], s[2], pc.one);
+                normalize(s[1]);
+                normalize(s[2]);
+            } else {                   // absorb the padding 1 into lane 1 (folded into rc)
+                rc0 = pc.rc_h2p2;
+            }
+        }
+        permute(pc, s, rc0);
+    }
+    out = s[1];
+    canonicalize(out);
+}
+// The same with the third input parked in a per-thread slot of `stash` (LDS on the device: stash[limb * stride]),
+// written by the caller and read back only where the second permutation absorbs it: nine registers fewer are live
+// across the first permutation, which is what lets ONE copy of the hash serve 2- and 3-input callers at 96 VGPRs.
+IMT_HD void hash23_stashed(const PoseidonConsts& pc, Fe& out, const Fe& a, const Fe& b, bool three,
+                           const uint32_t* stash, unsigned stride) {
+    Fe s[3] = {pc.cap0, a, b};
+#pragma unroll 1
+    for (int blk = 0; blk < 2; blk++) {
+        const Fe* rc0 = pc.rc_full[0];
+        if (blk == 1) {
+            if (three) {               // absorb [c, 1] into lanes 1, 2
+                Fe c;
+#pragma unroll
+                for (int i = 0; i < NL; i++) c.v[i] = stash[(size_t)i * stride];
                 add_lazy(s[1], s[1], c);
                 add_lazy(s[2], s[2], pc.one);
                 normalize(s[1]);

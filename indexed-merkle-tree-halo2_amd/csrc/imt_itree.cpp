@@ -1092,13 +1092,29 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         c->prof_end(pf, s);
         if (pipelined) IMT_HIP(c, hipEventRecord(P.wb_done[l], s));
     }
-    // the top kernel reads the stored root (old_root[0]) and rewrites the stored upper levels
-    if (prev) IMT_HIP(c, hipStreamWaitEvent(s, prev->done, 0));
-    if (g_old) launch::convert(s, t->d_nodes + t->h_off[t->depth] * 32, g_old, 1, IMT_FMT_DEVICE, fmt, c->d_err);
-    pf = c->prof_begin(IMT_PROF_TOP, s);
-    launch::sweep_top(s, P.d_val[L0 & 1], L0, t->depth, c->d_zero, t->d_nodes, t->d_off, 0, (uint32_t)E, (uint32_t)E,
-                      g_old, g_int, g_new, g_ls, g_ns, lay, fmt);
-    c->prof_end(pf, s);
+    // ---- levels [L0, depth): every event alone in node 0 against the empty subtree of that height.  Ordinary
+    // launches of the same kernel, so consecutive batches overlap here level by level as well; the last event's node
+    // of every level goes back to the stored tree.  old_root[0] is the root the previous batch left: it is read
+    // right before the launch that overwrites the stored root.
+    auto read_old_root = [&]() -> int {
+        if (prev) IMT_HIP(c, hipStreamWaitEvent(s, prev->done, 0));
+        if (g_old) launch::convert(s, t->d_nodes + t->h_off[t->depth] * 32, g_old, 1, IMT_FMT_DEVICE, fmt, c->d_err);
+        return IMT_OK;
+    };
+    for (unsigned l = L0; l < t->depth; l++) {
+        if (l + 1 == t->depth && (rc = read_old_root())) return rc;
+        // the previous batch stored node l + 1 (and node l, at its own L0) from its launch of this level
+        if (prev) IMT_HIP(c, hipStreamWaitEvent(s, l >= prev->l0 ? prev->wb_done[l] : prev->done, 0));
+        pf = c->prof_begin(IMT_PROF_TOP, s);
+        launch::sweep_upper(s, P.d_val[l & 1], P.d_val[(l & 1) ^ 1], c->d_zero + (size_t)l * 32, 0, (uint32_t)E,
+                            (uint32_t)E - 1, l == L0 ? t->d_nodes + t->h_off[l] * 32 : nullptr,
+                            t->d_nodes + t->h_off[l + 1] * 32, g_ls, g_ns, lay, l, fmt);
+        c->prof_end(pf, s);
+        if (pipelined) IMT_HIP(c, hipEventRecord(P.wb_done[l], s));
+    }
+    if (L0 == t->depth && (rc = read_old_root())) return rc;
+    launch::emit_roots(s, P.d_val[t->depth & 1], 0, (uint32_t)E, (uint32_t)E, g_old, g_int, g_new, fmt, nullptr,
+                       L0 == t->depth ? t->d_nodes + t->h_off[t->depth] * 32 : nullptr);
     IMT_HIP(c, hipMemcpyAsync(P.d_root, t->d_nodes + t->h_off[t->depth] * 32, 32, hipMemcpyDeviceToDevice, s));
     P.has_root = true;
     IMT_HIP(c, hipEventRecord(P.done, s));
@@ -1295,9 +1311,19 @@ extern "C" int imt_itree_batch_top(imt_itree* t, const void* val_l0, uint32_t e_
     IMT_PENDING(t, c);
     if (!val_l0 || !roots || !top_path || (size_t)e_begin + e_count > E)
         return c->fail(IMT_ERR_RANGE, "event range outside the batch");
-    launch::sweep_top(c->stream, (const uint8_t*)val_l0, L0, t->depth, c->d_zero, t->d_nodes, t->d_off, e_begin, e_count,
-                      (uint32_t)E, nullptr, nullptr, nullptr, nullptr, nullptr, launch::SibLayout{0, 0}, IMT_FMT_DEVICE,
-                      (uint8_t*)roots, (uint8_t*)top_path);
+    // levels [L0, depth) for this rank's events, ping-ponging through the plan's value scratch; the rank whose range
+    // holds the last event fills top_path with that event's node at every level >= L0
+    const uint8_t* vin = (const uint8_t*)val_l0;
+    uint8_t* tp = (uint8_t*)top_path;
+    for (unsigned l = L0; l < t->depth; l++) {
+        uint8_t* vout = P.d_val[l & 1];
+        launch::sweep_upper(c->stream, vin, vout, c->d_zero + (size_t)l * 32, e_begin, e_count, (uint32_t)E - 1,
+                            l == L0 ? tp : nullptr, tp + (size_t)(l + 1 - L0) * 32, nullptr, nullptr,
+                            launch::SibLayout{0, 0}, l, IMT_FMT_DEVICE);
+        vin = vout;
+    }
+    launch::emit_roots(c->stream, vin, e_begin, e_count, (uint32_t)E, nullptr, nullptr, nullptr, IMT_FMT_DEVICE,
+                       (uint8_t*)roots, L0 == t->depth ? tp : nullptr);
     return IMT_OK;
 }
 

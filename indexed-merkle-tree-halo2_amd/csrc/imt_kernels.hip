@@ -48,19 +48,41 @@ __device__ __forceinline__ void flag_err(int* err, bool ok) {
 // share a CU (IMT_PIPELINE) they then evict each other from the 64 KB instruction cache.  A called
 // function is the same instructions for all of them.  g_pc is referenced directly so that the
 // constant loads stay scalar (function arguments would be treated as divergent).
-// (Passing the inputs as vectors instead of structs would keep all of them in registers, but the
-// function then allocates 19-35 callee-saved VGPRs and saves them to scratch on every call; with
-// struct arguments only the first travels in registers, the others through 36 B of the caller's
-// stack each, and the function stays inside the caller-saved set.  The second costs less.)
+//
+// Arguments: the first input travels in registers; the second (and third) go through a per-thread slot
+// in LDS, [limb][thread] so that a wave's accesses hit 64 different banks.  Passed as further struct
+// arguments they went through 36 B of the caller's scratch each -- HBM-backed stack traffic that the
+// PMC pass of round 1 showed as 4.6 MB of the 13.3 MB a k_sweep_level launch writes; passed as
+// vectors they stay in registers but the function then saves 19-35 callee-saved VGPRs per call.
+// LDS is otherwise unused by these kernels; 2 x 9 x 256 x 4 B = 18 KB per block.
+__shared__ uint32_t s_hash_arg[2][NL][IMT_BLOCK];
+
 template <bool THREE>
-__device__ __noinline__ Fe hash_shared(Fe a, Fe b, Fe c) {
-    Fe o;
+__device__ __noinline__ Fe hash_shared(Fe a) {
+    Fe b, c, o;
+    const unsigned t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NL; i++) b.v[i] = s_hash_arg[0][i][t];
+    if (THREE) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) c.v[i] = s_hash_arg[1][i][t];
+    } else {
+        c = a;
+    }
     hash23(g_pc, o, a, b, c, THREE);
     return o;
 }
 __device__ __forceinline__ void hash_call(Fe& o, const Fe& a, const Fe& b, const Fe& c, bool three) {
-    if (three) o = hash_shared<true>(a, b, c);
-    else o = hash_shared<false>(a, b, a);
+    const unsigned t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NL; i++) s_hash_arg[0][i][t] = b.v[i];
+    if (three) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) s_hash_arg[1][i][t] = c.v[i];
+        o = hash_shared<true>(a);
+    } else {
+        o = hash_shared<false>(a);
+    }
 }
 
 // integer value (not Montgomery) of a device-form element, canonical limbs
@@ -88,34 +110,32 @@ __device__ __forceinline__ void fe_from_u64(Fe& r, uint64_t x) {
 }
 
 // ---------------------------------------------------------------------------------
-// One hash chain: optional 3-input leaf hash, then `depth` 2-input hashes up the tree.
-// The loop keeps a single copy of the permutation in the instruction stream.
+// One hash chain: `depth` 2-input hashes up the tree from `cur` (callers hash a 3-input leaf first, so
+// that nothing but `cur` and the index is live across the calls of the loop).
 //   right child at level l  <=>  bit l of idx is 1  (src/utils.rs:93-101)
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void hash_chain(Fe& cur, bool has_leaf3, const Fe pre[3], uint64_t idx,
-                                           const uint8_t* sib, launch::SibLayout lay, size_t item,
-                                           unsigned depth, unsigned fmt_in, bool& ok,
-                                           uint8_t* leaf_hash_out /*device fmt or NULL*/) {
+__device__ __forceinline__ void hash_chain(Fe& cur, uint64_t idx, const uint8_t* sib, launch::SibLayout lay, size_t item,
+                                           unsigned depth, unsigned fmt_in, bool& ok) {
 #pragma unroll 1
-    for (int it = has_leaf3 ? -1 : 0; it < (int)depth; it++) {
-        Fe a, b, c;
-        const bool three = it < 0;
-        if (three) {
-            a = pre[0]; b = pre[1]; c = pre[2];
-        } else {
-            Fe sv;
-            ok &= load_fe(g_pc, sv, sib + ((uint64_t)it * lay.level_stride + item * lay.item_stride) * 32, fmt_in);
-            const bool right = (idx >> it) & 1;
+    for (unsigned it = 0; it < depth; it++) {
+        Fe a, b, sv;
+        ok &= load_fe(g_pc, sv, sib + ((uint64_t)it * lay.level_stride + item * lay.item_stride) * 32, fmt_in);
+        const bool right = (idx >> it) & 1;
 #pragma unroll
-            for (int i = 0; i < NL; i++) {
-                a.v[i] = right ? sv.v[i] : cur.v[i];
-                b.v[i] = right ? cur.v[i] : sv.v[i];
-            }
-            c = a;
+        for (int i = 0; i < NL; i++) {
+            a.v[i] = right ? sv.v[i] : cur.v[i];
+            b.v[i] = right ? cur.v[i] : sv.v[i];
         }
-        hash_call(cur, a, b, c, three);
-        if (three && leaf_hash_out) store_packed(leaf_hash_out, cur);
+        hash_call(cur, a, b, a, false);
     }
+}
+// H(val, next_val, next_idx) of a leaf preimage at `p` ([3][32], fmt_in)
+__device__ __forceinline__ void leaf_hash(Fe& out, const uint8_t* p, unsigned fmt_in, bool& ok) {
+    Fe a, b, c;
+    ok &= load_fe(g_pc, a, p, fmt_in);
+    ok &= load_fe(g_pc, b, p + 32, fmt_in);
+    ok &= load_fe(g_pc, c, p + 64, fmt_in);
+    hash_call(out, a, b, c, true);
 }
 
 // ---- a1 / a10 --------------------------------------------------------------------
@@ -231,18 +251,12 @@ k_path_root(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3,
     const size_t i = gtid();
     if (i >= n) return;
     bool ok = true;
-    Fe cur, pre[3];
-    if (leaf3) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, pre[j], leaf3 + (i * 3 + j) * 32, fmt_in);
-        cur = pre[0];
-    } else {
-        ok &= load_fe(g_pc, cur, leaf + i * 32, fmt_in);
-        pre[0] = pre[1] = pre[2] = cur;
-    }
+    Fe cur;
+    if (leaf3) leaf_hash(cur, leaf3 + i * 96, fmt_in, ok);
+    else ok &= load_fe(g_pc, cur, leaf + i * 32, fmt_in);
     uint64_t idx = index[i];
     if (is_helper) idx = ~idx;   // helper 1 = left child (src/utils.rs:79)
-    hash_chain(cur, leaf3 != nullptr, pre, idx, sib, lay, i, depth, fmt_in, ok, nullptr);
+    hash_chain(cur, idx, sib, lay, i, depth, fmt_in, ok);
     if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
     if (ok_out) {
         Fe e;
@@ -262,25 +276,28 @@ k_non_membership(const uint8_t* __restrict__ root, unsigned root_stride, const u
     const size_t i = gtid();
     if (i >= n) return;
     bool ok = true;
-    Fe pre[3], nv, rt, cur;
-#pragma unroll
-    for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, pre[j], low_leaf + (i * 3 + j) * 32, fmt_in);
-    ok &= load_fe(g_pc, nv, new_val + i * 32, fmt_in);
-    ok &= load_fe(g_pc, rt, root + i * (size_t)root_stride, fmt_in);
     unsigned fail = 0;
-    {
-        Fe nvi, lvi, lni;
-        to_int(nvi, nv); to_int(lvi, pre[0]); to_int(lni, pre[1]);
+    {   // the range predicates first: their operands are dead before the hashing starts
+        Fe v, nx, nv, nvi, lvi, lni;
+        ok &= load_fe(g_pc, v, low_leaf + (i * 3 + 0) * 32, fmt_in);
+        ok &= load_fe(g_pc, nx, low_leaf + (i * 3 + 1) * 32, fmt_in);
+        ok &= load_fe(g_pc, nv, new_val + i * 32, fmt_in);
+        to_int(nvi, nv); to_int(lvi, v); to_int(lni, nx);
         const unsigned s = is_largest[i];
         if (s > 1) fail |= 0x80;                                    // assert_bit :41
-        const bool is_zero = fe_is_zero(pre[1]);                    // :143
+        const bool is_zero = fe_is_zero(nx);                        // :143
         const bool next_gr = int_lt(nvi, lni);                      // :180
         if (!(s ? is_zero : next_gr)) fail |= 0x01;                 // :182-191
         if (!int_lt(lvi, nvi)) fail |= 0x04;                        // :206-228
     }
-    cur = pre[0];
-    hash_chain(cur, true, pre, low_index[i], sib, lay, i, depth, fmt_in, ok, nullptr);   // :193-204
-    if (!fe_eq(cur, rt)) fail |= 0x02;
+    Fe cur;
+    leaf_hash(cur, low_leaf + i * 96, fmt_in, ok);                  // :193-194
+    hash_chain(cur, low_index[i], sib, lay, i, depth, fmt_in, ok);  // :196-204
+    {
+        Fe rt;
+        ok &= load_fe(g_pc, rt, root + i * (size_t)root_stride, fmt_in);
+        if (!fe_eq(cur, rt)) fail |= 0x02;
+    }
     fail_out[i] = (uint8_t)fail;
     if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
     flag_err(err, ok);
@@ -324,33 +341,33 @@ k_insert_chains(const uint8_t* __restrict__ low_leaf, const uint64_t* __restrict
     if (i >= n) return;
     const int chain = blockIdx.y;
     bool ok = true;
-    Fe pre[3], cur;
+    Fe cur;
     const uint8_t* sib = chain < 2 ? low_sib : new_sib;
     const uint64_t idx = chain < 2 ? low_index[i] : new_path_index[i];
     uint8_t* leaf_out = nullptr;
     uint8_t* root_out;
     if (chain == 0) {            // low leaf as given                       :193-204
-#pragma unroll
-        for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, pre[j], low_leaf + (i * 3 + j) * 32, fmt_in);
+        leaf_hash(cur, low_leaf + i * 96, fmt_in, ok);
         leaf_out = trace + (0 * n + i) * 32;
         root_out = trace + (1 * n + i) * 32;
     } else if (chain == 1) {     // {low.val, new.val, new_leaf_index}      :265-284
-        ok &= load_fe(g_pc, pre[0], low_leaf + (i * 3 + 0) * 32, fmt_in);
-        ok &= load_fe(g_pc, pre[1], new_leaf + (i * 3 + 0) * 32, fmt_in);
-        fe_from_u64(pre[2], new_index[i]);
+        Fe a, b, c;
+        ok &= load_fe(g_pc, a, low_leaf + (i * 3 + 0) * 32, fmt_in);
+        ok &= load_fe(g_pc, b, new_leaf + (i * 3 + 0) * 32, fmt_in);
+        fe_from_u64(c, new_index[i]);
+        hash_call(cur, a, b, c, true);
         leaf_out = trace + (2 * n + i) * 32;
         root_out = trace + (3 * n + i) * 32;
     } else if (chain == 2) {     // the zero leaf at the new slot           :286-294
-        pre[0] = pre[1] = pre[2] = g_pc.zero_leaf;
+        cur = g_pc.zero_leaf;
         root_out = trace + (4 * n + i) * 32;
     } else {                     // the new leaf                            :299-312
-#pragma unroll
-        for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, pre[j], new_leaf + (i * 3 + j) * 32, fmt_in);
+        leaf_hash(cur, new_leaf + i * 96, fmt_in, ok);
         leaf_out = trace + (5 * n + i) * 32;
         root_out = trace + (6 * n + i) * 32;
     }
-    cur = pre[0];
-    hash_chain(cur, chain != 2, pre, idx, sib, lay, i, depth, fmt_in, ok, leaf_out);
+    if (leaf_out) store_packed(leaf_out, cur);
+    hash_chain(cur, idx, sib, lay, i, depth, fmt_in, ok);
     store_packed(root_out, cur);
     flag_err(err, ok);
 }
@@ -477,59 +494,10 @@ __global__ void __launch_bounds__(BLOCK) k_fill_level(uint8_t* __restrict__ node
     o[1] = z[1];
 }
 
-// leaf versions: slot k of level 0 holds H(preimage of event time0[k])   (:662-671)
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
-k_sweep_leaves(const uint8_t* __restrict__ pre, const uint32_t* __restrict__ time0, uint8_t* __restrict__ val0,
-               uint32_t k_begin, uint32_t k_count, unsigned fmt_in, int* err) {
-    const size_t t = gtid();
-    if (t >= k_count) return;
-    const uint32_t k = k_begin + (uint32_t)t;
-    const uint8_t* p = pre + (size_t)time0[k] * 96;
-    Fe a, b, c, o;
-    bool ok = load_fe(g_pc, a, p, fmt_in);
-    ok &= load_fe(g_pc, b, p + 32, fmt_in);
-    ok &= load_fe(g_pc, c, p + 64, fmt_in);
-    hash_call(o, a, b, c, true);
-    store_packed(val0 + (size_t)k * 32, o);
-    flag_err(err, ok);
-}
-
 __global__ void __launch_bounds__(BLOCK) k_merge_level(sweep::LevelTable in, sweep::LevelOut out, uint32_t total) {
     const size_t k = gtid();
     if (k >= total) return;
     sweep::merge_element(in, out, (uint32_t)k, total);
-}
-
-// level l -> l+1: one hash per event version; the sibling read is the proof element
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
-k_sweep_level(const uint8_t* __restrict__ val_in, uint8_t* __restrict__ val_out, const uint32_t* __restrict__ from,
-              const int32_t* __restrict__ sibsrc, const uint32_t* __restrict__ node_below,
-              const uint32_t* __restrict__ time_next, const uint8_t* __restrict__ tree_l, uint64_t len_l,
-              const uint8_t* __restrict__ zero_l, uint32_t k_begin, uint32_t k_count, uint8_t* __restrict__ low_sib,
-              uint8_t* __restrict__ new_sib, launch::SibLayout lay, unsigned level, unsigned fmt_out) {
-    const size_t t = gtid();
-    if (t >= k_count) return;
-    const uint32_t kp = k_begin + (uint32_t)t;
-    const uint32_t k = from[kp] & ~sweep::LAST_BIT;
-    const uint32_t n = node_below[kp];
-    const int32_t ss = sibsrc[kp];
-    const uint64_t sn = (uint64_t)(n ^ 1u);
-    const uint8_t* sp = ss >= 0 ? val_in + (size_t)ss * 32 : (sn < len_l ? tree_l + sn * 32 : zero_l);
-    Fe cur, sv, a, b, o;
-    load_packed(cur, val_in + (size_t)k * 32);
-    load_packed(sv, sp);
-    const bool right = n & 1u;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-        a.v[i] = right ? sv.v[i] : cur.v[i];
-        b.v[i] = right ? cur.v[i] : sv.v[i];
-    }
-    // the sibling IS the proof element: stored before the call so that it need not survive it
-    const uint32_t e = time_next[kp];
-    uint8_t* dst = (e & 1u) ? new_sib : low_sib;
-    if (dst) store_fe(g_pc, dst + ((uint64_t)level * lay.level_stride + (uint64_t)(e >> 1) * lay.item_stride) * 32, sv, fmt_out);
-    hash_call(o, a, b, a, false);
-    store_packed(val_out + (size_t)kp * 32, o);
 }
 
 // final version of every touched node of level l goes back to the stored tree
@@ -546,33 +514,81 @@ k_writeback(const uint8_t* __restrict__ val_l, const uint32_t* __restrict__ from
     d[1] = s[1];
 }
 
-// levels [l0, depth): every event is alone in node 0 and its sibling is the empty subtree.
-// val is indexed by event id (the level-l0 order is pure time order).
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
-k_sweep_top(const uint8_t* __restrict__ val, unsigned l0, unsigned depth, const uint8_t* __restrict__ zero,
-            uint8_t* __restrict__ tree_nodes, const uint64_t* __restrict__ tree_off, uint32_t e_begin,
-            uint32_t e_count, uint32_t total, uint8_t* __restrict__ old_root, uint8_t* __restrict__ interim_root,
-            uint8_t* __restrict__ new_root, uint8_t* __restrict__ low_sib, uint8_t* __restrict__ new_sib,
-            launch::SibLayout lay, unsigned fmt_out, uint8_t* __restrict__ roots_dev, uint8_t* __restrict__ top_path) {
-    // sharded mode (roots_dev != NULL): the root after every event goes to roots_dev[e] in device format
-    // and the last event's node at every level >= l0 to top_path instead of the stored tree
+// -----------------------------------------------------------------------------------------------
+// THE hash kernel of a batch insertion: one hash per thread, the hash inlined exactly once.
+//   LEAVES  slot k of level 0 = H(preimage of event time0[k])                                   (:662-671)
+//   LEVEL   level l -> l+1: one hash2 per event version; the sibling read IS the proof element.  Below l0 the
+//           (from, sibsrc, node_below, time_next) tables of imt_sweep.hpp say who meets whom; at and above l0
+//           (from == NULL) every event is alone in node 0, its slot is its event id and its sibling the empty
+//           subtree of that height.
+// Why one kernel: under IMT_PIPELINE two of these launches (consecutive batches, any two phases) share every CU.
+// As separate kernels with the hash inlined they would be 47 KB copies evicting each other from the 64 KB
+// instruction cache; as separate kernels CALLING a shared hash function (round 1) the call ABI cost 36 B of scratch
+// per hash for the second argument plus callee-saved VGPR saves -- 4.6 MB of the 13.3 MB a level launch wrote to HBM
+// (profiles/r01_pmc_hbm_traffic.txt).  One kernel is one copy of the code for every phase of every batch in
+// flight and has no call.  Round 1 climbed the levels above l0 in a loop inside one launch; the loop-carried state
+// on top of the hash's ~90 registers spilled, so those levels are ordinary launches now (same hashes, and
+// consecutive batches overlap there level by level too).  The mode is a kernel argument: wave-uniform branches.
+// The third input of a leaf hash waits in LDS for the second permutation (hash23_stashed).
+// The other, much rarer hash kernels (paths, dense levels, lift) keep calling the shared function.
+// -----------------------------------------------------------------------------------------------
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_sweep(launch::SweepArgs a) {
+    __shared__ uint32_t stash[NL][BLOCK];
+    const size_t t = gtid();
+    if (t >= a.count) return;
+    const uint32_t x = a.begin + (uint32_t)t;        // slot (= event id at and above l0)
+    Fe A, B, o;
+    if (a.mode == launch::SWEEP_LEAVES) {
+        const uint8_t* p = a.pre + (size_t)a.time0[x] * 96;
+        Fe C;
+        bool ok = load_fe(g_pc, A, p, a.fmt_in);
+        ok &= load_fe(g_pc, B, p + 32, a.fmt_in);
+        ok &= load_fe(g_pc, C, p + 64, a.fmt_in);
+#pragma unroll
+        for (int i = 0; i < NL; i++) stash[i][threadIdx.x] = C.v[i];
+        flag_err(a.err, ok);
+    } else {
+        uint32_t k = x, n = 0, e = x;
+        const uint8_t* sp = a.zero_l;
+        if (a.from) {
+            k = a.from[x] & ~sweep::LAST_BIT;
+            n = a.node_below[x];
+            e = a.time_next[x];
+            const int32_t ss = a.sibsrc[x];
+            const uint64_t sn = (uint64_t)(n ^ 1u);
+            sp = ss >= 0 ? a.val_in + (size_t)ss * 32 : (sn < a.len_l ? a.tree_l + sn * 32 : a.zero_l);
+        }
+        Fe cur, sv;
+        load_packed(cur, a.val_in + (size_t)k * 32);
+        load_packed(sv, sp);
+        if (x == a.last_event && a.node_in) store_packed(a.node_in, cur);
+        const bool right = n & 1u;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            A.v[i] = right ? sv.v[i] : cur.v[i];
+            B.v[i] = right ? cur.v[i] : sv.v[i];
+        }
+        uint8_t* row = (e & 1u) ? a.new_sib : a.low_sib;
+        if (row) store_fe(g_pc, row + ((uint64_t)a.level * a.lay.level_stride + (uint64_t)(e >> 1) * a.lay.item_stride) * 32, sv, a.fmt_out);
+    }
+    hash23_stashed(g_pc, o, A, B, a.mode == launch::SWEEP_LEAVES, &stash[0][threadIdx.x], BLOCK);
+    store_packed(a.val_out + (size_t)x * 32, o);
+    if (x == a.last_event && a.node_out) store_packed(a.node_out, o);
+}
+
+// Roots of events [e_begin, e_begin + e_count) from the top values (indexed by event id), no hashing: event 2i is
+// "low leaf rewritten" (interim root of insertion i), event 2i+1 "new leaf written" (its new root = the old root of
+// insertion i+1).  Sharded mode (roots_dev != NULL): device format, one row per event.
+__global__ void __launch_bounds__(BLOCK)
+k_emit_roots(const uint8_t* __restrict__ val, uint32_t e_begin, uint32_t e_count, uint32_t total,
+             uint8_t* __restrict__ old_root, uint8_t* __restrict__ interim_root, uint8_t* __restrict__ new_root,
+             unsigned fmt_out, uint8_t* __restrict__ roots_dev, uint8_t* __restrict__ node_store) {
     const size_t t = gtid();
     if (t >= e_count) return;
     const uint32_t e = e_begin + (uint32_t)t;
-    const bool last = e == total - 1;
     Fe cur;
     load_packed(cur, val + (size_t)e * 32);
-    if (last) store_packed(top_path ? top_path : tree_nodes + tree_off[l0] * 32, cur);
-    uint8_t* dst = (e & 1u) ? new_sib : low_sib;
-#pragma unroll 1
-    for (unsigned l = l0; l < depth; l++) {
-        Fe z, o;
-        load_packed(z, zero + (size_t)l * 32);
-        if (dst) store_fe(g_pc, dst + ((uint64_t)l * lay.level_stride + (uint64_t)(e >> 1) * lay.item_stride) * 32, z, fmt_out);
-        hash_call(o, cur, z, cur, false);
-        cur = o;
-        if (last) store_packed(top_path ? top_path + (size_t)(l + 1 - l0) * 32 : tree_nodes + tree_off[l + 1] * 32, cur);
-    }
+    if (e == total - 1 && node_store) store_packed(node_store, cur);
     if (roots_dev) { store_packed(roots_dev + (size_t)e * 32, cur); return; }
     const uint32_t i = e >> 1;
     if (e & 1u) {
@@ -867,8 +883,12 @@ void fill_level(hipStream_t s, uint8_t* nodes, size_t n, const uint8_t* zero_l) 
 void sweep_leaves(hipStream_t s, const uint8_t* pre, const uint32_t* time0, uint8_t* val0, uint32_t k_begin,
                   uint32_t k_count, unsigned fmt_in, int* err) {
     if (!k_count) return;
-    hipLaunchKernelGGL(k_sweep_leaves, dim3(nblk(k_count)), dim3(BLOCK), 0, s, pre, time0, val0, k_begin, k_count,
-                       fmt_in, err);
+    SweepArgs a{};
+    a.mode = SWEEP_LEAVES;
+    a.begin = k_begin; a.count = k_count;
+    a.pre = pre; a.time0 = time0; a.val_out = val0; a.fmt_in = fmt_in; a.err = err;
+    a.last_event = 0xffffffffu;
+    hipLaunchKernelGGL(k_sweep, dim3(nblk(k_count)), dim3(BLOCK), 0, s, a);
 }
 void merge_level(hipStream_t s, sweep::LevelTable in, sweep::LevelOut out, uint32_t total) {
     if (!total) return;
@@ -879,22 +899,37 @@ void sweep_level(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const u
                  const uint8_t* zero_l, uint32_t k_begin, uint32_t k_count, uint8_t* low_sib, uint8_t* new_sib,
                  SibLayout lay, unsigned level, unsigned fmt_out) {
     if (!k_count) return;
-    hipLaunchKernelGGL(k_sweep_level, dim3(nblk(k_count)), dim3(BLOCK), 0, s, val_in, val_out, from, sibsrc, node_below,
-                       time_next, tree_l, len_l, zero_l, k_begin, k_count, low_sib, new_sib, lay, level, fmt_out);
+    SweepArgs a{};
+    a.mode = SWEEP_LEVEL;
+    a.begin = k_begin; a.count = k_count;
+    a.val_in = val_in; a.val_out = val_out; a.from = from; a.sibsrc = sibsrc; a.node_below = node_below;
+    a.time_next = time_next; a.tree_l = tree_l; a.len_l = len_l; a.zero_l = zero_l; a.level = level;
+    a.low_sib = low_sib; a.new_sib = new_sib; a.lay = lay; a.fmt_out = fmt_out;
+    a.last_event = 0xffffffffu;
+    hipLaunchKernelGGL(k_sweep, dim3(nblk(k_count)), dim3(BLOCK), 0, s, a);
+}
+void sweep_upper(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const uint8_t* zero_l, uint32_t e_begin,
+                 uint32_t e_count, uint32_t last_event, uint8_t* node_in, uint8_t* node_out, uint8_t* low_sib,
+                 uint8_t* new_sib, SibLayout lay, unsigned level, unsigned fmt_out) {
+    if (!e_count) return;
+    SweepArgs a{};
+    a.mode = SWEEP_LEVEL;
+    a.begin = e_begin; a.count = e_count;
+    a.val_in = val_in; a.val_out = val_out; a.zero_l = zero_l; a.level = level;
+    a.low_sib = low_sib; a.new_sib = new_sib; a.lay = lay; a.fmt_out = fmt_out;
+    a.last_event = last_event; a.node_in = node_in; a.node_out = node_out;
+    hipLaunchKernelGGL(k_sweep, dim3(nblk(e_count)), dim3(BLOCK), 0, s, a);
+}
+void emit_roots(hipStream_t s, const uint8_t* val, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
+                uint8_t* interim_root, uint8_t* new_root, unsigned fmt_out, uint8_t* roots_dev, uint8_t* node_store) {
+    if (!e_count) return;
+    hipLaunchKernelGGL(k_emit_roots, dim3(nblk(e_count)), dim3(BLOCK), 0, s, val, e_begin, e_count, total, old_root,
+                       interim_root, new_root, fmt_out, roots_dev, node_store);
 }
 void writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const uint32_t* node_below, uint8_t* tree_l,
                uint32_t total) {
     if (!total) return;
     hipLaunchKernelGGL(k_writeback, dim3(nblk(total)), dim3(BLOCK), 0, s, val_l, from, node_below, tree_l, total);
-}
-void sweep_top(hipStream_t s, const uint8_t* val, unsigned l0, unsigned depth, const uint8_t* zero, uint8_t* tree_nodes,
-               const uint64_t* tree_off, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
-               uint8_t* interim_root, uint8_t* new_root, uint8_t* low_sib, uint8_t* new_sib, SibLayout lay,
-               unsigned fmt_out, uint8_t* roots_dev, uint8_t* top_path) {
-    if (!e_count) return;
-    hipLaunchKernelGGL(k_sweep_top, dim3(nblk(e_count)), dim3(BLOCK), 0, s, val, l0, depth, zero, tree_nodes, tree_off,
-                       e_begin, e_count, total, old_root, interim_root, new_root, low_sib, new_sib, lay, fmt_out, roots_dev,
-                       top_path);
 }
 void lift_roots(hipStream_t s, uint8_t* old_root, uint8_t* interim_root, uint8_t* new_root, uint32_t n,
                 const uint8_t* top, uint64_t pos_bits, unsigned levels, unsigned fmt, int* err) {

@@ -84,6 +84,33 @@ void write_helpers(hipStream_t s, uint64_t index, unsigned depth, uint8_t* out, 
 
 
 // ---- batch insertion level sweep (imt_sweep.hpp) ----
+// argument block of k_sweep, the one hash kernel behind sweep_leaves / sweep_level / sweep_upper
+enum : int { SWEEP_LEAVES = 0, SWEEP_LEVEL = 1 };
+struct SweepArgs {
+    int mode;
+    uint32_t begin, count;                // slots [begin, begin + count)
+    // LEAVES
+    const uint8_t* pre;
+    const uint32_t* time0;
+    unsigned fmt_in;
+    int* err;
+    // LEVEL
+    const uint8_t* val_in;
+    uint8_t* val_out;                     // (LEAVES writes it too)
+    const uint32_t* from;                 // NULL at and above l0: slot = event, node 0, sibling = zero_l
+    const int32_t* sibsrc;
+    const uint32_t* node_below;
+    const uint32_t* time_next;
+    const uint8_t* tree_l;
+    uint64_t len_l;
+    const uint8_t* zero_l;
+    unsigned level;
+    uint32_t last_event;                  // the event whose node goes back to the stored tree (above l0), or ~0
+    uint8_t *node_in, *node_out;          // where its input / output value is stored (device format), or NULL
+    uint8_t *low_sib, *new_sib;           // proof rows
+    SibLayout lay;
+    unsigned fmt_out;
+};
 void fill_level(hipStream_t s, uint8_t* nodes, size_t n, const uint8_t* zero_l);
 void sweep_leaves(hipStream_t s, const uint8_t* pre, const uint32_t* time0, uint8_t* val0, uint32_t k_begin,
                   uint32_t k_count, unsigned fmt_in, int* err);
@@ -95,10 +122,14 @@ void sweep_level(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const u
                  SibLayout lay, unsigned level, unsigned fmt_out);
 void writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const uint32_t* node_below, uint8_t* tree_l,
                uint32_t total);
-void sweep_top(hipStream_t s, const uint8_t* val, unsigned l0, unsigned depth, const uint8_t* zero, uint8_t* tree_nodes,
-               const uint64_t* tree_off, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
-               uint8_t* interim_root, uint8_t* new_root, uint8_t* low_sib, uint8_t* new_sib, SibLayout lay,
-               unsigned fmt_out, uint8_t* roots_dev = nullptr, uint8_t* top_path = nullptr);
+// level l >= l0 for events [e_begin, e_begin + e_count): val indexed by event id, sibling = zero_l; the values
+// of `last_event` go to node_in (its input, i.e. the node at level l) / node_out (the node at level l + 1)
+void sweep_upper(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const uint8_t* zero_l, uint32_t e_begin,
+                 uint32_t e_count, uint32_t last_event, uint8_t* node_in, uint8_t* node_out, uint8_t* low_sib,
+                 uint8_t* new_sib, SibLayout lay, unsigned level, unsigned fmt_out);
+// roots per event from the top values (no hashing); sharded mode: roots_dev[e] in device format
+void emit_roots(hipStream_t s, const uint8_t* val, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
+                uint8_t* interim_root, uint8_t* new_root, unsigned fmt_out, uint8_t* roots_dev, uint8_t* node_store);
 
 // ---- subtree placement: lift subtree-level witnesses to the depth of the enclosing tree ----
 // top[j] (device format, j < levels) = sibling of this subtree's ancestor at height sub_depth + j;
