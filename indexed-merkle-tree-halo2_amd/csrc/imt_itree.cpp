@@ -54,10 +54,12 @@ unsigned ceil_log2(uint64_t x) {
 }
 
 // one set of plan buffers (device + pinned host staging)
-// Batches in flight on the GPU under IMT_PIPELINE.  3 was measured (with 5 and 6 waves/SIMD): no gain
-// over 2 -- two batches already keep two hash kernels resident 80 % of the time.
+// Batches in flight on the GPU under IMT_PIPELINE, each on its own stream, one tree level apart.  At 2^16
+// insertions per batch two already saturate the SIMDs (2, 4: 3.03 M insertions/s; 8: 2.97).  Four is for smaller
+// batches, whose 33 dependent launches cost 0.39 ms each whatever their size: 2^15 goes from 2.73 to 3.01 M/s,
+// 2^10..2^13 double (profiles/r02_small_batch_rates.txt).  More needs GPU_MAX_HW_QUEUES > 4 in the environment.
 #ifndef IMT_NPIPE
-#define IMT_NPIPE 2
+#define IMT_NPIPE 4
 #endif
 
 struct PlanSet {

@@ -186,7 +186,12 @@ __global__ void __launch_bounds__(BLOCK) k_convert(const uint8_t* __restrict__ i
 // One thread = one hash = 1208 / 1209 rows of 32 bytes.  Row j of item i goes to
 // trace + (j * row_stride + i * item_stride) * 32: row-major ([rows][n], row_stride = n) makes a wave's 64
 // stores of one row 2 KiB contiguous; item-major ([n][rows]) is the order a per-hash consumer reads.
-__global__ void __launch_bounds__(BLOCK)
+// No register cap: 140 VGPRs = 3 waves/SIMD without spills measured the same as 128 = 4 waves with 12 spilled
+// (one wave's dependent chain already fills 78 % of a SIMD's issue slots).
+#ifndef IMT_TRACE_WAVES
+#define IMT_TRACE_WAVES
+#endif
+__global__ IMT_TRACE_WAVES void __launch_bounds__(BLOCK)
 k_hash_trace(const uint8_t* __restrict__ in, size_t n, int arity, uint8_t* __restrict__ trace, uint64_t row_stride,
              uint64_t item_stride, unsigned fmt_in, unsigned fmt_out, int* err) {
     const size_t i = gtid();

@@ -27,7 +27,8 @@
 // Arithmetic: same radix-2^29 / R = 2^261 domain as the hash kernels, but every intermediate is an output, so the
 // lazy tricks of permute() do not apply.  All products use 29-bit quotient digits: for factors below 4p the result
 // is below 16 p^2 / R + p = 1.125 p (+ the addend of the fused forms); sums are brought below ~2.1 p by one
-// conditional subtraction of 2p (red2), so every operand stays below 4p and every stored limb below 2^29.
+// conditional subtraction of 2p (red2) only where they would otherwise keep growing (the linear lanes of the partial
+// rounds, the absorbed lanes), so every operand stays below 4p and every stored limb below 2^29.
 // The kernel is bound by its HBM writes (38.7 KB per hash) about as much as by the VALU: DESIGN.md section 6.
 #pragma once
 #include "imt_device.hpp"
@@ -66,25 +67,56 @@ IMT_HD void t_mulc_add(Fe& r, const Fe& c_uniform, const Fe& v, const Fe& addend
 #endif
 }
 
-// a -= 2p if a >= 2p   (normalised limbs, a < 6p)
-IMT_HD void red2(Fe& a) { cond_sub_p_shl<1>(a); }
+// a -= (p << SH) if a >= (p << SH), branch-free: the difference is formed with a borrow chain (3 instructions per
+// limb) and selected by the final borrow, instead of compare-then-subtract under a divergent branch.
+// Normalised limbs in (top limb: whatever is left), normalised limbs out.
+template <int SH>
+IMT_HD void csub(Fe& a) {
+    uint32_t d[NL];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+        const uint32_t x = a.v[i] - p29_shl<SH>(i) - borrow;
+        borrow = x >> 31;                              // limbs < 2^29: bit 31 set <=> went negative
+        d[i] = x & MASK29;
+    }
+    const uint32_t top = a.v[NL - 1] - p29_shl<SH>(NL - 1) - borrow;      // negative <=> a < (p << SH)
+    const bool keep = (int32_t)top < 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) a.v[i] = keep ? a.v[i] : d[i];
+    a.v[NL - 1] = keep ? a.v[NL - 1] : top;
+}
+IMT_HD void red2(Fe& a) { csub<1>(a); }               // a < 6p -> a < max(2p, a - 2p)
 
-// x * 2^261 (limbs normalised, value < 4p)  ->  canonical x * 2^256: what halo2curves keeps in memory.
-// Dividing by 2^5 is one 5-bit Montgomery step: p = 1 mod 32, so m = -a mod 32 clears the low five bits.
-IMT_HD void to_mont256_canonical(Fe& y, const Fe& a) {
+// x * 2^261 (limbs normalised, value < 4p)  ->  the eight words of canonical x * 2^256: what halo2curves keeps in
+// memory.  Dividing by 2^5 is one 5-bit Montgomery step: p = 1 mod 32, so m = -a mod 32 clears the low five bits
+// of t = a + m p.  The division itself is never carried out on the limbs: t is reduced against 32 p (t < 35 p, so once)
+// and the words are cut out of t five bits higher up.
+IMT_HD void store_mont256(void* ptr, const Fe& a) {
     const uint32_t m = (0u - a.v[0]) & 31u;
-    uint32_t t[NL];
+    Fe t;
     uint64_t acc = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-        acc += (uint64_t)a.v[i] + (uint64_t)m * p29(i);
-        t[i] = (i < NL - 1) ? ((uint32_t)acc & MASK29) : (uint32_t)acc;
+        acc += (uint64_t)m * p29(i);
+        acc += a.v[i];
+        t.v[i] = (i < NL - 1) ? ((uint32_t)acc & MASK29) : (uint32_t)acc;
         acc >>= 29;
     }
+    csub<5>(t);
+    uint32_t w[8];
 #pragma unroll
-    for (int i = 0; i < NL - 1; i++) y.v[i] = (t[i] >> 5) | ((t[i + 1] & 31u) << 24);
-    y.v[NL - 1] = t[NL - 1] >> 5;
-    cond_sub_p_shl<0>(y);          // (4p + 31p) / 32 < 1.1 p
+    for (int j = 0; j < 8; j++) {            // word j = bits [32j + 5, 32j + 37) of t
+        const int bit = 32 * j + 5, lo_limb = bit / 29, off = bit - 29 * lo_limb;
+        uint32_t x = t.v[lo_limb] >> off;
+        const int have = 29 - off;
+        if (have < 32 && lo_limb + 1 < NL) x |= t.v[lo_limb + 1] << have;
+        if (have + 29 < 32 && lo_limb + 2 < NL) x |= t.v[lo_limb + 2] << (have + 29);
+        w[j] = x;
+    }
+    Word4* q = reinterpret_cast<Word4*>(ptr);
+    q[0] = Word4{w[0], w[1], w[2], w[3]};
+    q[1] = Word4{w[4], w[5], w[6], w[7]};
 }
 
 struct TraceSink {
@@ -94,22 +126,24 @@ struct TraceSink {
 };
 // v: normalised limbs, value < 4p
 IMT_HD void t_emit(const PoseidonConsts& pc, TraceSink& o, const Fe& v) {
-    Fe y;
     if (o.fmt == FMT_MONT256) {
-        to_mont256_canonical(y, v);
-    } else if (o.fmt == FMT_DEVICE) {
-        y = v;
-        cond_sub_p_shl<1>(y);
-        cond_sub_p_shl<0>(y);
+        store_mont256(o.p, v);
     } else {
-        mont_dot<1, false, false>(y, &v, &pc.int_one, v);      // v / R + p
-        cond_sub_p_shl<0>(y);
+        Fe y;
+        if (o.fmt == FMT_DEVICE) {
+            y = v;
+            csub<1>(y);
+            csub<0>(y);
+        } else {
+            mont_dot<1, false, false>(y, &v, &pc.int_one, v);      // v / R + p
+            csub<0>(y);
+        }
+        store_packed(o.p, y);
     }
-    store_packed(o.p, y);
     o.p += o.stride;
 }
 
-// a + b (both < ~2.1p), normalised and below ~2.2p
+// a + b (a < 3.2p, b < p), normalised and below 2.2p
 IMT_HD void t_add(Fe& r, const Fe& a, const Fe& b) {
     add_lazy(r, a, b);
     normalize(r);
@@ -123,8 +157,7 @@ IMT_HD void t_x5c(const PoseidonConsts& pc, TraceSink& o, Fe& x, const Fe& c_uni
     t_emit(pc, o, x2);
     t_sqr(x4, x2);
     t_emit(pc, o, x4);
-    t_mul_add(x, x, x4, c_uniform);      // < 0.04p + p + p
-    red2(x);
+    t_mul_add(x, x, x4, c_uniform);      // x < 4p, x4 < 1.04p: < 4.2 p^2 / R + c + p < 2.04p, no reduction needed
     t_emit(pc, o, x);
 }
 
@@ -133,11 +166,9 @@ IMT_HD void t_inner(const PoseidonConsts& pc, TraceSink& o, Fe& r, const Fe* row
     Fe acc;
     t_mulc(acc, row_uniform[0], s[0]);
     t_emit(pc, o, acc);
-    t_mulc_add(acc, row_uniform[1], s[1], acc);      // < 0.04p + 1.2p + p
-    red2(acc);
+    t_mulc_add(acc, row_uniform[1], s[1], acc);      // < 0.04p + 1.04p + p
     t_emit(pc, o, acc);
-    t_mulc_add(r, row_uniform[2], s[2], acc);
-    red2(r);
+    t_mulc_add(r, row_uniform[2], s[2], acc);        // < 0.04p + 2.08p + p = 3.12p: fine as a factor (< 4p) and as a row
     t_emit(pc, o, r);
 }
 

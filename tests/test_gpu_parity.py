@@ -744,7 +744,8 @@ def test_config2_full_size_properties(imt, ctx, oracle):
     (1) every insert_leaf constraint holds for every insertion (witness kernels, independent of the
     sweep); (2) roots chain: old_root[i+1] == new_root[i]; (3) the final root equals an independent
     bulk build (leaf hashes -> dense level kernels -> zero extension); (4) batch-split invariance;
-    (5) the first 256 insertions equal the sequential CPU oracle bit for bit."""
+    (5) EVERY one of the 2^16 interim / new roots, low indices and flags equals the sequential CPU oracle's
+    (digests of its full run, tests/golden/config2_oracle_digest.json), as do final proofs; a prefix value by value."""
     depth, n = 32, 1 << 16
     vals = oracle_lib.synth_values(n, 0x494D5402)
     t = imt.IndexedTree(ctx, depth, 1 << 17)
@@ -764,7 +765,21 @@ def test_config2_full_size_properties(imt, ctx, oracle):
     cuts = [0, 1, 1000, 30000, 30001, n]
     roots = [t2.insert_batch(vals[a:b], proofs=False)["new_root"] for a, b in zip(cuts, cuts[1:])]
     assert (np.concatenate(roots) == r["new_root"]).all() and t2.root() == t.root()
-    # (5) prefix against the oracle
+    # (5) ALL 65 536 insertions against the sequential CPU oracle, through the committed digests of its full run
+    #     (tests/golden/make_config2_digest.py: six and a half minutes of one core, too long for a test)
+    import hashlib
+    dg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config2_oracle_digest.json")))
+    assert dg["n"] == n and dg["depth"] == depth
+    assert hashlib.sha256(r["interim_root"].tobytes()).hexdigest() == dg["sha256_interim_roots"]
+    assert hashlib.sha256(r["new_root"].tobytes()).hexdigest() == dg["sha256_new_roots"]
+    assert hashlib.sha256(r["low_index"].astype("<u8").tobytes()).hexdigest() == dg["sha256_low_index"]
+    assert hashlib.sha256(r["is_largest"].tobytes()).hexdigest() == dg["sha256_is_largest"]
+    assert t.root() == int(dg["final_root"])
+    for k, v in dg["root_after"].items():
+        assert ints(r["new_root"][int(k) - 1]) == [int(v)]
+    for i, hx in dg["sha256_final_proofs"].items():
+        assert hashlib.sha256(t.get_proof_batch([int(i)], item_major=True).tobytes()).hexdigest() == hx
+    # (5b) and a prefix value by value
     oh, rows, _ = _oracle_run(oracle, depth, 512, vals[:256])
     assert ints(r["new_root"][:256]) == [o["new_root"] for o in rows]
     assert ints(r["interim_root"][:256]) == [o["interim_root"] for o in rows]
