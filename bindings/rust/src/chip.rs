@@ -162,23 +162,19 @@ impl IndexedMerkleTreeChip {
         self.tree.insert_batch(vals).expect("imt_itree_insert_batch")
     }
 
-    /// The four `compute_merkle_root` calls of `insert_leaf`, in its order: low leaf (`:193-204`), rewritten low leaf
-    /// (`:271-284`), the zero leaf at the new slot (`:286-294`, no leaf hash: the zero-leaf hash is a constant), the
-    /// new leaf (`:299-312`) -- 3 + 4 d traces, queued on `hasher`.
-    pub fn prime_insert_traces<F: BigPrimeField>(&self, hasher: &TracedPoseidonHasher<F>, w: &InsertWitness<F>, zero_leaf_hash: F) {
+    /// The 3 + 4 d traces of every witness in one GPU call (`imt_insert_trace_batch`), in `insert_leaf`'s own order:
+    /// low leaf + path (`:193-204`), rewritten low leaf + path (`:271-284`), the zero leaf's path at the new slot
+    /// (`:286-294`; no leaf hash, the zero-leaf hash is a constant), new leaf + path (`:299-312`).
+    pub fn insert_traces<F: BigPrimeField>(&self, w: &[InsertWitness<F>]) -> Vec<Vec<F>> {
+        gpu::insert_traces(w, self.tree.depth).expect("imt_insert_trace_batch")
+    }
+
+    /// queue one insertion's traces (one element of `insert_traces`) on `hasher`, in call order
+    pub fn prime_insert_traces<F: BigPrimeField>(&self, hasher: &TracedPoseidonHasher<F>, rows: &[F]) {
         let d = self.tree.depth;
-        let low_idx = helper_to_index(&w.low_leaf_proof_helper);
-        let new_idx = helper_to_index(&w.new_leaf_proof_helper);
-        let new_low = [w.low_leaf[0], w.new_leaf[0], F::from(w.new_leaf_index)];
-        let with_leaf: Vec<usize> = std::iter::once(3).chain(std::iter::repeat(2).take(d)).collect();
-        let t = gpu::path_traces(None, Some(&[w.low_leaf]), &[low_idx], &w.low_leaf_proof, d).expect("trace");
-        hasher.push_traces(&t[0], &with_leaf);
-        let t = gpu::path_traces(None, Some(&[new_low]), &[low_idx], &w.low_leaf_proof, d).expect("trace");
-        hasher.push_traces(&t[0], &with_leaf);
-        let t = gpu::path_traces(Some(&[zero_leaf_hash]), None, &[new_idx], &w.new_leaf_proof, d).expect("trace");
-        hasher.push_traces(&t[0], &vec![2; d]);
-        let t = gpu::path_traces(None, Some(&[w.new_leaf]), &[new_idx], &w.new_leaf_proof, d).expect("trace");
-        hasher.push_traces(&t[0], &with_leaf);
+        let with_leaf = std::iter::once(3).chain(std::iter::repeat(2).take(d));
+        let arities: Vec<usize> = with_leaf.clone().chain(with_leaf.clone()).chain(std::iter::repeat(2).take(d)).chain(with_leaf).collect();
+        hasher.push_traces(rows, &arities);
     }
 
     /// loads one witness as `insert_leaf`'s arguments (`ctx.load_witness` per value, as the reference's tests do at
@@ -200,7 +196,3 @@ impl IndexedMerkleTreeChip {
     }
 }
 
-/// helper = 1 iff left child (`src/utils.rs:79`) -> bit l of the index is 0
-fn helper_to_index<F: BigPrimeField>(helper: &[F]) -> u64 {
-    helper.iter().enumerate().fold(0u64, |acc, (l, h)| if *h == F::ZERO { acc | (1u64 << l) } else { acc })
-}

@@ -116,6 +116,8 @@ extern "C" {
     pub fn imt_hash_trace_rows(arity: c_int) -> usize;
     pub fn imt_hash_trace_batch(ctx: *mut imt_ctx, input: *const c_void, arity: c_int, n: usize, trace: *mut c_void, flags: c_uint) -> c_int;
     pub fn imt_path_trace_batch(ctx: *mut imt_ctx, leaf: *const c_void, leaf3: *const c_void, index: *const u64, sib: *const c_void, depth: c_uint, n: usize, trace: *mut c_void, root_out: *mut c_void, flags: c_uint) -> c_int;
+    pub fn imt_insert_trace_rows(depth: c_uint) -> usize;
+    pub fn imt_insert_trace_batch(ctx: *mut imt_ctx, low_leaf: *const c_void, low_index: *const u64, low_sib: *const c_void, new_leaf: *const c_void, new_index: *const u64, new_path_index: *const u64, new_sib: *const c_void, depth: c_uint, n: usize, trace: *mut c_void, flags: c_uint) -> c_int;
     pub fn imt_hash_trace_layout(ctx: *mut imt_ctx, arity: c_int, cells: *mut imt_trace_cell, cells_cap: usize, n_cells: *mut usize, constants: *mut c_void, const_cap: usize, n_constants: *mut usize, out_row: *mut u32, flags: c_uint) -> c_int;
 
     // ---- a2 / a3 / a4: dense native tree

@@ -235,6 +235,41 @@ pub fn path_traces<F: ScalarField>(
     Ok(trace.chunks_exact(rows * 32).map(from_bytes).collect())
 }
 
+/// All 3 + 4 d hash traces of `insert_leaf` for every witness, in the circuit's call order, one `Vec<F>` of
+/// `imt_insert_trace_rows(depth)` rows per insertion (one GPU call for the whole slice: a call costs ~13 ms however
+/// few items it carries, so batch).  5.1 MB per insertion at depth 32.
+pub fn insert_traces<F: ScalarField>(w: &[InsertWitness<F>], depth: usize) -> Result<Vec<Vec<F>>, ImtError> {
+    let g = context().lock().unwrap();
+    let n = w.len();
+    let rows = unsafe { imt_insert_trace_rows(depth as u32) };
+    let idx = |h: &Vec<F>| h.iter().enumerate().fold(0u64, |a, (l, x)| if *x == F::ZERO { a | (1u64 << l) } else { a });
+    let low_leaf: Vec<u8> = w.iter().flat_map(|x| to_bytes(&x.low_leaf)).collect();
+    let new_leaf: Vec<u8> = w.iter().flat_map(|x| to_bytes(&x.new_leaf)).collect();
+    let low_index: Vec<u64> = w.iter().map(|x| idx(&x.low_leaf_proof_helper)).collect();
+    let new_path: Vec<u64> = w.iter().map(|x| idx(&x.new_leaf_proof_helper)).collect();
+    let new_index: Vec<u64> = w.iter().map(|x| x.new_leaf_index).collect();
+    let low_sib: Vec<u8> = w.iter().flat_map(|x| to_bytes(&x.low_leaf_proof)).collect();
+    let new_sib: Vec<u8> = w.iter().flat_map(|x| to_bytes(&x.new_leaf_proof)).collect();
+    let mut trace = vec![0u8; n * rows * 32];
+    check(&g, unsafe {
+        imt_insert_trace_batch(
+            g.ctx,
+            low_leaf.as_ptr() as *const c_void,
+            low_index.as_ptr(),
+            low_sib.as_ptr() as *const c_void,
+            new_leaf.as_ptr() as *const c_void,
+            new_index.as_ptr(),
+            new_path.as_ptr(),
+            new_sib.as_ptr() as *const c_void,
+            depth as u32,
+            n,
+            trace.as_mut_ptr() as *mut c_void,
+            IMT_FMT_CANONICAL | IMT_TRACE_ITEM_MAJOR, // = IMT_SIB_ITEM_MAJOR: per-item proofs, per-item traces
+        )
+    })?;
+    Ok(trace.chunks_exact(rows * 32).map(from_bytes).collect())
+}
+
 /// The static cell map of one hash (`imt_hash_trace_layout`): cells, constants, output row.
 pub fn trace_layout<F: ScalarField>(arity: usize) -> Result<(Vec<imt_trace_cell>, Vec<F>, usize), ImtError> {
     let g = context().lock().unwrap();

@@ -171,6 +171,18 @@ int imt_hash_trace_batch(imt_ctx *ctx, const void *in /*[n][arity][32]*/, int ar
 int imt_path_trace_batch(imt_ctx *ctx, const void *leaf /*[n][32] or NULL*/, const void *leaf3 /*[n][3][32] or NULL*/,
                          const uint64_t *index /*[n]*/, const void *sib, unsigned depth, size_t n, void *trace,
                          void *root_out /*[n][32] or NULL*/, unsigned flags);
+/* The traces of ALL 3 + 4 * depth hashes of insert_leaf (src/indexed_merkle_tree.rs:231-314) for n insertions, in the
+ * order the circuit reaches hash_fix_len_array: low leaf + its path (:193-204), rewritten low leaf {low.val, new.val,
+ * new_index} + the same path (:271-284), the zero leaf's path at the new slot (:286-294; no leaf hash, the zero-leaf
+ * hash is a constant), new leaf + its path (:299-312).  Inputs as imt_insert_witness_batch (what imt_itree_insert_batch
+ * returned).  trace: the four blocks one after the other, each as imt_path_trace_batch lays it out; item-major
+ * (IMT_TRACE_ITEM_MAJOR, which is the same bit as IMT_SIB_ITEM_MAJOR: siblings are then item-major too):
+ * [n][imt_insert_trace_rows(depth)].  5.1 MB per insertion at depth 32: size the batch to the memory at hand. */
+size_t imt_insert_trace_rows(unsigned depth);
+int imt_insert_trace_batch(imt_ctx *ctx, const void *low_leaf /*[n][3][32]*/, const uint64_t *low_index,
+                           const void *low_sib, const void *new_leaf /*[n][3][32]*/, const uint64_t *new_index,
+                           const uint64_t *new_path_index /*[n] or NULL = new_index*/, const void *new_sib,
+                           unsigned depth, size_t n, void *trace, unsigned flags);
 /* The advice column of ONE hash, cell by cell, in assignment order: where each cell's value comes from and where
  * the vertical gates a + b*c = d start (gate = 1 on cell a).  Static per arity; host pointers only. */
 #define IMT_CELL_CONST 0     /* constants[index] */

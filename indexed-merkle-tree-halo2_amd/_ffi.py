@@ -76,6 +76,9 @@ SIGNATURES = {
     "imt_hash_trace_batch": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_uint]),
     "imt_path_trace_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_size_t, c_void_p, c_void_p,
                                      c_uint]),
+    "imt_insert_trace_rows": (c_size_t, [c_uint]),
+    "imt_insert_trace_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint,
+                                       c_size_t, c_void_p, c_uint]),
     "imt_hash_trace_layout": (c_int, [c_void_p, c_int, P(TraceCell), c_size_t, P(c_size_t), c_void_p, c_size_t,
                                       P(c_size_t), P(ctypes.c_uint32), c_uint]),
     "imt_tree_new": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, P(c_void_p)]),

@@ -162,6 +162,22 @@ class Context:
                                              fmt | (_ffi.TRACE_ITEM_MAJOR if item_major else 0)))
         return out, roots
 
+    def insert_trace(self, low_leaf, low_index, low_sib, new_leaf, new_index, new_sib, depth, new_path_index=None,
+                     fmt=0, item_major=False):
+        """All 3 + 4*depth hash traces of insert_leaf for n insertions (imt_insert_trace_batch), in the circuit's call
+        order; uint8 [rows_total, n, 32] or item-major [n, rows_total, 32] (siblings then item-major too)."""
+        ll = _arr(low_leaf, (3, 32))
+        n = ll.shape[0]
+        args = [ll, np.ascontiguousarray(low_index, dtype=np.uint64), _arr(low_sib, (32,)), _arr(new_leaf, (3, 32)),
+                np.ascontiguousarray(new_index, dtype=np.uint64),
+                None if new_path_index is None else np.ascontiguousarray(new_path_index, dtype=np.uint64),
+                _arr(new_sib, (32,))]
+        total = lib.imt_insert_trace_rows(depth)
+        out = np.empty((n, total, 32) if item_major else (total, n, 32), dtype=np.uint8)
+        self._check(lib.imt_insert_trace_batch(self.h, *[_p(a) for a in args], depth, n, _p(out),
+                                               fmt | (_ffi.TRACE_ITEM_MAJOR if item_major else 0)))
+        return out
+
     def hash_trace_layout(self, arity, fmt=0):
         """(cells, constants, out_row): the advice column of one hash, cell by cell (imt_hash_trace_layout).
         cells: structured array with fields kind (_ffi.CELL_*), gate, index; constants: uint8 [k, 32]."""

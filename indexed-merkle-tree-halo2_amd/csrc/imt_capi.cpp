@@ -336,6 +336,27 @@ extern "C" int imt_hash_trace_batch(imt_ctx* c, const void* in, int arity, size_
     return io.finish();
 }
 
+namespace {
+// Traces of one compute_merkle_root per item into `trace` starting at block row `row0` (advanced): the leaf hash
+// (if leaf3) then `depth` path hashes.  All pointers are device pointers; `pairs` is scratch [depth][n][2][32].
+void path_trace_core(imt_ctx* c, const uint8_t* d_leaf, const uint8_t* d_leaf3, const uint64_t* d_idx, const uint8_t* d_sib,
+                     launch::SibLayout lay, unsigned depth, size_t n, uint8_t* d_tr, size_t rows_total, bool item_major,
+                     size_t& row0, uint8_t* pairs, uint8_t* d_root, unsigned fmt) {
+    const size_t r2 = dev::TRACE_ROWS_H2, r3 = dev::TRACE_ROWS_H3;
+    // the chain first (one fast hash per level), which yields the two inputs of every hash on the path ...
+    launch::path_pairs(c->stream, d_leaf, d_leaf3, d_idx, false, d_sib, lay, depth, n, pairs, d_root, fmt, fmt, c->d_err);
+    // ... then every hash of every path is an independent trace
+    auto block = [&](const uint8_t* in_l, int arity, unsigned fmt_in, size_t rows) {
+        uint8_t* base = d_tr + (item_major ? row0 : row0 * n) * 32;
+        launch::hash_trace(c->stream, in_l, n, arity, base, item_major ? 1 : n, item_major ? rows_total : 1, fmt_in, fmt,
+                           c->d_err);
+        row0 += rows;
+    };
+    if (d_leaf3) block(d_leaf3, 3, fmt, r3);
+    for (unsigned l = 0; l < depth; l++) block(pairs + (size_t)l * n * 64, 2, IMT_FMT_DEVICE, r2);
+}
+}  // namespace
+
 extern "C" int imt_path_trace_batch(imt_ctx* c, const void* leaf, const void* leaf3, const uint64_t* index,
                                     const void* sib, unsigned depth, size_t n, void* trace, void* root_out,
                                     unsigned flags) {
@@ -345,8 +366,7 @@ extern "C" int imt_path_trace_batch(imt_ctx* c, const void* leaf, const void* le
     if (n == 0) return IMT_OK;
     if ((!leaf) == (!leaf3)) return c->fail(IMT_ERR_ARG, "exactly one of leaf / leaf3 must be given");
     if (!index || !trace || (depth && !sib)) return c->fail(IMT_ERR_ARG, "null buffer");
-    const size_t r2 = dev::TRACE_ROWS_H2, r3 = dev::TRACE_ROWS_H3;
-    const size_t rows_total = (leaf3 ? r3 : 0) + (size_t)depth * r2;
+    const size_t rows_total = (leaf3 ? (size_t)dev::TRACE_ROWS_H3 : 0) + (size_t)depth * dev::TRACE_ROWS_H2;
     Io io(c, flags);
     const uint8_t* d_leaf = leaf ? io.in(leaf, n * 32) : nullptr;
     const uint8_t* d_leaf3 = leaf3 ? io.in(leaf3, n * 96) : nullptr;
@@ -356,21 +376,49 @@ extern "C" int imt_path_trace_batch(imt_ctx* c, const void* leaf, const void* le
     uint8_t* d_root = io.out(root_out, n * 32);
     uint8_t* pairs = io.temp((size_t)depth * n * 64);
     if (io.rc) return io.rc;
+    size_t row0 = 0;
+    path_trace_core(c, d_leaf, d_leaf3, d_idx, d_sib, sib_layout(flags & ~IMT_TRACE_ITEM_MAJOR, depth, n), depth, n, d_tr,
+                    rows_total, flags & IMT_TRACE_ITEM_MAJOR, row0, pairs, d_root, flags & IMT_FMT_MASK);
+    return io.finish();
+}
+
+extern "C" size_t imt_insert_trace_rows(unsigned depth) {
+    return 3 * (size_t)dev::TRACE_ROWS_H3 + 4 * (size_t)depth * dev::TRACE_ROWS_H2;
+}
+
+extern "C" int imt_insert_trace_batch(imt_ctx* c, const void* low_leaf, const uint64_t* low_index, const void* low_sib,
+                                      const void* new_leaf, const uint64_t* new_index, const uint64_t* new_path_index,
+                                      const void* new_sib, unsigned depth, size_t n, void* trace, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    if (depth > IMT_MAX_DEPTH) return c->fail(IMT_ERR_RANGE, "depth %u > %d", depth, IMT_MAX_DEPTH);
+    if (n == 0) return IMT_OK;
+    if (!low_leaf || !low_index || !new_leaf || !new_index || !trace || (depth && (!low_sib || !new_sib)))
+        return c->fail(IMT_ERR_ARG, "null buffer");
+    const size_t rows_total = imt_insert_trace_rows(depth);
+    Io io(c, flags);
+    const uint8_t* d_ll = io.in(low_leaf, n * 96);
+    const uint64_t* d_li = (const uint64_t*)io.in(low_index, n * 8);
+    const uint8_t* d_ls = io.in(low_sib, (size_t)depth * n * 32);
+    const uint8_t* d_nl = io.in(new_leaf, n * 96);
+    const uint64_t* d_ni = (const uint64_t*)io.in(new_index, n * 8);
+    const uint64_t* d_np = new_path_index ? (const uint64_t*)io.in(new_path_index, n * 8) : d_ni;
+    const uint8_t* d_ns = io.in(new_sib, (size_t)depth * n * 32);
+    uint8_t* d_tr = io.out(trace, n * rows_total * 32);
+    uint8_t* pairs = io.temp((size_t)depth * n * 64);
+    uint8_t* tmp3 = io.temp(n * 96);      // the rewritten low leaf {low.val, new.val, new_index}   :265-269
+    uint8_t* tmpz = io.temp(n * 32);      // the zero-leaf hash per item                            :247-251
+    if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     const bool item_major = flags & IMT_TRACE_ITEM_MAJOR;
-    // the chain first (one fast hash per level), which yields the two inputs of every hash on the path ...
-    launch::path_pairs(c->stream, d_leaf, d_leaf3, d_idx, false, d_sib, sib_layout(flags & ~IMT_TRACE_ITEM_MAJOR, depth, n),
-                       depth, n, pairs, d_root, fmt, fmt, c->d_err);
-    // ... then every hash of every path is an independent trace
+    const launch::SibLayout lay = sib_layout(flags, depth, n);
+    launch::insert_trace_inputs(c->stream, d_ll, d_nl, d_ni, n, tmp3, tmpz, fmt, c->d_err);
     size_t row0 = 0;
-    auto block = [&](const uint8_t* in_l, int arity, unsigned fmt_in, size_t rows) {
-        uint8_t* base = d_tr + (item_major ? row0 : row0 * n) * 32;
-        launch::hash_trace(c->stream, in_l, n, arity, base, item_major ? 1 : n, item_major ? rows_total : 1, fmt_in, fmt,
-                           c->d_err);
-        row0 += rows;
-    };
-    if (leaf3) block(d_leaf3, 3, fmt, r3);
-    for (unsigned l = 0; l < depth; l++) block(pairs + (size_t)l * n * 64, 2, IMT_FMT_DEVICE, r2);
+    // the order in which insert_leaf reaches hash_fix_len_array: :193-204, :271-284, :286-294, :299-312
+    path_trace_core(c, nullptr, d_ll, d_li, d_ls, lay, depth, n, d_tr, rows_total, item_major, row0, pairs, nullptr, fmt);
+    path_trace_core(c, nullptr, tmp3, d_li, d_ls, lay, depth, n, d_tr, rows_total, item_major, row0, pairs, nullptr, fmt);
+    path_trace_core(c, tmpz, nullptr, d_np, d_ns, lay, depth, n, d_tr, rows_total, item_major, row0, pairs, nullptr, fmt);
+    path_trace_core(c, nullptr, d_nl, d_np, d_ns, lay, depth, n, d_tr, rows_total, item_major, row0, pairs, nullptr, fmt);
     return io.finish();
 }
 

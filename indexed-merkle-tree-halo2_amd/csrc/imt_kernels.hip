@@ -247,6 +247,24 @@ k_path_pairs(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3
     flag_err(err, ok);
 }
 
+// inputs of imt_insert_trace_batch that no caller buffer holds: the rewritten low leaf and the zero-leaf hash
+__global__ void __launch_bounds__(BLOCK)
+k_insert_trace_inputs(const uint8_t* __restrict__ low_leaf, const uint8_t* __restrict__ new_leaf,
+                      const uint64_t* __restrict__ new_index, size_t n, uint8_t* __restrict__ new_low,
+                      uint8_t* __restrict__ zero_leaf, unsigned fmt, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    Fe a, b, c;
+    bool ok = load_fe(g_pc, a, low_leaf + (i * 3 + 0) * 32, fmt);
+    ok &= load_fe(g_pc, b, new_leaf + (i * 3 + 0) * 32, fmt);
+    fe_from_u64(c, new_index[i]);
+    store_fe(g_pc, new_low + (i * 3 + 0) * 32, a, fmt);
+    store_fe(g_pc, new_low + (i * 3 + 1) * 32, b, fmt);
+    store_fe(g_pc, new_low + (i * 3 + 2) * 32, c, fmt);
+    store_fe(g_pc, zero_leaf + i * 32, g_pc.zero_leaf, fmt);
+    flag_err(err, ok);
+}
+
 // ---- a5 / a8 / a9 ----------------------------------------------------------------
 __global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
 k_path_root(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3, const uint64_t* __restrict__ index,
@@ -800,6 +818,12 @@ void hash_trace(hipStream_t s, const uint8_t* in, size_t n, int arity, uint8_t* 
     if (!n) return;
     hipLaunchKernelGGL(k_hash_trace, dim3(nblk(n)), dim3(BLOCK), 0, s, in, n, arity, trace, row_stride, item_stride,
                        fmt_in, fmt_out, err);
+}
+void insert_trace_inputs(hipStream_t s, const uint8_t* low_leaf, const uint8_t* new_leaf, const uint64_t* new_index,
+                         size_t n, uint8_t* new_low, uint8_t* zero_leaf, unsigned fmt, int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_insert_trace_inputs, dim3(nblk(n)), dim3(BLOCK), 0, s, low_leaf, new_leaf, new_index, n, new_low,
+                       zero_leaf, fmt, err);
 }
 void path_pairs(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index, bool is_helper,
                 const uint8_t* sib, SibLayout lay, unsigned depth, size_t n, uint8_t* pairs, uint8_t* root_out,

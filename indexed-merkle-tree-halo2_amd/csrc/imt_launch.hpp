@@ -33,6 +33,9 @@ hipError_t upload_trace_consts(const dev::TraceConsts& tc);
 // trace + (j * row_stride + i * item_stride) * 32
 void hash_trace(hipStream_t s, const uint8_t* in, size_t n, int arity, uint8_t* trace, uint64_t row_stride,
                 uint64_t item_stride, unsigned fmt_in, unsigned fmt_out, int* err);
+// {low.val, new.val, new_index} per item -> new_low [n][3][32], and the zero-leaf hash -> zero_leaf [n][32] (fmt)
+void insert_trace_inputs(hipStream_t s, const uint8_t* low_leaf, const uint8_t* new_leaf, const uint64_t* new_index,
+                         size_t n, uint8_t* new_low, uint8_t* zero_leaf, unsigned fmt, int* err);
 // the (left, right) inputs of every hash2 along n paths: pairs[depth][n][2][32], device format
 void path_pairs(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index, bool is_helper,
                 const uint8_t* sib, SibLayout lay, unsigned depth, size_t n, uint8_t* pairs, uint8_t* root_out,

@@ -723,6 +723,45 @@ def test_path_trace_is_the_trace_of_every_hash_on_the_path(imt, ctx, oracle):
     assert ints(roots2) == [oracle.path_root(leaf[i], index[i], imt.to_bytes([sib[l][i] for l in range(depth)])) for i in range(n)]
 
 
+def test_insert_trace_is_what_the_circuit_would_assign(imt, ctx, oracle):
+    """imt_insert_trace_batch on real insertion witnesses: the 3 + 4 d traces per insertion, in insert_leaf's call
+    order, each equal to the oracle's trace of the hash the circuit computes there; the chains end in the roots."""
+    depth, n = 4, 6
+    t = imt.IndexedTree(ctx, depth, 16)
+    t.insert_batch([77, 5])
+    r = t.insert_batch([30, 10, 20, 5000, 50, 35])
+    tr = ctx.insert_trace(r["low_leaf"], r["low_index"], r["low_sib"], r["new_leaf"], r["new_index"], r["new_sib"], depth)
+    assert tr.shape == (imt.lib.imt_insert_trace_rows(depth), n, 32) and tr.shape[0] == 3 * 1209 + 4 * depth * 1208
+    zero_leaf = oracle.hash([0, 0, 0])
+    for i in range(n):
+        low, new = ints(r["low_leaf"][i]), ints(r["new_leaf"][i])
+        li, ni = int(r["low_index"][i]), int(r["new_index"][i])
+        chains = [(low, li, r["low_sib"][:, i], ints(r["old_root"][i])[0]),
+                  ([low[0], new[0], ni], li, r["low_sib"][:, i], ints(r["interim_root"][i])[0]),
+                  (None, ni, r["new_sib"][:, i], ints(r["interim_root"][i])[0]),
+                  (new, ni, r["new_sib"][:, i], ints(r["new_root"][i])[0])]
+        off = 0
+        for pre, idx, sib, root in chains:
+            if pre is not None:
+                assert ints(tr[off:off + 1209, i]) == ints(oracle.hash_trace(pre)["witness"]), (i, off)
+                cur = oracle.hash(pre)
+                off += 1209
+            else:
+                cur = zero_leaf
+            for l in range(depth):
+                s_ = ints(sib[l])[0]
+                pair = [s_, cur] if (idx >> l) & 1 else [cur, s_]
+                assert ints(tr[off:off + 1208, i]) == ints(oracle.hash_trace(pair)["witness"]), (i, off, l)
+                cur = oracle.hash(pair)
+                off += 1208
+            assert cur == root
+        assert off == tr.shape[0]
+    tim = ctx.insert_trace(r["low_leaf"], r["low_index"], r["low_sib"].transpose(1, 0, 2).copy(), r["new_leaf"],
+                           r["new_index"], r["new_sib"].transpose(1, 0, 2).copy(), depth, item_major=True)
+    assert (tim.transpose(1, 0, 2) == tr).all()
+    t.close()
+
+
 def test_hash_trace_2pow14_properties(imt, ctx):
     """2^14 traces in one launch (634 MB of rows): the output row of every item equals imt_hash2_batch, and sampled
     items satisfy every gate of the rebuilt column."""
