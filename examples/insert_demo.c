@@ -1,9 +1,11 @@
 /* insert_demo.c -- plain C against include/imt.h: 6 insertions into a depth-3 tree (the values of the
  * reference's test_insert_leaf_multiple_round, src/indexed_merkle_tree.rs:683-690), then every
- * insert_leaf constraint re-checked on the GPU.  Build:
+ * insert_leaf constraint re-checked on the GPU, then the witness trace of all 3 + 4*3 Poseidon gadget calls
+ * of every insert_leaf (what a chip assigns instead of recomputing) and its cell map.  Build:
  *   gcc -std=c11 -I include examples/insert_demo.c -L indexed-merkle-tree-halo2_amd/csrc -limt_hip -o insert_demo
  */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "imt.h"
 
@@ -45,6 +47,36 @@ int main(void) {
     int bad = 0;
     for (int i = 0; i < N; i++) bad |= fail[i];
     printf("insert_leaf constraints: %s\n", bad ? "VIOLATED" : "all satisfied");
+
+    /* f1: every new advice value of the 15 hashes of each insert_leaf, one insertion's rows next to each other */
+    const size_t rows = imt_insert_trace_rows(DEPTH);
+    unsigned char(*trace)[32] = malloc(N * rows * 32);
+    unsigned char low_sib_im[N][DEPTH][32], new_sib_im[N][DEPTH][32];      /* item-major proofs for this call */
+    for (int i = 0; i < N; i++)
+        for (int l = 0; l < DEPTH; l++) {
+            memcpy(low_sib_im[i][l], low_sib[l][i], 32);
+            memcpy(new_sib_im[i][l], new_sib[l][i], 32);
+        }
+    rc = imt_insert_trace_batch(ctx, low_leaf, low_index, low_sib_im, new_leaf, new_index, NULL, new_sib_im, DEPTH, N,
+                                trace, IMT_FMT_CANONICAL | IMT_TRACE_ITEM_MAJOR);
+    if (rc) { fprintf(stderr, "trace: %s\n", imt_last_error(ctx)); return 1; }
+    size_t n_cells = 0, n_consts = 0;
+    uint32_t out_row = 0;
+    rc = imt_hash_trace_layout(ctx, 2, NULL, 0, &n_cells, NULL, 0, &n_consts, &out_row, IMT_FMT_CANONICAL);
+    if (rc) { fprintf(stderr, "layout: %s\n", imt_last_error(ctx)); return 1; }
+    int trace_ok = rows == 3 * imt_hash_trace_rows(3) + 4 * DEPTH * imt_hash_trace_rows(2);
+    for (int i = 0; i < N; i++) {
+        /* the last hash of the last path of insertion i is the new root: its output row is new_root[i] */
+        const unsigned char *last = trace[(size_t)i * rows + rows - imt_hash_trace_rows(2) + out_row];
+        trace_ok &= memcmp(last, new_root[i], 32) == 0;
+        /* ... and the second block (rewritten low leaf) ends in the interim root */
+        const size_t blk = imt_hash_trace_rows(3) + DEPTH * imt_hash_trace_rows(2);
+        trace_ok &= memcmp(trace[(size_t)i * rows + 2 * blk - imt_hash_trace_rows(2) + out_row], interim_root[i], 32) == 0;
+    }
+    printf("witness trace: %zu rows per insert_leaf, %zu cells / %zu constants per 2-input hash, output row %u: %s\n", rows,
+           n_cells, n_consts, out_row, trace_ok ? "trace rows ok" : "MISMATCH");
+    bad |= !trace_ok;
+    free(trace);
     imt_itree_free(tree);
     imt_ctx_destroy(ctx);
     return bad != 0;

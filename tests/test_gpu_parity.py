@@ -630,7 +630,7 @@ def test_c_example_runs(imt):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "all satisfied" in r.stdout
+    assert "all satisfied" in r.stdout and "trace rows ok" in r.stdout and "4506 cells" in r.stdout
     want = int(GOLD["multi_round_depth3"][-1]["new_root"])
     assert f"{want:064x}" in r.stdout          # the last root of test_insert_leaf_multiple_round
 
@@ -1019,6 +1019,60 @@ def test_lift_batch_host_pointers_and_item_major(imt, ctx, oracle):
         t.close()
     assert (res[True]["low_sib"].transpose(1, 0, 2) == res[False]["low_sib"]).all()
     assert (res[True]["old_root"] == res[False]["old_root"]).all()
+
+
+def test_lift_above_the_subtrees_meets_empty_subtrees_and_world_one_is_a_no_op(imt, ctx, oracle):
+    """global depth > subtree height + log2(n_subtrees): the levels above the subtrees' common root climb against
+    Z[l]; a single subtree of full height is lifted by nothing.  Also: batch_abort, a non-power-of-two value
+    partition on both prepare paths."""
+    sub, world, g, depth, n = 5, 4, 1, 10, 6                     # k = 2, three more levels against Z[7], Z[8], Z[9]
+    vals = [v for v in oracle_lib.synth_values(200, 0x494D5442) if v % 3 == 2][:2 * n]
+    z = ints(oracle.zero_hashes(depth))
+    for host_prep in (False, True):
+        t = imt.IndexedTree(ctx, sub, 32)
+        t.set_placement(depth, g)
+        assert imt.lib.imt_itree_set_value_partition(t.h, 3, 2) == 0       # modulus 3: mod_small, not a mask
+        r = t.insert_batch(vals[:n], host_prep=host_prep)
+        with pytest.raises(ValueError, match="another subtree"):
+            t.insert_batch([vals[0] + 1], host_prep=host_prep)
+        sub_new = ints(r["new_root"])
+        before = ints_to_arr([oracle.hash([q, 1]) for q in range(world)])
+        after = ints_to_arr([oracle.hash([q, 2]) for q in range(world)])
+        t.lift_batch(r, before, after)
+        mixed = [ints(after)[q] if q < g else ints(before)[q] for q in range(world)]
+        for i in range(n):
+            x = oracle.hash([mixed[0], sub_new[i]])                          # g = 1: right child at the first level
+            x = oracle.hash([x, oracle.hash([mixed[2], mixed[3]])])          # then left child
+            for l in range(sub + 2, depth):
+                x = oracle.hash([x, z[l]])
+            assert ints(r["new_root"][i]) == [x], (host_prep, i)
+        assert ints(r["new_sib"][sub + 2:, 0]) == z[sub + 2:depth] and ints(r["low_sib"][sub + 1, n - 1]) == [
+            oracle.hash([mixed[2], mixed[3]])]
+        fail = ctx.insert_witness(r["old_root"], r["low_leaf"], r["low_index"], r["low_sib"], r["new_root"], r["new_leaf"],
+                                  r["new_index"], r["new_sib"], r["is_largest"], depth)
+        assert not fail.any()
+        t.close()
+    t = imt.IndexedTree(ctx, 6, 32)
+    t.set_placement(6, 0)                                          # world 1: the tree IS the global tree
+    r = t.insert_batch(vals[:n])
+    keep = {k: v.copy() for k, v in r.items()}
+    t.lift_batch(r, imt.to_bytes([[0]]).reshape(1, 32), imt.to_bytes([[0]]).reshape(1, 32))
+    assert all((r[k] == keep[k]).all() for k in keep)
+    # an open sharded batch can be given up; the tree is as before
+    import ctypes
+    ev, l0 = ctypes.c_uint32(), ctypes.c_uint32()
+    v = imt.to_bytes(vals[n:n + 4])
+    assert imt.lib.imt_itree_batch_begin(t.h, v.ctypes.data_as(ctypes.c_void_p), 4, 0, ctypes.byref(ev), ctypes.byref(l0)) == 0
+    assert imt.lib.imt_itree_insert_batch(t.h, v.ctypes.data_as(ctypes.c_void_p), 4, None, 0) == imt._ffi.ERR["ARG"]
+    assert imt.lib.imt_itree_batch_abort(t.h) == 0
+    root0, size0 = t.root(), t.size
+    r2 = t.insert_batch(vals[n:n + 4])
+    oh, rows, _ = _oracle_run(oracle, 6, 32, vals[:n + 4])
+    assert size0 == n + 1 and ints(r2["new_root"]) == [o["new_root"] for o in rows[n:]]
+    oracle.sparse_free(oh)
+    with pytest.raises(imt.ImtError):
+        t.set_placement(6, 0)                                      # placement only on an empty tree
+    t.close()
 
 
 def test_config4_eight_shards_2pow22_properties(imt, ctx, oracle):
