@@ -479,6 +479,36 @@ def test_device_pointer_mode_matches_host_mode(imt, ctx):
     c2.close()
 
 
+def test_device_pointer_inputs_may_still_be_in_production_on_the_callers_stream(imt, ctx):
+    """imt.h: with IMT_DEVICE_PTRS the work is enqueued on the context's stream.  The batch's preparation runs on an
+    internal side stream, so it must first be ordered behind what the caller has enqueued: here `vals` is all zeros
+    (value 0 = IMT_ERR_VALUE) until a copy lands that sits behind ~50 ms of busy-waiting on the caller's stream."""
+    import ctypes
+    import torch
+    depth, n = 32, 2048
+    dev = torch.device("cuda", 0)
+    c2 = imt.Context(0)
+    c2.set_stream(torch.cuda.current_stream().cuda_stream)
+    want_t = imt.IndexedTree(c2, depth, 8192)
+    real = imt.to_bytes(oracle_lib.synth_values(2 * n, 0x494D5443))
+    want = [want_t.insert_batch(real[i * n:(i + 1) * n], proofs=False)["new_root"] for i in range(2)]
+    t = imt.IndexedTree(c2, depth, 8192)
+    src = torch.from_numpy(real).to(dev)
+    for b, flags in enumerate((imt._ffi.DEVICE_PTRS, imt._ffi.DEVICE_PTRS | imt._ffi.PIPELINE)):
+        vals = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+        new_root = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+        out = imt._ffi.InsertOut(new_root=new_root.data_ptr())
+        torch.cuda.synchronize()
+        torch.cuda._sleep(120_000_000)                        # ~50 ms on the caller's stream
+        vals.copy_(src[b * n:(b + 1) * n], non_blocking=True)
+        rc = imt.lib.imt_itree_insert_batch(t.h, ctypes.c_void_p(vals.data_ptr()), n, ctypes.byref(out), flags)
+        assert rc == 0, imt.lib.imt_last_error(c2.h)          # read too early it would be "value 0 cannot be inserted"
+        c2.sync()
+        torch.cuda.synchronize()
+        assert (new_root.cpu().numpy() == want[b]).all()
+    t.close(); want_t.close(); c2.close()
+
+
 def test_snapshot_load_roundtrip(imt, ctx, oracle):
     depth = 32
     vals = oracle_lib.synth_values(700, 0x494D5406)
