@@ -177,6 +177,25 @@ impl IndexedMerkleTreeChip {
         hasher.push_traces(rows, &arities);
     }
 
+    /// non-membership (`verify_non_inclusion`, `:127-229`): witnesses for n candidate values against the current tree
+    pub fn non_inclusion<F: BigPrimeField>(&self, vals: &[F]) -> Vec<gpu::NonInclusionWitness<F>> {
+        self.tree.non_inclusion_witnesses(vals).expect("imt_itree_non_membership_witness")
+    }
+
+    /// queue the 1 + d traces `verify_non_inclusion` consumes (low-leaf hash `:193-194`, its path `:196-204`) for each
+    /// witness, in order; one GPU call for all of them
+    pub fn prime_non_inclusion_traces<F: BigPrimeField>(&self, hasher: &TracedPoseidonHasher<F>, w: &[gpu::NonInclusionWitness<F>]) {
+        let d = self.tree.depth;
+        let leaves: Vec<[F; 3]> = w.iter().map(|x| x.low_leaf).collect();
+        let index: Vec<u64> = w.iter().map(|x| x.low_leaf_index).collect();
+        let sib: Vec<F> = w.iter().flat_map(|x| x.low_leaf_proof.iter().copied()).collect();
+        let traces = gpu::path_traces(None, Some(&leaves), &index, &sib, d).expect("imt_path_trace_batch");
+        let arities: Vec<usize> = std::iter::once(3).chain(std::iter::repeat(2).take(d)).collect();
+        for rows in &traces {
+            hasher.push_traces(rows, &arities);
+        }
+    }
+
     /// loads one witness as `insert_leaf`'s arguments (`ctx.load_witness` per value, as the reference's tests do at
     /// `:444-474`)
     pub fn assign_insert<F: BigPrimeField>(&self, ctx: &mut Context<F>, w: &InsertWitness<F>) -> AssignedInsert<F> {

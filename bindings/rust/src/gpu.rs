@@ -193,6 +193,50 @@ impl IndexedTree {
             .collect())
     }
 }
+/// Everything `verify_non_inclusion` takes for one candidate value (`src/indexed_merkle_tree.rs:127-137`).
+#[derive(Clone, Debug)]
+pub struct NonInclusionWitness<F> {
+    pub root: F,
+    pub low_leaf: [F; 3],
+    pub low_leaf_index: u64,
+    pub low_leaf_proof: Vec<F>,
+    pub low_leaf_proof_helper: Vec<F>,
+    pub new_leaf_value: F,
+    pub is_new_leaf_largest: bool,
+}
+
+impl IndexedTree {
+    /// Non-membership witnesses of n candidate values against the current tree, from the device-resident sorted
+    /// index (`imt_itree_non_membership_witness`); `Err(code -10)` if a candidate is 0 or already stored.
+    pub fn non_inclusion_witnesses<F: ScalarField>(&self, vals: &[F]) -> Result<Vec<NonInclusionWitness<F>>, ImtError> {
+        let root: F = self.root()?;
+        let g = context().lock().unwrap();
+        let (n, d) = (vals.len(), self.depth);
+        let v = to_bytes(vals);
+        let mut low_index = vec![0u64; n];
+        let mut is_largest = vec![0u8; n];
+        let mut low_leaf = vec![0u8; n * 96];
+        let mut low_sib = vec![0u8; n * d * 32];
+        check(&g, unsafe {
+            imt_itree_non_membership_witness(self.handle, v.as_ptr() as *const c_void, n, low_index.as_mut_ptr(),
+                                             low_leaf.as_mut_ptr() as *mut c_void, is_largest.as_mut_ptr(),
+                                             low_sib.as_mut_ptr() as *mut c_void, IMT_FMT_CANONICAL | IMT_SIB_ITEM_MAJOR)
+        })?;
+        Ok((0..n)
+            .map(|i| NonInclusionWitness {
+                root,
+                low_leaf: [F::from_bytes_le(&low_leaf[i * 96..][..32]), F::from_bytes_le(&low_leaf[i * 96 + 32..][..32]),
+                           F::from_bytes_le(&low_leaf[i * 96 + 64..][..32])],
+                low_leaf_index: low_index[i],
+                low_leaf_proof: from_bytes(&low_sib[i * d * 32..][..d * 32]),
+                low_leaf_proof_helper: (0..d).map(|l| if (low_index[i] >> l) & 1 == 0 { F::from(1) } else { F::from(0) }).collect(),
+                new_leaf_value: vals[i],
+                is_new_leaf_largest: is_largest[i] != 0,
+            })
+            .collect())
+    }
+}
+
 impl Drop for IndexedTree {
     fn drop(&mut self) {
         let _g = context().lock().unwrap();
