@@ -792,6 +792,36 @@ def test_insert_trace_is_what_the_circuit_would_assign(imt, ctx, oracle):
     t.close()
 
 
+def test_trace_edge_cases(imt, ctx, oracle):
+    """empty batches, depth 0 (the leaf hash alone), wrong arity, device pointers"""
+    import ctypes
+    import torch
+    assert ctx.hash_trace(np.zeros((0, 2, 32), np.uint8)).shape == (1208, 0, 32)
+    leaf3 = imt.to_bytes([[5, 6, 7]])
+    tr, roots = ctx.path_trace([0], np.zeros((0, 32), np.uint8), 0, leaf3=leaf3)
+    assert tr.shape == (1209, 1, 32) and ints(tr[:, 0]) == ints(oracle.hash_trace([5, 6, 7])["witness"])
+    assert ints(roots) == [oracle.hash([5, 6, 7])]
+    assert imt.lib.imt_hash_trace_rows(4) == 0
+    out = np.empty((1208, 1, 32), np.uint8)
+    assert imt.lib.imt_hash_trace_batch(ctx.h, leaf3.ctypes.data_as(ctypes.c_void_p), 4, 1, out.ctypes.data_as(ctypes.c_void_p), 0) == imt._ffi.ERR["ARG"]
+    assert imt.lib.imt_insert_trace_rows(32) == 3 * 1209 + 128 * 1208
+    # device pointers, asynchronous on the context's stream; input errors surface at imt_ctx_sync
+    dev = torch.device("cuda", 0)
+    c2 = imt.Context(0)
+    c2.set_stream(torch.cuda.current_stream().cuda_stream)
+    inp = torch.from_numpy(imt.to_bytes([[1, 2], [3, 4]])).to(dev)
+    tr_d = torch.empty((1208, 2, 32), dtype=torch.uint8, device=dev)
+    rc = imt.lib.imt_hash_trace_batch(c2.h, ctypes.c_void_p(inp.data_ptr()), 2, 2, ctypes.c_void_p(tr_d.data_ptr()), imt._ffi.DEVICE_PTRS)
+    assert rc == 0
+    c2.sync()
+    assert ints(tr_d[:, 1].cpu().numpy()) == ints(oracle.hash_trace([3, 4])["witness"])
+    inp[0, 0, :] = 0xff                                                    # >= p
+    assert imt.lib.imt_hash_trace_batch(c2.h, ctypes.c_void_p(inp.data_ptr()), 2, 2, ctypes.c_void_p(tr_d.data_ptr()), imt._ffi.DEVICE_PTRS) == 0
+    with pytest.raises(imt.ImtError):
+        c2.sync()
+    c2.close()
+
+
 def test_hash_trace_2pow14_properties(imt, ctx):
     """2^14 traces in one launch (634 MB of rows): the output row of every item equals imt_hash2_batch, and sampled
     items satisfy every gate of the rebuilt column."""
