@@ -87,6 +87,8 @@ pub const IMT_PROF_WRITEBACK: usize = 4;
 pub const IMT_PROF_HOST: usize = 5;
 pub const IMT_PROF_CLASSES: usize = 6;
 
+pub const IMT_OPT_COOP_MAX_EVENTS: c_int = 1;
+
 pub const IMT_CELL_CONST: u8 = 0;
 pub const IMT_CELL_INPUT: u8 = 1;
 pub const IMT_CELL_INIT: u8 = 2;
@@ -102,6 +104,7 @@ extern "C" {
     pub fn imt_ctx_sync(ctx: *mut imt_ctx) -> c_int;
     pub fn imt_host_alloc(ctx: *mut imt_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn imt_host_free(ctx: *mut imt_ctx, ptr: *mut c_void) -> c_int;
+    pub fn imt_ctx_set_option(ctx: *mut imt_ctx, option: c_int, value: u64) -> c_int;
     pub fn imt_version() -> *const c_char;
     pub fn imt_measure_mad_peak(ctx: *mut imt_ctx, gmads: *mut c_double) -> c_int;
     pub fn imt_profile_enable(ctx: *mut imt_ctx, on: c_int) -> c_int;

@@ -115,6 +115,12 @@ int imt_ctx_sync(imt_ctx *ctx);
  * Plain host pointers (no IMT_DEVICE_PTRS) stay supported and are synchronous. */
 int imt_host_alloc(imt_ctx *ctx, size_t bytes, void **out);
 int imt_host_free(imt_ctx *ctx, void *ptr);
+/* Tuning knobs.  IMT_OPT_COOP_MAX_EVENTS: batch-insertion launches of at most this many events (2 per insertion) use
+ * the latency form of the hash kernel -- four lanes per hash, 0.6x the time per launch, 2.3x the lane-instructions --
+ * which pays while a launch leaves most of the chip idle.  Default 16384 (one wave per SIMD); 0 = never.  Results are
+ * bit-identical either way. */
+#define IMT_OPT_COOP_MAX_EVENTS 1
+int imt_ctx_set_option(imt_ctx *ctx, int option, uint64_t value);
 /* ABI / build identification, e.g. "imt-hip gfx950 r2" */
 const char *imt_version(void);
 /* Per-kernel timing with HIP events recorded on the context's stream around the launches of

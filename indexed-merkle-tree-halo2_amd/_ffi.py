@@ -66,6 +66,7 @@ SIGNATURES = {
     "imt_host_alloc": (c_int, [c_void_p, c_size_t, P(c_void_p)]),
     "imt_host_free": (c_int, [c_void_p, c_void_p]),
     "imt_ctx_sync": (c_int, [c_void_p]),
+    "imt_ctx_set_option": (c_int, [c_void_p, c_int, c_u64]),
     "imt_measure_mad_peak": (c_int, [c_void_p, P(ctypes.c_double)]),
     "imt_profile_enable": (c_int, [c_void_p, c_int]),
     "imt_profile_read": (c_int, [c_void_p, P(ctypes.c_double)]),
@@ -144,3 +145,4 @@ F_RANGE_PRED, F_LOW_IN_ROOT, F_LOW_LT_NEW, F_ZERO_SLOT, F_NEXT_VAL, F_NEXT_IDX, 
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80)
 CELL_CONST, CELL_INPUT, CELL_INIT, CELL_WITNESS, CELL_COPY = 0, 1, 2, 3, 4
 TRACE_ITEM_MAJOR = SIB_ITEM_MAJOR
+OPT_COOP_MAX_EVENTS = 1

@@ -8,6 +8,7 @@ Field elements are Python ints (canonical) at this level and numpy uint8[..., 32
 little-endian arrays underneath.  All arithmetic happens in libimt_hip.so on the GPU.
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -72,9 +73,12 @@ class Context:
                            else "imt_ctx_create failed")
         self.h = h
         self.device = device
+        self._children = weakref.WeakSet()      # trees of this context: imt.h wants them destroyed before it
 
     def close(self):
         if getattr(self, "h", None):
+            for child in list(getattr(self, "_children", ())):
+                child.close()
             lib.imt_ctx_destroy(self.h)
             self.h = None
 
@@ -93,6 +97,9 @@ class Context:
 
     def sync(self):
         self._check(lib.imt_ctx_sync(self.h))
+
+    def set_option(self, option, value):
+        self._check(lib.imt_ctx_set_option(self.h, option, value))
 
     def host_alloc(self, shape, dtype=np.uint8):
         """numpy array over page-locked, device-addressable host memory (imt_host_alloc); pass its
@@ -316,6 +323,7 @@ class IndexedMerkleTree:
 
     def __init__(self, ctx, handle):
         self.ctx, self.h = ctx, handle
+        ctx._children.add(self)
 
     @classmethod
     def new(cls, ctx, leaves):
@@ -436,6 +444,7 @@ class IndexedTree:
         h = ctypes.c_void_p()
         ctx._check(lib.imt_itree_new(ctx.h, depth, capacity, ctypes.byref(h)))
         self.h = h
+        ctx._children.add(self)
 
     def set_placement(self, global_depth, subtree_index):
         """Make this (empty) tree subtree `subtree_index` at height `depth` of a tree of depth `global_depth`:

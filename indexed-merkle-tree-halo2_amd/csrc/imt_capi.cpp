@@ -143,6 +143,18 @@ extern "C" int imt_profile_read(imt_ctx* c, double* out) {
     return IMT_OK;
 }
 
+extern "C" int imt_ctx_set_option(imt_ctx* c, int option, uint64_t value) {
+    if (!c) return IMT_ERR_ARG;
+    switch (option) {
+        case IMT_OPT_COOP_MAX_EVENTS:
+            if (value > 0xffffffffu) return c->fail(IMT_ERR_RANGE, "value out of range");
+            c->coop_max_events = (uint32_t)value;
+            return IMT_OK;
+        default:
+            return c->fail(IMT_ERR_ARG, "unknown option %d", option);
+    }
+}
+
 extern "C" const char* imt_version(void) { return "imt-hip gfx950 r2"; }
 
 extern "C" int imt_ctx_create(int device, imt_ctx** out) {

@@ -19,6 +19,7 @@ struct imt_ctx {
     int* d_err = nullptr;             // device word: kernels OR 1 into it on a non-canonical input
     uint8_t* d_zero = nullptr;        // Z[0..IMT_MAX_DEPTH] in device format
     std::string last_error;
+    uint32_t coop_max_events = 16384;   // IMT_OPT_COOP_MAX_EVENTS: launches up to this size use the quad-per-hash kernel
     struct Scratch { void* p = nullptr; size_t cap = 0; };
     std::vector<Scratch> scratch;     // grow-only staging buffers, indexed by slot
     // optional kernel timing (imt_profile_*)

@@ -1063,7 +1063,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
 
     // ---- leaf hashes, index phase (no hashing), then the hash sweep ----
     int pf = c->prof_begin(IMT_PROF_LEAVES, s);
-    launch::sweep_leaves(s, P.d_pre, P.d_tab[0][1], P.d_val[0], 0, (uint32_t)E, IMT_FMT_CANONICAL, c->d_err);
+    launch::sweep_leaves(s, P.d_pre, P.d_tab[0][1], P.d_val[0], 0, (uint32_t)E, IMT_FMT_CANONICAL, c->d_err, c->coop_max_events);
     c->prof_end(pf, s);
     pf = c->prof_begin(IMT_PROF_INDEX, s);
     for (unsigned l = 0; l < L0; l++) {
@@ -1087,7 +1087,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         pf = c->prof_begin(IMT_PROF_LEVEL, s);
         launch::sweep_level(s, vin, vout, P.d_from + o, P.d_sibsrc + o, P.d_nodeb + o, P.d_timen + o,
                             t->d_nodes + t->h_off[l] * 32, t->h_len[l], c->d_zero + (size_t)l * 32, 0, (uint32_t)E, g_ls,
-                            g_ns, lay, l, fmt);
+                            g_ns, lay, l, fmt, c->coop_max_events);
         c->prof_end(pf, s);
         pf = c->prof_begin(IMT_PROF_WRITEBACK, s);
         launch::writeback(s, vin, P.d_from + o, P.d_nodeb + o, t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
@@ -1110,7 +1110,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
         pf = c->prof_begin(IMT_PROF_TOP, s);
         launch::sweep_upper(s, P.d_val[l & 1], P.d_val[(l & 1) ^ 1], c->d_zero + (size_t)l * 32, 0, (uint32_t)E,
                             (uint32_t)E - 1, l == L0 ? t->d_nodes + t->h_off[l] * 32 : nullptr,
-                            t->d_nodes + t->h_off[l + 1] * 32, g_ls, g_ns, lay, l, fmt);
+                            t->d_nodes + t->h_off[l + 1] * 32, g_ls, g_ns, lay, l, fmt, c->coop_max_events);
         c->prof_end(pf, s);
         if (pipelined) IMT_HIP(c, hipEventRecord(P.wb_done[l], s));
     }
@@ -1292,7 +1292,8 @@ extern "C" int imt_itree_batch_begin(imt_itree* t, const void* vals, size_t n, u
 extern "C" int imt_itree_batch_leaves(imt_itree* t, void* val0, uint32_t k_begin, uint32_t k_count) {
     IMT_PENDING(t, c);
     if (!val0 || (size_t)k_begin + k_count > E) return c->fail(IMT_ERR_RANGE, "slot range outside the batch");
-    launch::sweep_leaves(c->stream, P.d_pre, P.d_tab[0][1], (uint8_t*)val0, k_begin, k_count, IMT_FMT_CANONICAL, c->d_err);
+    launch::sweep_leaves(c->stream, P.d_pre, P.d_tab[0][1], (uint8_t*)val0, k_begin, k_count, IMT_FMT_CANONICAL, c->d_err,
+                         c->coop_max_events);
     return IMT_OK;
 }
 
@@ -1304,7 +1305,8 @@ extern "C" int imt_itree_batch_level(imt_itree* t, unsigned level, const void* v
     const size_t o = (size_t)level * P.cap_events;
     launch::sweep_level(c->stream, (const uint8_t*)val_in, (uint8_t*)val_out, P.d_from + o, P.d_sibsrc + o, P.d_nodeb + o,
                         P.d_timen + o, t->d_nodes + t->h_off[level] * 32, t->h_len[level], c->d_zero + (size_t)level * 32,
-                        k_begin, k_count, nullptr, nullptr, launch::SibLayout{0, 0}, level, IMT_FMT_DEVICE);
+                        k_begin, k_count, nullptr, nullptr, launch::SibLayout{0, 0}, level, IMT_FMT_DEVICE,
+                        c->coop_max_events);
     return IMT_OK;
 }
 
@@ -1321,7 +1323,7 @@ extern "C" int imt_itree_batch_top(imt_itree* t, const void* val_l0, uint32_t e_
         uint8_t* vout = P.d_val[l & 1];
         launch::sweep_upper(c->stream, vin, vout, c->d_zero + (size_t)l * 32, e_begin, e_count, (uint32_t)E - 1,
                             l == L0 ? tp : nullptr, tp + (size_t)(l + 1 - L0) * 32, nullptr, nullptr,
-                            launch::SibLayout{0, 0}, l, IMT_FMT_DEVICE);
+                            launch::SibLayout{0, 0}, l, IMT_FMT_DEVICE, c->coop_max_events);
         vin = vout;
     }
     launch::emit_roots(c->stream, vin, e_begin, e_count, (uint32_t)E, nullptr, nullptr, nullptr, IMT_FMT_DEVICE,

@@ -14,6 +14,9 @@
 #include "imt_trace_device.hpp"
 #include "imt_launch.hpp"
 #include "imt_sweep.hpp"
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "imt_coop_device.hpp"
+#endif
 
 namespace imt {
 
@@ -599,6 +602,59 @@ __global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_sweep(launch::SweepArg
     if (x == a.last_event && a.node_out) store_packed(a.node_out, o);
 }
 
+// The same launch for SMALL batches: four lanes (a DPP quad) per event, three of them holding one state lane of the
+// permutation each (imt_coop_device.hpp).  0.6x the time per launch while the launch fits one wave per SIMD, 2.3x the
+// lane-instructions: chosen by the launcher below coop_max_events.  Lane 1 of a quad ends up with the hash.
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_sweep_coop(launch::SweepArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t tab[coop::TAB_DWORDS];
+    coop::tab_fill(tab, g_pc);                       // before anyone leaves: it ends in a barrier
+    const size_t t = gtid();
+    const size_t q = t >> 2;
+    if (q >= a.count) return;                        // whole quads leave together
+    const unsigned role = (unsigned)t & 3u, ri = role == 3u ? 0u : role;
+    const uint32_t x = a.begin + (uint32_t)q;
+    Fe X, C3, o;
+    C3 = g_pc.one;                                   // any value: only read for LEAVES
+    if (a.mode == launch::SWEEP_LEAVES) {
+        const uint8_t* p = a.pre + (size_t)a.time0[x] * 96;
+        bool ok = load_fe(g_pc, X, p + (ri == 2u ? 32 : 0), a.fmt_in);     // lane 1: val, lane 2: next_val
+        ok &= load_fe(g_pc, C3, p + 64, a.fmt_in);                         // next_idx, absorbed by lane 1
+        if (ri == 1u) ok &= load_fe(g_pc, o, p + 32, a.fmt_in);            // (every element validated once)
+        flag_err(a.err, ok);
+    } else {
+        uint32_t k = x, n = 0, e = x;
+        const uint8_t* sp = a.zero_l;
+        if (a.from) {
+            k = a.from[x] & ~sweep::LAST_BIT;
+            n = a.node_below[x];
+            e = a.time_next[x];
+            const int32_t ss = a.sibsrc[x];
+            const uint64_t sn = (uint64_t)(n ^ 1u);
+            sp = ss >= 0 ? a.val_in + (size_t)ss * 32 : (sn < a.len_l ? a.tree_l + sn * 32 : a.zero_l);
+        }
+        Fe cur, sv;
+        load_packed(cur, a.val_in + (size_t)k * 32);
+        load_packed(sv, sp);
+        const bool right = n & 1u;
+        // lane 1 holds the left input of the hash, lane 2 the right one
+        const bool take_sv = (ri == 2u) != right;    // lane 2 & left child, or lane 1 & right child: the sibling
+#pragma unroll
+        for (int i = 0; i < NL; i++) X.v[i] = take_sv ? sv.v[i] : cur.v[i];
+        if (role == 0u) {
+            if (x == a.last_event && a.node_in) store_packed(a.node_in, cur);
+            uint8_t* row = (e & 1u) ? a.new_sib : a.low_sib;
+            if (row) store_fe(g_pc, row + ((uint64_t)a.level * a.lay.level_stride + (uint64_t)(e >> 1) * a.lay.item_stride) * 32, sv, a.fmt_out);
+        }
+    }
+    coop::hash23(tab, o, X, C3, a.mode == launch::SWEEP_LEAVES, ri);
+    if (role == 1u) {
+        store_packed(a.val_out + (size_t)x * 32, o);
+        if (x == a.last_event && a.node_out) store_packed(a.node_out, o);
+    }
+#endif
+}
+
 // Roots of events [e_begin, e_begin + e_count) from the top values (indexed by event id), no hashing: event 2i is
 // "low leaf rewritten" (interim root of insertion i), event 2i+1 "new leaf written" (its new root = the old root of
 // insertion i+1).  Sharded mode (roots_dev != NULL): device format, one row per event.
@@ -909,8 +965,15 @@ void fill_level(hipStream_t s, uint8_t* nodes, size_t n, const uint8_t* zero_l) 
     if (!n) return;
     hipLaunchKernelGGL(k_fill_level, dim3(nblk(n)), dim3(BLOCK), 0, s, nodes, n, zero_l);
 }
+// one thread per event, or -- while the launch is small enough to leave most SIMDs idle -- one quad per event
+static void launch_sweep(hipStream_t s, const SweepArgs& a, uint32_t coop_max) {
+    if (a.count <= coop_max)
+        hipLaunchKernelGGL(k_sweep_coop, dim3(nblk((size_t)a.count * 4)), dim3(BLOCK), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_sweep, dim3(nblk(a.count)), dim3(BLOCK), 0, s, a);
+}
 void sweep_leaves(hipStream_t s, const uint8_t* pre, const uint32_t* time0, uint8_t* val0, uint32_t k_begin,
-                  uint32_t k_count, unsigned fmt_in, int* err) {
+                  uint32_t k_count, unsigned fmt_in, int* err, uint32_t coop_max) {
     if (!k_count) return;
     SweepArgs a{};
     a.mode = SWEEP_LEAVES;
@@ -926,7 +989,7 @@ void merge_level(hipStream_t s, sweep::LevelTable in, sweep::LevelOut out, uint3
 void sweep_level(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const uint32_t* from, const int32_t* sibsrc,
                  const uint32_t* node_below, const uint32_t* time_next, const uint8_t* tree_l, uint64_t len_l,
                  const uint8_t* zero_l, uint32_t k_begin, uint32_t k_count, uint8_t* low_sib, uint8_t* new_sib,
-                 SibLayout lay, unsigned level, unsigned fmt_out) {
+                 SibLayout lay, unsigned level, unsigned fmt_out, uint32_t coop_max) {
     if (!k_count) return;
     SweepArgs a{};
     a.mode = SWEEP_LEVEL;
@@ -935,11 +998,11 @@ void sweep_level(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const u
     a.time_next = time_next; a.tree_l = tree_l; a.len_l = len_l; a.zero_l = zero_l; a.level = level;
     a.low_sib = low_sib; a.new_sib = new_sib; a.lay = lay; a.fmt_out = fmt_out;
     a.last_event = 0xffffffffu;
-    hipLaunchKernelGGL(k_sweep, dim3(nblk(k_count)), dim3(BLOCK), 0, s, a);
+    launch_sweep(s, a, coop_max);
 }
 void sweep_upper(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const uint8_t* zero_l, uint32_t e_begin,
                  uint32_t e_count, uint32_t last_event, uint8_t* node_in, uint8_t* node_out, uint8_t* low_sib,
-                 uint8_t* new_sib, SibLayout lay, unsigned level, unsigned fmt_out) {
+                 uint8_t* new_sib, SibLayout lay, unsigned level, unsigned fmt_out, uint32_t coop_max) {
     if (!e_count) return;
     SweepArgs a{};
     a.mode = SWEEP_LEVEL;
@@ -947,7 +1010,7 @@ void sweep_upper(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const u
     a.val_in = val_in; a.val_out = val_out; a.zero_l = zero_l; a.level = level;
     a.low_sib = low_sib; a.new_sib = new_sib; a.lay = lay; a.fmt_out = fmt_out;
     a.last_event = last_event; a.node_in = node_in; a.node_out = node_out;
-    hipLaunchKernelGGL(k_sweep, dim3(nblk(e_count)), dim3(BLOCK), 0, s, a);
+    launch_sweep(s, a, coop_max);
 }
 void emit_roots(hipStream_t s, const uint8_t* val, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
                 uint8_t* interim_root, uint8_t* new_root, unsigned fmt_out, uint8_t* roots_dev, uint8_t* node_store) {

@@ -115,21 +115,23 @@ struct SweepArgs {
     unsigned fmt_out;
 };
 void fill_level(hipStream_t s, uint8_t* nodes, size_t n, const uint8_t* zero_l);
+// coop_max: launches of at most this many events use the latency form of the kernel (a quad of lanes per event,
+// imt_coop_device.hpp); 0 = never
 void sweep_leaves(hipStream_t s, const uint8_t* pre, const uint32_t* time0, uint8_t* val0, uint32_t k_begin,
-                  uint32_t k_count, unsigned fmt_in, int* err);
+                  uint32_t k_count, unsigned fmt_in, int* err, uint32_t coop_max);
 void merge_level(hipStream_t s, sweep::LevelTable in, sweep::LevelOut out, uint32_t total);
 // hashes slots [k_begin, k_begin + k_count) of level `level`+1 (a rank's share when sharded)
 void sweep_level(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const uint32_t* from, const int32_t* sibsrc,
                  const uint32_t* node_below, const uint32_t* time_next, const uint8_t* tree_l, uint64_t len_l,
                  const uint8_t* zero_l, uint32_t k_begin, uint32_t k_count, uint8_t* low_sib, uint8_t* new_sib,
-                 SibLayout lay, unsigned level, unsigned fmt_out);
+                 SibLayout lay, unsigned level, unsigned fmt_out, uint32_t coop_max);
 void writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const uint32_t* node_below, uint8_t* tree_l,
                uint32_t total);
 // level l >= l0 for events [e_begin, e_begin + e_count): val indexed by event id, sibling = zero_l; the values
 // of `last_event` go to node_in (its input, i.e. the node at level l) / node_out (the node at level l + 1)
 void sweep_upper(hipStream_t s, const uint8_t* val_in, uint8_t* val_out, const uint8_t* zero_l, uint32_t e_begin,
                  uint32_t e_count, uint32_t last_event, uint8_t* node_in, uint8_t* node_out, uint8_t* low_sib,
-                 uint8_t* new_sib, SibLayout lay, unsigned level, unsigned fmt_out);
+                 uint8_t* new_sib, SibLayout lay, unsigned level, unsigned fmt_out, uint32_t coop_max);
 // roots per event from the top values (no hashing); sharded mode: roots_dev[e] in device format
 void emit_roots(hipStream_t s, const uint8_t* val, uint32_t e_begin, uint32_t e_count, uint32_t total, uint8_t* old_root,
                 uint8_t* interim_root, uint8_t* new_root, unsigned fmt_out, uint8_t* roots_dev, uint8_t* node_store);

@@ -245,6 +245,36 @@ def test_random_small_batches_differential(imt, ctx, oracle):
         t.close()
 
 
+def test_quad_per_hash_kernel_is_bit_identical(imt, ctx, oracle):
+    """Small launches use the latency form of the hash kernel (four lanes per hash, imt_coop_device.hpp); the same
+    batches with it switched off (IMT_OPT_COOP_MAX_EVENTS = 0) and with it forced on for every size must give the same
+    bytes, and both equal the oracle.  Covers leaf hashes (3 inputs), table-driven levels and the levels above l0."""
+    depth = 32
+    vals = oracle_lib.synth_values(700, 0x494D5444)
+    cuts = [0, 1, 2, 5, 64, 65, 300, 700]
+    res = {}
+    for mode, coop_max in (("off", 0), ("default", 16384), ("always", 1 << 30)):
+        c2 = imt.Context(0)
+        c2.set_option(imt._ffi.OPT_COOP_MAX_EVENTS, coop_max)
+        t = imt.IndexedTree(c2, depth, 1024)
+        outs = [t.insert_batch(vals[a:b], host_prep=(i % 3 == 2)) for i, (a, b) in enumerate(zip(cuts, cuts[1:]))]
+        res[mode] = ({k: np.concatenate([o[k] for o in outs], axis=1 if k.endswith("_sib") else 0) for k in outs[0]}, t.root())
+        t.close(); c2.close()
+    for mode in ("default", "always"):
+        for k in res["off"][0]:
+            assert (res[mode][0][k] == res["off"][0][k]).all(), (mode, k)
+        assert res[mode][1] == res["off"][1]
+    oh, rows, root = _oracle_run(oracle, depth, 1024, vals)
+    r = res["always"][0]
+    assert ints(r["new_root"]) == [o["new_root"] for o in rows] and ints(r["interim_root"]) == [o["interim_root"] for o in rows]
+    assert all((r["low_sib"][:, i] == rows[i]["low_proof"]).all() and (r["new_sib"][:, i] == rows[i]["new_proof"]).all()
+               for i in range(0, 700, 37))
+    assert res["always"][1] == root
+    oracle.sparse_free(oh)
+    with pytest.raises(imt.ImtError):
+        ctx.set_option(99, 1)
+
+
 def test_gpu_prepare_equals_host_prepare(imt, ctx, oracle):
     """The default device-side low-leaf search and event building against IMT_HOST_PREP, batch by
     batch, including adversarial orders, mixed modes on one tree, and the error cases."""

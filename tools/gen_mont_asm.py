@@ -164,6 +164,11 @@ def main():
     body.append(gen("mul_uc_narrow", 1, "s", False, False, doc="r = a[0]*b[0] / R, a a uniform constant, 29-bit digits"))
     body.append(gen("mul_uc_add_narrow", 1, "s", True, False,
                     doc="r = (a[0]*b[0] + addend*R) / R, a a uniform constant, addend per lane, 29-bit digits"))
+    # the lane-cooperative hash for small batches (imt_coop_device.hpp): every factor is a per-lane value, because what
+    # is a constant for one lane of a quad is a state value for its neighbour; 29-bit digits throughout
+    body.append(gen("mul_vv_narrow", 1, "v", False, False, doc="r = a[0]*b[0] / R, 29-bit digits: r < a*b/R + p"))
+    body.append(gen("mul_vv_add_narrow", 1, "v", True, False, doc="r = (a[0]*b[0] + addend*R) / R, all per lane, 29-bit digits"))
+    body.append(gen("dot3_vv_narrow", 3, "v", False, False, doc="r = sum_{t<3} a[t]*b[t] / R, all per lane, 29-bit digits"))
     body.append(FOOTER)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "indexed-merkle-tree-halo2_amd", "csrc", "imt_mont_asm.hpp")

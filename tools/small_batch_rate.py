@@ -31,6 +31,8 @@ for lg in range(lo, hi + 1):
     for mode, flags in (("alone", F.DEVICE_PTRS), ("pipelined", F.DEVICE_PTRS | F.PIPELINE)):
         ctx = imt_amd.Context(0)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        if "IMT_COOP_MAX_EVENTS" in os.environ:          # 0 = one thread per hash at every size
+            ctx.set_option(F.OPT_COOP_MAX_EVENTS, int(os.environ["IMT_COOP_MAX_EVENTS"]))
         tree = imt_amd.IndexedTree(ctx, DEPTH, 1 << max(18, lg + 6))
         rng = np.random.default_rng(lg)
         raw = rng.integers(0, 256, size=((reps + 2) * bs, 32), dtype=np.uint8)
