@@ -49,7 +49,14 @@ def emul():
 
 @pytest.fixture(scope="session")
 def imt():
-    """The product package (needs csrc/libimt_hip.so; fails loudly if it is not built)."""
+    """The product package.  csrc/libimt_hip.so is (re)built first when it is missing or older than its sources
+    (hipcc cross-compiles for gfx950 without a GPU); a failed build fails loudly -- there is nothing to fall back to."""
+    csrc = os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc")
+    so = os.path.join(csrc, "libimt_hip.so")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".hpp"))] + [
+        os.path.join(ROOT, "include", "imt.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
+        _run(["make", "-C", csrc, "libimt_hip.so", "ARCH=gfx950"], ROOT)
     import imt_amd
     return imt_amd
 
