@@ -61,7 +61,7 @@ def test_every_export_is_bound_with_matching_shape():
         assert c[name] == r[name], (name, c[name], r[name])
 
 
-def test_the_library_exports_what_the_header_declares():
+def test_the_library_exports_what_the_header_declares(imt):
     """(also covered by _ffi.SIGNATURES at import time) every prototype is a dynamic symbol of libimt_hip.so"""
     import subprocess
     so = os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc", "libimt_hip.so")

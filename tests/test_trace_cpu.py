@@ -28,12 +28,6 @@ def _ints(a):
     return [int.from_bytes(x.tobytes(), "little") for x in np.asarray(a, np.uint8).reshape(-1, 32)]
 
 
-def _api():
-    """the Python helpers of the product package without loading libimt_hip.so's GPU side: pure functions only"""
-    import imt_amd
-    return imt_amd
-
-
 def test_oracle_trace_output_is_the_hash_and_every_gate_holds(oracle):
     cases = CASES + [oracle_lib.synth_values(3, 77)[:k] for k in (2, 3)]
     for xs in cases:
@@ -90,8 +84,7 @@ def test_product_trace_code_equals_oracle_in_every_format(oracle, emul):
 
 
 @pytest.mark.parametrize("arity", [2, 3])
-def test_product_cell_layout_equals_oracle_and_rebuilds_a_satisfied_column(oracle, emul, arity):
-    imt = _api()
+def test_product_cell_layout_equals_oracle_and_rebuilds_a_satisfied_column(oracle, emul, imt, arity):
     emul.emul_trace_layout.restype = ctypes.c_int
     cells, consts, out_row = imt.trace_layout(lambda *a: emul.emul_trace_layout(*a), arity, 0,
                                               lambda rc: (_ for _ in ()).throw(AssertionError(rc)) if rc else None)
