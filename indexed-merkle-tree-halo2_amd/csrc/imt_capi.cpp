@@ -586,7 +586,7 @@ static int path_common(imt_ctx* c, const void* leaf, const uint64_t* index, bool
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     launch::path_root(c->stream, d_leaf, nullptr, d_idx, is_helper, d_sib, sib_layout(flags, depth, n), depth, n, d_out,
-                      d_root, rstride, d_ok, fmt, fmt, c->d_err);
+                      d_root, rstride, d_ok, fmt, fmt, c->d_err, c->coop_max_events);
     return io.finish();
 }
 extern "C" int imt_path_root_batch(imt_ctx* c, const void* leaf, const uint64_t* index, const void* sib,

@@ -292,6 +292,59 @@ k_path_root(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3,
     flag_err(err, ok);
 }
 
+// The same for FEW paths: a quad of lanes per path, the latency form of the hash (imt_coop_device.hpp).  A path is
+// `depth` (+1) hashes one after the other in one thread -- 13 ms at depth 32 with one thread per path however few
+// paths there are (the reference calls verify_proof one proof at a time, src/indexed_merkle_tree.rs:397-400); this
+// form takes 0.6x that.  Lane 1 of a quad ends up with every hash and hands it to its neighbours for the next level.
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
+k_path_root_coop(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3, const uint64_t* __restrict__ index,
+                 int is_helper, const uint8_t* __restrict__ sib, launch::SibLayout lay, unsigned depth, size_t n,
+                 uint8_t* __restrict__ root_out, const uint8_t* __restrict__ expect, unsigned expect_stride,
+                 uint8_t* __restrict__ ok_out, unsigned fmt_in, unsigned fmt_out, int* err) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t tab[coop::TAB_DWORDS];
+    coop::tab_fill(tab, g_pc);
+    const size_t t = gtid();
+    const size_t i = t >> 2;
+    if (i >= n) return;
+    const unsigned role = (unsigned)t & 3u, ri = role == 3u ? 0u : role;
+    bool ok = true;
+    Fe cur, X, C3, o;
+    C3 = g_pc.one;
+    if (leaf3) {
+        ok &= load_fe(g_pc, X, leaf3 + i * 96 + (ri == 2u ? 32 : 0), fmt_in);
+        ok &= load_fe(g_pc, C3, leaf3 + i * 96 + 64, fmt_in);
+        if (ri == 1u) ok &= load_fe(g_pc, o, leaf3 + i * 96 + 32, fmt_in);     // every element validated once
+        coop::hash23(tab, o, X, C3, true, ri);
+        coop::quad_bcast<1>(cur, o);
+    } else {
+        ok &= load_fe(g_pc, cur, leaf + i * 32, fmt_in);
+    }
+    uint64_t idx = index[i];
+    if (is_helper) idx = ~idx;
+#pragma unroll 1
+    for (unsigned l = 0; l < depth; l++) {
+        Fe sv;
+        ok &= load_fe(g_pc, sv, sib + ((uint64_t)l * lay.level_stride + i * lay.item_stride) * 32, fmt_in);
+        const bool right = (idx >> l) & 1;
+        const bool take_sv = (ri == 2u) != right;        // lane 1 holds the left input, lane 2 the right one
+#pragma unroll
+        for (int q = 0; q < NL; q++) X.v[q] = take_sv ? sv.v[q] : cur.v[q];
+        coop::hash23(tab, o, X, C3, false, ri);
+        coop::quad_bcast<1>(cur, o);
+    }
+    if (role == 1u) {
+        if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
+        if (ok_out) {
+            Fe e;
+            ok &= load_fe(g_pc, e, expect + i * (size_t)expect_stride, fmt_in);
+            ok_out[i] = fe_eq(cur, e) ? 1 : 0;
+        }
+    }
+    flag_err(err, ok);
+#endif
+}
+
 // ---- a13: verify_non_inclusion (src/indexed_merkle_tree.rs:127-229) ---------------
 __global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
 k_non_membership(const uint8_t* __restrict__ root, unsigned root_stride, const uint8_t* __restrict__ low_leaf,
@@ -911,10 +964,14 @@ void split128(hipStream_t s, const uint8_t* vals, uint8_t* q, uint8_t* r, size_t
 void path_root(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index, bool is_helper,
                const uint8_t* sib, SibLayout lay, unsigned depth, size_t n, uint8_t* root_out,
                const uint8_t* expect, unsigned expect_stride, uint8_t* ok_out, unsigned fmt_in, unsigned fmt_out,
-               int* err) {
+               int* err, uint32_t coop_max) {
     if (!n) return;
-    hipLaunchKernelGGL(k_path_root, dim3(nblk(n)), dim3(BLOCK), 0, s, leaf, leaf3, index, is_helper ? 1 : 0, sib,
-                       lay, depth, n, root_out, expect, expect_stride, ok_out, fmt_in, fmt_out, err);
+    if (n * 4 <= coop_max)     // few paths: four lanes per path (the same one-wave-per-SIMD budget as the sweep)
+        hipLaunchKernelGGL(k_path_root_coop, dim3(nblk(n * 4)), dim3(BLOCK), 0, s, leaf, leaf3, index, is_helper ? 1 : 0,
+                           sib, lay, depth, n, root_out, expect, expect_stride, ok_out, fmt_in, fmt_out, err);
+    else
+        hipLaunchKernelGGL(k_path_root, dim3(nblk(n)), dim3(BLOCK), 0, s, leaf, leaf3, index, is_helper ? 1 : 0, sib,
+                           lay, depth, n, root_out, expect, expect_stride, ok_out, fmt_in, fmt_out, err);
 }
 void non_membership(hipStream_t s, const uint8_t* root, unsigned root_stride, const uint8_t* low_leaf,
                     const uint64_t* low_index, const uint8_t* sib, SibLayout lay, unsigned depth,

@@ -58,7 +58,7 @@ void split128(hipStream_t s, const uint8_t* vals, uint8_t* q, uint8_t* r, size_t
 void path_root(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index,
                bool is_helper, const uint8_t* sib, SibLayout lay, unsigned depth, size_t n,
                uint8_t* root_out, const uint8_t* expect, unsigned expect_stride, uint8_t* ok_out,
-               unsigned fmt_in, unsigned fmt_out, int* err);
+               unsigned fmt_in, unsigned fmt_out, int* err, uint32_t coop_max = 0);
 
 void non_membership(hipStream_t s, const uint8_t* root, unsigned root_stride, const uint8_t* low_leaf,
                     const uint64_t* low_index, const uint8_t* sib, SibLayout lay, unsigned depth,

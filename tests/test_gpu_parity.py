@@ -271,6 +271,22 @@ def test_quad_per_hash_kernel_is_bit_identical(imt, ctx, oracle):
                for i in range(0, 700, 37))
     assert res["always"][1] == root
     oracle.sparse_free(oh)
+    # the path kernel has the same two forms (few paths: a quad per path)
+    rng = random.Random(3)
+    n, d = 7, 32
+    leaf = [rng.randrange(P) for _ in range(n)]
+    sib = [[rng.randrange(P) for _ in range(n)] for _ in range(d)]
+    idx = [rng.randrange(1 << d) for _ in range(n)]
+    want = [oracle.path_root(leaf[i], idx[i], imt.to_bytes([sib[l][i] for l in range(d)])) for i in range(n)]
+    for coop_max in (0, 16384):
+        c2 = imt.Context(0)
+        c2.set_option(imt._ffi.OPT_COOP_MAX_EVENTS, coop_max)
+        assert ints(c2.path_root(imt.to_bytes(leaf), idx, imt.to_bytes(sib), d)) == want
+        hm = [(~i) & ((1 << d) - 1) for i in idx]
+        assert ints(c2.compute_merkle_root(imt.to_bytes(leaf), hm, imt.to_bytes(sib), d)) == want
+        ok = c2.verify_proof_batch(imt.to_bytes(leaf), idx, imt.to_bytes(want[:1] * n), imt.to_bytes(sib), d)
+        assert ok.tolist() == [True] + [False] * (n - 1)
+        c2.close()
     with pytest.raises(imt.ImtError):
         ctx.set_option(99, 1)
 
