@@ -344,28 +344,23 @@ extern "C" int imt_hash_trace_batch(imt_ctx* c, const void* in, int arity, size_
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     const bool item_major = flags & IMT_TRACE_ITEM_MAJOR;
-    launch::hash_trace(c->stream, d_in, n, arity, d_tr, item_major ? 1 : n, item_major ? rows : 1, fmt, fmt, c->d_err);
+    launch::hash_trace(c->stream, d_in, n, arity, d_tr, n, 0, rows, item_major, fmt, fmt, c->d_err);
     return io.finish();
 }
 
 namespace {
-// Traces of one compute_merkle_root per item into `trace` starting at block row `row0` (advanced): the leaf hash
-// (if leaf3) then `depth` path hashes.  All pointers are device pointers; `pairs` is scratch [depth][n][2][32].
-void path_trace_core(imt_ctx* c, const uint8_t* d_leaf, const uint8_t* d_leaf3, const uint64_t* d_idx, const uint8_t* d_sib,
-                     launch::SibLayout lay, unsigned depth, size_t n, uint8_t* d_tr, size_t rows_total, bool item_major,
-                     size_t& row0, uint8_t* pairs, uint8_t* d_root, unsigned fmt) {
-    const size_t r2 = dev::TRACE_ROWS_H2, r3 = dev::TRACE_ROWS_H3;
-    // the chain first (one fast hash per level), which yields the two inputs of every hash on the path ...
-    launch::path_pairs(c->stream, d_leaf, d_leaf3, d_idx, false, d_sib, lay, depth, n, pairs, d_root, fmt, fmt, c->d_err);
-    // ... then every hash of every path is an independent trace
-    auto block = [&](const uint8_t* in_l, int arity, unsigned fmt_in, size_t rows) {
-        uint8_t* base = d_tr + (item_major ? row0 : row0 * n) * 32;
-        launch::hash_trace(c->stream, in_l, n, arity, base, item_major ? 1 : n, item_major ? rows_total : 1, fmt_in, fmt,
-                           c->d_err);
-        row0 += rows;
-    };
-    if (d_leaf3) block(d_leaf3, 3, fmt, r3);
-    for (unsigned l = 0; l < depth; l++) block(pairs + (size_t)l * n * 64, 2, IMT_FMT_DEVICE, r2);
+// The traces of one compute_merkle_root per item, given the chain's pairs (path_pairs ran before): the leaf hash
+// (if leaf3) then `depth` path hashes, into `trace` from block row `row0` on (advanced).  ONE launch for the leaf
+// hashes, ONE for all levels: every hash of every path is an independent trace.
+void path_trace_blocks(imt_ctx* c, const uint8_t* d_leaf3, const uint8_t* pairs, unsigned depth, size_t n, uint8_t* d_tr,
+                       size_t rows_total, bool item_major, size_t& row0, unsigned fmt) {
+    if (d_leaf3) {
+        launch::hash_trace(c->stream, d_leaf3, n, 3, d_tr, n, row0, rows_total, item_major, fmt, fmt, c->d_err);
+        row0 += dev::TRACE_ROWS_H3;
+    }
+    launch::hash_trace(c->stream, pairs, (size_t)depth * n, 2, d_tr, n, row0, rows_total, item_major, IMT_FMT_DEVICE, fmt,
+                       c->d_err);
+    row0 += (size_t)depth * dev::TRACE_ROWS_H2;
 }
 }  // namespace
 
@@ -388,9 +383,16 @@ extern "C" int imt_path_trace_batch(imt_ctx* c, const void* leaf, const void* le
     uint8_t* d_root = io.out(root_out, n * 32);
     uint8_t* pairs = io.temp((size_t)depth * n * 64);
     if (io.rc) return io.rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    // the chain first (one fast hash per level), which yields the two inputs of every hash on the path
+    launch::PathChains pc{};
+    pc.c[0] = {d_leaf, d_leaf3, d_idx, d_sib, pairs, d_root};
+    pc.n_chains = 1;
+    pc.lay = sib_layout(flags & ~IMT_TRACE_ITEM_MAJOR, depth, n);
+    pc.depth = depth; pc.n = n; pc.fmt_in = fmt; pc.fmt_out = fmt; pc.err = c->d_err;
+    launch::path_pairs(c->stream, pc, c->coop_max_events);
     size_t row0 = 0;
-    path_trace_core(c, d_leaf, d_leaf3, d_idx, d_sib, sib_layout(flags & ~IMT_TRACE_ITEM_MAJOR, depth, n), depth, n, d_tr,
-                    rows_total, flags & IMT_TRACE_ITEM_MAJOR, row0, pairs, d_root, flags & IMT_FMT_MASK);
+    path_trace_blocks(c, d_leaf3, pairs, depth, n, d_tr, rows_total, flags & IMT_TRACE_ITEM_MAJOR, row0, fmt);
     return io.finish();
 }
 
@@ -417,20 +419,28 @@ extern "C" int imt_insert_trace_batch(imt_ctx* c, const void* low_leaf, const ui
     const uint64_t* d_np = new_path_index ? (const uint64_t*)io.in(new_path_index, n * 8) : d_ni;
     const uint8_t* d_ns = io.in(new_sib, (size_t)depth * n * 32);
     uint8_t* d_tr = io.out(trace, n * rows_total * 32);
-    uint8_t* pairs = io.temp((size_t)depth * n * 64);
+    uint8_t* pairs = io.temp(4 * (size_t)depth * n * 64);
     uint8_t* tmp3 = io.temp(n * 96);      // the rewritten low leaf {low.val, new.val, new_index}   :265-269
     uint8_t* tmpz = io.temp(n * 32);      // the zero-leaf hash per item                            :247-251
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     const bool item_major = flags & IMT_TRACE_ITEM_MAJOR;
-    const launch::SibLayout lay = sib_layout(flags, depth, n);
     launch::insert_trace_inputs(c->stream, d_ll, d_nl, d_ni, n, tmp3, tmpz, fmt, c->d_err);
+    // the four compute_merkle_root chains of insert_leaf as ONE launch, in the order the circuit reaches them:
+    // :193-204 low leaf, :271-284 rewritten low leaf, :286-294 the zero leaf at the new slot, :299-312 new leaf
+    const size_t ps = (size_t)depth * n * 64;
+    launch::PathChains pc{};
+    pc.c[0] = {nullptr, d_ll, d_li, d_ls, pairs, nullptr};
+    pc.c[1] = {nullptr, tmp3, d_li, d_ls, pairs + ps, nullptr};
+    pc.c[2] = {tmpz, nullptr, d_np, d_ns, pairs + 2 * ps, nullptr};
+    pc.c[3] = {nullptr, d_nl, d_np, d_ns, pairs + 3 * ps, nullptr};
+    pc.n_chains = 4;
+    pc.lay = sib_layout(flags, depth, n);
+    pc.depth = depth; pc.n = n; pc.fmt_in = fmt; pc.fmt_out = fmt; pc.err = c->d_err;
+    launch::path_pairs(c->stream, pc, c->coop_max_events);
     size_t row0 = 0;
-    // the order in which insert_leaf reaches hash_fix_len_array: :193-204, :271-284, :286-294, :299-312
-    path_trace_core(c, nullptr, d_ll, d_li, d_ls, lay, depth, n, d_tr, rows_total, item_major, row0, pairs, nullptr, fmt);
-    path_trace_core(c, nullptr, tmp3, d_li, d_ls, lay, depth, n, d_tr, rows_total, item_major, row0, pairs, nullptr, fmt);
-    path_trace_core(c, tmpz, nullptr, d_np, d_ns, lay, depth, n, d_tr, rows_total, item_major, row0, pairs, nullptr, fmt);
-    path_trace_core(c, nullptr, d_nl, d_np, d_ns, lay, depth, n, d_tr, rows_total, item_major, row0, pairs, nullptr, fmt);
+    for (int k = 0; k < 4; k++)
+        path_trace_blocks(c, pc.c[k].leaf3, pc.c[k].pairs, depth, n, d_tr, rows_total, item_major, row0, fmt);
     return io.finish();
 }
 

@@ -186,68 +186,104 @@ __global__ void __launch_bounds__(BLOCK) k_convert(const uint8_t* __restrict__ i
 }
 
 // ---- f1: witness trace of hash_fix_len_array (imt_trace_device.hpp) -----------------
-// One thread = one hash = 1208 / 1209 rows of 32 bytes.  Row j of item i goes to
-// trace + (j * row_stride + i * item_stride) * 32: row-major ([rows][n], row_stride = n) makes a wave's 64
-// stores of one row 2 KiB contiguous; item-major ([n][rows]) is the order a per-hash consumer reads.
+// One thread = one hash = 1208 / 1209 rows of 32 bytes.  The n_items hashes form blocks of n_per items (the levels
+// of a path trace; one block for a plain batch); block l starts at row row0 + l * rows of the trace, whose layout is
+// row-major ([rows_total][n_per]: a wave's 64 stores of one row are 2 KiB contiguous) or item-major
+// ([n_per][rows_total]: the order a per-hash consumer reads).
 // No register cap: 140 VGPRs = 3 waves/SIMD without spills measured the same as 128 = 4 waves with 12 spilled
 // (one wave's dependent chain already fills 78 % of a SIMD's issue slots).
 #ifndef IMT_TRACE_WAVES
 #define IMT_TRACE_WAVES
 #endif
 __global__ IMT_TRACE_WAVES void __launch_bounds__(BLOCK)
-k_hash_trace(const uint8_t* __restrict__ in, size_t n, int arity, uint8_t* __restrict__ trace, uint64_t row_stride,
-             uint64_t item_stride, unsigned fmt_in, unsigned fmt_out, int* err) {
-    const size_t i = gtid();
-    if (i >= n) return;
-    const uint8_t* p = in + i * 32 * (size_t)arity;
+k_hash_trace(const uint8_t* __restrict__ in, size_t n_items, int arity, uint8_t* __restrict__ trace, size_t n_per,
+             size_t row0, size_t rows_total, int item_major, unsigned fmt_in, unsigned fmt_out, int* err) {
+    const size_t q = gtid();
+    if (q >= n_items) return;
+    const uint8_t* p = in + q * 32 * (size_t)arity;
     Fe a, b, c;
     bool ok = load_fe(g_pc, a, p, fmt_in);
     ok &= load_fe(g_pc, b, p + 32, fmt_in);
     c = a;
     if (arity == 3) ok &= load_fe(g_pc, c, p + 64, fmt_in);
-    TraceSink o{trace + i * item_stride * 32, row_stride * 32, fmt_out};
+    const size_t l = q / n_per, i = q - l * n_per;
+    const size_t first = row0 + l * (size_t)(arity == 3 ? TRACE_ROWS_H3 : TRACE_ROWS_H2);
+    TraceSink o{item_major ? trace + (i * rows_total + first) * 32 : trace + (first * n_per + i) * 32,
+                item_major ? (uint64_t)32 : (uint64_t)n_per * 32, fmt_out};
     hash_trace(g_pc, g_tc, o, a, b, c, arity == 3);
     flag_err(err, ok);
 }
 
 // (left, right) inputs of every hash2 along n paths, for the trace of a whole path: pairs[l][i][2] in device
-// format, + the leaf hash's output as the level-0 start.  Same walk as k_path_root.
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
-k_path_pairs(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3, const uint64_t* __restrict__ index,
-             int is_helper, const uint8_t* __restrict__ sib, launch::SibLayout lay, unsigned depth, size_t n,
-             uint8_t* __restrict__ pairs, uint8_t* __restrict__ root_out, unsigned fmt_in, unsigned fmt_out, int* err) {
+// format (the leaf hash's output is the level-0 start).  Same walk as k_path_root.  blockIdx.y selects one of up to
+// four chains (the four compute_merkle_root calls of insert_leaf run as one launch).
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_path_pairs(launch::PathChains a) {
     const size_t i = gtid();
-    if (i >= n) return;
+    if (i >= a.n) return;
+    const launch::PathChains::Chain ch = a.c[blockIdx.y];
     bool ok = true;
     Fe cur;
-    if (leaf3) {
-        Fe pre[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) ok &= load_fe(g_pc, pre[j], leaf3 + (i * 3 + j) * 32, fmt_in);
-        hash_call(cur, pre[0], pre[1], pre[2], true);
-    } else {
-        ok &= load_fe(g_pc, cur, leaf + i * 32, fmt_in);
-    }
-    uint64_t idx = index[i];
-    if (is_helper) idx = ~idx;
+    if (ch.leaf3) leaf_hash(cur, ch.leaf3 + i * 96, a.fmt_in, ok);
+    else ok &= load_fe(g_pc, cur, ch.leaf + i * 32, a.fmt_in);
+    const uint64_t idx = ch.index[i];
 #pragma unroll 1
-    for (unsigned l = 0; l < depth; l++) {
-        Fe sv, a, b, o;
-        ok &= load_fe(g_pc, sv, sib + ((uint64_t)l * lay.level_stride + i * lay.item_stride) * 32, fmt_in);
+    for (unsigned l = 0; l < a.depth; l++) {
+        Fe sv, x, y, o;
+        ok &= load_fe(g_pc, sv, ch.sib + ((uint64_t)l * a.lay.level_stride + i * a.lay.item_stride) * 32, a.fmt_in);
         const bool right = (idx >> l) & 1;
 #pragma unroll
         for (int q = 0; q < NL; q++) {
-            a.v[q] = right ? sv.v[q] : cur.v[q];
-            b.v[q] = right ? cur.v[q] : sv.v[q];
+            x.v[q] = right ? sv.v[q] : cur.v[q];
+            y.v[q] = right ? cur.v[q] : sv.v[q];
         }
-        uint8_t* dst = pairs + ((size_t)l * n + i) * 64;
-        store_packed(dst, a);
-        store_packed(dst + 32, b);
-        hash_call(o, a, b, a, false);
+        uint8_t* dst = ch.pairs + ((size_t)l * a.n + i) * 64;
+        store_packed(dst, x);
+        store_packed(dst + 32, y);
+        hash_call(o, x, y, x, false);
         cur = o;
     }
-    if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
-    flag_err(err, ok);
+    if (ch.root_out) store_fe(g_pc, ch.root_out + i * 32, cur, a.fmt_out);
+    flag_err(a.err, ok);
+}
+
+// the same for few paths: a quad of lanes per path (imt_coop_device.hpp); lane 1 holds the left input, lane 2 the right
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_path_pairs_coop(launch::PathChains a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t tab[coop::TAB_DWORDS];
+    coop::tab_fill(tab, g_pc);
+    const size_t t = gtid();
+    const size_t i = t >> 2;
+    if (i >= a.n) return;
+    const launch::PathChains::Chain ch = a.c[blockIdx.y];
+    const unsigned role = (unsigned)t & 3u, ri = role == 3u ? 0u : role;
+    bool ok = true;
+    Fe cur, X, C3, o;
+    C3 = g_pc.one;
+    if (ch.leaf3) {
+        ok &= load_fe(g_pc, X, ch.leaf3 + i * 96 + (ri == 2u ? 32 : 0), a.fmt_in);
+        ok &= load_fe(g_pc, C3, ch.leaf3 + i * 96 + 64, a.fmt_in);
+        if (ri == 1u) ok &= load_fe(g_pc, o, ch.leaf3 + i * 96 + 32, a.fmt_in);
+        coop::hash23(tab, o, X, C3, true, ri);
+        coop::quad_bcast<1>(cur, o);
+    } else {
+        ok &= load_fe(g_pc, cur, ch.leaf + i * 32, a.fmt_in);
+    }
+    const uint64_t idx = ch.index[i];
+#pragma unroll 1
+    for (unsigned l = 0; l < a.depth; l++) {
+        Fe sv;
+        ok &= load_fe(g_pc, sv, ch.sib + ((uint64_t)l * a.lay.level_stride + i * a.lay.item_stride) * 32, a.fmt_in);
+        const bool right = (idx >> l) & 1;
+        const bool take_sv = (ri == 2u) != right;
+#pragma unroll
+        for (int q = 0; q < NL; q++) X.v[q] = take_sv ? sv.v[q] : cur.v[q];
+        if (role == 1u || role == 2u) store_packed(ch.pairs + ((size_t)l * a.n + i) * 64 + (role == 2u ? 32 : 0), X);
+        coop::hash23(tab, o, X, C3, false, ri);
+        coop::quad_bcast<1>(cur, o);
+    }
+    if (role == 1u && ch.root_out) store_fe(g_pc, ch.root_out + i * 32, cur, a.fmt_out);
+    flag_err(a.err, ok);
+#endif
 }
 
 // inputs of imt_insert_trace_batch that no caller buffer holds: the rewritten low leaf and the zero-leaf hash
@@ -929,11 +965,11 @@ hipError_t upload_consts(const dev::PoseidonConsts& pc) {
 hipError_t upload_trace_consts(const dev::TraceConsts& tc) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tc), &tc, sizeof(tc), 0, hipMemcpyHostToDevice);
 }
-void hash_trace(hipStream_t s, const uint8_t* in, size_t n, int arity, uint8_t* trace, uint64_t row_stride,
-                uint64_t item_stride, unsigned fmt_in, unsigned fmt_out, int* err) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_hash_trace, dim3(nblk(n)), dim3(BLOCK), 0, s, in, n, arity, trace, row_stride, item_stride,
-                       fmt_in, fmt_out, err);
+void hash_trace(hipStream_t s, const uint8_t* in, size_t n_items, int arity, uint8_t* trace, size_t n_per, size_t row0,
+                size_t rows_total, bool item_major, unsigned fmt_in, unsigned fmt_out, int* err) {
+    if (!n_items) return;
+    hipLaunchKernelGGL(k_hash_trace, dim3(nblk(n_items)), dim3(BLOCK), 0, s, in, n_items, arity, trace, n_per, row0,
+                       rows_total, item_major ? 1 : 0, fmt_in, fmt_out, err);
 }
 void insert_trace_inputs(hipStream_t s, const uint8_t* low_leaf, const uint8_t* new_leaf, const uint64_t* new_index,
                          size_t n, uint8_t* new_low, uint8_t* zero_leaf, unsigned fmt, int* err) {
@@ -941,12 +977,12 @@ void insert_trace_inputs(hipStream_t s, const uint8_t* low_leaf, const uint8_t* 
     hipLaunchKernelGGL(k_insert_trace_inputs, dim3(nblk(n)), dim3(BLOCK), 0, s, low_leaf, new_leaf, new_index, n, new_low,
                        zero_leaf, fmt, err);
 }
-void path_pairs(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index, bool is_helper,
-                const uint8_t* sib, SibLayout lay, unsigned depth, size_t n, uint8_t* pairs, uint8_t* root_out,
-                unsigned fmt_in, unsigned fmt_out, int* err) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_path_pairs, dim3(nblk(n)), dim3(BLOCK), 0, s, leaf, leaf3, index, is_helper ? 1 : 0, sib, lay,
-                       depth, n, pairs, root_out, fmt_in, fmt_out, err);
+void path_pairs(hipStream_t s, const PathChains& a, uint32_t coop_max) {
+    if (!a.n || a.n_chains <= 0) return;
+    if (a.n * 4 * (size_t)a.n_chains <= coop_max)
+        hipLaunchKernelGGL(k_path_pairs_coop, dim3(nblk(a.n * 4), (unsigned)a.n_chains), dim3(BLOCK), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_path_pairs, dim3(nblk(a.n), (unsigned)a.n_chains), dim3(BLOCK), 0, s, a);
 }
 
 void hash_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, int arity, unsigned fmt_in,

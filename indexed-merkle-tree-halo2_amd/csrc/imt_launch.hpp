@@ -29,17 +29,33 @@ struct TreeView {
 hipError_t upload_consts(const dev::PoseidonConsts& pc);
 hipError_t upload_trace_consts(const dev::TraceConsts& tc);
 
-// f1: every witness of hash_fix_len_array for n hashes of `arity` inputs; row j of item i at
-// trace + (j * row_stride + i * item_stride) * 32
-void hash_trace(hipStream_t s, const uint8_t* in, size_t n, int arity, uint8_t* trace, uint64_t row_stride,
-                uint64_t item_stride, unsigned fmt_in, unsigned fmt_out, int* err);
+// f1: every witness of hash_fix_len_array for n_items hashes of `arity` inputs.  The items form blocks of n_per (the
+// levels of a path; a single block otherwise); block l occupies rows [row0 + l * rows, ...) of a trace of rows_total
+// rows per item column, row-major [rows_total][n_per] or item-major [n_per][rows_total].
+void hash_trace(hipStream_t s, const uint8_t* in, size_t n_items, int arity, uint8_t* trace, size_t n_per, size_t row0,
+                size_t rows_total, bool item_major, unsigned fmt_in, unsigned fmt_out, int* err);
 // {low.val, new.val, new_index} per item -> new_low [n][3][32], and the zero-leaf hash -> zero_leaf [n][32] (fmt)
 void insert_trace_inputs(hipStream_t s, const uint8_t* low_leaf, const uint8_t* new_leaf, const uint64_t* new_index,
                          size_t n, uint8_t* new_low, uint8_t* zero_leaf, unsigned fmt, int* err);
-// the (left, right) inputs of every hash2 along n paths: pairs[depth][n][2][32], device format
-void path_pairs(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const uint64_t* index, bool is_helper,
-                const uint8_t* sib, SibLayout lay, unsigned depth, size_t n, uint8_t* pairs, uint8_t* root_out,
-                unsigned fmt_in, unsigned fmt_out, int* err);
+// the (left, right) inputs of every hash2 along n paths, for up to four chains in one launch:
+// chain k writes pairs[depth][n][2][32] (device format) and optionally its roots
+struct PathChains {
+    struct Chain {
+        const uint8_t* leaf;      // [n][32], or
+        const uint8_t* leaf3;     // [n][3][32]: the chain starts from H(leaf3)
+        const uint64_t* index;
+        const uint8_t* sib;
+        uint8_t* pairs;
+        uint8_t* root_out;        // or NULL
+    } c[4];
+    int n_chains;
+    SibLayout lay;
+    unsigned depth;
+    size_t n;
+    unsigned fmt_in, fmt_out;
+    int* err;
+};
+void path_pairs(hipStream_t s, const PathChains& a, uint32_t coop_max);
 
 void hash_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, int arity, unsigned fmt_in,
                 unsigned fmt_out, int* err);
