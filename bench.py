@@ -236,7 +236,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     ranks_seen = 1
-    if world > 1:
+    # IMT_BENCH_FORCE_DIST: rehearsal of the N > 1 code path (process group, root all-gather, lift, reductions) with
+    # whatever world size the launcher gave, 1 included -- the only way to run the RCCL calls on a one-GPU box
+    if world > 1 or os.environ.get("IMT_BENCH_FORCE_DIST"):
         import torch.distributed as dist_mod
         dist = dist_mod
         if backend == "nccl":
@@ -279,7 +281,7 @@ def main():
     def step(i, flags=None):
         th = time.perf_counter()
         v = vals[i * BATCH:(i + 1) * BATCH]
-        if world == 1 or flags is not None:
+        if dist is None or flags is not None:
             last_slot[0] = be.insert(v, flags)
         else:
             tree.step(v)            # inserts batch i, then exchanges roots for and lifts batch i-1 (one step behind)
@@ -292,7 +294,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if dist is not None:
         tree.flush()                # the timed region then holds exactly `steps` inserts, exchanges and lifts
     sync()
     lib.imt_profile_enable(ctx.h, 1)
@@ -300,7 +302,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, steps_total):
         step(i)
-    if world > 1:
+    if dist is not None:
         last_slot[0] = tree.pending
         tree.flush()                # exchange + lift of the last batch: inside the timed region
     sync()
@@ -323,7 +325,7 @@ def main():
                                             _ffi.DEVICE_PTRS))
     be.sync()
     verified = int(fail.max()) == 0 and bool((o["old_root"][1:] == o["new_root"][:-1]).all())
-    if world == 1:
+    if dist is None:
         root_now = torch.from_numpy(imt_amd.to_bytes(be.tree.root()))
         verified = verified and bool((o["new_root"][-1].cpu() == root_now).all())
     elif rank == world - 1:         # the last rank's last insertion closes the step: its new root is the global root
@@ -427,7 +429,7 @@ def main():
             "unit": "insertions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 limbs (9 x 29-bit, Montgomery mod p), 64-bit accumulate",
-            "data": "synthetic", "ranks_seen": ranks_seen, "collective_backend": backend if world > 1 else None,
+            "data": "synthetic", "ranks_seen": ranks_seen, "collective_backend": backend if dist is not None else None,
             "verified": verified,
             "config": {"workload": "depth=32, 2^16 sequential-semantics insertions per step per GPU "
                                    "(BASELINE configs[1]); per insertion: old/interim/new depth-32 root + two 32-sibling "

@@ -158,7 +158,7 @@ class ShardedIndexedTree:
 
     def gather_roots(self, mine):
         """[world, 32]: every rank's subtree root -- the one collective of the path"""
-        if self.world == 1:
+        if self.dist is None:
             return mine.reshape(1, 32).clone()
         if self.via_host:       # gloo rehearsal: through host memory
             m = mine.cpu()

@@ -218,3 +218,29 @@ def test_bench_gpus2_as_typed_rehearsal():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                         capture_output=True, text=True, timeout=300, env=env2, cwd=ROOT)
     assert r2.returncode != 0 and "does not match WORLD_SIZE" in (r2.stdout + r2.stderr)
+
+
+def test_bench_rccl_calls_with_one_rank():
+    """The driver's N > 1 form (torch.distributed.run around bench.py, backend "nccl" = RCCL) needs one GPU per
+    rank, so a one-GPU box can run it with ONE rank only: IMT_BENCH_FORCE_DIST makes that rank go through the
+    process group, the device-tensor all-gather of the subtree roots, the lift, the combine and the reductions
+    exactly as eight ranks would."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, IMT_BENCH_FORCE_DIST="1", IMT_BENCH_NO_TRACE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IMT_BENCH_COLLECTIVE", "IMT_BENCH_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["ranks_seen"] == 1 and res["collective_backend"] == "nccl"
+    assert res["verified"] is True and res["value"] > 0
