@@ -304,3 +304,22 @@ def test_header_is_plain_c_and_example_links():
                         "-Wl,-rpath," + os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc"), "-o", exe],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_cpp_host_side_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/imt.hpp (the compiled-language mirror of the reference's host types) and the re-enacted reference
+    tests build with g++ alone, warnings as errors.  Run without a GPU the program must stop at context creation with
+    IMT_ERR_NO_DEVICE: no hash is ever computed on the CPU.  (With a GPU it simply passes.)"""
+    import subprocess
+    import torch
+    csrc = os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc")
+    exe = str(tmp_path / "reference_tests")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "native", "reference_tests.cpp"), "-L", csrc, "-limt_hip",
+                        "-Wl,-rpath," + csrc, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "imt::Error -7" in r.stderr and "no CPU path" in r.stderr
+    assert "hash_zero" not in r.stdout
