@@ -195,9 +195,10 @@ __global__ void __launch_bounds__(BLOCK) k_convert(const uint8_t* __restrict__ i
 #ifndef IMT_TRACE_WAVES
 #define IMT_TRACE_WAVES
 #endif
+template <unsigned FMT_OUT>
 __global__ IMT_TRACE_WAVES void __launch_bounds__(BLOCK)
 k_hash_trace(const uint8_t* __restrict__ in, size_t n_items, int arity, uint8_t* __restrict__ trace, size_t n_per,
-             size_t row0, size_t rows_total, int item_major, unsigned fmt_in, unsigned fmt_out, int* err) {
+             size_t row0, size_t rows_total, int item_major, unsigned fmt_in, int* err) {
     const size_t q = gtid();
     if (q >= n_items) return;
     const uint8_t* p = in + q * 32 * (size_t)arity;
@@ -209,8 +210,8 @@ k_hash_trace(const uint8_t* __restrict__ in, size_t n_items, int arity, uint8_t*
     const size_t l = q / n_per, i = q - l * n_per;
     const size_t first = row0 + l * (size_t)(arity == 3 ? TRACE_ROWS_H3 : TRACE_ROWS_H2);
     TraceSink o{item_major ? trace + (i * rows_total + first) * 32 : trace + (first * n_per + i) * 32,
-                item_major ? (uint64_t)32 : (uint64_t)n_per * 32, fmt_out};
-    hash_trace(g_pc, g_tc, o, a, b, c, arity == 3);
+                item_major ? (uint64_t)32 : (uint64_t)n_per * 32};
+    hash_trace<FMT_OUT>(g_pc, g_tc, o, a, b, c, arity == 3);
     flag_err(err, ok);
 }
 
@@ -968,8 +969,10 @@ hipError_t upload_trace_consts(const dev::TraceConsts& tc) {
 void hash_trace(hipStream_t s, const uint8_t* in, size_t n_items, int arity, uint8_t* trace, size_t n_per, size_t row0,
                 size_t rows_total, bool item_major, unsigned fmt_in, unsigned fmt_out, int* err) {
     if (!n_items) return;
-    hipLaunchKernelGGL(k_hash_trace, dim3(nblk(n_items)), dim3(BLOCK), 0, s, in, n_items, arity, trace, n_per, row0,
-                       rows_total, item_major ? 1 : 0, fmt_in, fmt_out, err);
+    auto* k = fmt_out == FMT_MONT256 ? k_hash_trace<FMT_MONT256>
+              : fmt_out == FMT_DEVICE ? k_hash_trace<FMT_DEVICE> : k_hash_trace<FMT_CANONICAL>;
+    hipLaunchKernelGGL(k, dim3(nblk(n_items)), dim3(BLOCK), 0, s, in, n_items, arity, trace, n_per, row0, rows_total,
+                       item_major ? 1 : 0, fmt_in, err);
 }
 void insert_trace_inputs(hipStream_t s, const uint8_t* low_leaf, const uint8_t* new_leaf, const uint64_t* new_index,
                          size_t n, uint8_t* new_low, uint8_t* zero_leaf, unsigned fmt, int* err) {

@@ -111,9 +111,19 @@ extern "C" int emul_hash_trace(const uint8_t* in, int arity, uint8_t* rows, unsi
     ok &= dev::load_fe(g_consts, b, in + 32, fmt_in);
     c = a;
     if (arity == 3) ok &= dev::load_fe(g_consts, c, in + 64, fmt_in);
-    dev::TraceSink o{rows, 32, fmt_out};
-    dev::hash_trace(g_consts, g_tconsts, o, a, b, c, arity == 3);
+    dev::TraceSink o{rows, 32};
+    if (fmt_out == dev::FMT_MONT256) dev::hash_trace<dev::FMT_MONT256>(g_consts, g_tconsts, o, a, b, c, arity == 3);
+    else if (fmt_out == dev::FMT_DEVICE) dev::hash_trace<dev::FMT_DEVICE>(g_consts, g_tconsts, o, a, b, c, arity == 3);
+    else dev::hash_trace<dev::FMT_CANONICAL>(g_consts, g_tconsts, o, a, b, c, arity == 3);
     return ok ? (int)((o.p - rows) / 32) : -5;
+}
+// store_mont256 alone: 9 normalised limbs of a value below 4p -> the 32 bytes it stores (value / 32 mod p)
+extern "C" void emul_store_mont256(const uint32_t* limbs, uint8_t* out) {
+    dev::Fe a;
+    for (int i = 0; i < dev::NL; i++) a.v[i] = limbs[i];
+    alignas(16) uint8_t row[32];
+    dev::store_mont256(row, a);
+    std::memcpy(out, row, 32);
 }
 // the product's cell layout (imt_trace_layout.cpp) without a GPU: a context that only carries the tables
 #include "imt_ctx.hpp"

@@ -110,3 +110,36 @@ def test_product_cell_layout_equals_oracle_and_rebuilds_a_satisfied_column(oracl
     _, consts_m, _ = imt.trace_layout(lambda *a: emul.emul_trace_layout(*a), arity, 1, lambda rc: None)
     assert _ints(consts_m) == [(v * R256) % P for v in _ints(consts)]
     assert len(set(_ints(consts))) == len(consts) < 420          # de-duplicated table
+
+
+def test_store_mont256_division_by_32_edge_cases(emul):
+    """store_mont256 (imt_trace_device.hpp): a value a < 4p in nine 29-bit limbs leaves as the canonical a / 32 mod p,
+    as a + ms p with the signed multiplier ms = m or m - 32, never normalised.  Which one is decided by the top limbs
+    except when they are equal -- about once in 2^25 rows, so never in a random test: crafted here, together with
+    the values right at the boundaries a = (32 - m) p for m = 29, 30, 31."""
+    import ctypes
+    import random
+    inv32 = pow(32, -1, P)
+
+    def run(a):
+        limbs = (ctypes.c_uint32 * 9)(*[(a >> (29 * i)) & ((1 << 29) - 1) if i < 8 else a >> 232 for i in range(9)])
+        out = (ctypes.c_uint8 * 32)()
+        emul.emul_store_mont256(limbs, out)
+        return int.from_bytes(bytes(out), "little")
+
+    rng = random.Random(5)
+    cases = []
+    for k in (1, 2, 3):                     # a = k p (+- multiples of 32 keep m): the flip point of the subtraction
+        for d in (-64, -32, 0, 32, 64, 32 * 12345):
+            cases.append(k * P + d)
+        top = (k * P) >> 232                # same top limb as k p, anything below: the slow path on both sides
+        for _ in range(200):
+            low = rng.randrange(1 << 232)
+            a = (top << 232) | low
+            cases.append(a - ((a - k * P) % 32))          # congruent to k p mod 32 -> m = 32 - k
+    cases += [0, 1, 31, 32, P - 1, P, P + 1, 4 * P - 1, 2 * P + 12345]
+    cases += [rng.randrange(4 * P) for _ in range(20000)]
+    for a in cases:
+        assert 0 <= a < 4 * P
+        got = run(a)
+        assert got == a * inv32 % P, hex(a)

@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(256) NAME(unsigned* out, unsigned seed) {     
     for (int i = 0; i < ITER; i++) {                                               \
         asm volatile(ASM(%0) ASM(%1) ASM(%2) ASM(%3) ASM(%4) ASM(%5) ASM(%6) ASM(%7) \
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
-                     : "v"(b), "v"(c) : "vcc");                                    \
+                     : "v"(b), "v"(c) : "vcc", "s10", "s11");                      \
     }                                                                              \
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7; \
 }
@@ -73,10 +73,25 @@ __global__ void __launch_bounds__(256) NAME(unsigned* out, unsigned seed) {     
 #define A_MAD_U32_U16(x)  "v_mad_u32_u16 " #x ", " #x ", %8, %9\n"
 #define A_PK_FMA_F32(x)   "v_pk_fma_f32 " #x ", " #x ", " #x ", " #x "\n"
 #define A_CNDMASK(x)      "v_cndmask_b32 " #x ", " #x ", %8, vcc\n"
+#define A_CNDMASK_E64(x)  "v_cndmask_b32_e64 " #x ", " #x ", %8, s[10:11]\n"
+#define A_CNDMASK_ADD(x)  "v_cndmask_b32 " #x ", " #x ", %8, vcc\n v_add_u32 " #x ", " #x ", %9\n"
+#define A_CNDMASK_MAD(x)  "v_cndmask_b32 " #x ", " #x ", %8, vcc\n v_mul_lo_u32 " #x ", " #x ", %9\n v_mul_lo_u32 " #x ", " #x ", %9\n v_mul_lo_u32 " #x ", " #x ", %9\n"
+#define A_BFI_B32(x)      "v_bfi_b32 " #x ", %8, " #x ", %9\n"
+#define A_AND_B32(x)      "v_and_b32 " #x ", " #x ", %8\n"
+#define A_OR_B32(x)       "v_or_b32 " #x ", " #x ", %8\n"
+#define A_LSHRREV_B32(x)  "v_lshrrev_b32 " #x ", 3, " #x "\n"
+#define A_LSHLREV_B32(x)  "v_lshlrev_b32 " #x ", 3, " #x "\n"
+#define A_SUB_U32(x)      "v_sub_u32 " #x ", " #x ", %8\n"
+#define A_MOV_B32(x)      "v_mov_b32 " #x ", %8\n"
+#define A_ASHRREV_I32(x)  "v_ashrrev_i32 " #x ", 3, " #x "\n"
+#define A_XOR_B32(x)      "v_xor_b32 " #x ", " #x ", %8\n"
 // 64-bit destination ops (x is a VGPR pair)
 #define A_MAD_U64_U32(x)  "v_mad_u64_u32 " #x ", vcc, %8, %9, " #x "\n"
 #define A_LSHL_ADD_U64(x) "v_lshl_add_u64 " #x ", " #x ", 0, " #x "\n"
 #define A_LSHLREV_B64(x)  "v_lshlrev_b64 " #x ", 1, " #x "\n"
+#define A_LSHRREV_B64(x)  "v_lshrrev_b64 " #x ", 29, " #x "\n"
+#define A_ASHRREV_I64(x)  "v_ashrrev_i64 " #x ", 29, " #x "\n"
+#define A_MAD_I64_I32(x)  "v_mad_i64_i32 " #x ", vcc, %8, %9, " #x "\n"
 // f64 ops
 #define A_FMA_F64(x)      "v_fma_f64 " #x ", " #x ", %8, %9\n"
 #define A_ADD_F64(x)      "v_add_f64 " #x ", " #x ", %9\n"
@@ -98,6 +113,21 @@ KERNEL32(k_and_or, A_AND_OR)
 KERNEL32(k_dot4_u8, A_DOT4_U8)
 KERNEL32(k_mad_u32_u16, A_MAD_U32_U16)
 KERNEL32(k_cndmask, A_CNDMASK)
+KERNEL32(k_cndmask_e64, A_CNDMASK_E64)
+KERNEL32(k_cndmask_add, A_CNDMASK_ADD)
+KERNEL32(k_cndmask_mad, A_CNDMASK_MAD)
+KERNEL32(k_bfi_b32, A_BFI_B32)
+KERNEL32(k_and_b32, A_AND_B32)
+KERNEL32(k_or_b32, A_OR_B32)
+KERNEL32(k_lshrrev_b32, A_LSHRREV_B32)
+KERNEL32(k_lshlrev_b32, A_LSHLREV_B32)
+KERNEL32(k_sub_u32, A_SUB_U32)
+KERNEL32(k_mov_b32, A_MOV_B32)
+KERNEL32(k_ashrrev_i32, A_ASHRREV_I32)
+KERNEL32(k_xor_b32, A_XOR_B32)
+KERNEL64(k_lshrrev_b64, A_LSHRREV_B64)
+KERNEL64(k_ashrrev_i64, A_ASHRREV_I64)
+KERNEL64(k_mad_i64_i32, A_MAD_I64_I32)
 KERNEL64(k_pk_fma_f32, A_PK_FMA_F32)
 KERNEL64(k_mad_u64_u32, A_MAD_U64_U32)
 KERNEL64(k_lshl_add_u64, A_LSHL_ADD_U64)
@@ -204,6 +234,11 @@ int main() {
         {"v_lshl_or_b32", k_lshl_or, 8}, {"v_and_or_b32", k_and_or, 8}, {"v_dot4_u32_u8", k_dot4_u8, 8},
         {"v_pk_fma_f32", k_pk_fma_f32, 8}, {"v_mad_u64_u32", k_mad_u64_u32, 8},
         {"v_lshl_add_u64", k_lshl_add_u64, 8}, {"v_lshlrev_b64", k_lshlrev_b64, 8},
+        {"v_cndmask_b32", k_cndmask, 8}, {"v_cndmask_b32_e64 s[10:11]", k_cndmask_e64, 8},
+        {"cndmask + add_u32 (pairs)", k_cndmask_add, 16}, {"cndmask + 3 mul_lo (quads)", k_cndmask_mad, 32}, {"v_bfi_b32", k_bfi_b32, 8}, {"v_and_b32", k_and_b32, 8}, {"v_or_b32", k_or_b32, 8}, {"v_xor_b32", k_xor_b32, 8},
+        {"v_lshrrev_b32", k_lshrrev_b32, 8}, {"v_lshlrev_b32", k_lshlrev_b32, 8}, {"v_ashrrev_i32", k_ashrrev_i32, 8},
+        {"v_sub_u32", k_sub_u32, 8}, {"v_mov_b32", k_mov_b32, 8},
+        {"v_lshrrev_b64", k_lshrrev_b64, 8}, {"v_ashrrev_i64", k_ashrrev_i64, 8}, {"v_mad_i64_i32", k_mad_i64_i32, 8},
         {"v_fma_f64", k_fma_f64, 8}, {"v_add_f64", k_add_f64, 8}, {"v_mul_f64", k_mul_f64, 8},
         {"mix 4x(fma_f64+add_u32)", k_mix_fma64_int, 8}, {"mix 4x(mad_u64+addc)", k_mix_mad64_add, 8},
         {"mad_u64 1 dependent chain", k_mad_dep1, 8}, {"mad_u64 2 dependent chains", k_mad_dep2, 8},
