@@ -337,7 +337,7 @@ def main():
 
     # ---- kernel attribution pass (not part of `value`): two more steps WITHOUT IMT_PIPELINE, so that each
     # kernel has the GPU to itself and its HIP-event duration is a clean roofline input.  In the timed
-    # region two hash kernels of consecutive batches share the SIMDs and stretch each other.
+    # region the hash kernels of up to four consecutive batches share the SIMDs and stretch each other.
     b2b = (ctypes.c_double * 12)()
     extra = 0 if os.environ.get("IMT_BENCH_NO_ATTRIBUTION") else extra_steps
     if extra:
@@ -451,8 +451,8 @@ def main():
                          "duration_source": ("attribution pass: 2 un-pipelined steps after the timed region, the kernel "
                                              "alone on the GPU" if alone_ms else "timed region (pipelined)"),
                          "pipelined": {"avg_launch_ms": pipe_ms, "achieved": pipe_gbps, "frac": pipe_gbps / HBM_PEAK_GBPS,
-                                       "what": "the same kernel inside the timed region, sharing the SIMDs with a hash "
-                                               "kernel of the neighbouring batch"},
+                                       "what": "the same kernel inside the timed region, sharing the SIMDs with the hash "
+                                               "kernels of the neighbouring batches (up to four in flight)"},
                          "note": "declared HBM per the contract; the kernel is integer-VALU bound, see valu"},
             "valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep (level launches)",
                      "peak_gmads_measured_now": mad_peak.value,

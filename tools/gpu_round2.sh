@@ -20,6 +20,8 @@ timeout -k 10 300 python tools/trace_rate.py 16 17 18 19 > $O/trace_rate.txt 2>&
 ( timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_trace_write -o w -- python3 tools/trace_rate.py 18 > /dev/null 2> $O/pmc_trace_write.err ) && echo "pmc trace ok" &&
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/pmc_bench_summary.txt && python tools/pmc_summary.py $O/pmc_trace_fetch $O/pmc_trace_write > $O/pmc_trace_summary.txt &&
 ( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo; timeout -k 10 400 python3 bench.py --gpus 2 --steps 6 --warmup 2 > $O/bench_2rank_rehearsal.json 2> $O/bench_2rank.err ) && echo "2-rank ok" &&
+( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo; timeout -k 10 400 python3 bench.py --gpus 4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_4rank_rehearsal.json 2> $O/bench_4rank.err ) && echo "4-rank ok" &&
+timeout -k 10 300 python tools/verify_latency.py > $O/verify_latency.txt 2>&1 && echo "verify latency ok" &&
 timeout -k 10 300 python tools/small_batch_rate.py 8 16 > $O/small_batch.txt 2>&1 && echo "small batch ok" &&
 timeout -k 10 300 python tools/bench_aux.py > $O/bench_aux.txt 2>&1 && echo "aux ok" &&
 SOAK_SECONDS=60 timeout -k 10 400 python tools/differential_soak.py > $O/differential_soak.txt 2>&1 && echo "soak ok" &&
