@@ -44,7 +44,7 @@ int imt_ctx::sync_and_check() {
     IMT_HIP(this, hipMemcpyAsync(&h, d_err, sizeof(int), hipMemcpyDeviceToHost, stream));
     IMT_HIP(this, hipStreamSynchronize(stream));
     if (h) {
-        hipMemsetAsync(d_err, 0, sizeof(int), stream);
+        IMT_HIP(this, hipMemsetAsync(d_err, 0, sizeof(int), stream));
         return fail(IMT_ERR_NONCANONICAL, "a field element in the input is not reduced (>= p)");
     }
     return IMT_OK;
@@ -182,9 +182,9 @@ extern "C" int imt_ctx_create(int device, imt_ctx** out) {
         return e == hipErrorNoDevice ? IMT_ERR_NO_DEVICE : IMT_ERR_HIP;
     }
     c->stream = c->own_stream;
-    hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream);
+    e = hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream);
     launch::zero_chain(c->stream, c->d_zero, IMT_MAX_DEPTH);
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+    if (e != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
         imt_ctx_destroy(c);
         return IMT_ERR_HIP;
     }
@@ -487,8 +487,11 @@ extern "C" int imt_tree_new(imt_ctx* c, const void* leaves, size_t n, unsigned f
         imt_tree_free(t);
         return c->hip_fail(e, "hipMalloc(tree)");
     }
-    hipMemcpyAsync(t->d_off, t->h_off.data(), nl * 8, hipMemcpyHostToDevice, c->stream);
-    hipMemcpyAsync(t->d_len, t->h_len.data(), nl * 8, hipMemcpyHostToDevice, c->stream);
+    if ((e = hipMemcpyAsync(t->d_off, t->h_off.data(), nl * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(t->d_len, t->h_len.data(), nl * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) {
+        imt_tree_free(t);
+        return c->hip_fail(e, "hipMemcpyAsync(tree offsets)");
+    }
     Io io(c, flags);
     const uint8_t* d_in = io.in(leaves, n * 32);
     if (io.rc) { imt_tree_free(t); return io.rc; }

@@ -288,7 +288,7 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
         // different priorities: the runtime may otherwise map the streams to one hardware queue, which
         // serialises them (seen with rocprofv3: same Queue_Id, zero overlap)
         int least = 0, greatest = 0;
-        hipDeviceGetStreamPriorityRange(&least, &greatest);      // numerically: least >= greatest
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;   // numerically: least >= greatest
         for (int i = 0; i < imt_itree::NPIPE; i++) {
             const int prio = std::max(greatest, std::min(least, 0 - i));
             if ((e = hipStreamCreateWithPriority(&t->pipe_stream[i], hipStreamNonBlocking, prio)) != hipSuccess) {
@@ -308,10 +308,13 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
                 imt_itree_free(t);
                 return c->hip_fail(e, "hipEventCreate");
             }
-    hipMemsetAsync(t->d_val, 0, 32, c->stream);          // leaf 0: the sentinel value 0
-    hipMemsetAsync(t->d_sorted[0], 0, 4, c->stream);     // sorted index = [leaf 0]
-    hipMemcpyAsync(t->d_off, t->h_off.data(), (depth + 1) * 8, hipMemcpyHostToDevice, c->stream);
-    hipMemcpyAsync(t->d_len, t->h_len.data(), (depth + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    if ((e = hipMemsetAsync(t->d_val, 0, 32, c->stream)) != hipSuccess ||          // leaf 0: the sentinel value 0
+        (e = hipMemsetAsync(t->d_sorted[0], 0, 4, c->stream)) != hipSuccess ||     // sorted index = [leaf 0]
+        (e = hipMemcpyAsync(t->d_off, t->h_off.data(), (depth + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(t->d_len, t->h_len.data(), (depth + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) {
+        imt_itree_free(t);
+        return c->hip_fail(e, "imt_itree_new init copies");
+    }
     for (unsigned l = 0; l <= depth; l++)   // every stored node starts as the empty subtree of its height
         launch::fill_level(c->stream, t->d_nodes + t->h_off[l] * 32, t->h_len[l], c->d_zero + (size_t)l * 32);
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) {
