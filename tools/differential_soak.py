@@ -15,6 +15,7 @@ budget = float(os.environ.get("SOAK_SECONDS", "60"))
 t0 = time.time()
 total = 0
 case = 0
+forms = {}
 while time.time() - t0 < budget:
     depth = rng.choice([4, 9, 14, 32, 32])
     cap = min(1 << depth, 1 << 13)
@@ -34,6 +35,11 @@ while time.time() - t0 < budget:
     oh = orc.sparse_new(depth, cap)
     rows = [orc.sparse_insert(oh, depth, v) for v in vals]
     oroot = orc.sparse_root(oh)
+    # which form of the hash kernel the batches of this tree run: always a quad of lanes per hash (the default for
+    # batches this small), never, or split at 1000 insertions
+    coop_max = rng.choice([16384, 0, 2000])
+    ctx.set_option(imt_amd._ffi.OPT_COOP_MAX_EVENTS, coop_max)
+    forms[coop_max] = forms.get(coop_max, 0) + 1
     t = imt_amd.IndexedTree(ctx, depth, cap)
     i = 0
     while i < n_total:
@@ -54,4 +60,5 @@ while time.time() - t0 < budget:
     t.close()
     total += n_total
     case += 1
-print("differential soak: %d trees, %d insertions, every root and low index equal to the oracle (%.0f s)" % (case, total, time.time() - t0))
+print("differential soak: %d trees, %d insertions, every root and low index equal to the oracle (%.0f s); "
+      "trees per IMT_OPT_COOP_MAX_EVENTS setting: %s" % (case, total, time.time() - t0, dict(sorted(forms.items()))))
