@@ -16,9 +16,11 @@
 
 typedef unsigned W4 __attribute__((ext_vector_type(4)));
 
-template <int WORK, bool NT>
+// XCD: workgroups go to the 8 XCDs round-robin; with the remap XCD x works on a contiguous eighth of the items
+template <int WORK, bool NT, bool XCD = false>
 __global__ void __launch_bounds__(256) k_pattern(W4* out, unsigned n, unsigned rows, int item_major, unsigned seed) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned blk = XCD ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const unsigned i = blk * blockDim.x + threadIdx.x;
     if (i >= n) return;
     unsigned long long acc = seed + i;
     unsigned x = i * 2654435761u + 1;
@@ -38,15 +40,15 @@ __global__ void __launch_bounds__(256) k_pattern(W4* out, unsigned n, unsigned r
     }
 }
 
-template <int WORK, bool NT>
+template <int WORK, bool NT, bool XCD = false>
 static void run(W4* d, unsigned n, unsigned rows, int item_major) {
     hipEvent_t e0, e1;
     OK(hipEventCreate(&e0));
     OK(hipEventCreate(&e1));
-    k_pattern<WORK, NT><<<(n + 255) / 256, 256>>>(d, n, rows, item_major, 1);
+    k_pattern<WORK, NT, XCD><<<(n + 255) / 256, 256>>>(d, n, rows, item_major, 1);
     OK(hipDeviceSynchronize());
     OK(hipEventRecord(e0));
-    for (int it = 0; it < 3; it++) k_pattern<WORK, NT><<<(n + 255) / 256, 256>>>(d, n, rows, item_major, it);
+    for (int it = 0; it < 3; it++) k_pattern<WORK, NT, XCD><<<(n + 255) / 256, 256>>>(d, n, rows, item_major, it);
     OK(hipEventRecord(e1));
     OK(hipEventSynchronize(e1));
     float ms;
@@ -54,7 +56,7 @@ static void run(W4* d, unsigned n, unsigned rows, int item_major) {
     ms /= 3;
     const double bytes = (double)n * rows * 32;
     std::printf("n=2^%d rows=%u %-10s %s work=%4d mads/row  %8.3f ms  %7.1f GB/s  %6.1f Mitems/s\n", __builtin_ctz(n), rows,
-                item_major ? "item-major" : "row-major", NT ? "nontemporal" : "plain      ", WORK, ms, bytes / ms / 1e6, n / ms / 1e3);
+                item_major ? "item-major" : "row-major", NT ? "nontemporal" : XCD ? "xcd-remap  " : "plain      ", WORK, ms, bytes / ms / 1e6, n / ms / 1e3);
 }
 
 int main(int argc, char** argv) {
@@ -65,7 +67,9 @@ int main(int argc, char** argv) {
     for (int im = 0; im < 2; im++) {
         run<0, false>(d, n, rows, im);
         run<0, true>(d, n, rows, im);
+        run<0, false, true>(d, n, rows, im);
         run<64, false>(d, n, rows, im);
+        run<128, false, true>(d, n, rows, im);
         run<128, false>(d, n, rows, im);
         run<128, true>(d, n, rows, im);
         run<256, false>(d, n, rows, im);
