@@ -328,14 +328,18 @@ int imt_itree_get_leaves(imt_itree *t, const uint64_t *index, size_t n, void *pr
  * otherwise), then rebuilds every stored level on the GPU (n leaf hashes + one pass of k_tree_level
  * per level: about 2 hashes per leaf, the "final root only" build of SURVEY.md 8d). */
 int imt_itree_load(imt_itree *t, const void *preimages /*[n][3][32]*/, uint64_t n, unsigned flags);
-/* low leaf (greatest val < v) for n candidate values; IMT_ERR_VALUE if some v is 0 or present */
+/* low leaf (greatest val < v) for n candidate values; IMT_ERR_VALUE if some v is 0, present, or (with a value
+ * partition set) of another subtree's residue */
 int imt_itree_find_low_batch(imt_itree *t, const void *vals /*[n][32]*/, size_t n,
                              uint64_t *low_index /*[n]*/, unsigned flags);
 
 /* Witness of verify_non_inclusion for n candidate values against the current tree, produced on the
  * GPU from the device-resident index: the low leaf (greatest stored value below the candidate), its
  * preimage, the is_largest flag and its `depth` siblings.  Outputs feed imt_non_membership_batch
- * unchanged.  Any output pointer may be NULL.  IMT_ERR_VALUE if a candidate is 0 or already stored. */
+ * unchanged.  Any output pointer may be NULL.  IMT_ERR_VALUE if a candidate is 0, already stored, or -- with a value
+ * partition set (imt_itree_set_value_partition) -- of another subtree's residue: this subtree's list says nothing about it.
+ * On a placed tree low_sib holds the subtree's `depth` rows; imt_itree_lift_batch with out = {low_sib} and
+ * roots_before = roots_after = the subtrees' current roots appends the rows above (a depth-global_depth witness). */
 int imt_itree_non_membership_witness(imt_itree *t, const void *vals /*[n][32]*/, size_t n,
                                      uint64_t *low_index /*[n]*/, void *low_leaf /*[n][3][32]*/,
                                      uint8_t *is_largest /*[n]*/, void *low_sib /*[depth][n][32]*/,

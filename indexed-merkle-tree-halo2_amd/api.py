@@ -540,9 +540,29 @@ class IndexedTree:
         self.ctx._check(rc)
         return out
 
-    def non_membership_witness(self, vals, host=False):
+    def non_membership_witness(self, vals, host=False, subtree_roots=None):
         """Witness for verify_non_inclusion of every value: (low index, low leaf, siblings, is_largest).
-        Built on the GPU from the device-resident index; host=True uses the host mirror instead."""
+        Built on the GPU from the device-resident index; host=True uses the host mirror instead.
+        A placed tree (set_placement) returns `depth` siblings against its own root; with subtree_roots (uint8
+        [n_subtrees, 32], every subtree's current root) the siblings above it are appended (imt_itree_lift_batch)
+        and the witness is one of depth `global_depth` against the global root."""
+        if subtree_roots is not None:
+            if host:
+                raise ValueError("subtree_roots needs the GPU path")
+            v = to_bytes(vals) if not isinstance(vals, np.ndarray) else _arr(vals, (32,))
+            n = v.shape[0]
+            low = np.empty(n, np.uint64)
+            leaves = np.empty((n, 3, 32), np.uint8)
+            largest = np.empty(n, np.uint8)
+            sib = np.zeros((self.global_depth, n, 32), np.uint8)       # rows [0, depth) from the tree, the rest lifted
+            rc = lib.imt_itree_non_membership_witness(self.h, _p(v), n, _p(low), _p(leaves), _p(largest), _p(sib), 0)
+            if rc == _ffi.ERR["VALUE"]:
+                raise ValueError(lib.imt_last_error(self.ctx.h).decode())
+            self.ctx._check(rc)
+            r = _arr(subtree_roots, (32,))
+            out = _ffi.InsertOut(low_sib=sib.ctypes.data)
+            self.ctx._check(lib.imt_itree_lift_batch(self.h, _p(r), _p(r), r.shape[0], n, ctypes.byref(out), 0))
+            return low, leaves, sib, largest
         if host:
             low = self.find_low(vals)
             leaves = self.get_leaves(low)

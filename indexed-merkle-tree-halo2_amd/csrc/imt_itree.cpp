@@ -490,6 +490,8 @@ extern "C" int imt_itree_find_low_batch(imt_itree* t, const void* vals, size_t n
     std::vector<uint64_t> res(n);
     for (size_t i = 0; i < n; i++) {
         size_t pos;
+        if (t->part_mod > 1 && prep::mod_small(reinterpret_cast<const uint8_t*>(v[i].data()), t->part_mod) != t->part_res)
+            return c->fail(IMT_ERR_VALUE, "value %zu belongs to another subtree (v %% %u != %u)", i, t->part_mod, t->part_res);
         if (find_pred(t, v[i], pos)) return c->fail(IMT_ERR_VALUE, "value %zu is zero or already in the tree", i);
         res[i] = t->index_base + t->sorted[pos].idx;
     }
@@ -616,7 +618,7 @@ extern "C" int imt_itree_non_membership_witness(imt_itree* t, const void* vals, 
     uint8_t* g_sib = outbuf(low_sib, sib_bytes);
     if (!g_low || (low_leaf && !g_leaf) || (is_largest && !g_lg) || (low_sib && !g_sib)) return IMT_ERR_HIP;
     prep::nm_witness(s, d_vals, t->d_val, t->d_sorted[t->sorted_cur], (uint32_t)t->size, (uint32_t)n, t->index_base,
-                     g_low, g_leaf, g_lg, d_perr);
+                     t->part_mod, t->part_res, g_low, g_leaf, g_lg, d_perr);
     if (g_leaf && fmt != IMT_FMT_CANONICAL) launch::convert(s, g_leaf, g_leaf, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
     if (g_sib) {
         launch::TreeView tv{t->d_nodes, t->d_off, t->d_len, c->d_zero, t->index_base};
@@ -633,6 +635,9 @@ extern "C" int imt_itree_non_membership_witness(imt_itree* t, const void* vals, 
     }
     IMT_HIP(c, hipStreamSynchronize(s));
     if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a candidate is not reduced (>= p)");
+    if (perr & prep::ERR_FOREIGN)
+        return c->fail(IMT_ERR_VALUE, "a candidate belongs to another subtree (v %% %u != %u): this list says nothing about it",
+                       t->part_mod, t->part_res);
     if (perr & (prep::ERR_ZERO | prep::ERR_DUPLICATE))
         return c->fail(IMT_ERR_VALUE, "a candidate is 0 or already in the tree (it has no non-membership witness)");
     return IMT_OK;

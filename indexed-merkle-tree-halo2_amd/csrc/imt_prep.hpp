@@ -65,9 +65,11 @@ hipError_t run(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val
                uint8_t* o_new_leaf);
 
 // non-membership witness: low leaf index, its preimage {val, next_val, next_idx} (canonical) and the
-// is_largest flag of every candidate; any output may be NULL
+// is_largest flag of every candidate; any output may be NULL.  part_mod > 1: candidates with v % part_mod != part_res
+// belong to another subtree's list (ERR_FOREIGN)
 void nm_witness(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
-                uint64_t base, uint64_t* low_index, uint8_t* low_leaf, uint8_t* is_largest, int* err);
+                uint64_t base, uint32_t part_mod, uint32_t part_res, uint64_t* low_index, uint8_t* low_leaf,
+                uint8_t* is_largest, int* err);
 
 // predecessor search only (imt_itree_find_low_batch): low[i] = leaf index of the greatest value < vals[i]
 void find_low(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,

@@ -110,6 +110,14 @@ class GpuBackend:
                                                                ctypes.c_void_p(out.data_ptr()), self.flags))
         return out
 
+    def non_membership_witness(self, vals, roots):
+        """(low index, low leaf, siblings [depth, n, 32], is_largest), numpy: verify_non_inclusion's witness for values
+        of this rank's residue against the GLOBAL root whose subtree roots are `roots` (the tree must be idle)"""
+        self.sync()
+        r = roots.cpu().numpy() if torch.is_tensor(roots) else roots
+        v = vals.cpu().numpy() if torch.is_tensor(vals) else vals
+        return self.tree.non_membership_witness(v, subtree_roots=r)
+
     def outputs(self, slot):
         """the slot's witness tensors (valid on the host after sync()) + the global index of its first new leaf"""
         d = dict(self.sets[slot])
@@ -155,6 +163,13 @@ class ShardedIndexedTree:
         done = self._finish(0)
         self.pending = None
         return done
+
+    def non_membership_witness(self, vals):
+        """BASELINE config 3 in the sharded layout: the depth-`depth` non-membership witness of values this rank owns,
+        against `global_root` (call after flush(): no insertion pending)"""
+        if self.pending is not None:
+            raise RuntimeError("flush() first: a batch is still waiting for its root exchange")
+        return self.backend.non_membership_witness(vals, self.roots_prev)
 
     def gather_roots(self, mine):
         """[world, 32]: every rank's subtree root -- the one collective of the path"""

@@ -1160,6 +1160,57 @@ def test_lift_batch_host_pointers_and_item_major(imt, ctx, oracle):
     assert (res[True]["old_root"] == res[False]["old_root"]).all()
 
 
+def test_sharded_non_membership_at_depth_32(imt, ctx, oracle):
+    """BASELINE config 3 in the sharded layout: four value-partitioned subtrees of height 30 (one GPU, one after the
+    other), non-membership witnesses for values none of them holds, lifted to depth 32 with the four subtree roots:
+    every item passes verify_non_inclusion (imt_non_membership_batch, all constraints) against the GLOBAL root with
+    its global low-leaf index; a value that IS in the tree is refused, one of another rank's residue too."""
+    depth, world, n_ins, n_q = 32, 4, 300, 200
+    sub = depth - 2
+    pool = oracle_lib.synth_values(6 * (n_ins + n_q), 0x494D5443)
+    trees, roots, held = [], [], []
+    for g in range(world):
+        mine = [v for v in pool if v % world == g]
+        t = imt.IndexedTree(ctx, sub, 1 << 10)
+        t.set_placement(depth, g)
+        ctx._check(imt.lib.imt_itree_set_value_partition(t.h, world, g))
+        t.insert_batch(mine[:n_ins], proofs=False)
+        trees.append(t)
+        roots.append(t.root())
+        held.append(mine)
+    roots_arr = ints_to_arr(roots)
+    global_root = ctx.combine_subtree_roots(roots_arr, sub, depth)
+    # the oracle builds the same four subtrees and agrees on the global root
+    oroots = []
+    for g in range(world):
+        oh = oracle.sparse_new(sub, 1 << 10)
+        oracle.sparse_set_index_base(oh, g << sub)
+        for v in held[g][:n_ins]:
+            oracle.sparse_insert(oh, sub, v)
+        oroots.append(oracle.sparse_root(oh))
+        oracle.sparse_free(oh)
+    assert oroots == roots
+    top = oracle.hash([oracle.hash(oroots[0:2]), oracle.hash(oroots[2:4])])
+    assert ints(global_root) == [top]
+    for g in range(world):
+        q = held[g][n_ins:n_ins + n_q]
+        low, leaves, sib, largest = trees[g].non_membership_witness(q, subtree_roots=roots_arr)
+        assert sib.shape == (depth, n_q, 32)
+        assert ((low >> sub) == g).all()                               # global indices inside subtree g
+        fail = ctx.non_membership(global_root, leaves, low, sib, depth, imt.to_bytes(q), largest)
+        assert not fail.any()
+        # the two appended siblings are the neighbouring subtree's root and the other pair's hash
+        assert ints(sib[sub, 0]) == [oroots[g ^ 1]]
+        other = oracle.hash(oroots[2:4]) if g < 2 else oracle.hash(oroots[0:2])
+        assert ints(sib[sub + 1, n_q - 1]) == [other]
+        with pytest.raises(ValueError):
+            trees[g].non_membership_witness([held[g][0]], subtree_roots=roots_arr)          # present
+        with pytest.raises(ValueError):
+            trees[g].non_membership_witness([held[g ^ 1][n_ins]], subtree_roots=roots_arr)  # another rank's value
+    for t in trees:
+        t.close()
+
+
 def test_lift_above_the_subtrees_meets_empty_subtrees_and_world_one_is_a_no_op(imt, ctx, oracle):
     """global depth > subtree height + log2(n_subtrees): the levels above the subtrees' common root climb against
     Z[l]; a single subtree of full height is lifted by nothing.  Also: batch_abort, a non-power-of-two value

@@ -132,6 +132,13 @@ def _sub_worker(rank, world, port, depth, q):
         if done is not None:
             take(done)
     take(tree.flush())
+    # config 3 in the same layout: values of this rank's residue that were never inserted, witnessed at full depth
+    # against the global root and checked by the independent non-membership kernel
+    import oracle_lib
+    cand = [v for v in oracle_lib.synth_values(64 * world, 0x494D5460 + depth) if v % world == rank and v not in vals][:16]
+    low, leaves, sib, largest = tree.non_membership_witness(imt_amd.to_bytes(cand))
+    nm_fail = be.ctx.non_membership(tree.global_root.cpu().numpy(), leaves, low, sib, depth, imt_amd.to_bytes(cand), largest)
+    assert sib.shape == (depth, 16, 32) and not nm_fail.any() and ((low >> (depth - k)) == rank).all()
     q.put((rank, finished, roots, fails))
     dist.barrier()
     dist.destroy_process_group()
