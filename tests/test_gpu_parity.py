@@ -3,6 +3,7 @@ inputs -- bit-exact, since everything is integer arithmetic mod p.  Mirrors the 
 own tests (src/indexed_merkle_tree.rs:349-810) and adds the cases it leaves out."""
 import json
 import os
+import sys
 import random
 
 import numpy as np
@@ -709,6 +710,30 @@ def test_c_example_runs(imt):
     assert "all satisfied" in r.stdout and "trace rows ok" in r.stdout and "4506 cells" in r.stdout
     want = int(GOLD["multi_round_depth3"][-1]["new_root"])
     assert f"{want:064x}" in r.stdout          # the last root of test_insert_leaf_multiple_round
+
+
+def test_c_abi_survives_null_and_nonsense_arguments(imt):
+    """tests/native/null_args_probe.py in a child process: every int-returning entry point with a NULL handle, with a
+    valid handle and NULL everything else, and with the unknown format 3.  Nothing may crash; a NULL handle is always an
+    error; every return value is a documented code; the handles work afterwards."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "native", "null_args_probe.py")], capture_output=True,
+                       text=True, timeout=300, cwd=root, env=dict(os.environ, PYTHONPATH=root))
+    calls = [l.split()[1:3] for l in r.stdout.splitlines() if l.startswith("CALL ")]
+    rcs = {(l.split()[1], l.split()[2]): int(l.split()[3]) for l in r.stdout.splitlines() if l.startswith("RC ")}
+    last = calls[-1] if calls else None
+    assert r.returncode == 0 and "ALIVE" in r.stdout, f"died in {last}: " + r.stderr[-1500:]
+    assert len(rcs) == len(calls) > 120
+    for (name, label), rc in rcs.items():
+        assert -12 <= rc <= 0, (name, label, rc)
+        if label == "null-handle":
+            assert rc < 0, (name, rc)
+    # spot checks of the documented codes
+    assert rcs[("imt_hash2_batch", "null-args")] == imt._ffi.ERR["ARG"]
+    assert rcs[("imt_itree_insert_batch", "null-args")] == imt._ffi.ERR["ARG"]
+    assert rcs[("imt_hash2_batch", "bad-format")] == imt._ffi.ERR["ARG"]
+    assert rcs[("imt_tree_new", "null-args")] == imt._ffi.ERR["ARG"]
 
 
 def test_reference_tests_in_cpp(imt, oracle, tmp_path):
