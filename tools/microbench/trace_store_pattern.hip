@@ -40,6 +40,46 @@ __global__ void __launch_bounds__(256) k_pattern(W4* out, unsigned n, unsigned r
     }
 }
 
+// item-major with the four rows of a 128-byte line written together (what staging rows in LDS / registers would do)
+template <int WORK>
+__global__ void __launch_bounds__(256) k_pattern_lines(W4* out, unsigned n, unsigned rows, unsigned seed) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long acc = seed + i;
+    unsigned x = i * 2654435761u + 1;
+    for (unsigned r = 0; r < rows; r += 4) {
+        W4 v[8];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int k = 0; k < WORK; k++) acc = (unsigned long long)x * (unsigned)acc + (acc >> 29);
+            const unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32);
+            v[2 * q] = W4{lo, hi, r + q, i};
+            v[2 * q + 1] = W4{hi, lo, i, r + q};
+        }
+        W4* dst = out + 2 * ((size_t)i * rows + r);
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[q] = v[q];
+    }
+}
+template <int WORK>
+static void run_lines(W4* d, unsigned n, unsigned rows) {
+    hipEvent_t e0, e1;
+    OK(hipEventCreate(&e0));
+    OK(hipEventCreate(&e1));
+    k_pattern_lines<WORK><<<(n + 255) / 256, 256>>>(d, n, rows, 1);
+    OK(hipDeviceSynchronize());
+    OK(hipEventRecord(e0));
+    for (int it = 0; it < 3; it++) k_pattern_lines<WORK><<<(n + 255) / 256, 256>>>(d, n, rows, it);
+    OK(hipEventRecord(e1));
+    OK(hipEventSynchronize(e1));
+    float ms;
+    OK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 3;
+    std::printf("n=2^%d rows=%u item-major 128-B lines work=%4d mads/row  %8.3f ms  %7.1f GB/s  %6.1f Mitems/s\n", __builtin_ctz(n),
+                rows, WORK, ms, (double)n * rows * 32 / ms / 1e6, n / ms / 1e3);
+}
+
 template <int WORK, bool NT, bool XCD = false>
 static void run(W4* d, unsigned n, unsigned rows, int item_major) {
     hipEvent_t e0, e1;
@@ -75,6 +115,9 @@ int main(int argc, char** argv) {
         run<256, false>(d, n, rows, im);
         run<256, true>(d, n, rows, im);
     }
+    run_lines<0>(d, n, rows);
+    run_lines<128>(d, n, rows);
+    run_lines<256>(d, n, rows);
     OK(hipFree(d));
     return 0;
 }
