@@ -1083,7 +1083,7 @@ void sweep_leaves(hipStream_t s, const uint8_t* pre, const uint32_t* time0, uint
     a.begin = k_begin; a.count = k_count;
     a.pre = pre; a.time0 = time0; a.val_out = val0; a.fmt_in = fmt_in; a.err = err;
     a.last_event = 0xffffffffu;
-    hipLaunchKernelGGL(k_sweep, dim3(nblk(k_count)), dim3(BLOCK), 0, s, a);
+    launch_sweep(s, a, coop_max);
 }
 void merge_level(hipStream_t s, sweep::LevelTable in, sweep::LevelOut out, uint32_t total) {
     if (!total) return;
