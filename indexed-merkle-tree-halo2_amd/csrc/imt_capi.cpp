@@ -352,14 +352,15 @@ namespace {
 // The traces of one compute_merkle_root per item, given the chain's pairs (path_pairs ran before): the leaf hash
 // (if leaf3) then `depth` path hashes, into `trace` from block row `row0` on (advanced).  ONE launch for the leaf
 // hashes, ONE for all levels: every hash of every path is an independent trace.
-void path_trace_blocks(imt_ctx* c, const uint8_t* d_leaf3, const uint8_t* pairs, unsigned depth, size_t n, uint8_t* d_tr,
-                       size_t rows_total, bool item_major, size_t& row0, unsigned fmt) {
+// appends the trace jobs of one compute_merkle_root call: the leaf hash (if the chain starts from a preimage), then all
+// levels of the path as one group of depth * n hashes
+void path_trace_jobs(launch::TraceJobs& tj, const uint8_t* d_leaf3, const uint8_t* pairs, unsigned depth, size_t n,
+                     size_t& row0, unsigned fmt) {
     if (d_leaf3) {
-        launch::hash_trace(c->stream, d_leaf3, n, 3, d_tr, n, row0, rows_total, item_major, fmt, fmt, c->d_err);
+        tj.j[tj.n_jobs++] = {d_leaf3, n, 3, row0, fmt};
         row0 += dev::TRACE_ROWS_H3;
     }
-    launch::hash_trace(c->stream, pairs, (size_t)depth * n, 2, d_tr, n, row0, rows_total, item_major, IMT_FMT_DEVICE, fmt,
-                       c->d_err);
+    if (depth) tj.j[tj.n_jobs++] = {pairs, (size_t)depth * n, 2, row0, IMT_FMT_DEVICE};
     row0 += (size_t)depth * dev::TRACE_ROWS_H2;
 }
 }  // namespace
@@ -392,7 +393,11 @@ extern "C" int imt_path_trace_batch(imt_ctx* c, const void* leaf, const void* le
     pc.depth = depth; pc.n = n; pc.fmt_in = fmt; pc.fmt_out = fmt; pc.err = c->d_err;
     launch::path_pairs(c->stream, pc, c->coop_max_events);
     size_t row0 = 0;
-    path_trace_blocks(c, d_leaf3, pairs, depth, n, d_tr, rows_total, flags & IMT_TRACE_ITEM_MAJOR, row0, fmt);
+    launch::TraceJobs tj{};
+    tj.trace = d_tr; tj.n_per = n; tj.rows_total = rows_total; tj.item_major = (flags & IMT_TRACE_ITEM_MAJOR) ? 1 : 0;
+    tj.err = c->d_err;
+    path_trace_jobs(tj, d_leaf3, pairs, depth, n, row0, fmt);
+    launch::hash_trace_jobs(c->stream, tj, fmt);
     return io.finish();
 }
 
@@ -438,9 +443,12 @@ extern "C" int imt_insert_trace_batch(imt_ctx* c, const void* low_leaf, const ui
     pc.lay = sib_layout(flags, depth, n);
     pc.depth = depth; pc.n = n; pc.fmt_in = fmt; pc.fmt_out = fmt; pc.err = c->d_err;
     launch::path_pairs(c->stream, pc, c->coop_max_events);
+    // every hash of the call -- 3 leaf hashes and 4 x depth path hashes per item -- traced by ONE launch
     size_t row0 = 0;
-    for (int k = 0; k < 4; k++)
-        path_trace_blocks(c, pc.c[k].leaf3, pc.c[k].pairs, depth, n, d_tr, rows_total, item_major, row0, fmt);
+    launch::TraceJobs tj{};
+    tj.trace = d_tr; tj.n_per = n; tj.rows_total = rows_total; tj.item_major = item_major ? 1 : 0; tj.err = c->d_err;
+    for (int k = 0; k < 4; k++) path_trace_jobs(tj, pc.c[k].leaf3, pc.c[k].pairs, depth, n, row0, fmt);
+    launch::hash_trace_jobs(c->stream, tj, fmt);
     return io.finish();
 }
 

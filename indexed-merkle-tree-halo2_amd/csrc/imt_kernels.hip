@@ -10,6 +10,8 @@
 // Reference rows: a1/a10 hash_batch, a2 tree_level, a4 gather_proof,
 // a5/a8/a9 path_root, a13 non_membership, a14 insert_witness, a15 sweep_* (index logic in imt_sweep.hpp;
 // the hash-free batch preparation is a separate translation unit, imt_prep.hip).
+#include <algorithm>
+
 #include "imt_device.hpp"
 #include "imt_trace_device.hpp"
 #include "imt_launch.hpp"
@@ -196,23 +198,22 @@ __global__ void __launch_bounds__(BLOCK) k_convert(const uint8_t* __restrict__ i
 #define IMT_TRACE_WAVES
 #endif
 template <unsigned FMT_OUT>
-__global__ IMT_TRACE_WAVES void __launch_bounds__(BLOCK)
-k_hash_trace(const uint8_t* __restrict__ in, size_t n_items, int arity, uint8_t* __restrict__ trace, size_t n_per,
-             size_t row0, size_t rows_total, int item_major, unsigned fmt_in, int* err) {
+__global__ IMT_TRACE_WAVES void __launch_bounds__(BLOCK) k_hash_trace(launch::TraceJobs a) {
+    const launch::TraceJobs::Job jb = a.j[blockIdx.y];         // wave-uniform
     const size_t q = gtid();
-    if (q >= n_items) return;
-    const uint8_t* p = in + q * 32 * (size_t)arity;
-    Fe a, b, c;
-    bool ok = load_fe(g_pc, a, p, fmt_in);
-    ok &= load_fe(g_pc, b, p + 32, fmt_in);
-    c = a;
-    if (arity == 3) ok &= load_fe(g_pc, c, p + 64, fmt_in);
-    const size_t l = q / n_per, i = q - l * n_per;
-    const size_t first = row0 + l * (size_t)(arity == 3 ? TRACE_ROWS_H3 : TRACE_ROWS_H2);
-    TraceSink o{item_major ? trace + (i * rows_total + first) * 32 : trace + (first * n_per + i) * 32,
-                item_major ? (uint64_t)32 : (uint64_t)n_per * 32};
-    hash_trace<FMT_OUT>(g_pc, g_tc, o, a, b, c, arity == 3);
-    flag_err(err, ok);
+    if (q >= jb.n_items) return;
+    const uint8_t* p = jb.in + q * 32 * (size_t)jb.arity;
+    Fe x, y, z;
+    bool ok = load_fe(g_pc, x, p, jb.fmt_in);
+    ok &= load_fe(g_pc, y, p + 32, jb.fmt_in);
+    z = x;
+    if (jb.arity == 3) ok &= load_fe(g_pc, z, p + 64, jb.fmt_in);
+    const size_t l = q / a.n_per, i = q - l * a.n_per;
+    const size_t first = jb.row0 + l * (size_t)(jb.arity == 3 ? TRACE_ROWS_H3 : TRACE_ROWS_H2);
+    TraceSink o{a.item_major ? a.trace + (i * a.rows_total + first) * 32 : a.trace + (first * a.n_per + i) * 32,
+                a.item_major ? (uint64_t)32 : (uint64_t)a.n_per * 32};
+    hash_trace<FMT_OUT>(g_pc, g_tc, o, x, y, z, jb.arity == 3);
+    flag_err(a.err, ok);
 }
 
 // (left, right) inputs of every hash2 along n paths, for the trace of a whole path: pairs[l][i][2] in device
@@ -966,13 +967,21 @@ hipError_t upload_consts(const dev::PoseidonConsts& pc) {
 hipError_t upload_trace_consts(const dev::TraceConsts& tc) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tc), &tc, sizeof(tc), 0, hipMemcpyHostToDevice);
 }
-void hash_trace(hipStream_t s, const uint8_t* in, size_t n_items, int arity, uint8_t* trace, size_t n_per, size_t row0,
-                size_t rows_total, bool item_major, unsigned fmt_in, unsigned fmt_out, int* err) {
-    if (!n_items) return;
+void hash_trace_jobs(hipStream_t s, const TraceJobs& a, unsigned fmt_out) {
+    size_t most = 0;
+    for (int k = 0; k < a.n_jobs; k++) most = std::max(most, a.j[k].n_items);
+    if (!most || a.n_jobs <= 0) return;
     auto* k = fmt_out == FMT_MONT256 ? k_hash_trace<FMT_MONT256>
               : fmt_out == FMT_DEVICE ? k_hash_trace<FMT_DEVICE> : k_hash_trace<FMT_CANONICAL>;
-    hipLaunchKernelGGL(k, dim3(nblk(n_items)), dim3(BLOCK), 0, s, in, n_items, arity, trace, n_per, row0, rows_total,
-                       item_major ? 1 : 0, fmt_in, err);
+    hipLaunchKernelGGL(k, dim3(nblk(most), (unsigned)a.n_jobs), dim3(BLOCK), 0, s, a);
+}
+void hash_trace(hipStream_t s, const uint8_t* in, size_t n_items, int arity, uint8_t* trace, size_t n_per, size_t row0,
+                size_t rows_total, bool item_major, unsigned fmt_in, unsigned fmt_out, int* err) {
+    TraceJobs a{};
+    a.j[0] = {in, n_items, arity, row0, fmt_in};
+    a.n_jobs = 1;
+    a.trace = trace; a.n_per = n_per; a.rows_total = rows_total; a.item_major = item_major ? 1 : 0; a.err = err;
+    hash_trace_jobs(s, a, fmt_out);
 }
 void insert_trace_inputs(hipStream_t s, const uint8_t* low_leaf, const uint8_t* new_leaf, const uint64_t* new_index,
                          size_t n, uint8_t* new_low, uint8_t* zero_leaf, unsigned fmt, int* err) {

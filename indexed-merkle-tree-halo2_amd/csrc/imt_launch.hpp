@@ -34,6 +34,24 @@ hipError_t upload_trace_consts(const dev::TraceConsts& tc);
 // rows per item column, row-major [rows_total][n_per] or item-major [n_per][rows_total].
 void hash_trace(hipStream_t s, const uint8_t* in, size_t n_items, int arity, uint8_t* trace, size_t n_per, size_t row0,
                 size_t rows_total, bool item_major, unsigned fmt_in, unsigned fmt_out, int* err);
+// The same for up to eight groups of hashes in ONE launch (blockIdx.y = group): the 3 leaf hashes and 4 paths of an
+// insert_leaf call do not depend on each other once the path inputs are known, and for a few items one thread per hash
+// leaves the chip empty -- seven launches in a row would cost seven times one hash's 0.9 ms.
+struct TraceJobs {
+    struct Job {
+        const uint8_t* in;       // [n_items][arity][32]
+        size_t n_items;          // item q -> block q / n_per (rows row0 + (q / n_per) * rows(arity) ...) of column q % n_per
+        int arity;
+        size_t row0;
+        unsigned fmt_in;
+    } j[8];
+    int n_jobs;
+    uint8_t* trace;
+    size_t n_per, rows_total;
+    int item_major;
+    int* err;
+};
+void hash_trace_jobs(hipStream_t s, const TraceJobs& a, unsigned fmt_out);
 // {low.val, new.val, new_index} per item -> new_low [n][3][32], and the zero-leaf hash -> zero_leaf [n][32] (fmt)
 void insert_trace_inputs(hipStream_t s, const uint8_t* low_leaf, const uint8_t* new_leaf, const uint64_t* new_index,
                          size_t n, uint8_t* new_low, uint8_t* zero_leaf, unsigned fmt, int* err);
