@@ -94,6 +94,21 @@ class OracleBackend:
     def outputs(self, slot):
         return self.slots[slot]
 
+    def non_membership_witness(self, vals, roots):
+        """list of dicts {low (global), low_leaf (3 ints), largest, proof [depth, 32]}: verify_non_inclusion's witness
+        at full depth, the top siblings from `roots` (before = after: no step is open)"""
+        pre = [[_i(x) for x in self.orc.sparse_preimage(self.h, i)] for i in range(self.size)]
+        r = roots.numpy()
+        top = [_b(s) for s, _ in self._top(r, r)]
+        out = []
+        for v in (int(x) for x in vals):
+            if v % self.world != self.rank or v == 0 or any(p[0] == v for p in pre):
+                raise ValueError(f"value {v} has no non-membership witness in subtree {self.rank}")
+            low = max(range(self.size), key=lambda i: (pre[i][0] < v, pre[i][0]))       # greatest value below v
+            proof = np.concatenate([self.orc.sparse_proof(self.h, self.sub_height, low)] + [t[None] for t in top])
+            out.append(dict(low=self.base + low, low_leaf=pre[low], largest=int(pre[low][1] == 0), proof=proof))
+        return out
+
 
 def dense_global_replay(orc, depth, world, steps):
     """steps: list over steps of [vals of rank 0, vals of rank 1, ...].  Returns, per step and rank, a list of

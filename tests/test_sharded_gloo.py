@@ -58,6 +58,27 @@ def _worker(rank, world, port, q):
         refused = False
     except ValueError:
         refused = True
+    # non-membership at full depth against the global root (BASELINE config 3 in the sharded layout): values of this
+    # rank's residue that were never inserted; a pending batch, a foreign value and a stored value are refused
+    cand = [v for v in oracle_lib.synth_values(400, 0x494D5405) if v % world == rank and v not in vals][:6]
+    groot = int.from_bytes(bytes(tree.global_root.numpy()), "little")
+    for v, w in zip(cand, tree.non_membership_witness(cand)):
+        helper = np.zeros((DEPTH, 32), np.uint8)
+        helper[:, 0] = [1 - ((w["low"] >> l) & 1) for l in range(DEPTH)]              # 1 = left child (src/utils.rs:79)
+        fail, root_out = orc.verify_non_inclusion(groot, w["low_leaf"], w["proof"], helper, v, w["largest"])
+        assert fail == 0 and root_out == groot and (w["low"] >> (DEPTH - 1)) == rank
+    for bad in ([vals[0]], [cand[0] + 1]):
+        try:
+            tree.non_membership_witness(bad)
+            refused = False
+        except ValueError:
+            pass
+    tree.step([v for v in oracle_lib.synth_values(400, 0x494D5406) if v % world == rank and v not in vals][:N_PER_STEP])
+    try:
+        tree.non_membership_witness(cand[:1])
+        refused = False
+    except RuntimeError:
+        tree.flush()
     q.put((rank, finished, roots, refused))
     dist.barrier()
     dist.destroy_process_group()
