@@ -5,6 +5,7 @@
 //
 //   imt::Poseidon                pse_poseidon::Poseidon<Fr, 3, 2>::new(8, 57): update / squeeze_and_reset
 //                                (src/utils.rs:46-47,96-100; src/indexed_merkle_tree.rs:666-667)
+//                                + hash_fix_len_array_trace: the gadget-side witness trace (f1)
 //   imt::IndexedMerkleTreeLeaf   src/utils.rs:12-17
 //   imt::IndexedMerkleTree       src/utils.rs:5-107: create (= `new`, a keyword here), get_root, get_proof, verify_proof,
 //                                the same two error strings (:25, :35)
@@ -144,6 +145,25 @@ public:
         ctx_->check(arity == 2 ? imt_hash2_batch(ctx_->get(), in.data(), out.data(), out.size(), IMT_FMT_CANONICAL)
                                : imt_hash3_batch(ctx_->get(), in.data(), out.data(), out.size(), IMT_FMT_CANONICAL));
         return out;
+    }
+    // f1: what halo2-base's PoseidonHasher::hash_fix_len_array(ctx, gate, inputs) assigns for these inputs
+    // (src/indexed_merkle_tree.rs:92,194,271-275,299-303): every NEW advice value in assignment order (1208 rows for two
+    // inputs, 1209 for three); rows[out_row] is the hash.  A chip assigns these instead of recomputing the permutations.
+    struct Trace {
+        std::vector<Fr> rows;
+        uint32_t out_row = 0;
+        const Fr& output() const { return rows[out_row]; }
+    };
+    Trace hash_fix_len_array_trace(const std::vector<Fr>& inputs) {
+        const int arity = (int)inputs.size();
+        if (arity != 2 && arity != 3) throw Error(IMT_ERR_ARG, "hash_fix_len_array_trace: 2 or 3 inputs");
+        Trace t;
+        t.rows.resize(imt_hash_trace_rows(arity));
+        ctx_->check(imt_hash_trace_batch(ctx_->get(), inputs.data(), arity, 1, t.rows.data(), IMT_FMT_CANONICAL));
+        size_t n_cells = 0, n_consts = 0;
+        ctx_->check(imt_hash_trace_layout(ctx_->get(), arity, nullptr, 0, &n_cells, nullptr, 0, &n_consts, &t.out_row,
+                                          IMT_FMT_CANONICAL));
+        return t;
     }
     Context& context() const { return *ctx_; }
 

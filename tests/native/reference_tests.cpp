@@ -51,7 +51,15 @@ static Fr random_fr(std::mt19937_64& rng) {
 static void test_hash_zero() {
     imt::Poseidon native_hasher(8, 57);
     native_hasher.update({Fr::zero(), Fr::zero(), Fr::zero()});
-    std::printf("hash_zero=%s\n", native_hasher.squeeze_and_reset().hex().c_str());
+    const Fr h = native_hasher.squeeze_and_reset();
+    std::printf("hash_zero=%s\n", h.hex().c_str());
+    // the gadget's side of the same hash (hasher.hash_fix_len_array, :194): the trace a chip would assign ends in it
+    const auto t3 = native_hasher.hash_fix_len_array_trace({Fr::zero(), Fr::zero(), Fr::zero()});
+    CHECK(t3.rows.size() == 1209 && t3.output() == h);
+    native_hasher.update({Fr::from((uint64_t)7), Fr::from((uint64_t)11)});
+    const Fr h2 = native_hasher.squeeze_and_reset();
+    const auto t2 = native_hasher.hash_fix_len_array_trace({Fr::from((uint64_t)7), Fr::from((uint64_t)11)});
+    CHECK(t2.rows.size() == 1208 && t2.output() == h2 && t2.out_row == 1204);
 }
 
 // :361-478
