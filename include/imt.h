@@ -129,10 +129,10 @@ const char *imt_version(void);
  * imt_profile_read synchronises the stream, adds up the finished intervals, writes
  * out[2*c] = total milliseconds and out[2*c+1] = number of launches / calls for class c
  * (IMT_PROF_*), and resets the counters. */
-#define IMT_PROF_LEAVES 0      /* k_sweep_leaves: 3-input leaf hashes */
+#define IMT_PROF_LEAVES 0      /* k_sweep, leaf launches: the 3-input leaf hashes */
 #define IMT_PROF_INDEX 1       /* k_merge_level + table copies: index phase, no hashing */
-#define IMT_PROF_LEVEL 2       /* k_sweep_level: one hash per event per level */
-#define IMT_PROF_TOP 3         /* k_sweep_top: the levels above the highest meeting point */
+#define IMT_PROF_LEVEL 2       /* k_sweep, the levels below the highest meeting point: one hash per event per level */
+#define IMT_PROF_TOP 3         /* k_sweep, the levels above it (every event against the empty subtree) */
 #define IMT_PROF_WRITEBACK 4   /* k_writeback */
 #define IMT_PROF_HOST 5        /* host side of imt_itree_insert_batch (wall time, waits excluded) */
 #define IMT_PROF_CLASSES 6

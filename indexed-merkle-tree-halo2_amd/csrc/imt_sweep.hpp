@@ -13,9 +13,9 @@
 // version of the sibling node with time < e, or the stored tree value if there is none.
 // Sorting events by (node, time) level by level is a merge of the two children's runs,
 // so all of it is index arithmetic (merge_element below), done before any hashing.
-// Then level l is 2N independent hashes (k_sweep_level), and above the highest level at
+// Then level l is 2N independent hashes (k_sweep, one launch per level), and above the highest level at
 // which two events can meet every event climbs alone against empty-subtree constants
-// (k_sweep_top).  Every sibling read on the way IS the insertion's Merkle proof.
+// (the same kernel, one launch per upper level).  Every sibling read on the way IS the insertion's Merkle proof.
 #pragma once
 #include <cstdint>
 #include "imt_consts.hpp"
