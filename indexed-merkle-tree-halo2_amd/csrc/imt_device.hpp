@@ -182,6 +182,30 @@ IMT_HD void mont_sqr(Fe& r, const Fe& a) {
 }
 
 // limb-wise add without carry propagation (limbs grow by one bit)
+// r = a / R mod p (+ < p): out of the Montgomery domain without the 81 limb products of a multiplication by 1.
+// a: normalised limbs (29-bit digits).  Same column structure as mont_dot with the value in the low nine columns.
+IMT_HD void mont_redc(Fe& r, const Fe& a) {
+    uint32_t m[NL];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        acc += a.v[k];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p29(k - i);
+        m[k] = mont_digit<false>(acc);
+        acc += (uint64_t)m[k] * p29(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = k - (NL - 1); i < NL; i++) acc += (uint64_t)m[i] * p29(k - i);
+        r.v[k - NL] = (uint32_t)acc & MASK29;
+        acc >>= 29;
+    }
+    r.v[NL - 1] = (uint32_t)acc;
+}
+
 IMT_HD void add_lazy(Fe& r, const Fe& a, const Fe& b) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + b.v[i];

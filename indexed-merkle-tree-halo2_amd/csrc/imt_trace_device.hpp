@@ -143,7 +143,11 @@ IMT_HD void t_emit(const PoseidonConsts& pc, TraceSink& o, const Fe& v) {
             csub<1>(y);
             csub<0>(y);
         } else {
-            mont_dot<1, false, false>(y, &v, &pc.int_one, v);      // v / R + p
+#ifdef IMT_MONT_ASM
+            masm::redc_v_narrow(y, v);                                 // v / R + p
+#else
+            mont_redc(y, v);
+#endif
             csub<0>(y);
         }
         store_packed(o.p, y);

@@ -138,6 +138,7 @@ def test_generated_assembly_header_is_current(tmp_path):
             # the witness-trace kernel's one-product forms; "+ 8": the addend limbs enter as mad(e, 1)
             "sqr_v_narrow": 45 + 81, "mul_vv_adds_narrow": 81 + 81 + 8, "mul_uc_narrow": 81 + 81,
             "mul_uc_add_narrow": 81 + 81 + 8,
+            "redc_v_narrow": 9 + 81,       # a / R: the nine limbs enter as mad(a, 1), no limb products
             # the lane-cooperative hash
             "mul_vv_narrow": 81 + 81, "mul_vv_add_narrow": 81 + 81 + 8, "dot3_vv_narrow": 243 + 81}
     for b in blocks:

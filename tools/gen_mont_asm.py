@@ -31,16 +31,16 @@ ACC_LO = "v38"
 MASK = "0x1fffffff"
 
 
-def gen(name, nt, a_kind, add, wide, sqr=False, doc="", add_kind="v"):
+def gen(name, nt, a_kind, add, wide, sqr=False, doc="", add_kind="v", redc=False):
     """a_kind: 's' = the first factor of every term is a wave-uniform constant held in SGPRs,
     'v' = per-lane values.  The second factor is always per-lane.  add_kind: the same for the addend."""
     lines = []
     ops_out = ["[r%d] \"=&v\"(r%d)" % (j, j) for j in range(NL)]
     ops_in = []
-    if sqr:
+    if sqr or redc:
         for i in range(NL):
             ops_in.append("[a%d] \"v\"(a.v[%d])" % (i, i))
-        for i in range(NL - 1):
+        for i in range(NL - 1 if sqr else 0):
             ops_in.append("[d%d] \"v\"(d%d)" % (i, i))
     else:
         for t in range(nt):
@@ -64,7 +64,10 @@ def gen(name, nt, a_kind, add, wide, sqr=False, doc="", add_kind="v"):
 
     def products(k):
         lo, hi = max(0, k - (NL - 1)), min(k, NL - 1)
-        if sqr:
+        if redc:                    # the value itself sits in the low nine columns: r = a / R
+            if k < NL:
+                mad("%%[a%d]" % k, "1")
+        elif sqr:
             for i in range(lo, hi + 1):
                 if 2 * i < k:
                     mad("%%[d%d]" % i, "%%[a%d]" % (k - i))
@@ -100,7 +103,7 @@ def gen(name, nt, a_kind, add, wide, sqr=False, doc="", add_kind="v"):
         lines.append("v_alignbit_b32 %%[r%d], %s, %s, 29" % (NL - 1, "v39", ACC_LO))
 
     n_mad = sum(1 for l in lines if l.startswith("v_mad_u64_u32"))
-    if sqr:
+    if sqr or redc:
         sig = "Fe& r, const Fe& a"
     else:
         sig = "Fe& r, const Fe* a, const Fe* b" + (", const Fe& addend" if add else "")
@@ -164,6 +167,8 @@ def main():
     body.append(gen("mul_uc_narrow", 1, "s", False, False, doc="r = a[0]*b[0] / R, a a uniform constant, 29-bit digits"))
     body.append(gen("mul_uc_add_narrow", 1, "s", True, False,
                     doc="r = (a[0]*b[0] + addend*R) / R, a a uniform constant, addend per lane, 29-bit digits"))
+    body.append(gen("redc_v_narrow", 0, "v", False, False, redc=True,
+                    doc="r = a / R (out of the Montgomery domain), 29-bit digits: r < a/R + p"))
     # the lane-cooperative hash for small batches (imt_coop_device.hpp): every factor is a per-lane value, because what
     # is a constant for one lane of a quad is a state value for its neighbour; 29-bit digits throughout
     body.append(gen("mul_vv_narrow", 1, "v", False, False, doc="r = a[0]*b[0] / R, 29-bit digits: r < a*b/R + p"))
