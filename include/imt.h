@@ -69,8 +69,9 @@ extern "C" {
                                      event ordering on the host instead of on the GPU (the default keeps a
                                      device-resident sorted index and the host only launches kernels).
                                      Same results either way; the two can be mixed on one tree. */
-#define IMT_PIPELINE 0x80u        /* imt_itree_insert_batch with IMT_DEVICE_PTRS only: consecutive batches run on two
-                                     internal streams one tree level apart, so two hash kernels share the GPU.
+#define IMT_PIPELINE 0x80u        /* imt_itree_insert_batch with IMT_DEVICE_PTRS only: consecutive batches run on
+                                     internal streams (up to four in flight) one tree level apart, so their hash
+                                     kernels share the GPU.
                                      The outputs of such a batch are ordered by imt_ctx_sync() (or by the next
                                      imt_itree_root / get_proof / non-pipelined call on the tree), not by
                                      the context's stream. */

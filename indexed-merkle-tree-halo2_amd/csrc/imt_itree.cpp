@@ -119,9 +119,9 @@ struct imt_itree {
     uint64_t batch_no = 0;
     hipStream_t up_stream = nullptr;
     hipEvent_t up_done = nullptr;
-    // IMT_PIPELINE: consecutive batches alternate between two internal streams and run one level
-    // apart (batch k+1 sweeps level l once batch k has written level l back), so two hash kernels
-    // share the GPU and the SIMDs see twice the waves of a single 2^16 batch.
+    // IMT_PIPELINE: consecutive batches rotate over NPIPE internal streams and run one level
+    // apart (batch k+1 sweeps level l once batch k has written level l back), so up to NPIPE hash
+    // kernels share the GPU and the SIMDs see several times the waves of a single 2^16 batch.
     hipStream_t pipe_stream[NPIPE] = {};
     hipEvent_t user_mark = nullptr;  // position of the context's stream when a pipelined call starts
     bool pipe_pending = false;       // pipelined work the context's stream has not been ordered behind
@@ -1032,7 +1032,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     if (rc) return rc;
     IMT_HIP(c, hipEventRecord(t->up_done, t->up_stream));
 
-    // ---- compute stream: the context's, or one of the two pipeline streams ----
+    // ---- compute stream: the context's, or one of the NPIPE pipeline streams ----
     const bool pipelined = dev && (flags & IMT_PIPELINE);
     hipStream_t s = c->stream;
     const PlanSet* prev = nullptr;      // the batch before this one, if it is still on a pipeline stream
