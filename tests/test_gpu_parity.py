@@ -941,6 +941,55 @@ def test_hash_trace_2pow14_properties(imt, ctx):
         assert imt.check_vertical_gates(cells, col) == 1208
 
 
+def test_hash_trace_mont256_rows_are_canonical_2pow18(imt, ctx):
+    """store_mont256 (imt_trace_device.hpp) decides by the top limbs whether a row leaves as a + m p or a + (m - 32) p
+    and falls back to an exact test when they are equal -- about once in 2^25 rows, so a launch of 2^18 hashes (3.2e8
+    rows, 10 GB, device pointers) meets that path about ten times.  A wrong decision in either direction leaves a row
+    outside [0, p): every row of the launch is range-checked on the GPU, the output rows equal imt_hash2_batch, and
+    sampled items equal the canonical-format trace times 2^256."""
+    import ctypes
+    import torch
+    n = 1 << 18
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    inp = torch.randint(0, 256, (n, 2, 32), dtype=torch.uint8, generator=g)
+    inp[:, :, 31] &= 0x0f
+    d_in = inp.to(dev)
+    rows = 1208
+    tr = torch.empty((rows, n, 32), dtype=torch.uint8, device=dev)
+    c2 = imt.Context(0)
+    c2.set_stream(torch.cuda.current_stream().cuda_stream)
+    F = imt._ffi
+    c2._check(imt.lib.imt_hash_trace_batch(c2.h, ctypes.c_void_p(d_in.data_ptr()), 2, n, ctypes.c_void_p(tr.data_ptr()),
+                                           F.DEVICE_PTRS | F.FMT_MONT256))
+    out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    c2._check(imt.lib.imt_hash2_batch(c2.h, ctypes.c_void_p(d_in.data_ptr()), ctypes.c_void_p(out.data_ptr()), n,
+                                      F.DEVICE_PTRS | F.FMT_MONT256))
+    c2.sync()
+    assert bool((tr[1204] == out).all())
+    # unsigned 256-bit "row < p" on little-endian 64-bit words (sign bit flipped: signed compare = unsigned compare)
+    flip = -(1 << 63)
+    pw = [((P >> (64 * k)) & ((1 << 64) - 1)) for k in range(4)]
+    pw = [x - (1 << 64) if x >= (1 << 63) else x for x in pw]
+    pw = [torch.tensor(x, dtype=torch.int64, device=dev) ^ flip for x in pw]
+    bad = 0
+    for r0 in range(0, rows, 151):
+        w = tr[r0:r0 + 151].view(torch.int64).view(-1, n, 4) ^ flip
+        lt = w[..., 0] < pw[0]
+        for k in (1, 2, 3):
+            lt = (w[..., k] < pw[k]) | ((w[..., k] == pw[k]) & lt)
+        bad += int((~lt).sum())
+    assert bad == 0
+    # sampled items against the canonical-format trace of the same inputs
+    idx = [0, 77777, n - 1]
+    R256 = (1 << 256) % P
+    inv = pow(R256, -1, P)                              # the launch read the bytes as x * 2^256
+    can = ctx.hash_trace(imt.to_bytes([[v * inv % P for v in ints(inp[i].numpy())] for i in idx]))
+    for j, i in enumerate(idx):
+        assert ints(tr[:, i].cpu().numpy()) == [v * R256 % P for v in ints(can[:, j])]
+    c2.close()
+
+
 # ---------------------------------------------------------------- BASELINE-size properties
 def test_config2_full_size_properties(imt, ctx, oracle):
     """depth 32, 2^16 insertions (BASELINE config 2), checked through size-independent properties:
