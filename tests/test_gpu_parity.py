@@ -944,7 +944,7 @@ def test_hash_trace_2pow14_properties(imt, ctx):
 def test_hash_trace_mont256_rows_are_canonical_2pow18(imt, ctx):
     """store_mont256 (imt_trace_device.hpp) decides by the top limbs whether a row leaves as a + m p or a + (m - 32) p
     and falls back to an exact test when they are equal -- about once in 2^25 rows, so a launch of 2^18 hashes (3.2e8
-    rows, 10 GB, device pointers) meets that path about ten times.  A wrong decision in either direction leaves a row
+    rows, 10 GB, device pointers) meets that path a few times.  A wrong decision in either direction leaves a row
     outside [0, p): every row of the launch is range-checked on the GPU, the output rows equal imt_hash2_batch, and
     sampled items equal the canonical-format trace times 2^256."""
     import ctypes
