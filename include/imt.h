@@ -117,7 +117,7 @@ int imt_ctx_sync(imt_ctx *ctx);
 int imt_host_alloc(imt_ctx *ctx, size_t bytes, void **out);
 int imt_host_free(imt_ctx *ctx, void *ptr);
 /* Tuning knobs.  IMT_OPT_COOP_MAX_EVENTS: batch-insertion launches of at most this many events (2 per insertion) use
- * the latency form of the hash kernel -- four lanes per hash, 0.6x the time per launch, 2.3x the lane-instructions --
+ * the latency form of the hash kernel -- four lanes per hash, 0.55x the time per launch, 2x the lane-instructions --
  * which pays while a launch leaves most of the chip idle; likewise path recomputes (imt_path_root_batch,
  * imt_compute_merkle_root_batch, imt_verify_proof_batch) of at most a quarter as many paths.  Default 16384 (one wave
  * per SIMD); 0 = never.  Results are bit-identical either way. */

@@ -6,11 +6,13 @@
 // chip is empty, so lanes are free: here the three state lanes of the permutation live in three lanes of a DPP quad
 // and every round costs the critical lane
 //   full round     3 products (x^2, x^4, x^5) + one 3-term row                       (was 9 products + 3 rows)
-//   partial round  3 products + ONE fused product: lane 0 squares while lanes 1, 2 multiply their row entries into
-//                  their state lanes (that part of the row does not depend on the fresh S-box output), then all three
-//                  lanes run the same "constant x y + addend": lane 0 finishes the row, lanes 1, 2 take their column
-//                  update                                                               (was 8 products)
-// i.e. 4 dependent products per round, which is the data-dependency floor of this permutation at product granularity.
+//   partial round  2 products + ONE fused product: with y = x^5 = x^4 (x), every product of the linear layer that
+//                  involves y is regrouped as x^4 (constant x), and "constant x" does not wait for the S-box: step 1
+//                  lane 0 squares x while lanes 1, 2 form col_i x and the FOURTH lane row_0 x; step 2 lane 0 squares
+//                  again while lanes 1, 2 multiply their row entries into their state lanes; step 3 all lanes run the
+//                  same "x^4 (.) + addend": lane 0 finishes the row, lanes 1, 2 take their column update
+//                                                                                        (was 8 products)
+// i.e. 4 dependent products per full round and 3 per partial round.
 // ~54 k instructions per permutation on every lane instead of 92 k on one: the hash takes 0.6x the time and 2.3x the
 // lane-instructions, so it is used only while the launch fits one wave per SIMD (imt_launch: coop_max_events).
 // Same values as hash23 (plain-form-identical schedule; all products with 29-bit quotient digits so that the linear
@@ -78,24 +80,31 @@ __device__ __forceinline__ void permute(const uint32_t* tab, Fe& S, unsigned ri,
             tab_fe(M[2], tab, row + 2);
             masm::dot3_vv_narrow(S, M, Y);
         } else {
+            // s0' = row0 y + row1 s1 + row2 s2 and s_i' = s_i + col_i y with y = x^5, regrouped as x^4 (row0 x) and
+            // x^4 (col_i x): the products with x do not wait for the S-box, so the round is THREE dependent products
+            // (x^2 | col_i x | row0 x;  x^4 | row_i s_i;  x^4 (.) + addend) instead of four, the fourth lane of the
+            // quad taking row0 x.  Lane 3 otherwise shadows lane 0 (same constants, same state), also through here.
             const unsigned p = (unsigned)(st - RF / 2);
-            Fe k, v, r, a, b, ua, x4, y, Y0, U1, U2, c, add;
+            const bool lane0 = (threadIdx.x & 3u) == 0u;        // is0 is true on lanes 0 AND 3
+            Fe k, v, X, a1, e1, a2, b2, e2, X4, T, U1, U2, yf, add;
             tab_fe(k, tab, IMT_COOP_E(k_partial) + p);
-            add_lazy(v, S, k);                                   // meaningful on lane 0 only
-            tab_fe(r, tab, IMT_COOP_E(sp_row) + 3u * p + ri);    // lane 0: row[0] (for the last step); i: row[i]
-            sel(a, is0, v, r);
-            sel(b, is0, v, S);
-            masm::mul_vv_narrow(ua, &a, &b);                     // lane 0: x^2      lane i: row[i] * s_i
-            masm::sqr_v_narrow(x4, ua);                          // lane 0: x^4
-            masm::mul_vv_narrow(y, &x4, &v);                     // lane 0: x^5
-            quad_bcast<0>(Y0, y);
-            quad_bcast<1>(U1, ua);
-            quad_bcast<2>(U2, ua);
-            tab_fe(c, tab, IMT_COOP_E(sp_col) + 2u * p + (is0 ? 0u : ri - 1u));
-            sel(c, is0, r, c);                                   // lane 0: row[0]   lane i: col[i]
+            add_lazy(v, S, k);                                   // x = s0 + k (lanes 0, 3)
+            quad_bcast<0>(X, v);
+            tab_fe(a1, tab, is0 ? IMT_COOP_E(sp_row) + 3u * p : IMT_COOP_E(sp_col) + 2u * p + (ri - 1u));
+            sel(a1, lane0, X, a1);
+            masm::mul_vv_narrow(e1, &a1, &X);                    // lane 0: x^2   lane i: col[i] x   lane 3: row[0] x
+            tab_fe(a2, tab, IMT_COOP_E(sp_row) + 3u * p + ri);
+            sel(a2, lane0, e1, a2);
+            sel(b2, lane0, e1, S);
+            masm::mul_vv_narrow(e2, &a2, &b2);                   // lane 0: x^4   lane i: row[i] s_i   (lane 3: unused)
+            quad_bcast<0>(X4, e2);
+            quad_bcast<3>(T, e1);
+            quad_bcast<1>(U1, e2);
+            quad_bcast<2>(U2, e2);
             add_lazy(add, U1, U2);
-            sel(add, is0, add, S);                               // lane 0: the rest of the row   lane i: s_i
-            masm::mul_vv_add_narrow(S, &c, &Y0, add);            // lane 0: new s_0   lane i: s_i + col[i] * y
+            sel(yf, is0, T, e1);                                 // lanes 0, 3: row[0] x   lane i: col[i] x
+            sel(add, is0, add, S);                               // lanes 0, 3: the rest of the row   lane i: s_i
+            masm::mul_vv_add_narrow(S, &X4, &yf, add);           // lanes 0, 3: new s_0   lane i: s_i + col[i] x^5
         }
     }
 }
