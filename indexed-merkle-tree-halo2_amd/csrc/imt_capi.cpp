@@ -653,7 +653,7 @@ extern "C" int imt_non_membership_batch(imt_ctx* c, const void* root, const void
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     launch::non_membership(c->stream, d_root, rstride, d_low, d_idx, d_sib, sib_layout(flags, depth, n), depth, d_nv,
-                           d_lg, n, d_fail, d_rout, fmt, fmt, c->d_err);
+                           d_lg, n, d_fail, d_rout, fmt, fmt, c->d_err, c->coop_max_events);
     return io.finish();
 }
 
@@ -704,7 +704,7 @@ extern "C" int imt_insert_witness_batch(imt_ctx* c, const void* old_root, const 
     uint8_t* d_trace = (d_trace_user && fmt == IMT_FMT_DEVICE) ? d_trace_user : io.temp(7 * n * 32);
     if (io.rc) return io.rc;
     launch::insert_witness(c->stream, d_or, d_ll, d_li, d_ls, d_nr, d_nl, d_ni, d_np, d_ns, sib_layout(flags, depth, n),
-                           d_lg, depth, n, d_fail, d_trace, fmt, fmt, c->d_err);
+                           d_lg, depth, n, d_fail, d_trace, fmt, fmt, c->d_err, c->coop_max_events);
     if (d_trace_user && d_trace_user != d_trace)
         launch::convert(c->stream, d_trace, d_trace_user, 7 * n, IMT_FMT_DEVICE, fmt, c->d_err);
     return io.finish();

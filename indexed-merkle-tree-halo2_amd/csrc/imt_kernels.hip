@@ -420,6 +420,62 @@ k_non_membership(const uint8_t* __restrict__ root, unsigned root_stride, const u
     flag_err(err, ok);
 }
 
+// the same for few items: a quad of lanes per item (imt_coop_device.hpp) -- one verify_non_inclusion call is a chain of
+// 33 dependent hashes, which is all its time
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
+k_non_membership_coop(const uint8_t* __restrict__ root, unsigned root_stride, const uint8_t* __restrict__ low_leaf,
+                      const uint64_t* __restrict__ low_index, const uint8_t* __restrict__ sib, launch::SibLayout lay,
+                      unsigned depth, const uint8_t* __restrict__ new_val, const uint8_t* __restrict__ is_largest,
+                      size_t n, uint8_t* __restrict__ fail_out, uint8_t* __restrict__ root_out, unsigned fmt_in,
+                      unsigned fmt_out, int* err) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t tab[coop::TAB_DWORDS];
+    coop::tab_fill(tab, g_pc);
+    const size_t t = gtid();
+    const size_t i = t >> 2;
+    if (i >= n) return;
+    const unsigned role = (unsigned)t & 3u, ri = role == 3u ? 0u : role;
+    bool ok = true;
+    unsigned fail = 0;
+    {   // the range predicates, on every lane of the quad alike (lane 1 reports)
+        Fe v, nx, nv, nvi, lvi, lni;
+        ok &= load_fe(g_pc, v, low_leaf + (i * 3 + 0) * 32, fmt_in);
+        ok &= load_fe(g_pc, nx, low_leaf + (i * 3 + 1) * 32, fmt_in);
+        ok &= load_fe(g_pc, nv, new_val + i * 32, fmt_in);
+        to_int(nvi, nv); to_int(lvi, v); to_int(lni, nx);
+        const unsigned s = is_largest[i];
+        if (s > 1) fail |= 0x80;
+        if (!(s ? fe_is_zero(nx) : int_lt(nvi, lni))) fail |= 0x01;
+        if (!int_lt(lvi, nvi)) fail |= 0x04;
+    }
+    Fe cur, X, C3, o;
+    ok &= load_fe(g_pc, X, low_leaf + i * 96 + (ri == 2u ? 32 : 0), fmt_in);
+    ok &= load_fe(g_pc, C3, low_leaf + i * 96 + 64, fmt_in);
+    coop::hash23(tab, o, X, C3, true, ri);
+    coop::quad_bcast<1>(cur, o);
+    const uint64_t idx = low_index[i];
+#pragma unroll 1
+    for (unsigned l = 0; l < depth; l++) {
+        Fe sv;
+        ok &= load_fe(g_pc, sv, sib + ((uint64_t)l * lay.level_stride + i * lay.item_stride) * 32, fmt_in);
+        const bool right = (idx >> l) & 1;
+        const bool take_sv = (ri == 2u) != right;
+#pragma unroll
+        for (int q = 0; q < NL; q++) X.v[q] = take_sv ? sv.v[q] : cur.v[q];
+        coop::hash23(tab, o, X, C3, false, ri);
+        coop::quad_bcast<1>(cur, o);
+    }
+    if (role == 1u) {
+        Fe rt;
+        ok &= load_fe(g_pc, rt, root + i * (size_t)root_stride, fmt_in);
+        if (!fe_eq(cur, rt)) fail |= 0x02;
+        fail_out[i] = (uint8_t)fail;
+        if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
+    }
+    flag_err(err, ok);
+#endif
+}
+
 // ---- a11: 128-bit limb split (src/indexed_merkle_tree.rs:145-178) ------------------
 __global__ void __launch_bounds__(BLOCK) k_split128(const uint8_t* __restrict__ vals, uint8_t* __restrict__ q,
                                                     uint8_t* __restrict__ r, size_t n, unsigned fmt, int* err) {
@@ -487,6 +543,66 @@ k_insert_chains(const uint8_t* __restrict__ low_leaf, const uint64_t* __restrict
     hash_chain(cur, idx, sib, lay, i, depth, fmt_in, ok);
     store_packed(root_out, cur);
     flag_err(err, ok);
+}
+
+// the same for few items: a quad of lanes per (item, chain)
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
+k_insert_chains_coop(const uint8_t* __restrict__ low_leaf, const uint64_t* __restrict__ low_index,
+                     const uint8_t* __restrict__ low_sib, const uint8_t* __restrict__ new_leaf,
+                     const uint64_t* __restrict__ new_index, const uint64_t* __restrict__ new_path_index,
+                     const uint8_t* __restrict__ new_sib, launch::SibLayout lay, unsigned depth, size_t n,
+                     uint8_t* __restrict__ trace, unsigned fmt_in, int* err) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t tab[coop::TAB_DWORDS];
+    coop::tab_fill(tab, g_pc);
+    const size_t t = gtid();
+    const size_t i = t >> 2;
+    if (i >= n) return;
+    const unsigned role = (unsigned)t & 3u, ri = role == 3u ? 0u : role;
+    const int chain = blockIdx.y;
+    bool ok = true;
+    const uint8_t* sib = chain < 2 ? low_sib : new_sib;
+    const uint64_t idx = chain < 2 ? low_index[i] : new_path_index[i];
+    uint8_t* leaf_out = nullptr;
+    uint8_t* root_out;
+    Fe cur, X, C3, o;
+    C3 = g_pc.one;
+    if (chain == 2) {            // the zero leaf at the new slot           :286-294
+        cur = g_pc.zero_leaf;
+        root_out = trace + (4 * n + i) * 32;
+    } else {
+        // lane 1: first input, lane 2: second input, C3: third input (absorbed by lane 1)
+        if (chain == 1) {        // {low.val, new.val, new_leaf_index}      :265-284
+            ok &= load_fe(g_pc, X, (ri == 2u ? new_leaf : low_leaf) + (i * 3 + 0) * 32, fmt_in);
+            fe_from_u64(C3, new_index[i]);
+            leaf_out = trace + (2 * n + i) * 32;
+            root_out = trace + (3 * n + i) * 32;
+        } else {                 // a leaf as given: the low leaf :193-204, the new leaf :299-312
+            const uint8_t* lf = chain == 0 ? low_leaf : new_leaf;
+            ok &= load_fe(g_pc, X, lf + i * 96 + (ri == 2u ? 32 : 0), fmt_in);
+            ok &= load_fe(g_pc, C3, lf + i * 96 + 64, fmt_in);
+            if (ri == 1u) ok &= load_fe(g_pc, o, lf + i * 96 + 32, fmt_in);       // (every element validated once)
+            leaf_out = trace + ((chain == 0 ? 0 : 5) * n + i) * 32;
+            root_out = trace + ((chain == 0 ? 1 : 6) * n + i) * 32;
+        }
+        coop::hash23(tab, o, X, C3, true, ri);
+        coop::quad_bcast<1>(cur, o);
+        if (role == 1u) store_packed(leaf_out, cur);
+    }
+#pragma unroll 1
+    for (unsigned l = 0; l < depth; l++) {
+        Fe sv;
+        ok &= load_fe(g_pc, sv, sib + ((uint64_t)l * lay.level_stride + i * lay.item_stride) * 32, fmt_in);
+        const bool right = (idx >> l) & 1;
+        const bool take_sv = (ri == 2u) != right;
+#pragma unroll
+        for (int q = 0; q < NL; q++) X.v[q] = take_sv ? sv.v[q] : cur.v[q];
+        coop::hash23(tab, o, X, C3, false, ri);
+        coop::quad_bcast<1>(cur, o);
+    }
+    if (role == 1u) store_packed(root_out, cur);
+    flag_err(err, ok);
+#endif
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -1031,20 +1147,28 @@ void path_root(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const u
 void non_membership(hipStream_t s, const uint8_t* root, unsigned root_stride, const uint8_t* low_leaf,
                     const uint64_t* low_index, const uint8_t* sib, SibLayout lay, unsigned depth,
                     const uint8_t* new_val, const uint8_t* is_largest, size_t n, uint8_t* fail_out,
-                    uint8_t* root_out, unsigned fmt_in, unsigned fmt_out, int* err) {
+                    uint8_t* root_out, unsigned fmt_in, unsigned fmt_out, int* err, uint32_t coop_max) {
     if (!n) return;
-    hipLaunchKernelGGL(k_non_membership, dim3(nblk(n)), dim3(BLOCK), 0, s, root, root_stride, low_leaf, low_index,
-                       sib, lay, depth, new_val, is_largest, n, fail_out, root_out, fmt_in, fmt_out, err);
+    if (n * 4 <= coop_max)
+        hipLaunchKernelGGL(k_non_membership_coop, dim3(nblk(n * 4)), dim3(BLOCK), 0, s, root, root_stride, low_leaf,
+                           low_index, sib, lay, depth, new_val, is_largest, n, fail_out, root_out, fmt_in, fmt_out, err);
+    else
+        hipLaunchKernelGGL(k_non_membership, dim3(nblk(n)), dim3(BLOCK), 0, s, root, root_stride, low_leaf, low_index,
+                           sib, lay, depth, new_val, is_largest, n, fail_out, root_out, fmt_in, fmt_out, err);
 }
 void insert_witness(hipStream_t s, const uint8_t* old_root, const uint8_t* low_leaf, const uint64_t* low_index,
                     const uint8_t* low_sib, const uint8_t* new_root, const uint8_t* new_leaf,
                     const uint64_t* new_index, const uint64_t* new_path_index, const uint8_t* new_sib, SibLayout lay,
                     const uint8_t* is_largest, unsigned depth, size_t n, uint8_t* fail_out, uint8_t* trace,
-                    unsigned fmt_in, unsigned fmt_out, int* err) {
+                    unsigned fmt_in, unsigned fmt_out, int* err, uint32_t coop_max) {
     (void)fmt_out;
     if (!n) return;
-    hipLaunchKernelGGL(k_insert_chains, dim3(nblk(n), 4), dim3(BLOCK), 0, s, low_leaf, low_index, low_sib, new_leaf,
-                       new_index, new_path_index, new_sib, lay, depth, n, trace, fmt_in, err);
+    if (n * 16 <= coop_max)
+        hipLaunchKernelGGL(k_insert_chains_coop, dim3(nblk(n * 4), 4), dim3(BLOCK), 0, s, low_leaf, low_index, low_sib,
+                           new_leaf, new_index, new_path_index, new_sib, lay, depth, n, trace, fmt_in, err);
+    else
+        hipLaunchKernelGGL(k_insert_chains, dim3(nblk(n), 4), dim3(BLOCK), 0, s, low_leaf, low_index, low_sib, new_leaf,
+                           new_index, new_path_index, new_sib, lay, depth, n, trace, fmt_in, err);
     hipLaunchKernelGGL(k_insert_check, dim3(nblk(n)), dim3(BLOCK), 0, s, old_root, low_leaf, new_root, new_leaf,
                        is_largest, n, trace, fail_out, fmt_in, err);
 }

@@ -97,14 +97,14 @@ void path_root(hipStream_t s, const uint8_t* leaf, const uint8_t* leaf3, const u
 void non_membership(hipStream_t s, const uint8_t* root, unsigned root_stride, const uint8_t* low_leaf,
                     const uint64_t* low_index, const uint8_t* sib, SibLayout lay, unsigned depth,
                     const uint8_t* new_val, const uint8_t* is_largest, size_t n, uint8_t* fail_out,
-                    uint8_t* root_out, unsigned fmt_in, unsigned fmt_out, int* err);
+                    uint8_t* root_out, unsigned fmt_in, unsigned fmt_out, int* err, uint32_t coop_max);
 
 // 4 chains per item; trace [7][n][32] (device buffer, required), then the check kernel
 void insert_witness(hipStream_t s, const uint8_t* old_root, const uint8_t* low_leaf,
                     const uint64_t* low_index, const uint8_t* low_sib, const uint8_t* new_root,
                     const uint8_t* new_leaf, const uint64_t* new_index, const uint64_t* new_path_index,
                     const uint8_t* new_sib, SibLayout lay, const uint8_t* is_largest, unsigned depth, size_t n,
-                    uint8_t* fail_out, uint8_t* trace, unsigned fmt_in, unsigned fmt_out, int* err);
+                    uint8_t* fail_out, uint8_t* trace, unsigned fmt_in, unsigned fmt_out, int* err, uint32_t coop_max);
 
 // next[i] = hash2(prev[2i], prev[2i+1]), device format
 void tree_level(hipStream_t s, const uint8_t* prev, uint8_t* next, size_t n_parents);

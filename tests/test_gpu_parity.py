@@ -409,7 +409,19 @@ def test_reference_tests_through_the_mirror_api(imt, ctx, oracle):
             assert ei.value.mask & imt._ffi.F_LOW_LT_NEW
 
 
-def test_non_membership_batch_vs_oracle(imt, ctx, oracle):
+@pytest.fixture(scope="module")
+def ctx_thread_per_hash(imt):
+    """a context with the quad-per-hash (latency) kernels switched off: small launches run one thread per hash / item"""
+    c = imt.Context(0)
+    c.set_option(imt._ffi.OPT_COOP_MAX_EVENTS, 0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("form", ["quad", "thread"])
+def test_non_membership_batch_vs_oracle(imt, ctx, ctx_thread_per_hash, oracle, form):
+    """both forms of the kernels: few items run a quad of lanes per item (k_non_membership_coop), many one thread"""
+    ctx = ctx if form == "quad" else ctx_thread_per_hash
     depth, cap = 32, 256
     vals = oracle_lib.synth_values(100, 0x494D5403)
     t = imt.IndexedTree(ctx, depth, cap)
@@ -444,7 +456,10 @@ def test_non_membership_batch_vs_oracle(imt, ctx, oracle):
     assert fail[0] & imt._ffi.F_BAD_BIT and not fail[1:].any()
 
 
-def test_insert_witness_batch_vs_oracle(imt, ctx, oracle):
+@pytest.mark.parametrize("form", ["quad", "thread"])
+def test_insert_witness_batch_vs_oracle(imt, ctx, ctx_thread_per_hash, oracle, form):
+    """both forms: few items run a quad of lanes per (item, chain) (k_insert_chains_coop), many one thread per chain"""
+    ctx = ctx if form == "quad" else ctx_thread_per_hash
     depth, cap, n = 32, 256, 120
     vals = oracle_lib.synth_values(n, 0x494D5404)
     t = imt.IndexedTree(ctx, depth, cap)
