@@ -118,7 +118,7 @@ int imt_host_alloc(imt_ctx *ctx, size_t bytes, void **out);
 int imt_host_free(imt_ctx *ctx, void *ptr);
 /* Tuning knobs.  IMT_OPT_COOP_MAX_EVENTS: batch-insertion launches of at most this many events (2 per insertion) use
  * the latency form of the hash kernel -- four lanes per hash, 0.55x the time per launch, 2x the lane-instructions --
- * which pays while a launch leaves most of the chip idle; likewise path recomputes (imt_path_root_batch,
+ * which pays while a launch leaves most of the chip idle; likewise plain hashes (imt_hash2/3_batch), path recomputes (imt_path_root_batch,
  * imt_compute_merkle_root_batch, imt_verify_proof_batch, imt_non_membership_batch, the path inputs of the trace calls)
  * of at most a quarter as many paths and imt_insert_witness_batch of at most a sixteenth as many items.  Default 16384
  * (one wave per SIMD); 0 = never.  Results are bit-identical either way. */

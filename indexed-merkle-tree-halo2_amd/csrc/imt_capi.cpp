@@ -305,7 +305,7 @@ static int hash_n(imt_ctx* c, const void* in, void* out, size_t n, int arity, un
     uint8_t* d_out = io.out(out, n * 32);
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
-    launch::hash_batch(c->stream, d_in, d_out, n, arity, fmt, fmt, c->d_err);
+    launch::hash_batch(c->stream, d_in, d_out, n, arity, fmt, fmt, c->d_err, c->coop_max_events);
     return io.finish();
 }
 extern "C" int imt_hash2_batch(imt_ctx* c, const void* in, void* out, size_t n, unsigned flags) {

@@ -160,6 +160,30 @@ __global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_hash_batch(const uint8
     flag_err(err, ok);
 }
 
+// the same for few hashes: a quad of lanes per hash (imt_coop_device.hpp): one hasher.update / squeeze_and_reset pair
+// of the reference (src/utils.rs:46-47) is one hash, and its latency is all there is to it
+__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_hash_batch_coop(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                           size_t n, int arity, unsigned fmt_in, unsigned fmt_out,
+                                                           int* err) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t tab[coop::TAB_DWORDS];
+    coop::tab_fill(tab, g_pc);
+    const size_t t = gtid();
+    const size_t i = t >> 2;
+    if (i >= n) return;
+    const unsigned role = (unsigned)t & 3u, ri = role == 3u ? 0u : role;
+    const uint8_t* p = in + i * 32 * (size_t)arity;
+    Fe X, C3, o;
+    C3 = g_pc.one;
+    bool ok = load_fe(g_pc, X, p + (ri == 2u ? 32 : 0), fmt_in);            // lane 1: first input, lane 2: second
+    if (ri == 1u) ok &= load_fe(g_pc, o, p + 32, fmt_in);                   // (every element validated once)
+    if (arity == 3) ok &= load_fe(g_pc, C3, p + 64, fmt_in);
+    coop::hash23(tab, o, X, C3, arity == 3, ri);
+    if (role == 1u) store_fe(g_pc, out + i * 32, o, fmt_out);
+    flag_err(err, ok);
+#endif
+}
+
 __global__ void __launch_bounds__(BLOCK) k_permute_batch(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                          size_t n, unsigned fmt_in, unsigned fmt_out, int* err) {
     const size_t i = gtid();
@@ -1114,9 +1138,12 @@ void path_pairs(hipStream_t s, const PathChains& a, uint32_t coop_max) {
 }
 
 void hash_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, int arity, unsigned fmt_in,
-                unsigned fmt_out, int* err) {
+                unsigned fmt_out, int* err, uint32_t coop_max) {
     if (!n) return;
-    hipLaunchKernelGGL(k_hash_batch, dim3(nblk(n)), dim3(BLOCK), 0, s, in, out, n, arity, fmt_in, fmt_out, err);
+    if (n * 4 <= coop_max)
+        hipLaunchKernelGGL(k_hash_batch_coop, dim3(nblk(n * 4)), dim3(BLOCK), 0, s, in, out, n, arity, fmt_in, fmt_out, err);
+    else
+        hipLaunchKernelGGL(k_hash_batch, dim3(nblk(n)), dim3(BLOCK), 0, s, in, out, n, arity, fmt_in, fmt_out, err);
 }
 void permute_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, unsigned fmt_in, unsigned fmt_out,
                    int* err) {

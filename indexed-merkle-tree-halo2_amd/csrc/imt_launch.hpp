@@ -76,7 +76,7 @@ struct PathChains {
 void path_pairs(hipStream_t s, const PathChains& a, uint32_t coop_max);
 
 void hash_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, int arity, unsigned fmt_in,
-                unsigned fmt_out, int* err);
+                unsigned fmt_out, int* err, uint32_t coop_max = 0);
 void permute_batch(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, unsigned fmt_in,
                    unsigned fmt_out, int* err);
 void convert(hipStream_t s, const uint8_t* in, uint8_t* out, size_t n, unsigned fmt_in,

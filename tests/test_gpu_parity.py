@@ -22,7 +22,9 @@ def ints(a):
 
 
 # ---------------------------------------------------------------- a1 / a10
-def test_kat_and_golden_vectors(imt, ctx):
+@pytest.mark.parametrize("form", ["quad", "thread"])
+def test_kat_and_golden_vectors(imt, ctx, ctx_thread_per_hash, form):
+    ctx = ctx if form == "quad" else ctx_thread_per_hash
     assert ints(ctx.hash3(ints_to_arr([0, 0, 0]).reshape(1, 3, 32))) == [KAT_ZERO]      # reference :248
     h2 = [e for e in GOLD["entries"] if e["kind"] == "hash2"]
     h3 = [e for e in GOLD["entries"] if e["kind"] == "hash3"]
@@ -43,9 +45,12 @@ def test_kat_and_golden_vectors(imt, ctx):
             assert ints(z[int(e["in"][0])]) == [int(e["out"])]
 
 
-def test_hash_batches_random_and_ragged(imt, ctx, oracle):
+@pytest.mark.parametrize("form", ["quad", "thread"])
+def test_hash_batches_random_and_ragged(imt, ctx, ctx_thread_per_hash, oracle, form):
+    """few hashes run a quad of lanes per hash (k_hash_batch_coop, up to 4096 hashes by default), many one thread"""
+    ctx = ctx if form == "quad" else ctx_thread_per_hash
     rng = random.Random(10)
-    for n in (1, 63, 64, 65, 257, 1000):       # ragged against the 256-thread blocks
+    for n in (1, 63, 64, 65, 257, 1000, 4096, 4097):       # ragged against the 256-thread blocks, across the switch
         a = ints_to_arr([rng.randrange(P) for _ in range(2 * n)]).reshape(n, 2, 32)
         assert (ctx.hash2(a) == oracle.hash2_batch(a)).all()
         b = ints_to_arr([rng.randrange(P) for _ in range(3 * n)]).reshape(n, 3, 32)
