@@ -505,7 +505,8 @@ extern "C" int imt_tree_new(imt_ctx* c, const void* leaves, size_t n, unsigned f
     if (io.rc) { imt_tree_free(t); return io.rc; }
     launch::convert(c->stream, d_in, t->d_nodes, n, flags & IMT_FMT_MASK, IMT_FMT_DEVICE, c->d_err);
     for (size_t l = 1; l < nl; l++)   // while current_level.len() > 1 (src/utils.rs:41-51)
-        launch::tree_level(c->stream, t->d_nodes + t->h_off[l - 1] * 32, t->d_nodes + t->h_off[l] * 32, t->h_len[l]);
+        launch::tree_level(c->stream, t->d_nodes + t->h_off[l - 1] * 32, t->d_nodes + t->h_off[l] * 32, t->h_len[l],
+                           c->coop_max_events);
     rc = c->sync_and_check();
     if (rc) { imt_tree_free(t); return rc; }
     *out = t;
@@ -743,7 +744,7 @@ extern "C" int imt_combine_subtree_roots(imt_ctx* c, const void* sub_roots, size
     const unsigned fmt = flags & IMT_FMT_MASK;
     launch::convert(c->stream, d_in, a, n_roots, fmt, IMT_FMT_DEVICE, c->d_err);
     for (size_t m = n_roots; m > 1; m >>= 1) {
-        launch::tree_level(c->stream, a, b, m / 2);
+        launch::tree_level(c->stream, a, b, m / 2, c->coop_max_events);
         std::swap(a, b);
     }
     launch::extend_root(c->stream, a, c->d_zero, sub_height + k, depth);

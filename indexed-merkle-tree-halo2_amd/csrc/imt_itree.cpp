@@ -1489,7 +1489,7 @@ extern "C" int imt_itree_lift_batch(imt_itree* t, const void* roots_before, cons
         launch::mix_roots(s, d_b, d_a, tree_buf, (uint32_t)n_subtrees, (uint32_t)t->sub_index, fmt, c->d_err);
         size_t off = 0;
         for (size_t m = n_subtrees; m > 1; m >>= 1) {
-            launch::tree_level(s, tree_buf + off * 32, tree_buf + (off + m) * 32, m / 2);
+            launch::tree_level(s, tree_buf + off * 32, tree_buf + (off + m) * 32, m / 2, c->coop_max_events);
             off += m;
         }
     }

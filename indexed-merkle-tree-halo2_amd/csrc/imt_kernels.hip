@@ -45,7 +45,7 @@ constexpr int BLOCK = IMT_BLOCK;   // 256 = 4 waves = one per SIMD of a CU
 
 __device__ __forceinline__ size_t gtid() { return (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
 __device__ __forceinline__ void flag_err(int* err, bool ok) {
-    if (!ok) atomicOr(err, 1);
+    if (!ok && err) atomicOr(err, 1);
 }
 
 // ONE copy of the hash in the code object, shared by every kernel.  Inlined per kernel, the 47 KB
@@ -1199,9 +1199,13 @@ void insert_witness(hipStream_t s, const uint8_t* old_root, const uint8_t* low_l
     hipLaunchKernelGGL(k_insert_check, dim3(nblk(n)), dim3(BLOCK), 0, s, old_root, low_leaf, new_root, new_leaf,
                        is_largest, n, trace, fail_out, fmt_in, err);
 }
-void tree_level(hipStream_t s, const uint8_t* prev, uint8_t* next, size_t n_parents) {
+void tree_level(hipStream_t s, const uint8_t* prev, uint8_t* next, size_t n_parents, uint32_t coop_max) {
     if (!n_parents) return;
-    hipLaunchKernelGGL(k_tree_level, dim3(nblk(n_parents)), dim3(BLOCK), 0, s, prev, next, n_parents);
+    if (n_parents * 4 <= coop_max)      // a level of a small tree is n_parents two-input hashes in device format
+        hipLaunchKernelGGL(k_hash_batch_coop, dim3(nblk(n_parents * 4)), dim3(BLOCK), 0, s, prev, next, n_parents, 2,
+                           (unsigned)FMT_DEVICE, (unsigned)FMT_DEVICE, (int*)nullptr);
+    else
+        hipLaunchKernelGGL(k_tree_level, dim3(nblk(n_parents)), dim3(BLOCK), 0, s, prev, next, n_parents);
 }
 void zero_chain(hipStream_t s, uint8_t* out, unsigned depth) {
     hipLaunchKernelGGL(k_zero_chain, dim3(1), dim3(64), 0, s, out, depth);

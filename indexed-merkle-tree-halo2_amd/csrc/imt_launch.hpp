@@ -107,7 +107,7 @@ void insert_witness(hipStream_t s, const uint8_t* old_root, const uint8_t* low_l
                     uint8_t* fail_out, uint8_t* trace, unsigned fmt_in, unsigned fmt_out, int* err, uint32_t coop_max);
 
 // next[i] = hash2(prev[2i], prev[2i+1]), device format
-void tree_level(hipStream_t s, const uint8_t* prev, uint8_t* next, size_t n_parents);
+void tree_level(hipStream_t s, const uint8_t* prev, uint8_t* next, size_t n_parents, uint32_t coop_max = 0);
 // chain: out[l+1] = hash2(out[l], out[l]) for l < depth, out[0] = H(0,0,0); one thread
 void zero_chain(hipStream_t s, uint8_t* out, unsigned depth);
 // cur = hash2(cur, zero[l]) for l in [from, to): extends a subtree root up the left spine
