@@ -84,8 +84,10 @@ def test_dense_tree_new_errors(imt, ctx):
     assert t.get_root() == 7 and t.num_levels() == 1 and t.get_proof(0) == ([], [])
 
 
+@pytest.mark.parametrize("form", ["quad", "thread"])
 @pytest.mark.parametrize("depth", [1, 3, 8])
-def test_dense_tree_matches_oracle(imt, ctx, oracle, depth):
+def test_dense_tree_matches_oracle(imt, ctx, ctx_thread_per_hash, oracle, depth, form):
+    ctx = ctx if form == "quad" else ctx_thread_per_hash
     rng = random.Random(depth)
     n = 1 << depth
     leaves = ints_to_arr([rng.randrange(P) for _ in range(n)])
