@@ -14,6 +14,8 @@ cp $O/trace_rate.txt $P/r02_trace_rate.txt
 cp $O/bench_2rank_rehearsal.json $P/r02_bench_2rank_rehearsal_one_gpu.json
 cp $O/bench_4rank_rehearsal.json $P/r02_bench_4rank_rehearsal_one_gpu.json
 cp $O/verify_latency.txt $P/r02_verify_latency.txt
+grep check $O/witness_check_latency.txt > $P/r02_witness_check_latency.txt
+grep insert_trace $O/insert_trace_latency.txt > $P/r02_insert_trace_latency.txt
 cp $O/bench_aux.txt $P/r02_bench_aux.txt
 cp $O/differential_soak.txt $P/r02_differential_soak.txt
 cp $O/scale_check.txt $P/r02_scale_check.txt

@@ -22,6 +22,7 @@ python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/pmc_bench_summary.txt
 ( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo; timeout -k 10 400 python3 bench.py --gpus 2 --steps 6 --warmup 2 > $O/bench_2rank_rehearsal.json 2> $O/bench_2rank.err ) && echo "2-rank ok" &&
 ( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo; timeout -k 10 400 python3 bench.py --gpus 4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_4rank_rehearsal.json 2> $O/bench_4rank.err ) && echo "4-rank ok" &&
 timeout -k 10 300 python tools/verify_latency.py > $O/verify_latency.txt 2>&1 && echo "verify latency ok" &&
+timeout -k 10 300 python tools/witness_check_latency.py > $O/witness_check_latency.txt 2>&1 && timeout -k 10 300 python tools/insert_trace_latency.py > $O/insert_trace_latency.txt 2>&1 && echo "check / trace latency ok" &&
 timeout -k 10 300 python tools/small_batch_rate.py 8 16 > $O/small_batch.txt 2>&1 && echo "small batch ok" &&
 timeout -k 10 300 python tools/bench_aux.py > $O/bench_aux.txt 2>&1 && echo "aux ok" &&
 SOAK_SECONDS=60 timeout -k 10 400 python tools/differential_soak.py > $O/differential_soak.txt 2>&1 && echo "soak ok" &&
