@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- indexed-tree insertions/s at depth 32 over bn256::Fr on MI355X.
 
-A step = one batch of 2^16 sequential-semantics insertions (BASELINE.json configs[1]) through
-imt_itree_insert_batch: low-leaf search + leaf preimages on the host, all 2 + 2*32 hashes per
-insertion on the GPU (level sweep), every per-insertion output written to HBM: old / interim /
-new root and both 32-sibling proofs.  Values are resident in HBM before the timed region.
+A step = 2^16 sequential-semantics insertions PER GPU (BASELINE.json configs[1]): low-leaf search + leaf preimages
+(GPU, hash-free), all 2 + 2*32 hashes per insertion (level sweep), every per-insertion output written to HBM: old /
+interim / new root and both 32-sibling proofs.  Values are resident in HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W
       N > 1 without WORLD_SIZE in the environment: this process only LAUNCHES N ranks (python -m
@@ -13,26 +12,39 @@ new root and both 32-sibling proofs.  Values are resident in HBM before the time
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU: the
       driver's form; --gpus must equal WORLD_SIZE)
 
-N > 1: the value space is partitioned by v mod N; rank g owns the leaf-index range
-[g*2^(32-k), (g+1)*2^(32-k)) of the depth-32 tree as an indexed subtree of height 32-k (k = log2 N).
-Every step the ranks all-gather their subtree roots (RCCL, 32 bytes each; one step behind the
-insertions) and every rank lifts its own witnesses to depth 32 (imt_itree_lift_batch: k more hashes per
-root, k more siblings per proof), so an insertion is the same 2 + 2*32 = 66 hashes and the same depth-32
-outputs at every N.  Per-GPU work is fixed (weak scaling); there is no other data-path collective.
+N = 1: one tree, imt_itree_insert_batch, four batches in flight.
+N > 1 runs BOTH multi-GPU modes in one invocation and reports both (`modes`); `value` is the first:
+  single-list  ONE indexed tree, the reference's data structure (one sorted list, update_idx_leaf's sequential
+               semantics), bit-exact with one GPU at any N.  A step's N x 2^16 insertions are cut into N consecutive
+               slices; rank g hashes slice g; every rank keeps a replica; what a slice writes back to the stored tree
+               travels level by level (RCCL all-gather, asynchronous, consumed two levels later): a systolic chain
+               (indexed-merkle-tree-halo2_amd/sliced.py, imt_itree_slice_*).
+  subtrees     north_star's layout: the value space partitioned by v mod N, rank g owns leaf-index range
+               [g*2^(32-k), (g+1)*2^(32-k)) as an indexed subtree with its own sentinel; per step ONE all-gather of the
+               N subtree roots + lift of every witness to depth 32.  Scales without data exchange, but the root commits
+               to N sorted lists: a circuit needs one more constraint per witness.
+Per-GPU work is fixed (weak scaling) in both.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, algorithmic
-bytes of SURVEY.md 8d) and `cpu_baseline` (the C oracle, 1 thread, bounded sample) added, plus a
-`valu` object: the path is integer-VALU bound, so that is the roofline that says something.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, algorithmic bytes of SURVEY.md 8d,
+durations of the TIMED REGION) and `cpu_baseline` (the C oracle, 1 thread, bounded sample) added, plus a `valu` object:
+the path is integer-VALU bound, so that is the roofline that says something.  Exit status 1 if the outputs of the
+timed region do not verify.
 """
-import argparse
-import ctypes
-import json
 import os
-import sys
-import time
 
-import numpy as np
-import torch
+# before anything can touch the GPU, in every launch form (typed as is, under the driver's torch.distributed.run, as a
+# child of launch_ranks): RCCL and device-tensor sharing across processes need dmabuf IPC on this host
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
+import argparse  # noqa: E402
+import ctypes  # noqa: E402
+import json  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -40,38 +52,42 @@ sys.path.insert(0, ROOT)
 DEPTH = 32
 BATCH = 1 << 16
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+P_TOP_LIMB = P >> 192
 BYTES_PER_INSERTION = 2320          # 2 paths x (32*32 + 96 + 8 + 32)
 HASHES_PER_INSERTION = 66           # 2 + 2*32
+LAUNCHES_PER_STEP = DEPTH + 1       # k_sweep launches per 2^16-insertion batch: leaves + 32 levels
 BYTES_PER_PATH_LEVEL = 1160.0 / 33  # one event, one level: a path's 1160 B spread over its 33 hashes
 MADS_PER_HASH = 2 * 76140           # v_mad_u64_u32 per 2-permutation hash
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GMADS = 36443.0           # measured v_mad_u64_u32 lane-ops/ns (profiles/r01_valu_rates.txt, 8 waves/SIMD)
 # HBM bytes of one k_sweep launch at E = 2^17 events from separate rocprofv3 --pmc passes: 2 x FETCH_SIZE (gfx950
-# reports half of 16-B/lane reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, counter unit KB, mean over the 99 k_sweep
-# dispatches of the run (3 leaf launches, 51 levels below l0, 45 at and above).  bench.py cannot read PMC counters
-# itself, so this is a STATIC figure, reported as roofline.traffic_static with its source.  (Round 1, three kernels
-# calling a shared hash function: 22.0 MB, of which 4.6 MB call-ABI scratch; profiles/r01_pmc_hbm_traffic.txt.)
+# reports half of 16-B/lane reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, counter unit KB, mean over the k_sweep
+# dispatches of the run.  bench.py cannot read PMC counters itself, so this is a STATIC figure, reported as
+# roofline.traffic_static with its source.
 PMC_TRAFFIC_SWEEP_LEVEL = {"bytes": int((2 * 3580.1 + 8067.9) * 1024), "fetch_size_kb": 3580.1, "write_size_kb": 8067.9,
                            "source": "profiles/r02_pmc_hbm_traffic.txt", "measured_at_commit": "round-2 k_sweep build"}
 TRACE_ROWS = 1208                   # witnesses per 2-input hash (imt_hash_trace_batch)
+DTYPE = "u32 limbs (9 x 29-bit, Montgomery mod p), 64-bit accumulate"
+METRIC = "indexed-tree insertions/sec at depth=32 (bn256::Fr)"
 
 
 def synth_values(total, residue, modulus, seed):
-    """Distinct random field elements v with 0 < v < p and v % modulus == residue (254-bit draws with
-    the top 2 bits cleared, rejected until < p: mirrors src/indexed_merkle_tree.rs:381-386)."""
+    """Random field elements 0 < v < p with v % modulus == residue (modulus a power of two): 4 x 64-bit draws with the
+    top 2 bits cleared, rejected until < p (mirrors src/indexed_merkle_tree.rs:381-386).  256-bit draws do not repeat;
+    the library refuses a step with a duplicate anyway.  uint8 [total, 32], little-endian."""
+    assert modulus & (modulus - 1) == 0
     rng = np.random.default_rng(seed)
-    out, seen = [], set()
-    while len(out) < total:
-        limbs = rng.integers(0, 1 << 64, size=(total + 1024, 4), dtype=np.uint64)
-        for row in limbs:
-            v = int(row[0]) | (int(row[1]) << 64) | (int(row[2]) << 128) | ((int(row[3]) & ((1 << 62) - 1)) << 192)
-            v = v - (v % modulus) + residue
-            if 0 < v < P and v not in seen:
-                seen.add(v)
-                out.append(v)
-                if len(out) == total:
-                    break
-    return np.frombuffer(b"".join(v.to_bytes(32, "little") for v in out), dtype=np.uint8).reshape(total, 32).copy()
+    parts, have = [], 0
+    while have < total:
+        limbs = rng.integers(0, 1 << 64, size=(total - have + 4096, 4), dtype=np.uint64)
+        limbs[:, 3] &= np.uint64((1 << 62) - 1)
+        limbs = limbs[limbs[:, 3] < np.uint64(P_TOP_LIMB)]          # strictly below p's top limb: v < p
+        if modulus > 1:
+            limbs[:, 0] = (limbs[:, 0] & ~np.uint64(modulus - 1)) | np.uint64(residue)
+        limbs = limbs[(limbs != 0).any(axis=1)]
+        parts.append(limbs)
+        have += limbs.shape[0]
+    return np.ascontiguousarray(np.concatenate(parts)[:total]).view(np.uint8).reshape(total, 32)
 
 
 def cpu_baseline(vals, budget_s=15.0):
@@ -99,8 +115,8 @@ def cpu_baseline(vals, budget_s=15.0):
 
 def cpu_baseline_all_cores(vals, budget_s=8.0):
     """The same oracle on every host core: T independent depth-32 trees, thread k inserting the values
-    k, k+T, ... (the value-partitioned form the multi-GPU bench uses).  Extra information beside the
-    one-thread `cpu_baseline` the contract asks for; ctypes releases the GIL during the C call."""
+    k, k+T, ... .  Extra information beside the one-thread `cpu_baseline` the contract asks for; ctypes releases the
+    GIL during the C call."""
     import threading
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -133,58 +149,10 @@ def cpu_baseline_all_cores(vals, budget_s=8.0):
             "sample": f"{n} insertions over {T} threads, one depth-32 tree per thread, C oracle, {dt:.1f} s"}
 
 
-def bench_single_list(args, world, rank, local_rank, dist, backend, ctx, imt_amd):
-    """N > 1, IMT_BENCH_MODE=single-list: ONE depth-32 tree (the reference's single sorted list, bit-exact),
-    replicated on every rank; a step inserts world x 2^16 values, each rank hashes 1/world of every level and
-    the ranks all-gather the level's node versions (sharded.ReplicatedIndexedTree)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("imt_sharded", os.path.join(ROOT, "indexed-merkle-tree-halo2_amd",
-                                                                               "sharded.py"))
-    sharded = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(sharded)
-    steps_total = args.warmup + args.steps
-    gb = BATCH * world
-    tree = imt_amd.IndexedTree(ctx, DEPTH, 1 << (steps_total * gb).bit_length())
-    rep = sharded.ReplicatedIndexedTree(imt_amd, ctx, tree, world, rank, dist, via_host=(backend != "nccl"))
-    vals = torch.from_numpy(synth_values(steps_total * gb, 0, 1, 0x494D5402)).to(torch.device("cuda", local_rank))
-
-    def sync():
-        ctx.sync()
-        torch.cuda.synchronize()
-        dist.barrier()
-
-    for i in range(args.warmup):
-        rep.insert_batch(vals[i * gb:(i + 1) * gb])
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, steps_total):
-        rep.insert_batch(vals[i * gb:(i + 1) * gb])
-    sync()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=("cuda" if backend == "nccl" else "cpu"))
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    if rank == 0:
-        value = args.steps * gb / dt
-        print(json.dumps({
-            "metric": "indexed-tree insertions/sec at depth=32 (bn256::Fr)", "value": value, "unit": "insertions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 limbs (9 x 29-bit, Montgomery mod p), 64-bit accumulate", "data": "synthetic",
-            "config": {"workload": "depth=32, ONE indexed tree, world x 2^16 sequential-semantics insertions per step; "
-                                   "every rank returns roots + both proofs of its 2^16 insertions",
-                       "batch_per_gpu": BATCH, "depth": DEPTH,
-                       "parallelism": f"single sorted list replicated on {world} GPUs, per-level slot-range sharding + "
-                                      "all-gather of node versions"},
-            "roofline": None, "cpu_baseline": None,
-            "valu": {"whole_step_frac": value / world * 66 * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS}}))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
 def launch_ranks(args):
     """`python bench.py --gpus N` typed as is: start the N ranks as CHILD processes (torch.distributed.run) before
-    anything in this process has touched the GPU, relay their output, return their status."""
+    anything in this process has touched the GPU, relay their output, return their status (non-zero if any rank
+    failed: torch.distributed.run reports a failed child with its own non-zero status)."""
     import socket
     import subprocess
     with socket.socket() as s:
@@ -195,86 +163,205 @@ def launch_ranks(args):
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this host
-    env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=env).returncode
+    return subprocess.run(cmd, env=dict(os.environ)).returncode
 
 
-def load_sharded():
+def load_module(name):
     import importlib.util
-    spec = importlib.util.spec_from_file_location("imt_sharded", os.path.join(ROOT, "indexed-merkle-tree-halo2_amd",
-                                                                               "sharded.py"))
+    spec = importlib.util.spec_from_file_location("imt_" + name, os.path.join(ROOT, "indexed-merkle-tree-halo2_amd",
+                                                                             name + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-    if args.gpus < 1 or args.gpus & (args.gpus - 1):
-        raise SystemExit("--gpus must be a power of two (subtrees of equal height)")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args))
+class Env:
+    """what every leg needs: ranks, devices, the process group, the library"""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    # rehearsal switches (one-GPU box): IMT_BENCH_DEVICE pins every rank to one device and
-    # IMT_BENCH_COLLECTIVE=gloo runs the root exchange through host memory.  The driver's runs use
-    # neither: one rank per GPU, backend "nccl" (= RCCL over xGMI).
-    if "IMT_BENCH_DEVICE" in os.environ:
-        local_rank = int(os.environ["IMT_BENCH_DEVICE"])
-    backend = os.environ.get("IMT_BENCH_COLLECTIVE", "nccl")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    ranks_seen = 1
-    # IMT_BENCH_FORCE_DIST: rehearsal of the N > 1 code path (process group, root all-gather, lift, reductions) with
-    # whatever world size the launcher gave, 1 included -- the only way to run the RCCL calls on a one-GPU box
-    if world > 1 or os.environ.get("IMT_BENCH_FORCE_DIST"):
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-        ranks_seen = dist.get_world_size()
+    def __init__(self, args):
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if args.gpus != self.world:
+            raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {self.world}")
+        # rehearsal switches (one-GPU box): IMT_BENCH_DEVICE pins every rank to one device and
+        # IMT_BENCH_COLLECTIVE=gloo runs the collectives through host memory.  The driver's runs use
+        # neither: one rank per GPU, backend "nccl" (= RCCL over xGMI).
+        if "IMT_BENCH_DEVICE" in os.environ:
+            self.local_rank = int(os.environ["IMT_BENCH_DEVICE"])
+        self.backend = os.environ.get("IMT_BENCH_COLLECTIVE", "nccl")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.dist = None
+        self.ranks_seen = 1
+        # IMT_BENCH_FORCE_DIST: rehearsal of the N > 1 code path (process group, collectives, lift, reductions) with
+        # whatever world size the launcher gave, 1 included -- the only way to run the RCCL calls on a one-GPU box
+        if self.world > 1 or os.environ.get("IMT_BENCH_FORCE_DIST"):
+            import datetime
+            import torch.distributed as dist_mod
+            self.dist = dist_mod
+            to = datetime.timedelta(seconds=int(os.environ.get("IMT_BENCH_DIST_TIMEOUT", "300")))
+            if self.backend == "nccl":
+                self.dist.init_process_group("nccl", device_id=self.dev, timeout=to)
+            else:
+                self.dist.init_process_group(self.backend, timeout=to)
+            self.ranks_seen = self.dist.get_world_size()
+        import imt_amd
+        self.imt = imt_amd
+        self.lib = imt_amd.lib
+        self.F = imt_amd._ffi
+        self.red_dev = self.dev if self.backend == "nccl" else "cpu"
 
-    import imt_amd
-    from imt_amd import _ffi
-    lib = imt_amd.lib
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
 
-    mode = os.environ.get("IMT_BENCH_MODE", "subtrees")     # N > 1: "subtrees" (default) or "single-list"
-    if world > 1 and mode == "single-list":
-        ctx = imt_amd.Context(local_rank)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        return bench_single_list(args, world, rank, local_rank, dist, backend, ctx, imt_amd)
-    sharded = load_sharded()
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.red_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_true(self, ok):
+        if self.dist is None:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.red_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
+
+def witness_check(env, ctx, o, first_new_index, n):
+    """the outputs `o` (device tensors of n insertions) through the independent witness kernels
+    (imt_insert_witness_batch: 3 leaf hashes + 4 depth-32 paths per insertion, every insert_leaf constraint) and the
+    root chain inside the batch"""
+    P_ = lambda x: ctypes.c_void_p(x.data_ptr())
+    fail = torch.empty(n, dtype=torch.uint8, device=env.dev)
+    new_index = torch.arange(first_new_index, first_new_index + n, dtype=torch.int64, device=env.dev)
+    ctx._check(env.lib.imt_insert_witness_batch(ctx.h, P_(o["old_root"]), P_(o["low_leaf"]), P_(o["low_index"]),
+                                                P_(o["low_sib"]), P_(o["new_root"]), P_(o["new_leaf"]), P_(new_index), None,
+                                                P_(o["new_sib"]), P_(o["is_largest"]), DEPTH, n, P_(fail), None,
+                                                env.F.DEVICE_PTRS))
+    ctx.sync()
+    torch.cuda.synchronize()
+    return int(fail.max()) == 0 and bool((o["old_root"][1:] == o["new_root"][:-1]).all())
+
+
+def sweep_lines(prof, steps):
+    """per-class totals of imt_profile_read -> dict + the level-launch average"""
+    names = ["k_sweep[leaves]", "index(k_merge_level)", "k_sweep[level<l0]", "k_sweep[level>=l0]", "k_writeback",
+             "host_prepare"]
+    kern = {names[c]: {"ms_total": prof[2 * c], "launches": int(prof[2 * c + 1])} for c in range(6)}
+    n_lv = prof[5] + prof[7]
+    return kern, ((prof[4] + prof[6]) / n_lv if n_lv else None)
+
+
+def roofline_objects(ms_per_batch, alone_ms, pipe_ms, copy_gbps, mad_peak, hashes_per_insertion):
+    """The dominant kernel is k_sweep: LAUNCHES_PER_STEP launches per 2^16-insertion batch, each hashing 2 x 2^16 events
+    up one level.  `avg_launch_ms` is the TIMED REGION's: wall time per batch / launches per batch -- under the batch
+    pipeline up to four launches overlap, so a single launch's own HIP-event duration (`pipelined`) is longer than its
+    share of the wall clock, and the kernel alone on the GPU (`alone`) is a different schedule again; both stay as
+    secondary fields."""
+    alg_bytes = 2 * BATCH * BYTES_PER_PATH_LEVEL
+    eff_ms = ms_per_batch / LAUNCHES_PER_STEP
+
+    def gbps(ms):
+        return alg_bytes / (ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": gbps(eff_ms), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": gbps(eff_ms) / HBM_PEAK_GBPS, "traffic": None, "traffic_static": PMC_TRAFFIC_SWEEP_LEVEL,
+            "peak_copy_measured": copy_gbps, "avg_launch_ms": eff_ms, "algorithmic_bytes_per_launch": alg_bytes,
+            "launches_per_batch": LAUNCHES_PER_STEP,
+            "duration_source": "timed region: wall time of a 2^16-insertion batch on one GPU / its 33 k_sweep launches",
+            "alone": None if not alone_ms else {
+                "avg_launch_ms": alone_ms, "achieved": gbps(alone_ms), "frac": gbps(alone_ms) / HBM_PEAK_GBPS,
+                "what": "HIP events around the level launches of two un-pipelined batches after the timed region: the "
+                        "kernel alone on the GPU (2 waves per SIMD); rocprofv3 of this: profiles/*alone_kernel_stats.csv"},
+            "pipelined": None if not pipe_ms else {
+                "avg_launch_ms": pipe_ms, "achieved": gbps(pipe_ms), "frac": gbps(pipe_ms) / HBM_PEAK_GBPS,
+                "what": "HIP events around the same launches inside the timed region, where up to four of them share "
+                        "the SIMDs; rocprofv3 of this: profiles/*pipelined_kernel_stats.csv"},
+            "note": "declared HBM per the contract; the kernel is integer-VALU bound, see valu"}
+    hps = 2 * BATCH / (eff_ms * 1e-3)
+    valu = {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep", "peak_gmads_measured_now": mad_peak,
+            "achieved_gmads": hps * MADS_PER_HASH / 1e9, "peak_gmads": VALU_PEAK_GMADS,
+            "frac": hps * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS,
+            "frac_of_measured": hps * MADS_PER_HASH / 1e9 / mad_peak if mad_peak else None,
+            "hashes_per_s": hps,
+            "alone_frac": (2 * BATCH / (alone_ms * 1e-3)) * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS if alone_ms else None,
+            "note": "timed region: all hashes of a batch / its wall time on one GPU, against the v_mad_u64_u32 issue rate"}
+    return roof, valu
+
+
+def device_probes(env, ctx):
+    """this device, this run: v_mad_u64_u32 issue rate, plain copy rate, the f1 trace kernel"""
+    lib, dev = env.lib, env.dev
+    mad_peak = ctypes.c_double(0.0)
+    lib.imt_measure_mad_peak(ctx.h, ctypes.byref(mad_peak))
+    a = torch.empty(1 << 29, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 2 * a.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    trace_line = None
+    if not os.environ.get("IMT_BENCH_NO_TRACE"):
+        # f1, secondary line: the witness-trace kernel (every new advice value of hash_fix_len_array, 38.7 KB per hash)
+        # is the one kernel of this library with a meaningful HBM roofline.  2^18 hashes, rows in halo2curves' in-memory
+        # form, row-major; algorithmic bytes = the rows it must deliver (PMC WRITE_SIZE equals them: profiles/).
+        nt = 1 << 18
+        tin = torch.randint(0, 256, (nt, 2, 32), dtype=torch.uint8, device=dev)
+        tin[:, :, 31] &= 0x0f
+        tout = torch.empty((TRACE_ROWS, nt, 32), dtype=torch.uint8, device=dev)
+        tcall = lambda: ctx._check(lib.imt_hash_trace_batch(ctx.h, ctypes.c_void_p(tin.data_ptr()), 2, nt,
+                                                            ctypes.c_void_p(tout.data_ptr()),
+                                                            env.F.DEVICE_PTRS | env.F.FMT_MONT256))
+        tcall()
+        tcall()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            tcall()
+        e1.record()
+        torch.cuda.synchronize()
+        tms = e0.elapsed_time(e1) / 5
+        tgbps = nt * TRACE_ROWS * 32 / (tms * 1e-3) / 1e9
+        trace_line = {"kernel": "k_hash_trace", "bound": "hbm", "hashes_per_launch": nt, "avg_launch_ms": tms,
+                      "hashes_per_s": nt / (tms * 1e-3), "achieved": tgbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": tgbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": nt * TRACE_ROWS * 32,
+                      "traffic_static": {"write_bytes": 10135000000, "source": "profiles/r02_pmc_trace_traffic.txt"}}
+        del tin, tout
+    return mad_peak.value, copy_gbps, trace_line
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def bench_subtrees(env):
+    """N = 1: the single tree.  N > 1: value-partitioned subtrees (sharded.ShardedIndexedTree over GpuBackend)."""
+    args, world, rank, dist, lib, F = env.args, env.world, env.rank, env.dist, env.lib, env.F
+    sharded = load_module("sharded")
     k = world.bit_length() - 1
     sub_height = DEPTH - k
     steps_total = args.warmup + args.steps
-    extra_steps = 2                                                  # kernel-attribution pass after the timed region
+    extra_steps = 0 if os.environ.get("IMT_BENCH_NO_ATTRIBUTION") else 2      # kernel-attribution pass after the timed region
     cap = 1 << ((steps_total + extra_steps) * BATCH).bit_length()
     vals_h = synth_values((steps_total + extra_steps) * BATCH, rank, world, 0x494D5402 + rank)
-    dev = torch.device("cuda", local_rank)
-    vals = torch.from_numpy(vals_h).to(dev)
+    vals = torch.from_numpy(vals_h).to(env.dev)
     out_pinned = os.environ.get("IMT_BENCH_OUT") == "pinned"        # secondary measurement (DESIGN.md, PCIe note)
     gpu_prep = os.environ.get("IMT_BENCH_PREP", "gpu") == "gpu"     # low-leaf search + event build on the GPU
     pipelined = not os.environ.get("IMT_NO_PIPELINE")
-    # Two output sets: the two batches in flight never share rows, and the set of a batch is rewritten only by the
+    # Two output sets: the batches in flight never share rows, and the set of a batch is rewritten only by the
     # batch after next -- by then its lift (N > 1) has run.  The bench does not consume the outputs between steps, so
     # the hash-free output buffers are idle when a batch starts (IMT_INPUTS_READY).
-    be = sharded.GpuBackend(imt_amd, local_rank, DEPTH, world, rank, cap, BATCH, pipeline=pipelined, inputs_ready=True,
-                            nbuf=2, host_prep=not gpu_prep, pinned_outputs=out_pinned)
+    be = sharded.GpuBackend(env.imt, env.local_rank, DEPTH, world, rank, cap, BATCH, pipeline=pipelined,
+                            inputs_ready=True, nbuf=2, host_prep=not gpu_prep, pinned_outputs=out_pinned)
     ctx = be.ctx
-    tree = sharded.ShardedIndexedTree(be, DEPTH, world, rank, dist, via_host=(backend != "nccl"))
+    tree = sharded.ShardedIndexedTree(be, DEPTH, world, rank, dist, via_host=(env.backend != "nccl"))
     host_s = [0.0]
     last_slot = [None]
 
@@ -289,8 +376,7 @@ def main():
 
     def sync():
         be.sync()
-        if dist is not None:
-            dist.barrier()
+        env.barrier()
 
     for i in range(args.warmup):
         step(i)
@@ -311,174 +397,219 @@ def main():
     lib.imt_profile_read(ctx.h, prof)
     lib.imt_profile_enable(ctx.h, 0)
 
-    # ---- verification of what the timed region produced (outside it): the LAST step's outputs, as they lie in
-    # HBM, go through the independent witness kernels (imt_insert_witness_batch: 3 leaf hashes + 4 depth-32 paths
-    # per insertion, every insert_leaf constraint) with global leaf indices, and its last new_root must be the
-    # tree's root.
+    # ---- verification of what the timed region produced (outside it): the LAST step's outputs, as they lie in HBM,
+    # through the independent witness kernels with global leaf indices; its last new_root must be the tree's root.
     o = be.outputs(last_slot[0])
-    P_ = lambda x: ctypes.c_void_p(x.data_ptr())
-    fail = torch.empty(BATCH, dtype=torch.uint8, device=dev)
-    new_index = torch.arange(o["first_new_index"], o["first_new_index"] + BATCH, dtype=torch.int64, device=dev)
-    ctx._check(lib.imt_insert_witness_batch(ctx.h, P_(o["old_root"]), P_(o["low_leaf"]), P_(o["low_index"]),
-                                            P_(o["low_sib"]), P_(o["new_root"]), P_(o["new_leaf"]), P_(new_index), None,
-                                            P_(o["new_sib"]), P_(o["is_largest"]), DEPTH, BATCH, P_(fail), None,
-                                            _ffi.DEVICE_PTRS))
-    be.sync()
-    verified = int(fail.max()) == 0 and bool((o["old_root"][1:] == o["new_root"][:-1]).all())
+    verified = witness_check(env, ctx, o, o["first_new_index"], BATCH)
     if dist is None:
-        root_now = torch.from_numpy(imt_amd.to_bytes(be.tree.root()))
+        root_now = torch.from_numpy(env.imt.to_bytes(be.tree.root()))
         verified = verified and bool((o["new_root"][-1].cpu() == root_now).all())
     elif rank == world - 1:         # the last rank's last insertion closes the step: its new root is the global root
         verified = verified and bool((o["new_root"][-1].cpu() == tree.global_root.cpu()).all())
-    if dist is not None:
-        vt = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(vt, op=dist.ReduceOp.MIN)
-        verified = bool(vt.item())
+    verified = env.all_true(verified)
 
     # ---- kernel attribution pass (not part of `value`): two more steps WITHOUT IMT_PIPELINE, so that each
-    # kernel has the GPU to itself and its HIP-event duration is a clean roofline input.  In the timed
-    # region the hash kernels of up to four consecutive batches share the SIMDs and stretch each other.
+    # kernel has the GPU to itself.  Secondary figure (roofline.alone).
     b2b = (ctypes.c_double * 12)()
-    extra = 0 if os.environ.get("IMT_BENCH_NO_ATTRIBUTION") else extra_steps
-    if extra:
+    if extra_steps:
         lib.imt_profile_enable(ctx.h, 1)
-        alone = (be.ins_flags & ~_ffi.PIPELINE)
-        for i in range(steps_total, steps_total + extra):
+        alone = (be.ins_flags & ~F.PIPELINE)
+        for i in range(steps_total, steps_total + extra_steps):
             step(i, alone)
         sync()
         lib.imt_profile_read(ctx.h, b2b)
         lib.imt_profile_enable(ctx.h, 0)
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = env.max_over_ranks(dt)
+    kern, pipe_ms = sweep_lines(prof, args.steps)
+    _, alone_ms = sweep_lines(b2b, extra_steps)
+    res = {"mode": "single tree" if world == 1 else "subtrees", "value": args.steps * BATCH * world / dt,
+           "ms_per_step": dt / args.steps * 1e3, "verified": verified, "alone_ms": alone_ms, "pipe_ms": pipe_ms,
+           "kernels": kern, "gpu_kernel_ms_per_step": sum(v["ms_total"] for n_, v in kern.items() if n_ != "host_prepare") / args.steps,
+           "host_call_ms_per_step": host_s[0] / args.steps * 1e3,
+           "host_prepare_ms_per_step": kern["host_prepare"]["ms_total"] / args.steps,
+           "hashes_per_insertion": 2 + 2 * sub_height + 2 * k, "subtree_height": sub_height,
+           "prepare": "gpu (imt_prep.hip)" if gpu_prep else "host",
+           "outputs": "pinned host memory, written by the kernels over PCIe" if out_pinned else "HBM",
+           "collectives_per_step": 0 if dist is None else 1,
+           "bytes_gathered_per_step_per_rank": 0 if dist is None else 32 * world,
+           "vals_h": vals_h, "ctx": ctx, "be": be}
+    return res
 
-    mad_peak = ctypes.c_double(0.0)
-    copy_gbps = None
-    if rank == 0:
-        lib.imt_measure_mad_peak(ctx.h, ctypes.byref(mad_peak))   # this device, this run (devices differ)
-        # the HBM ceiling of a plain copy on this box, printed beside the vendor peak
-        a = torch.empty(1 << 29, dtype=torch.uint8, device=dev)
-        b = torch.empty_like(a)
-        b.copy_(a)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            b.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbps = 2 * a.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del a, b
-    trace_line = None
-    if rank == 0 and not os.environ.get("IMT_BENCH_NO_TRACE"):
-        # f1, secondary line: the witness-trace kernel (every new advice value of hash_fix_len_array, 38.7 KB per hash)
-        # is the one kernel of this library with a meaningful HBM roofline.  2^18 hashes, rows in halo2curves' in-memory
-        # form, row-major; algorithmic bytes = the rows it must deliver (PMC WRITE_SIZE equals them: profiles/).
-        nt = 1 << 18
-        tin = torch.randint(0, 256, (nt, 2, 32), dtype=torch.uint8, device=dev)
-        tin[:, :, 31] &= 0x0f
-        tout = torch.empty((TRACE_ROWS, nt, 32), dtype=torch.uint8, device=dev)
-        tcall = lambda: ctx._check(lib.imt_hash_trace_batch(ctx.h, ctypes.c_void_p(tin.data_ptr()), 2, nt,
-                                                            ctypes.c_void_p(tout.data_ptr()),
-                                                            _ffi.DEVICE_PTRS | _ffi.FMT_MONT256))
-        tcall()
-        tcall()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            tcall()
-        e1.record()
-        torch.cuda.synchronize()
-        tms = e0.elapsed_time(e1) / 5
-        tgbps = nt * TRACE_ROWS * 32 / (tms * 1e-3) / 1e9
-        trace_line = {"kernel": "k_hash_trace", "bound": "hbm", "hashes_per_launch": nt, "avg_launch_ms": tms,
-                      "hashes_per_s": nt / (tms * 1e-3), "achieved": tgbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                      "frac": tgbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": nt * TRACE_ROWS * 32,
-                      "traffic_static": {"write_bytes": 10135000000, "source": "profiles/r02_pmc_trace_traffic.txt"}}
-        del tin, tout
-    if rank == 0:
-        n_ins = args.steps * BATCH * world
-        value = n_ins / dt
-        # one hash kernel, k_sweep, in three launch classes (HIP events per class): leaf hashes, the levels below l0
-        # (table-driven) and the levels from l0 to the root (every event against the empty subtree)
-        names = ["k_sweep[leaves]", "index(k_merge_level)", "k_sweep[level<l0]", "k_sweep[level>=l0]", "k_writeback",
-                 "host_prepare"]
-        kern = {names[c]: {"ms_total": prof[2 * c], "launches": int(prof[2 * c + 1])} for c in range(6)}
-        gpu_ms = sum(v["ms_total"] for n_, v in kern.items() if n_ != "host_prepare")
-        # dominant kernel by time: k_sweep; every one of its level launches hashes 2*BATCH events up one level
-        sweep = [2, 3]                       # profile classes of the level launches
-        pipe_ms = sum(prof[2 * c] for c in sweep) / max(sum(prof[2 * c + 1] for c in sweep), 1)
-        alone_ms = (sum(b2b[2 * c] for c in sweep) / sum(b2b[2 * c + 1] for c in sweep)) if b2b[5] else None
-        alg_bytes = 2 * BATCH * BYTES_PER_PATH_LEVEL
 
-        def line(ms):
-            gbps = alg_bytes / (ms * 1e-3) / 1e9
-            hps = 2 * BATCH / (ms * 1e-3)
-            return gbps, hps
-        # roofline inputs: the kernel ALONE on the GPU (attribution pass).  The pipelined launches of the timed
-        # region overlap a hash kernel of the neighbouring batch, so their durations add up to more than the wall
-        # time and are reported as a secondary field only.
-        ms = alone_ms if alone_ms else pipe_ms
-        achieved, hashes_per_s = line(ms)
-        pipe_gbps, _ = line(pipe_ms) if pipe_ms > 0 else (0.0, 0.0)
-        hashes_per_insertion = 2 + 2 * sub_height + 2 * k
+def bench_single_list(env):
+    """N > 1 (or IMT_BENCH_FORCE_DIST): ONE depth-32 tree on all ranks, time-sliced (sliced.SlicedIndexedTree)."""
+    args, world, rank, dist, lib = env.args, env.world, env.rank, env.dist, env.lib
+    sliced = load_module("sliced")
+    steps_total = args.warmup + args.steps
+    gb = BATCH * world
+    cap = 1 << (steps_total * gb).bit_length()
+    be = sliced.SliceGpuBackend(env.imt, env.local_rank, DEPTH, cap, BATCH)
+    ctx = be.ctx
+    tp = sliced.DistTransport(dist, via_host=(env.backend != "nccl"))
+    lag = int(os.environ["IMT_BENCH_LAG"]) if os.environ.get("IMT_BENCH_LAG") else None
+    tree = sliced.SlicedIndexedTree(be, world, rank, tp, lag)
+    # every rank sees the whole step: the same seed everywhere
+    vals = torch.from_numpy(synth_values(steps_total * gb, 0, 1, 0x494D5403)).to(env.dev)
+
+    def sync():
+        be.sync()
+        env.barrier()
+
+    for i in range(args.warmup):
+        tree.step(vals[i * gb:(i + 1) * gb])
+    tree.flush()                    # the timed region then holds exactly `steps` rounds, fill and drain included
+    sync()
+    c0, b0 = tp.collectives, tp.bytes_moved
+    lib.imt_profile_enable(ctx.h, 1)
+    t0 = time.perf_counter()
+    host_s = 0.0
+    for i in range(args.warmup, steps_total):
+        th = time.perf_counter()
+        tree.step(vals[i * gb:(i + 1) * gb])
+        host_s += time.perf_counter() - th
+    tree.flush()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = (ctypes.c_double * 12)()
+    lib.imt_profile_read(ctx.h, prof)
+    lib.imt_profile_enable(ctx.h, 0)
+    dt = env.max_over_ranks(dt)
+    # ---- verification: the last round's witnesses of THIS rank's slice through the witness kernels; the slices chain
+    # (rank g's first old root = rank g - 1's last new root); every replica holds the same root = the last new root
+    R = steps_total - 1
+    o = tree.outputs(R)
+    ok = witness_check(env, ctx, o, o["first_insertion"], BATCH)
+    ends = torch.stack([o["old_root"][0], o["new_root"][-1], torch.from_numpy(env.imt.to_bytes(be.tree.root())).to(env.dev)])
+    if dist is not None and world > 1:
+        allends = torch.empty((world,) + tuple(ends.shape), dtype=torch.uint8, device=env.red_dev)
+        dist.all_gather_into_tensor(allends.view(-1), ends.to(env.red_dev).reshape(-1))
+        allends = allends.cpu()
+    else:
+        allends = ends.cpu().unsqueeze(0)
+    for g in range(1, world):
+        ok = ok and bool((allends[g, 0] == allends[g - 1, 1]).all())
+    for g in range(world):
+        ok = ok and bool((allends[g, 2] == allends[world - 1, 1]).all())
+    verified = env.all_true(ok)
+    kern, pipe_ms = sweep_lines(prof, args.steps)
+    sc = tree.sched
+    return {"mode": "single-list", "value": args.steps * gb / dt, "ms_per_step": dt / args.steps * 1e3, "verified": verified,
+            "alone_ms": None, "pipe_ms": pipe_ms, "kernels": kern,
+            "gpu_kernel_ms_per_step": sum(v["ms_total"] for n_, v in kern.items() if n_ != "host_prepare") / args.steps,
+            "host_call_ms_per_step": host_s / args.steps * 1e3, "hashes_per_insertion": HASHES_PER_INSERTION,
+            "collectives_per_step": (tp.collectives - c0) / args.steps,
+            "bytes_gathered_per_step_per_rank": (tp.bytes_moved - b0) / args.steps,
+            "schedule": {"lag_levels": sc.lag, "round_period_ticks": sc.period, "gathers_per_round": sc.gathers,
+                         "rounds_in_flight": -(-sc.round_ticks // sc.period), "payload_bytes": be.payload_bytes},
+            "ctx": ctx, "be": be}
+
+
+def mode_summary(r, world):
+    """what the line says about one multi-GPU mode"""
+    ms_batch = r["ms_per_step"]             # every rank hashes one 2^16 batch per step in both modes
+    eff = ms_batch / LAUNCHES_PER_STEP
+    gbps = 2 * BATCH * BYTES_PER_PATH_LEVEL / (eff * 1e-3) / 1e9
+    out = {k: r[k] for k in ("value", "ms_per_step", "verified", "hashes_per_insertion", "collectives_per_step",
+                             "bytes_gathered_per_step_per_rank", "host_call_ms_per_step", "gpu_kernel_ms_per_step")}
+    out["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": gbps / HBM_PEAK_GBPS, "avg_launch_ms": eff, "traffic": None,
+                       "pipelined_avg_launch_ms": r["pipe_ms"]}
+    out["valu_frac"] = r["value"] / world * r["hashes_per_insertion"] * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS
+    out["cpu_baseline"] = None
+    if "schedule" in r:
+        out["schedule"] = r["schedule"]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.gpus < 1 or args.gpus & (args.gpus - 1):
+        raise SystemExit("--gpus must be a power of two (slices / subtrees of equal size)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    env = Env(args)
+    world, rank, dist = env.world, env.rank, env.dist
+    # N > 1: "both" (default; `value` = single-list), or one of "single-list" / "subtrees" alone
+    mode = os.environ.get("IMT_BENCH_MODE", "both" if dist is not None else "subtrees")
+    legs, failed = {}, None
+    if mode in ("both", "subtrees") or dist is None:
+        legs["subtrees"] = bench_subtrees(env)
+    if dist is not None and mode in ("both", "single-list"):
+        if "subtrees" in legs:      # free the first leg's tree and buffers; keep its context for the probes
+            legs["subtrees"]["be"].tree.close()
+            legs["subtrees"]["be"].sets = legs["subtrees"]["be"].structs = None
+            torch.cuda.empty_cache()
+        try:
+            legs["single-list"] = bench_single_list(env)
+        except Exception as e:      # keep the leg that finished: the line says what happened
+            if "subtrees" not in legs:
+                raise
+            failed = f"{type(e).__name__}: {e}"
+    head = legs.get("single-list") or legs["subtrees"]
+    ok = all(r["verified"] for r in legs.values()) and failed is None
+    if rank == 0:
+        mad_peak, copy_gbps, trace_line = device_probes(env, head["ctx"])
+        roof, valu = roofline_objects(head["ms_per_step"], head["alone_ms"], head["pipe_ms"], copy_gbps, mad_peak,
+                                      head["hashes_per_insertion"])
+        single = legs.get("subtrees") if dist is None else None
+        if world == 1 and dist is None:
+            par = "single tree"
+        elif head["mode"] == "single-list":
+            par = (f"ONE indexed tree (the reference's single sorted list) on {world} GPUs: a step's {world} x 2^16 "
+                   f"insertions in {world} consecutive slices, one per rank; replicas kept equal by all-gathers (RCCL) of "
+                   f"each slice's per-level write-backs, consumed {head['schedule']['lag_levels']} levels later")
+        else:
+            par = (f"{world} value-partitioned subtrees by leaf-index range; per step one RCCL all-gather of the "
+                   f"subtree roots (one step behind) + lift of every witness to depth 32 on its own rank")
         res = {
-            "metric": "indexed-tree insertions/sec at depth=32 (bn256::Fr)", "value": value,
-            "unit": "insertions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 limbs (9 x 29-bit, Montgomery mod p), 64-bit accumulate",
-            "data": "synthetic", "ranks_seen": ranks_seen, "collective_backend": backend if dist is not None else None,
-            "verified": verified,
+            "metric": METRIC, "value": head["value"], "unit": "insertions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "ranks_seen": env.ranks_seen,
+            "collective_backend": env.backend if dist is not None else None, "verified": ok,
+            "value_is": head["mode"] + (" (the reference's data structure, bit-exact with one GPU)"
+                                        if head["mode"] != "subtrees" else
+                                        " (N sorted lists under one root: needs one more circuit constraint per witness, INTEGRATION.md sec. 4)"),
             "config": {"workload": "depth=32, 2^16 sequential-semantics insertions per step per GPU "
                                    "(BASELINE configs[1]); per insertion: old/interim/new depth-32 root + two 32-sibling "
                                    "proofs written to HBM; values resident in HBM",
-                       "batch_per_gpu": BATCH, "depth": DEPTH, "subtree_height_per_gpu": sub_height,
-                       "parallelism": "single tree" if world == 1 else
-                       f"{world} value-partitioned subtrees by leaf-index range; per step one RCCL all-gather of the "
-                       f"subtree roots (one step behind) + lift of every witness to depth 32 on its own rank",
-                       "hashes_per_insertion": hashes_per_insertion,
-                       "prepare": "gpu (imt_prep.hip)" if gpu_prep else "host",
-                       "outputs": "pinned host memory, written by the kernels over PCIe" if out_pinned else "HBM",
+                       "batch_per_gpu": BATCH, "depth": DEPTH, "parallelism": par,
+                       "hashes_per_insertion": head["hashes_per_insertion"],
                        "verified_how": "last timed step's outputs through imt_insert_witness_batch(depth=32, global "
-                                       "indices) + root chain + tree root, after the timed region"},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep (level launches)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "traffic_static": PMC_TRAFFIC_SWEEP_LEVEL,
-                         "peak_copy_measured": copy_gbps,
-                         "avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "duration_source": ("attribution pass: 2 un-pipelined steps after the timed region, the kernel "
-                                             "alone on the GPU" if alone_ms else "timed region (pipelined)"),
-                         "pipelined": {"avg_launch_ms": pipe_ms, "achieved": pipe_gbps, "frac": pipe_gbps / HBM_PEAK_GBPS,
-                                       "what": "the same kernel inside the timed region, sharing the SIMDs with the hash "
-                                               "kernels of the neighbouring batches (up to four in flight)"},
-                         "note": "declared HBM per the contract; the kernel is integer-VALU bound, see valu"},
-            "valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep (level launches)",
-                     "peak_gmads_measured_now": mad_peak.value,
-                     "whole_step_frac_of_measured": (value / world * hashes_per_insertion * MADS_PER_HASH / 1e9 /
-                                                     mad_peak.value if mad_peak.value else None),
-                     "achieved_gmads": hashes_per_s * MADS_PER_HASH / 1e9, "peak_gmads": VALU_PEAK_GMADS,
-                     "frac": hashes_per_s * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS,
-                     "hashes_per_s": hashes_per_s,
-                     "whole_step_frac": value / world * hashes_per_insertion * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS,
-                     "note": "kernel figures from the attribution pass (kernel alone); whole_step_frac = all hashes of "
-                             "the step / wall time of the timed region"},
-            "trace_roofline": trace_line,
-            "kernels": kern, "gpu_kernel_ms_per_step": gpu_ms / args.steps,
-            "host_call_ms_per_step": host_s[0] / args.steps * 1e3,
-            "host_prepare_ms_per_step": kern["host_prepare"]["ms_total"] / args.steps,
-            "whole_step_algorithmic_GBps": value * BYTES_PER_INSERTION / 1e9,
+                                       "indices) + root chain (inside a batch, across ranks) + tree root, after the "
+                                       "timed region"},
+            "roofline": roof, "valu": valu, "trace_roofline": trace_line,
+            "kernels": head["kernels"], "gpu_kernel_ms_per_step": head["gpu_kernel_ms_per_step"],
+            "host_call_ms_per_step": head["host_call_ms_per_step"],
+            "whole_step_algorithmic_GBps": head["value"] * BYTES_PER_INSERTION / 1e9,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(vals_h)
-            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(vals_h)
+        if single is not None:
+            res["config"]["prepare"] = single["prepare"]
+            res["config"]["outputs"] = single["outputs"]
+            res["host_prepare_ms_per_step"] = single["host_prepare_ms_per_step"]
+        if dist is not None:
+            res["modes"] = {name.replace("-", "_"): mode_summary(r, world) for name, r in legs.items()}
+            if failed:
+                res["modes"]["single_list"] = {"error": failed}
+            res["collectives_per_step"] = head["collectives_per_step"]
+            res["bytes_gathered_per_step_per_rank"] = head["bytes_gathered_per_step_per_rank"]
+        if world == 1 and dist is None and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(single["vals_h"])
+            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(single["vals_h"])
         else:
             res["cpu_baseline"] = None
+            res["cpu_baseline_why_null"] = ("measured on rank 0 at N = 1 only (contract)" if world > 1 or dist is not None
+                                            else "--no-cpu-baseline")
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -172,6 +172,13 @@ extern "C" {
     pub fn imt_itree_batch_end(t: *mut imt_itree, val_levels: *const *const c_void, top_path: *const c_void) -> c_int;
     pub fn imt_itree_batch_abort(t: *mut imt_itree) -> c_int;
 
+    // ---- e: one tree on several GPUs, single sorted list, time-sliced
+    pub fn imt_itree_slice_payload_bytes(n: usize) -> usize;
+    pub fn imt_itree_slice_prepare(t: *mut imt_itree, vals: *const c_void, n_before: usize, n_own: usize, n_after: usize, out: *const imt_insert_out, flags: c_uint, slice_out: *mut c_int, l0_out: *mut u32) -> c_int;
+    pub fn imt_itree_slice_unit(t: *mut imt_itree, slice: c_int, unit: c_uint, payload: *mut c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn imt_itree_slice_apply(t: *mut imt_itree, size_before: u64, n: usize, unit: c_uint, payload: *const c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn imt_itree_slice_apply_gathered(t: *mut imt_itree, gathered: *const c_void, stride: usize, count: usize, size_before: *const u64, n: *const u64, unit: *const i32, hip_stream: *mut c_void) -> c_int;
+
     // ---- e: multi-GPU helpers
     pub fn imt_combine_subtree_roots(ctx: *mut imt_ctx, sub_roots: *const c_void, n_roots: usize, sub_height: c_uint, depth: c_uint, root: *mut c_void, flags: c_uint) -> c_int;
     pub fn imt_zero_hashes(ctx: *mut imt_ctx, depth: c_uint, out: *mut c_void, flags: c_uint) -> c_int;

@@ -407,6 +407,41 @@ int imt_itree_batch_end(imt_itree *t, const void *const *val_levels, const void 
 /* gives up an open batch (after a failed collective, say): the tree is as it was before imt_itree_batch_begin */
 int imt_itree_batch_abort(imt_itree *t);
 
+/* ---- e: one tree on several GPUs, sequential semantics, TIME-SLICED ---------------------------
+ * The reference's single sorted list (update_idx_leaf, src/indexed_merkle_tree.rs:632-660) at any number of GPUs,
+ * bit-exact with one GPU.  A step's insertions are cut into consecutive slices, one per GPU, in insertion order:
+ * GPU g hashes slice g -- low-leaf rewrites, new leaves, every node version up to the root, 2 + 2 * depth hashes per
+ * insertion, and writes the witnesses of its own insertions directly -- and every GPU keeps a replica of the
+ * stored tree and of the sorted index.  A slice is hashed unit by unit (unit 0 = its leaf hashes, unit 1 + l = level
+ * l -> l + 1) on a stream the caller names; each unit leaves a PAYLOAD -- the nodes it wrote back to level l of the
+ * stored tree -- which the caller all-gathers (RCCL) and applies on the other replicas.  Correctness rule, kept by
+ * the caller's schedule (sharded.py: SlicedIndexedTree; slice k of the global sequence runs its unit u no earlier
+ * than slice k - 1's unit u has been applied here): a slice's level l sees the level-l write-backs of every earlier
+ * slice and of no later one.  Device pointers only.
+ *   prepare : vals = the step's values for the slices before this GPU's, its own, and those after, in step order
+ *             (identical on every GPU).  Index work for all of them on the tree's side stream (sort, low-leaf
+ *             search, merge into the sorted index), events + level tables for the own slice only; the hash-free
+ *             outputs (low_index, is_largest, low_leaf, new_leaf) are written now.  Blocks until the values are
+ *             checked: IMT_ERR_VALUE / IMT_ERR_NONCANONICAL / IMT_ERR_FULL as imt_itree_insert_batch, the same
+ *             verdict on every GPU, tree and index unchanged.  On success the index holds the whole step and
+ *             *slice_out names the slice (up to 4 may be open).  `out` pointers are kept until the last unit.
+ *   unit    : enqueue unit `unit` (0 .. depth, in order) of an open slice on hip_stream; payload (NULL = none
+ *             wanted) receives imt_itree_slice_payload_bytes(n_own) bytes, stream-ordered.
+ *   apply   : enqueue another GPU's payload for (slice of n insertions into a tree of size_before leaves, unit) on
+ *             hip_stream: writes that unit's nodes into this replica.
+ * After the last apply the caller synchronises the streams it passed before any other call on the tree. */
+size_t imt_itree_slice_payload_bytes(size_t n);
+int imt_itree_slice_prepare(imt_itree *t, const void *vals /*[n_before + n_own + n_after][32]*/, size_t n_before,
+                            size_t n_own, size_t n_after, const imt_insert_out *out, unsigned flags, int *slice_out,
+                            uint32_t *l0_out);
+int imt_itree_slice_unit(imt_itree *t, int slice, unsigned unit, void *payload, void *hip_stream);
+int imt_itree_slice_apply(imt_itree *t, uint64_t size_before, size_t n, unsigned unit, const void *payload,
+                          void *hip_stream);
+/* the same for the `count` payloads of one all-gather (payload r at gathered + r * stride); unit[r] < 0 = skip */
+int imt_itree_slice_apply_gathered(imt_itree *t, const void *gathered, size_t stride, size_t count,
+                                   const uint64_t *size_before /*[count]*/, const uint64_t *n /*[count]*/,
+                                   const int32_t *unit /*[count]*/, void *hip_stream);
+
 /* ---- e: multi-GPU helpers ------------------------------------------------------ */
 /* Root of a depth-`depth` tree whose 2^k subtrees of height `sub_height` have the given
  * roots (k = log2(n_roots)); the levels above sub_height + k are extended with the

@@ -121,6 +121,13 @@ SIGNATURES = {
                                         c_uint]),
     "imt_itree_batch_end": (c_int, [c_void_p, P(c_void_p), c_void_p]),
     "imt_itree_batch_abort": (c_int, [c_void_p]),
+    "imt_itree_slice_payload_bytes": (c_size_t, [c_size_t]),
+    "imt_itree_slice_prepare": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, P(InsertOut), c_uint, P(c_int),
+                                        P(ctypes.c_uint32)]),
+    "imt_itree_slice_unit": (c_int, [c_void_p, c_int, c_uint, c_void_p, c_void_p]),
+    "imt_itree_slice_apply": (c_int, [c_void_p, c_u64, c_size_t, c_uint, c_void_p, c_void_p]),
+    "imt_itree_slice_apply_gathered": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, P(c_u64), P(c_u64),
+                                               P(ctypes.c_int32), c_void_p]),
     "imt_itree_set_placement": (c_int, [c_void_p, c_uint, c_u64]),
     "imt_itree_set_value_partition": (c_int, [c_void_p, ctypes.c_uint32, ctypes.c_uint32]),
     "imt_itree_lift_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, P(InsertOut), c_uint]),

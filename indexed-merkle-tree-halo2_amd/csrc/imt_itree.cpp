@@ -83,6 +83,15 @@ struct PlanSet {
     bool in_flight = false;
     bool pipelined = false;              // ran on a pipeline stream (IMT_PIPELINE)
     unsigned l0 = 0;                     // its L0
+    uint8_t* d_canon = nullptr;          // [E/2][32] canonical copy of the batch's values when they arrive in another format
+    // a time slice of a multi-GPU step (imt_itree_slice_*): prepared here, hashed unit by unit on the caller's streams
+    hipEvent_t prep_done = nullptr;      // recorded on the side stream behind the slice's preparation and index phase
+    bool open = false;                   // prepared, last unit not yet issued
+    size_t slice_n = 0;
+    imt_insert_out slice_out = {};
+    unsigned slice_fmt = 0;
+    unsigned slice_next_unit = 0;
+    launch::SibLayout slice_lay = {0, 0};
 };
 
 }  // namespace
@@ -133,6 +142,10 @@ struct imt_itree {
     std::vector<uint8_t> w_largest;
     std::vector<uint32_t> w_hist;
     std::vector<SortedEnt> w_merged;
+    // imt_itree_slice_prepare: index workspace for the values other GPUs hash, canonical copy of a step's values
+    prep::Workspace fws;
+    uint8_t* d_canon_all = nullptr;
+    size_t canon_all_cap = 0;
 };
 
 static void plan_free(PlanSet& p) {
@@ -150,6 +163,7 @@ static void plan_free(PlanSet& p) {
     if (p.d_root) hipFree(p.d_root);
     if (p.d_slot) hipFree(p.d_slot);
     if (p.d_valptr) hipFree(p.d_valptr);
+    if (p.d_canon) hipFree(p.d_canon);
     for (void* q : {(void*)p.ws.o_low, (void*)p.ws.o_largest, (void*)p.ws.o_lowleaf, (void*)p.ws.o_newleaf})
         if (q) hipFree(q);
     for (void* q : {(void*)p.ws.iota, (void*)p.ws.bsorted, (void*)p.ws.gap, (void*)p.ws.st, (void*)p.ws.low,
@@ -157,6 +171,7 @@ static void plan_free(PlanSet& p) {
         if (q) hipFree(q);
     PlanSet keep;
     keep.done = p.done;
+    keep.prep_done = p.prep_done;
     for (int l = 0; l <= IMT_MAX_DEPTH; l++) keep.wb_done[l] = p.wb_done[l];
     p = keep;
 }
@@ -205,6 +220,7 @@ static int plan_reserve(imt_ctx* c, PlanSet& p, size_t events, unsigned levels, 
     }
     A((void**)&p.d_slot, (size_t)(L + 1) * E * 4);
     A((void**)&p.d_valptr, (size_t)(L + 1) * sizeof(void*));
+    A((void**)&p.d_canon, (E / 2) * 32);
     if (e != hipSuccess) {
         plan_free(p);
         return c->hip_fail(e, "hipMalloc(plan)");
@@ -222,6 +238,7 @@ extern "C" void imt_itree_free(imt_itree* t) {
     for (auto& p : t->plan) {
         plan_free(p);
         if (p.done) hipEventDestroy(p.done);
+        if (p.prep_done) hipEventDestroy(p.prep_done);
         for (auto& e : p.wb_done)
             if (e) hipEventDestroy(e);
     }
@@ -243,6 +260,9 @@ extern "C" void imt_itree_free(imt_itree* t) {
     for (auto q : t->d_sorted)
         if (q) hipFree(q);
     if (t->h_err_pin) hipHostFree(t->h_err_pin);
+    for (void* q : {(void*)t->fws.iota, (void*)t->fws.bsorted, (void*)t->fws.gap, (void*)t->fws.st, t->fws.tmp,
+                    (void*)t->d_canon_all})
+        if (q) hipFree(q);
     delete t;
 }
 
@@ -297,7 +317,8 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
             }
         }
         for (auto& pl : t->plan)
-            if ((e = hipEventCreateWithFlags(&pl.done, hipEventDisableTiming)) != hipSuccess) {
+            if ((e = hipEventCreateWithFlags(&pl.done, hipEventDisableTiming)) != hipSuccess ||
+                (e = hipEventCreateWithFlags(&pl.prep_done, hipEventDisableTiming)) != hipSuccess) {
                 imt_itree_free(t);
                 return c->hip_fail(e, "hipEventCreate");
             }
@@ -940,10 +961,11 @@ int gpu_prepare(imt_itree* t, PlanSet& P, const void* vals, size_t n, unsigned f
     }
     IMT_HIP(c, hipMemsetAsync(P.ws.err, 0, sizeof(int), ps));
     if (fmt != IMT_FMT_CANONICAL) {
-        uint8_t* can = (uint8_t*)c->dev_scratch(slot++, n * 32);
-        if (!can) return IMT_ERR_HIP;
-        launch::convert(ps, d_vals, can, n, fmt, IMT_FMT_CANONICAL, P.ws.err);   // sets bit 0 = non-canonical
-        d_vals = can;
+        // the plan's own buffer, not context scratch: this runs on the side stream, which IMT_INPUTS_READY leaves
+        // unordered behind the context's stream, where an earlier asynchronous call (imt_itree_lift_batch,
+        // imt_insert_trace_batch) may still be using the context's scratch slots
+        launch::convert(ps, d_vals, P.d_canon, n, fmt, IMT_FMT_CANONICAL, P.ws.err);   // sets bit 0 = non-canonical
+        d_vals = P.d_canon;
     }
     if (out) {
         auto dev_out = [&](void* user, size_t bytes) -> void* {
@@ -1416,6 +1438,276 @@ extern "C" int imt_itree_batch_end(imt_itree* t, const void* const* val_levels, 
     t->cur = (t->cur + 1) % imt_itree::NSETS;
     t->batch_no++;
     t->pending.active = false;
+    return IMT_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// e: one tree on several GPUs, sequential semantics, time-sliced (imt_itree_slice_*)
+// ------------------------------------------------------------------------------------
+// A step's insertions are cut into consecutive slices, one per GPU.  A slice is an ordinary batch for the GPU that
+// hashes it -- same plan, same kernels, same 2 + 2 * depth hashes per insertion, proofs and roots written directly --
+// except that its level sweeps are issued one UNIT at a time on the caller's stream, so that between units the caller
+// can exchange with the other GPUs what each unit wrote back to the stored tree (the "payload" of a unit) and apply
+// theirs (imt_itree_slice_apply).  Unit 0 = the leaf hashes, unit 1 + l = level l -> l + 1.  A slice's level l may run
+// once every earlier slice's level l has been applied here, and nothing later: the caller's schedule (sharded.py,
+// SlicedIndexedTree) guarantees both.  The values other GPUs hash only enter this replica's index (sort + merge, no
+// events, no hashing).
+namespace {
+constexpr size_t SLICE_HDR = 128;      // payload header: node at l0 (32 B), node above (32 B), root (32 B), pad
+
+int fws_reserve(imt_itree* t, size_t n) {
+    imt_ctx* c = t->ctx;
+    prep::Workspace& w = t->fws;
+    const size_t tmp_need = prep::temp_bytes_needed(n, t->cap);
+    if (w.cap_n >= n && w.tmp_bytes >= tmp_need) return IMT_OK;
+    IMT_HIP(c, hipStreamSynchronize(t->up_stream));
+    for (void* q : {(void*)w.iota, (void*)w.bsorted, (void*)w.gap, (void*)w.st, w.tmp})
+        if (q) hipFree(q);
+    w = prep::Workspace();
+    const size_t N = n + n / 4;
+    hipError_t e = hipSuccess;
+    auto A = [&](void** ptr, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(ptr, bytes);
+    };
+    A((void**)&w.iota, N * 4);
+    A((void**)&w.bsorted, N * 4);
+    A((void**)&w.gap, N * 4);
+    A((void**)&w.st, N * 4);
+    w.tmp_bytes = prep::temp_bytes_needed(N, t->cap);
+    A(&w.tmp, w.tmp_bytes);
+    if (e != hipSuccess) {
+        for (void* q : {(void*)w.iota, (void*)w.bsorted, (void*)w.gap, (void*)w.st, w.tmp})
+            if (q) hipFree(q);
+        w = prep::Workspace();
+        return c->hip_fail(e, "hipMalloc(slice index workspace)");
+    }
+    w.cap_n = N;
+    return IMT_OK;
+}
+}  // namespace
+
+extern "C" size_t imt_itree_slice_payload_bytes(size_t n) { return SLICE_HDR + 80 * n; }
+
+extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_before, size_t n_own, size_t n_after,
+                                       const imt_insert_out* out, unsigned flags, int* slice_out, uint32_t* l0_out) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (!vals || n_own == 0 || !slice_out) return c->fail(IMT_ERR_ARG, "null / empty slice");
+    if (!(flags & IMT_DEVICE_PTRS)) return c->fail(IMT_ERR_ARG, "imt_itree_slice_prepare takes device pointers");
+    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
+    if (t->index_base || t->part_mod > 1) return c->fail(IMT_ERR_ARG, "a placed / partitioned tree is not sliced");
+    if (t->pending.active) return c->fail(IMT_ERR_ARG, "a sharded batch is open (imt_itree_batch_end first)");
+    const size_t n_all = n_before + n_own + n_after;
+    if (n_all > ((size_t)1 << 30)) return c->fail(IMT_ERR_RANGE, "step too large");
+    const uint64_t M0 = t->size;
+    if (M0 + n_all > t->cap) return c->fail(IMT_ERR_FULL, "tree capacity %llu exceeded", (unsigned long long)t->cap);
+    int rc = c->set_device();
+    if (rc) return rc;
+    if ((rc = ensure_device_index(t))) return rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    const int set = t->cur;
+    PlanSet& P = t->plan[set];
+    if (P.open) return c->fail(IMT_ERR_ARG, "too many slices prepared ahead (%d plan sets)", imt_itree::NSETS);
+    if (P.in_flight) {
+        IMT_HIP(c, hipEventSynchronize(P.done));
+        P.in_flight = false;
+    }
+    if ((rc = plan_reserve(c, P, 2 * n_own, t->depth, t->cap))) return rc;
+    if (n_before || n_after)
+        if ((rc = fws_reserve(t, std::max(n_before, n_after)))) return rc;
+    hipStream_t ps = t->up_stream;
+    if (!(flags & IMT_INPUTS_READY)) {
+        IMT_HIP(c, hipEventRecord(t->in_mark, c->stream));
+        IMT_HIP(c, hipStreamWaitEvent(ps, t->in_mark, 0));
+    }
+    IMT_HIP(c, hipMemsetAsync(P.ws.err, 0, sizeof(int), ps));
+    const uint8_t* d_vals = (const uint8_t*)vals;
+    if (fmt != IMT_FMT_CANONICAL) {
+        if (t->canon_all_cap < n_all * 32) {
+            IMT_HIP(c, hipStreamSynchronize(ps));
+            if (t->d_canon_all) hipFree(t->d_canon_all);
+            t->d_canon_all = nullptr;
+            t->canon_all_cap = 0;
+            IMT_HIP(c, hipMalloc((void**)&t->d_canon_all, n_all * 40));
+            t->canon_all_cap = n_all * 40;
+        }
+        launch::convert(ps, d_vals, t->d_canon_all, n_all, fmt, IMT_FMT_CANONICAL, P.ws.err);
+        d_vals = t->d_canon_all;
+    }
+    // ---- the index, in the order of the step: the slices before this one, this one (with its events), those after ----
+    int cur = t->sorted_cur;
+    uint64_t M = M0;
+    t->fws.err = P.ws.err;
+    t->fws.part_mod = t->fws.part_res = 0;
+    P.ws.part_mod = P.ws.part_res = 0;
+    if (n_before) {
+        IMT_HIP(c, prep::index_only(ps, t->fws, d_vals, t->d_val, t->d_sorted[cur], t->d_sorted[cur ^ 1], (uint32_t)M,
+                                    (uint32_t)n_before));
+        cur ^= 1;
+        M += n_before;
+    }
+    const uint64_t M_own = M;
+    IMT_HIP(c, prep::run(ps, P.ws, d_vals + n_before * 32, t->d_val, t->d_sorted[cur], t->d_sorted[cur ^ 1], (uint32_t)M,
+                         (uint32_t)n_own, 0, P.d_pre, P.d_tab[0][0], P.d_tab[0][1], P.d_tab[0][2], P.d_tab[0][3],
+                         out ? out->low_index : nullptr, out ? out->is_largest : nullptr,
+                         out ? (uint8_t*)out->low_leaf : nullptr, out ? (uint8_t*)out->new_leaf : nullptr));
+    cur ^= 1;
+    M += n_own;
+    if (n_after) {
+        IMT_HIP(c, prep::index_only(ps, t->fws, d_vals + (n_before + n_own) * 32, t->d_val, t->d_sorted[cur],
+                                    t->d_sorted[cur ^ 1], (uint32_t)M, (uint32_t)n_after));
+        cur ^= 1;
+    }
+    IMT_HIP(c, hipMemcpyAsync(t->h_err_pin, P.ws.err, sizeof(int), hipMemcpyDeviceToHost, ps));
+    // ---- this slice's index phase (no hashing) on the side stream as well ----
+    const size_t E = 2 * n_own;
+    const unsigned L0 = std::min(ceil_log2(M_own + n_own), t->depth);
+    for (unsigned l = 0; l < L0; l++) {
+        const int a = l & 1, b = a ^ 1;
+        const uint32_t* time_in = l == 0 ? P.d_tab[0][1] : P.d_timen + (size_t)(l - 1) * P.cap_events;
+        sweep::LevelTable in{P.d_tab[a][0], time_in, P.d_tab[a][2], P.d_tab[a][3]};
+        sweep::LevelOut o{P.d_tab[b][0], P.d_timen + (size_t)l * P.cap_events, P.d_tab[b][2], P.d_tab[b][3],
+                          P.d_from + (size_t)l * P.cap_events, P.d_sibsrc + (size_t)l * P.cap_events,
+                          P.d_nodeb + (size_t)l * P.cap_events, nullptr};
+        launch::merge_level(ps, in, o, (uint32_t)E);
+    }
+    if (out && fmt != IMT_FMT_CANONICAL) {
+        if (out->low_leaf) launch::convert(ps, (uint8_t*)out->low_leaf, (uint8_t*)out->low_leaf, n_own * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+        if (out->new_leaf) launch::convert(ps, (uint8_t*)out->new_leaf, (uint8_t*)out->new_leaf, n_own * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+    }
+    IMT_HIP(c, hipEventRecord(P.prep_done, ps));
+    IMT_HIP(c, hipStreamSynchronize(ps));
+    const int perr = *t->h_err_pin;      // the same verdict on every GPU: they all see all values of the step
+    if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
+    if (perr & prep::ERR_ZERO) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
+    if (perr & prep::ERR_DUPLICATE) return c->fail(IMT_ERR_VALUE, "duplicate value (inside the step or already in the tree)");
+    // ---- commit the index; the hashing follows unit by unit ----
+    t->sorted_cur = cur;
+    t->size = M0 + n_all;
+    t->mirror_valid = false;
+    P.open = true;
+    P.slice_n = n_own;
+    P.slice_out = out ? *out : imt_insert_out{};
+    P.slice_fmt = fmt;
+    P.slice_next_unit = 0;
+    P.slice_lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->depth} : launch::SibLayout{n_own, 1};
+    P.l0 = L0;
+    P.has_root = false;
+    t->cur = (t->cur + 1) % imt_itree::NSETS;
+    t->batch_no++;
+    *slice_out = set;
+    if (l0_out) *l0_out = L0;
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_slice_unit(imt_itree* t, int slice, unsigned unit, void* payload, void* hip_stream) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (slice < 0 || slice >= imt_itree::NSETS || !t->plan[slice].open) return c->fail(IMT_ERR_ARG, "no such open slice");
+    PlanSet& P = t->plan[slice];
+    if (unit != P.slice_next_unit) return c->fail(IMT_ERR_ARG, "slice unit %u out of order (next is %u)", unit, P.slice_next_unit);
+    int rc = c->set_device();
+    if (rc) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const size_t n = P.slice_n, E = 2 * n;
+    const unsigned L0 = P.l0, depth = t->depth, fmt = P.slice_fmt;
+    const imt_insert_out& o = P.slice_out;
+    uint8_t* pl = (uint8_t*)payload;
+    uint8_t* root_node = t->d_nodes + t->h_off[depth] * 32;
+    P.slice_next_unit = unit + 1;
+    if (unit == 0) {
+        IMT_HIP(c, hipStreamWaitEvent(s, P.prep_done, 0));
+        int pf = c->prof_begin(IMT_PROF_LEAVES, s);
+        launch::sweep_leaves(s, P.d_pre, P.d_tab[0][1], P.d_val[0], 0, (uint32_t)E, IMT_FMT_CANONICAL, c->d_err, c->coop_max_events);
+        c->prof_end(pf, s);
+        return IMT_OK;
+    }
+    const unsigned l = unit - 1;
+    uint8_t* g_old = (uint8_t*)o.old_root;
+    if (l < L0) {
+        const size_t off = (size_t)l * P.cap_events;
+        const uint8_t* vin = P.d_val[l & 1];
+        int pf = c->prof_begin(IMT_PROF_LEVEL, s);
+        launch::sweep_level(s, vin, P.d_val[(l & 1) ^ 1], P.d_from + off, P.d_sibsrc + off, P.d_nodeb + off, P.d_timen + off,
+                            t->d_nodes + t->h_off[l] * 32, t->h_len[l], c->d_zero + (size_t)l * 32, 0, (uint32_t)E,
+                            (uint8_t*)o.low_sib, (uint8_t*)o.new_sib, P.slice_lay, l, fmt, c->coop_max_events);
+        c->prof_end(pf, s);
+        pf = c->prof_begin(IMT_PROF_WRITEBACK, s);
+        launch::writeback(s, vin, P.d_from + off, P.d_nodeb + off, t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
+        if (pl) {       // what the other replicas need to write the same nodes back
+            IMT_HIP(c, hipMemcpyAsync(pl + SLICE_HDR, vin, E * 32, hipMemcpyDeviceToDevice, s));
+            IMT_HIP(c, hipMemcpyAsync(pl + SLICE_HDR + E * 32, P.d_from + off, E * 4, hipMemcpyDeviceToDevice, s));
+            IMT_HIP(c, hipMemcpyAsync(pl + SLICE_HDR + E * 36, P.d_nodeb + off, E * 4, hipMemcpyDeviceToDevice, s));
+        }
+        c->prof_end(pf, s);
+    } else {
+        if (l + 1 == depth && g_old)
+            launch::convert(s, root_node, g_old, 1, IMT_FMT_DEVICE, fmt, c->d_err);
+        uint8_t* node_in = l == L0 ? t->d_nodes + t->h_off[l] * 32 : nullptr;
+        uint8_t* node_out = t->d_nodes + t->h_off[l + 1] * 32;
+        int pf = c->prof_begin(IMT_PROF_TOP, s);
+        launch::sweep_upper(s, P.d_val[l & 1], P.d_val[(l & 1) ^ 1], c->d_zero + (size_t)l * 32, 0, (uint32_t)E, (uint32_t)E - 1,
+                            node_in, node_out, (uint8_t*)o.low_sib, (uint8_t*)o.new_sib, P.slice_lay, l, fmt, c->coop_max_events);
+        c->prof_end(pf, s);
+        if (pl) {
+            if (node_in) IMT_HIP(c, hipMemcpyAsync(pl, node_in, 32, hipMemcpyDeviceToDevice, s));
+            IMT_HIP(c, hipMemcpyAsync(pl + 32, node_out, 32, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    if (l + 1 == depth) {       // the last unit: roots of every event, the batch's root, done
+        if (L0 == depth && g_old) launch::convert(s, root_node, g_old, 1, IMT_FMT_DEVICE, fmt, c->d_err);
+        launch::emit_roots(s, P.d_val[depth & 1], 0, (uint32_t)E, (uint32_t)E, g_old, (uint8_t*)o.interim_root,
+                           (uint8_t*)o.new_root, fmt, nullptr, L0 == depth ? root_node : nullptr);
+        if (pl && L0 == depth) IMT_HIP(c, hipMemcpyAsync(pl + 64, root_node, 32, hipMemcpyDeviceToDevice, s));
+        IMT_HIP(c, hipMemcpyAsync(P.d_root, root_node, 32, hipMemcpyDeviceToDevice, s));
+        P.has_root = true;
+        IMT_HIP(c, hipEventRecord(P.done, s));
+        P.in_flight = true;
+        P.pipelined = true;         // not on the context's stream: join_top orders that stream behind it
+        t->pipe_pending = true;
+        P.open = false;
+    }
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_slice_apply(imt_itree* t, uint64_t size_before, size_t n, unsigned unit, const void* payload,
+                                     void* hip_stream) {
+    if (!t) return IMT_ERR_ARG;
+    imt_ctx* c = t->ctx;
+    if (!payload || n == 0) return c->fail(IMT_ERR_ARG, "null / empty payload");
+    if (unit > t->depth) return c->fail(IMT_ERR_RANGE, "unit %u beyond depth %u", unit, t->depth);
+    if (size_before + n > t->cap) return c->fail(IMT_ERR_RANGE, "slice outside the tree's capacity");
+    if (unit == 0) return IMT_OK;          // leaf hashes: nothing is stored yet
+    int rc = c->set_device();
+    if (rc) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const size_t E = 2 * n;
+    const unsigned depth = t->depth, l = unit - 1;
+    const unsigned L0 = std::min(ceil_log2(size_before + n), depth);
+    const uint8_t* pl = (const uint8_t*)payload;
+    if (l < L0) {
+        launch::writeback(s, pl + SLICE_HDR, (const uint32_t*)(pl + SLICE_HDR + E * 32), (const uint32_t*)(pl + SLICE_HDR + E * 36),
+                          t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
+    } else {
+        if (l == L0) IMT_HIP(c, hipMemcpyAsync(t->d_nodes + t->h_off[l] * 32, pl, 32, hipMemcpyDeviceToDevice, s));
+        IMT_HIP(c, hipMemcpyAsync(t->d_nodes + t->h_off[l + 1] * 32, pl + 32, 32, hipMemcpyDeviceToDevice, s));
+    }
+    if (l + 1 == depth && L0 == depth)
+        IMT_HIP(c, hipMemcpyAsync(t->d_nodes + t->h_off[depth] * 32, pl + 64, 32, hipMemcpyDeviceToDevice, s));
+    return IMT_OK;
+}
+
+extern "C" int imt_itree_slice_apply_gathered(imt_itree* t, const void* gathered, size_t stride, size_t count,
+                                              const uint64_t* size_before, const uint64_t* n, const int32_t* unit,
+                                              void* hip_stream) {
+    if (!t) return IMT_ERR_ARG;
+    if (!gathered || !size_before || !n || !unit) return t->ctx->fail(IMT_ERR_ARG, "null argument");
+    for (size_t r = 0; r < count; r++) {
+        if (unit[r] < 0) continue;
+        const int rc = imt_itree_slice_apply(t, size_before[r], (size_t)n[r], (unsigned)unit[r],
+                                             (const uint8_t*)gathered + r * stride, hip_stream);
+        if (rc) return rc;
+    }
     return IMT_OK;
 }
 

@@ -243,6 +243,24 @@ hipError_t run(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val
     return hipGetLastError();      // a failed launch anywhere in the sequence
 }
 
+hipError_t index_only(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val, const uint32_t* sorted_old,
+                      uint32_t* sorted_new, uint32_t M, uint32_t n) {
+    hipError_t e;
+    if (n > ws.cap_n || temp_bytes_needed(n, (size_t)M) > ws.tmp_bytes) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_scatter, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, M, n, ws.part_mod, ws.part_res, ws.iota,
+                       ws.err);
+    size_t tb = ws.tmp_bytes;
+    if ((e = rocprim::merge_sort(ws.tmp, tb, ws.iota, ws.bsorted, (size_t)n, ValLess{d_val}, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gap, dim3(nblk(n)), dim3(BLOCK), 0, s, d_val, sorted_old, M, ws.bsorted, n, ws.gap, ws.st,
+                       ws.err);
+    tb = ws.tmp_bytes;
+    if ((e = rocprim::merge(ws.tmp, tb, sorted_old, ws.bsorted, sorted_new, (size_t)M, (size_t)n, ValLess{d_val}, s)) !=
+        hipSuccess)
+        return e;
+    return hipGetLastError();
+}
+
 void nm_witness(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
                 uint64_t base, uint32_t part_mod, uint32_t part_res, uint64_t* low_index, uint8_t* low_leaf,
                 uint8_t* is_largest, int* err) {

@@ -64,6 +64,12 @@ hipError_t run(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val
                uint32_t* rs, uint32_t* re, uint64_t* o_low_index, uint8_t* o_is_largest, uint8_t* o_low_leaf,
                uint8_t* o_new_leaf);
 
+// The index part of run() alone -- values into rows [M, M+n) of d_val, the checks (non-canonical, zero, duplicate),
+// sorted_old[M] -> sorted_new[M+n] -- for values whose hashing is another GPU's share (imt_itree_slice_prepare): needs
+// only iota / bsorted / gap / st[n] / tmp / err of the workspace.
+hipError_t index_only(hipStream_t s, Workspace& ws, const uint8_t* vals, uint8_t* d_val, const uint32_t* sorted_old,
+                      uint32_t* sorted_new, uint32_t M, uint32_t n);
+
 // non-membership witness: low leaf index, its preimage {val, next_val, next_idx} (canonical) and the
 // is_largest flag of every candidate; any output may be NULL.  part_mod > 1: candidates with v % part_mod != part_res
 // belong to another subtree's list (ERR_FOREIGN)

@@ -218,7 +218,13 @@ def test_bench_gpus2_as_typed_rehearsal():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["collective_backend"] == "gloo"
     assert res["verified"] is True
-    assert res["config"]["hashes_per_insertion"] == 66 and res["config"]["subtree_height_per_gpu"] == 31
+    # both multi-GPU modes in one invocation; `value` is the reference's single list
+    assert res["value_is"].startswith("single-list") and res["config"]["hashes_per_insertion"] == 66
+    sl, st = res["modes"]["single_list"], res["modes"]["subtrees"]
+    assert sl["verified"] is True and st["verified"] is True and res["value"] == sl["value"]
+    assert sl["hashes_per_insertion"] == 66 and st["hashes_per_insertion"] == 66
+    assert sl["collectives_per_step"] > 30 and sl["bytes_gathered_per_step_per_rank"] > 0 and st["collectives_per_step"] == 1
+    assert sl["roofline"]["frac"] > 0 and st["roofline"]["frac"] > 0 and res["cpu_baseline"] is None
     assert res["value"] > 0 and res["steps"] == 2 and res["scaling"] == "weak"
     # --gpus that contradicts the launcher's world size is an error, not silently ignored
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
@@ -251,3 +257,6 @@ def test_bench_rccl_calls_with_one_rank():
     res = json.loads(lines[0])
     assert res["ranks_seen"] == 1 and res["collective_backend"] == "nccl"
     assert res["verified"] is True and res["value"] > 0
+    # the sliced single-list leg issued its all-gathers through RCCL (asynchronous, waited for on the round's stream)
+    assert res["modes"]["single_list"]["verified"] is True and res["modes"]["single_list"]["collectives_per_step"] >= 32
+    assert res["modes"]["subtrees"]["verified"] is True

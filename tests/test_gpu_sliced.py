@@ -1,0 +1,210 @@
+"""GPU (MI355X): the multi-GPU single-list mode (indexed-merkle-tree-halo2_amd/sliced.py over imt_itree_slice_*)
+against the ONE-GPU tree (imt_itree_insert_batch) on the same value sequence -- which is itself pinned to the CPU
+oracle's sequential update_idx_leaf + rebuild (/root/reference/src/indexed_merkle_tree.rs:632-671, :715-735) by
+tests/test_gpu_parity.py.  Bit-exact: every low index, preimage, flag, old / interim / new root and both proofs of
+every insertion, and the stored tree of every replica.
+
+ * LocalWorld: world = 1, 2, 4, 8 replicas in this process on the one GPU (device-to-device copies as the all-gather)
+ * two processes over gloo (host-staged all-gather): tests the torch.distributed transport with real kernels
+ * small depth where the tree fills up to its last level (l0 == depth), halo2curves' Montgomery format, refused values
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_lib  # noqa: E402
+from test_sliced_schedule import load_sliced  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("low_index", "low_leaf", "is_largest", "old_root", "interim_root", "new_root", "new_leaf", "low_sib", "new_sib")
+
+
+def reference_run(imt, ctx, depth, cap, vals, per_call):
+    """the one-GPU tree over the same sequence, `per_call` insertions per imt_itree_insert_batch"""
+    ref = imt.IndexedTree(ctx, depth, cap)
+    outs = [ref.insert_batch(vals[i:i + per_call]) for i in range(0, len(vals), per_call)]
+    root = ref.root()
+    ref.close()
+    return outs, root
+
+
+def check_round(want, got, lo, hi):
+    """want: one-GPU results of the whole step; got: a rank's witnesses of insertions [lo, hi) of that step"""
+    for k in FIELDS:
+        g = got[k].cpu().numpy()
+        w = np.asarray(want[k])
+        w = w[:, lo:hi] if k in ("low_sib", "new_sib") else w[lo:hi]
+        assert g.shape == w.shape, k
+        assert (g == w).all(), k
+
+
+@pytest.mark.parametrize("world,batch,rounds", [(1, 256, 6), (2, 256, 6), (4, 192, 6), (8, 64, 7), (2, 8192, 3)])
+def test_local_world_equals_one_gpu_tree(imt, ctx, world, batch, rounds):
+    sl = load_sliced()
+    depth, cap = 32, 1 << 17
+    vals = oracle_lib.synth_values(world * batch * rounds, 0x494D5431 + world)
+    want, want_root = reference_run(imt, ctx, depth, cap, vals, world * batch)
+    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch) for _ in range(world)]
+    w = sl.LocalWorld(bes)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    # witnesses must be read before their rotating buffer set is reused: check a round once it is `nbuf - 1` rounds old
+    checked = 0
+    for r in range(rounds):
+        step = arr[r * world * batch:(r + 1) * world * batch]
+        assert w.step([step] * world) == r
+        while checked <= r - 3:
+            for rk in w.ranks:
+                rk.done_event(checked).synchronize()
+                check_round(want[checked], rk.outputs(checked), rk.rank * batch, (rk.rank + 1) * batch)
+            checked += 1
+    w.flush()
+    while checked < rounds:
+        for rk in w.ranks:
+            check_round(want[checked], rk.outputs(checked), rk.rank * batch, (rk.rank + 1) * batch)
+        checked += 1
+    for be in bes:                       # every replica is the same tree
+        assert be.tree.root() == want_root
+        assert be.size() == 1 + world * batch * rounds
+    if world > 1:
+        assert w.tp.collectives > 0
+    # the replicas stay usable through the ordinary calls: a proof from replica 0 verifies against the root
+    idx = np.array([1, 5, world * batch * rounds], dtype=np.uint64)
+    sib = bes[0].tree.get_proof_batch(idx)
+    leaves = bes[-1].tree.get_leaves(idx)
+    h = ctx.hash3(leaves)
+    roots = ctx.path_root(h, idx, sib, depth)
+    assert all(int.from_bytes(bytes(x), "little") == want_root for x in roots)
+    for be in bes:
+        be.tree.close()
+        be.ctx.close()
+
+
+def test_local_world_fills_a_small_tree_to_its_last_level(imt, ctx):
+    """depth 8, 4 replicas: l0 reaches the depth (no empty-subtree levels left), the root travels in the payload"""
+    sl = load_sliced()
+    depth, cap, world, batch = 8, 256, 4, 15
+    rounds = 4                               # 1 + 240 leaves of 256
+    vals = oracle_lib.synth_values(world * batch * rounds, 0x494D5441)
+    want, want_root = reference_run(imt, ctx, depth, cap, vals, world * batch)
+    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch) for _ in range(world)]
+    w = sl.LocalWorld(bes)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    for r in range(rounds):
+        w.step([arr[r * world * batch:(r + 1) * world * batch]] * world)
+    w.flush()
+    for r in range(rounds):
+        for rk in w.ranks:
+            check_round(want[r], rk.outputs(r), rk.rank * batch, (rk.rank + 1) * batch)
+    assert all(be.tree.root() == want_root for be in bes)
+    # the oracle's sequential insertion agrees on the final root (depth 8 is cheap on the CPU)
+    orc = oracle_lib.load()
+    h = orc.sparse_new(depth, cap)
+    for v in vals:
+        assert orc.sparse_insert(h, depth, v)["rc"] == 0
+    assert orc.sparse_root(h) == want_root
+    orc.sparse_free(h)
+    for be in bes:
+        be.tree.close()
+        be.ctx.close()
+
+
+def test_local_world_montgomery_format_and_refused_values(imt, ctx):
+    sl = load_sliced()
+    depth, cap, world, batch = 32, 1 << 12, 2, 128
+    vals = oracle_lib.synth_values(world * batch * 2, 0x494D5451)
+    F = imt._ffi
+    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch, fmt=F.FMT_MONT256) for _ in range(world)]
+    w = sl.LocalWorld(bes)
+    R = 1 << 256
+    mont = torch.from_numpy(oracle_lib.ints_to_arr([v * R % oracle_lib.P for v in vals])).cuda()
+    w.step([mont[:world * batch]] * world)
+    # a step with a duplicate (of a stored value, in the second rank's slice) is refused by EVERY rank, nothing changes
+    bad = mont[world * batch:].clone()
+    bad[batch + 3] = mont[5]
+    for rk in w.ranks:
+        with pytest.raises(ValueError):
+            rk._start_round(bad)
+        assert rk.be.size() == 1 + world * batch
+    w.step([mont[world * batch:]] * world)
+    w.flush()
+    ref = imt.IndexedTree(ctx, depth, cap)
+    for r in range(2):
+        want = ref.insert_batch(vals[r * world * batch:(r + 1) * world * batch])
+        for rk in w.ranks:
+            got = rk.outputs(r)
+            lo, hi = rk.rank * batch, (rk.rank + 1) * batch
+            for k in ("old_root", "interim_root", "new_root"):
+                g = [int.from_bytes(bytes(x), "little") for x in got[k].cpu().numpy()]
+                assert g == [int.from_bytes(bytes(x), "little") * R % oracle_lib.P for x in want[k][lo:hi]], k
+            assert (got["low_index"].cpu().numpy() == want["low_index"][lo:hi]).all()
+            g = [int.from_bytes(bytes(x), "little") for x in got["low_sib"].cpu().numpy()[:, 7]]
+            assert g == [int.from_bytes(bytes(x), "little") * R % oracle_lib.P for x in want["low_sib"][:, lo + 7]]
+    assert all(be.tree.root() == ref.root() for be in bes)
+    ref.close()
+    for be in bes:
+        be.tree.close()
+        be.ctx.close()
+
+
+# ---------------------------------------------------------------- two processes, gloo
+P_DEPTH, P_BATCH, P_ROUNDS = 32, 384, 5
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import imt_amd
+    sl = load_sliced()
+    be = sl.SliceGpuBackend(imt_amd, 0, P_DEPTH, 1 << 13, P_BATCH)
+    tree = sl.SlicedIndexedTree(be, world, rank, sl.DistTransport(dist, via_host=True))
+    vals = oracle_lib.synth_values(world * P_BATCH * P_ROUNDS, 0x494D5461)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    res = []
+    for r in range(P_ROUNDS):
+        tree.step(arr[r * world * P_BATCH:(r + 1) * world * P_BATCH])
+        if r >= 3:                      # read a finished round while later ones are in flight
+            tree.done_event(r - 3).synchronize()
+            res.append({k: v.cpu().numpy().copy() for k, v in tree.outputs(r - 3).items() if torch.is_tensor(v)})
+    tree.flush()
+    for r in range(max(0, P_ROUNDS - 3), P_ROUNDS):
+        res.append({k: v.cpu().numpy().copy() for k, v in tree.outputs(r).items() if torch.is_tensor(v)})
+    q.put((rank, res, be.tree.root(), tree.tp.collectives, tree.tp.bytes_moved))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_over_gloo_equal_one_gpu_tree(imt, ctx):
+    world = 2
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [mpctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    vals = oracle_lib.synth_values(world * P_BATCH * P_ROUNDS, 0x494D5461)
+    want, want_root = reference_run(imt, ctx, P_DEPTH, 1 << 13, vals, world * P_BATCH)
+    for rank, res, root, ncoll, nbytes in got:
+        assert root == want_root
+        assert ncoll > 0 and nbytes > 0
+        for r in range(P_ROUNDS):
+            for k in FIELDS:
+                w = np.asarray(want[r][k])
+                w = w[:, rank * P_BATCH:(rank + 1) * P_BATCH] if k.endswith("_sib") else w[rank * P_BATCH:(rank + 1) * P_BATCH]
+                assert (res[r][k] == w).all(), (rank, r, k)

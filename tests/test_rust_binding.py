@@ -21,7 +21,7 @@ def c_class(t):
     base = t.rsplit(" ", 1)[0] if " " in t else t           # drop the parameter name
     base = base.replace("const ", "").strip()
     return {"int": "i32", "unsigned": "u32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64",
-            "void": "void", "uint8_t": "u8"}[base]
+            "void": "void", "uint8_t": "u8", "int32_t": "i32"}[base]
 
 
 def rust_class(t):
