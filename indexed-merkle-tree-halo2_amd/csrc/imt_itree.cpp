@@ -146,6 +146,7 @@ struct imt_itree {
     prep::Workspace fws;
     uint8_t* d_canon_all = nullptr;
     size_t canon_all_cap = 0;
+    uint32_t* d_sorted_extra = nullptr;      // third index buffer: a step's up to three merges never write the committed one
 };
 
 static void plan_free(PlanSet& p) {
@@ -261,7 +262,7 @@ extern "C" void imt_itree_free(imt_itree* t) {
         if (q) hipFree(q);
     if (t->h_err_pin) hipHostFree(t->h_err_pin);
     for (void* q : {(void*)t->fws.iota, (void*)t->fws.bsorted, (void*)t->fws.gap, (void*)t->fws.st, t->fws.tmp,
-                    (void*)t->d_canon_all})
+                    (void*)t->d_canon_all, (void*)t->d_sorted_extra})
         if (q) hipFree(q);
     delete t;
 }
@@ -1534,29 +1535,38 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
         launch::convert(ps, d_vals, t->d_canon_all, n_all, fmt, IMT_FMT_CANONICAL, P.ws.err);
         d_vals = t->d_canon_all;
     }
-    // ---- the index, in the order of the step: the slices before this one, this one (with its events), those after ----
-    int cur = t->sorted_cur;
+    // ---- the index, in the order of the step: the slices before this one, this one (with its events), those after.
+    // Up to three merges, none of which may write the committed index (a refused step leaves the tree as it was): they
+    // go committed -> ... -> spare, through a third buffer when there are two or three of them.
+    if (!t->d_sorted_extra) IMT_HIP(c, hipMalloc((void**)&t->d_sorted_extra, t->cap * 4));
+    const int n_merges = 1 + (n_before ? 1 : 0) + (n_after ? 1 : 0);
+    uint32_t* const committed = t->d_sorted[t->sorted_cur];
+    uint32_t* const spare = t->d_sorted[t->sorted_cur ^ 1];
+    uint32_t* chain[4] = {committed, spare, spare, spare};
+    if (n_merges == 2) chain[1] = t->d_sorted_extra;
+    if (n_merges == 3) chain[2] = t->d_sorted_extra;
+    int link = 0;
     uint64_t M = M0;
     t->fws.err = P.ws.err;
     t->fws.part_mod = t->fws.part_res = 0;
     P.ws.part_mod = P.ws.part_res = 0;
     if (n_before) {
-        IMT_HIP(c, prep::index_only(ps, t->fws, d_vals, t->d_val, t->d_sorted[cur], t->d_sorted[cur ^ 1], (uint32_t)M,
+        IMT_HIP(c, prep::index_only(ps, t->fws, d_vals, t->d_val, chain[link], chain[link + 1], (uint32_t)M,
                                     (uint32_t)n_before));
-        cur ^= 1;
+        link++;
         M += n_before;
     }
     const uint64_t M_own = M;
-    IMT_HIP(c, prep::run(ps, P.ws, d_vals + n_before * 32, t->d_val, t->d_sorted[cur], t->d_sorted[cur ^ 1], (uint32_t)M,
+    IMT_HIP(c, prep::run(ps, P.ws, d_vals + n_before * 32, t->d_val, chain[link], chain[link + 1], (uint32_t)M,
                          (uint32_t)n_own, 0, P.d_pre, P.d_tab[0][0], P.d_tab[0][1], P.d_tab[0][2], P.d_tab[0][3],
                          out ? out->low_index : nullptr, out ? out->is_largest : nullptr,
                          out ? (uint8_t*)out->low_leaf : nullptr, out ? (uint8_t*)out->new_leaf : nullptr));
-    cur ^= 1;
+    link++;
     M += n_own;
     if (n_after) {
-        IMT_HIP(c, prep::index_only(ps, t->fws, d_vals + (n_before + n_own) * 32, t->d_val, t->d_sorted[cur],
-                                    t->d_sorted[cur ^ 1], (uint32_t)M, (uint32_t)n_after));
-        cur ^= 1;
+        IMT_HIP(c, prep::index_only(ps, t->fws, d_vals + (n_before + n_own) * 32, t->d_val, chain[link], chain[link + 1],
+                                    (uint32_t)M, (uint32_t)n_after));
+        link++;
     }
     IMT_HIP(c, hipMemcpyAsync(t->h_err_pin, P.ws.err, sizeof(int), hipMemcpyDeviceToHost, ps));
     // ---- this slice's index phase (no hashing) on the side stream as well ----
@@ -1582,7 +1592,7 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
     if (perr & prep::ERR_ZERO) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
     if (perr & prep::ERR_DUPLICATE) return c->fail(IMT_ERR_VALUE, "duplicate value (inside the step or already in the tree)");
     // ---- commit the index; the hashing follows unit by unit ----
-    t->sorted_cur = cur;
+    t->sorted_cur ^= 1;          // chain[n_merges] == spare
     t->size = M0 + n_all;
     t->mirror_valid = false;
     P.open = true;

@@ -73,10 +73,18 @@ class SliceSchedule:
     def has_gather(self, rt):
         return rt < self.gathers and any(q >= 0 for q in self.payload_units(rt))
 
-    def active_rounds(self, T, rounds_started):
-        """rounds with work at global tick T, oldest first"""
-        lo = max(0, (T - self.round_ticks) // self.period)
-        return [R for R in range(lo, rounds_started) if 0 <= T - R * self.period < self.round_ticks]
+    def next_start(self, starts, T):
+        """global tick at which the next round starts: one period after the previous one, or now if the schedule has
+        run dry in between (flush)"""
+        return T if not starts else max(T, starts[-1] + self.period)
+
+    def active_rounds(self, T, starts):
+        """[(round, round tick)] with work at global tick T, oldest first; starts[R] = global tick of round R's tick 0"""
+        out = []
+        for R in range(max(0, len(starts) - self.STREAMS), len(starts)):
+            if 0 <= T - starts[R] < self.round_ticks:
+                out.append((R, T - starts[R]))
+        return out
 
 
 class SliceGpuBackend:
@@ -193,6 +201,7 @@ class SlicedIndexedTree:
         self.tick_ev = [[backend.new_event() for _ in range(self.sched.round_ticks)] for _ in range(S)]
         self.done_ev = [backend.new_event() for _ in range(S)]
         self.rounds = []                 # per round: dict(slice=.., out_slot=.., size_before=.., n=..)
+        self.starts = []                 # global tick of every round's tick 0 (the same on every rank)
         self.T = 0                       # next global tick to issue
 
     # ---- the three phases of (round R, round tick rt) ----
@@ -256,13 +265,13 @@ class SlicedIndexedTree:
         out_slot = R % len(self.be.sets)
         sl = self.be.prepare(vals, self.rank * b, b, (self.world - 1 - self.rank) * b, out_slot)
         self.rounds.append(dict(slice=sl, out_slot=out_slot, size_before=size_before, n=b))
+        self.starts.append(self.sched.next_start(self.starts, self.T))
         return R
 
     def _run_ticks(self, upto):
         sc = self.sched
         while self.T < upto:
-            for R in sc.active_rounds(self.T, len(self.rounds)):
-                rt = self.T - R * sc.period
+            for R, rt in sc.active_rounds(self.T, self.starts):
                 self.phase_apply(R, rt)
                 self.phase_compute(R, rt)
                 self.phase_send(R, rt)
@@ -270,12 +279,13 @@ class SlicedIndexedTree:
 
     def step(self, vals):
         R = self._start_round(vals)
-        self._run_ticks((R + 1) * self.sched.period)
+        self._run_ticks(self.starts[R] + self.sched.period)
         return R
 
     def flush(self):
+        """issue everything that is left of the rounds in flight and wait for it"""
         if self.rounds:
-            self._run_ticks((len(self.rounds) - 1) * self.sched.period + self.sched.round_ticks)
+            self._run_ticks(self.starts[-1] + self.sched.round_ticks)
         self.be.sync()
 
     def outputs(self, R):
@@ -332,8 +342,7 @@ class LocalWorld:
     def _run_ticks(self, upto):
         sc = self.sched
         while self.T < upto:
-            for R in sc.active_rounds(self.T, len(self.ranks[0].rounds)):
-                rt = self.T - R * sc.period
+            for R, rt in sc.active_rounds(self.T, self.ranks[0].starts):
                 slot, ring = R % sc.STREAMS, rt % self.ranks[0].ring
                 for rk in self.ranks:
                     rk.phase_apply(R, rt)
@@ -349,13 +358,13 @@ class LocalWorld:
         """vals_per_rank: the step's values, one copy per rank (each on that rank's device)"""
         R = None
         for rk, v in zip(self.ranks, vals_per_rank):
+            rk.T = self.T
             R = rk._start_round(v)
-        self._run_ticks((R + 1) * self.sched.period)
+        self._run_ticks(self.ranks[0].starts[R] + self.sched.period)
         return R
 
     def flush(self):
-        n = len(self.ranks[0].rounds)
-        if n:
-            self._run_ticks((n - 1) * self.sched.period + self.sched.round_ticks)
+        if self.ranks[0].rounds:
+            self._run_ticks(self.ranks[0].starts[-1] + self.sched.round_ticks)
         for rk in self.ranks:
             rk.be.sync()

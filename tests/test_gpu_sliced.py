@@ -61,6 +61,8 @@ def test_local_world_equals_one_gpu_tree(imt, ctx, world, batch, rounds):
     for r in range(rounds):
         step = arr[r * world * batch:(r + 1) * world * batch]
         assert w.step([step] * world) == r
+        if r == 2 and world != 4:
+            w.flush()                    # run the schedule dry in the middle and go on (bench.py after its warm-up)
         while checked <= r - 3:
             for rk in w.ranks:
                 rk.done_event(checked).synchronize()

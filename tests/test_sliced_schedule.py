@@ -68,6 +68,8 @@ def test_every_level_sees_exactly_the_earlier_slices(world, depth, lag):
             assert w.step([FakeVals(4 * world)] * world) == r
             if seed % 2 and r == 3:
                 sim.run()                    # a caller that synchronises in the middle
+            if seed % 4 == 2 and r in (1, 4):
+                w.flush()                    # ... or runs the schedule dry and goes on (bench.py: warm-up, then the timed region)
         w.flush()
         for be in bes:
             assert sorted(be.computed) == [(r * world + be.rank, q) for r in range(rounds) for q in range(depth + 1)]
@@ -92,6 +94,8 @@ def _worker(rank, world, port, depth, lag, q):
     rounds = 6
     for r in range(rounds):
         assert tree.step(FakeVals(4 * world)) == r
+        if r == 2:
+            tree.flush()
     tree.flush()
     ok = (sorted(be.computed) == [(r * world + rank, u) for r in range(rounds) for u in range(depth + 1)]
           and all(lvl == list(range(rounds * world)) for lvl in be.levels))
