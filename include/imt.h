@@ -176,7 +176,9 @@ int imt_hash_trace_batch(imt_ctx *ctx, const void *in /*[n][arity][32]*/, int ar
 /* The traces of ALL hashes of compute_merkle_root (src/indexed_merkle_tree.rs:78-96) for n paths: the leaf hash
  * (3 inputs; only when leaf3 is given instead of leaf) followed by the `depth` path hashes bottom-up, each with the
  * (left, right) inputs dual_mux selects.  trace = the blocks one after the other, [1209][n] (if leaf3) then depth x
- * [1208][n]; item-major: [n][1209 + depth * 1208].  root_out (optional) = the recomputed roots. */
+ * [1208][n]; item-major: [n][1209 + depth * 1208] (IMT_TRACE_ITEM_MAJOR is the same bit as IMT_SIB_ITEM_MAJOR: the siblings
+ * are then read item-major too, sib[item][level] -- the reference's per-proof Vec<F> -- exactly as in
+ * imt_insert_trace_batch).  root_out (optional) = the recomputed roots. */
 int imt_path_trace_batch(imt_ctx *ctx, const void *leaf /*[n][32] or NULL*/, const void *leaf3 /*[n][3][32] or NULL*/,
                          const uint64_t *index /*[n]*/, const void *sib, unsigned depth, size_t n, void *trace,
                          void *root_out /*[n][32] or NULL*/, unsigned flags);

@@ -156,7 +156,8 @@ class Context:
 
     def path_trace(self, index, sib, depth, leaf=None, leaf3=None, fmt=0, item_major=False):
         """Traces of every hash of compute_merkle_root for n paths (imt_path_trace_batch); returns (trace, roots).
-        trace: uint8 [total_rows, n, 32] (blocks: leaf hash if leaf3, then the levels) or item-major [n, total_rows, 32]."""
+        trace: uint8 [total_rows, n, 32] (blocks: leaf hash if leaf3, then the levels) or item-major [n, total_rows, 32]
+        (siblings then item-major too: sib[item][level])."""
         src = _arr(leaf3, (3, 32)) if leaf3 is not None else _arr(leaf, (32,))
         n = src.shape[0]
         idx = np.ascontiguousarray(index, dtype=np.uint64)

@@ -258,6 +258,15 @@ struct Io {
         outs.push_back({p, (const uint8_t*)d, bytes});
         return (uint8_t*)d;
     }
+    // field-element buffers: the kernels move an element as two 16-byte words, so a DEVICE pointer the caller hands
+    // over must be 16-byte aligned (include/imt.h); a misaligned one is an argument error here, not a GPU fault there
+    bool aligned(const void* p) {
+        if (!dev || !p || ((uintptr_t)p & 15u) == 0) return true;
+        rc = c->fail(IMT_ERR_ARG, "device pointer %p to field elements is not 16-byte aligned", p);
+        return false;
+    }
+    const uint8_t* in_fe(const void* p, size_t bytes) { return (rc || !bytes || aligned(p)) ? in(p, bytes) : nullptr; }
+    uint8_t* out_fe(void* p, size_t bytes) { return (rc || !bytes || aligned(p)) ? out(p, bytes) : nullptr; }
     uint8_t* temp(size_t bytes) {
         if (rc) return nullptr;
         void* d = c->dev_scratch(next_slot++, bytes ? bytes : 1);
@@ -301,8 +310,8 @@ static int hash_n(imt_ctx* c, const void* in, void* out, size_t n, int arity, un
     if (n == 0) return IMT_OK;
     if (!in || !out) return c->fail(IMT_ERR_ARG, "null buffer");
     Io io(c, flags);
-    const uint8_t* d_in = io.in(in, n * 32 * (size_t)arity);
-    uint8_t* d_out = io.out(out, n * 32);
+    const uint8_t* d_in = io.in_fe(in, n * 32 * (size_t)arity);
+    uint8_t* d_out = io.out_fe(out, n * 32);
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     launch::hash_batch(c->stream, d_in, d_out, n, arity, fmt, fmt, c->d_err, c->coop_max_events);
@@ -320,8 +329,8 @@ extern "C" int imt_permute_batch(imt_ctx* c, const void* in, void* out, size_t n
     if (n == 0) return IMT_OK;
     if (!in || !out) return c->fail(IMT_ERR_ARG, "null buffer");
     Io io(c, flags);
-    const uint8_t* d_in = io.in(in, n * 96);
-    uint8_t* d_out = io.out(out, n * 96);
+    const uint8_t* d_in = io.in_fe(in, n * 96);
+    uint8_t* d_out = io.out_fe(out, n * 96);
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     launch::permute_batch(c->stream, d_in, d_out, n, fmt, fmt, c->d_err);
@@ -339,8 +348,8 @@ extern "C" int imt_hash_trace_batch(imt_ctx* c, const void* in, int arity, size_
     if (n == 0) return IMT_OK;
     if (!in || !trace) return c->fail(IMT_ERR_ARG, "null buffer");
     Io io(c, flags);
-    const uint8_t* d_in = io.in(in, n * 32 * (size_t)arity);
-    uint8_t* d_tr = io.out(trace, n * rows * 32);
+    const uint8_t* d_in = io.in_fe(in, n * 32 * (size_t)arity);
+    uint8_t* d_tr = io.out_fe(trace, n * rows * 32);
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     const bool item_major = flags & IMT_TRACE_ITEM_MAJOR;
@@ -376,12 +385,12 @@ extern "C" int imt_path_trace_batch(imt_ctx* c, const void* leaf, const void* le
     if (!index || !trace || (depth && !sib)) return c->fail(IMT_ERR_ARG, "null buffer");
     const size_t rows_total = (leaf3 ? (size_t)dev::TRACE_ROWS_H3 : 0) + (size_t)depth * dev::TRACE_ROWS_H2;
     Io io(c, flags);
-    const uint8_t* d_leaf = leaf ? io.in(leaf, n * 32) : nullptr;
-    const uint8_t* d_leaf3 = leaf3 ? io.in(leaf3, n * 96) : nullptr;
+    const uint8_t* d_leaf = leaf ? io.in_fe(leaf, n * 32) : nullptr;
+    const uint8_t* d_leaf3 = leaf3 ? io.in_fe(leaf3, n * 96) : nullptr;
     const uint64_t* d_idx = (const uint64_t*)io.in(index, n * 8);
-    const uint8_t* d_sib = io.in(sib, (size_t)depth * n * 32);
-    uint8_t* d_tr = io.out(trace, n * rows_total * 32);
-    uint8_t* d_root = io.out(root_out, n * 32);
+    const uint8_t* d_sib = io.in_fe(sib, (size_t)depth * n * 32);
+    uint8_t* d_tr = io.out_fe(trace, n * rows_total * 32);
+    uint8_t* d_root = io.out_fe(root_out, n * 32);
     uint8_t* pairs = io.temp((size_t)depth * n * 64);
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
@@ -389,7 +398,7 @@ extern "C" int imt_path_trace_batch(imt_ctx* c, const void* leaf, const void* le
     launch::PathChains pc{};
     pc.c[0] = {d_leaf, d_leaf3, d_idx, d_sib, pairs, d_root};
     pc.n_chains = 1;
-    pc.lay = sib_layout(flags & ~IMT_TRACE_ITEM_MAJOR, depth, n);
+    pc.lay = sib_layout(flags, depth, n);     // IMT_TRACE_ITEM_MAJOR is IMT_SIB_ITEM_MAJOR: siblings item-major too, as in imt_insert_trace_batch
     pc.depth = depth; pc.n = n; pc.fmt_in = fmt; pc.fmt_out = fmt; pc.err = c->d_err;
     launch::path_pairs(c->stream, pc, c->coop_max_events);
     size_t row0 = 0;
@@ -416,14 +425,14 @@ extern "C" int imt_insert_trace_batch(imt_ctx* c, const void* low_leaf, const ui
         return c->fail(IMT_ERR_ARG, "null buffer");
     const size_t rows_total = imt_insert_trace_rows(depth);
     Io io(c, flags);
-    const uint8_t* d_ll = io.in(low_leaf, n * 96);
+    const uint8_t* d_ll = io.in_fe(low_leaf, n * 96);
     const uint64_t* d_li = (const uint64_t*)io.in(low_index, n * 8);
-    const uint8_t* d_ls = io.in(low_sib, (size_t)depth * n * 32);
-    const uint8_t* d_nl = io.in(new_leaf, n * 96);
+    const uint8_t* d_ls = io.in_fe(low_sib, (size_t)depth * n * 32);
+    const uint8_t* d_nl = io.in_fe(new_leaf, n * 96);
     const uint64_t* d_ni = (const uint64_t*)io.in(new_index, n * 8);
     const uint64_t* d_np = new_path_index ? (const uint64_t*)io.in(new_path_index, n * 8) : d_ni;
-    const uint8_t* d_ns = io.in(new_sib, (size_t)depth * n * 32);
-    uint8_t* d_tr = io.out(trace, n * rows_total * 32);
+    const uint8_t* d_ns = io.in_fe(new_sib, (size_t)depth * n * 32);
+    uint8_t* d_tr = io.out_fe(trace, n * rows_total * 32);
     uint8_t* pairs = io.temp(4 * (size_t)depth * n * 64);
     uint8_t* tmp3 = io.temp(n * 96);      // the rewritten low leaf {low.val, new.val, new_index}   :265-269
     uint8_t* tmpz = io.temp(n * 32);      // the zero-leaf hash per item                            :247-251
@@ -501,7 +510,7 @@ extern "C" int imt_tree_new(imt_ctx* c, const void* leaves, size_t n, unsigned f
         return c->hip_fail(e, "hipMemcpyAsync(tree offsets)");
     }
     Io io(c, flags);
-    const uint8_t* d_in = io.in(leaves, n * 32);
+    const uint8_t* d_in = io.in_fe(leaves, n * 32);
     if (io.rc) { imt_tree_free(t); return io.rc; }
     launch::convert(c->stream, d_in, t->d_nodes, n, flags & IMT_FMT_MASK, IMT_FMT_DEVICE, c->d_err);
     for (size_t l = 1; l < nl; l++)   // while current_level.len() > 1 (src/utils.rs:41-51)
@@ -525,7 +534,7 @@ extern "C" int imt_tree_get_level(imt_tree* t, size_t level, void* out, size_t* 
     if (rc) return rc;
     Io io(c, flags);
     const size_t n = t->h_len[level];
-    uint8_t* d = io.out(out, n * 32);
+    uint8_t* d = io.out_fe(out, n * 32);
     if (io.rc) return io.rc;
     launch::convert(c->stream, t->d_nodes + t->h_off[level] * 32, d, n, IMT_FMT_DEVICE, flags & IMT_FMT_MASK, c->d_err);
     return io.finish();
@@ -549,7 +558,7 @@ extern "C" int imt_tree_get_proof_batch(imt_tree* t, const uint64_t* index, size
             if (index[i] >= t->n_leaves) return c->fail(IMT_ERR_RANGE, "leaf index %llu out of range", (unsigned long long)index[i]);
     Io io(c, flags);
     const uint64_t* d_idx = (const uint64_t*)io.in(index, n * 8);
-    uint8_t* d_out = io.out(proof, (size_t)depth * n * 32);
+    uint8_t* d_out = io.out_fe(proof, (size_t)depth * n * 32);
     if (io.rc) return io.rc;
     launch::TreeView tv{t->d_nodes, t->d_off, t->d_len, c->d_zero};
     launch::gather_proof(c->stream, tv, d_idx, n, depth, d_out, sib_layout(flags, depth, n), flags & IMT_FMT_MASK);
@@ -567,7 +576,7 @@ extern "C" int imt_tree_get_proof(imt_tree* t, size_t index, void* proof, void* 
     const unsigned depth = (unsigned)(t->n_levels - 1);
     if (!depth) return IMT_OK;
     Io io(c, flags);
-    uint8_t* d = io.out(helper, (size_t)depth * 32);
+    uint8_t* d = io.out_fe(helper, (size_t)depth * 32);
     if (io.rc) return io.rc;
     launch::write_helpers(c->stream, index, depth, d, flags & IMT_FMT_MASK);
     return io.finish();
@@ -598,12 +607,12 @@ static int path_common(imt_ctx* c, const void* leaf, const uint64_t* index, bool
     if (n == 0) return IMT_OK;
     if (!leaf || !index || (depth && !sib)) return c->fail(IMT_ERR_ARG, "null buffer");
     Io io(c, flags);
-    const uint8_t* d_leaf = io.in(leaf, n * 32);
+    const uint8_t* d_leaf = io.in_fe(leaf, n * 32);
     const uint64_t* d_idx = (const uint64_t*)io.in(index, n * 8);
-    const uint8_t* d_sib = io.in(sib, (size_t)depth * n * 32);
+    const uint8_t* d_sib = io.in_fe(sib, (size_t)depth * n * 32);
     const unsigned rstride = (flags & IMT_ROOT_PER_ITEM) ? 32 : 0;
-    const uint8_t* d_root = ok_out ? io.in(root, rstride ? n * 32 : 32) : nullptr;
-    uint8_t* d_out = io.out(root_out, n * 32);
+    const uint8_t* d_root = ok_out ? io.in_fe(root, rstride ? n * 32 : 32) : nullptr;
+    uint8_t* d_out = io.out_fe(root_out, n * 32);
     uint8_t* d_ok = io.out(ok_out, n);
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
@@ -643,14 +652,14 @@ extern "C" int imt_non_membership_batch(imt_ctx* c, const void* root, const void
         return c->fail(IMT_ERR_ARG, "null buffer");
     Io io(c, flags);
     const unsigned rstride = (flags & IMT_ROOT_PER_ITEM) ? 32 : 0;
-    const uint8_t* d_root = io.in(root, rstride ? n * 32 : 32);
-    const uint8_t* d_low = io.in(low_leaf, n * 96);
+    const uint8_t* d_root = io.in_fe(root, rstride ? n * 32 : 32);
+    const uint8_t* d_low = io.in_fe(low_leaf, n * 96);
     const uint64_t* d_idx = (const uint64_t*)io.in(low_index, n * 8);
-    const uint8_t* d_sib = io.in(low_sib, (size_t)depth * n * 32);
-    const uint8_t* d_nv = io.in(new_val, n * 32);
+    const uint8_t* d_sib = io.in_fe(low_sib, (size_t)depth * n * 32);
+    const uint8_t* d_nv = io.in_fe(new_val, n * 32);
     const uint8_t* d_lg = io.in(is_largest, n);
     uint8_t* d_fail = io.out(fail_out, n);
-    uint8_t* d_rout = io.out(root_out, n * 32);
+    uint8_t* d_rout = io.out_fe(root_out, n * 32);
     if (io.rc) return io.rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     launch::non_membership(c->stream, d_root, rstride, d_low, d_idx, d_sib, sib_layout(flags, depth, n), depth, d_nv,
@@ -664,9 +673,9 @@ extern "C" int imt_split128_batch(imt_ctx* c, const void* vals, void* q, void* r
     if (n == 0) return IMT_OK;
     if (!vals || !q || !r) return c->fail(IMT_ERR_ARG, "null buffer");
     Io io(c, flags);
-    const uint8_t* d_in = io.in(vals, n * 32);
-    uint8_t* d_q = io.out(q, n * 32);
-    uint8_t* d_r = io.out(r, n * 32);
+    const uint8_t* d_in = io.in_fe(vals, n * 32);
+    uint8_t* d_q = io.out_fe(q, n * 32);
+    uint8_t* d_r = io.out_fe(r, n * 32);
     if (io.rc) return io.rc;
     launch::split128(c->stream, d_in, d_q, d_r, n, flags & IMT_FMT_MASK, c->d_err);
     return io.finish();
@@ -689,19 +698,19 @@ extern "C" int imt_insert_witness_batch(imt_ctx* c, const void* old_root, const 
         (depth && (!low_sib || !new_sib)))
         return c->fail(IMT_ERR_ARG, "null buffer");
     Io io(c, flags);
-    const uint8_t* d_or = io.in(old_root, n * 32);
-    const uint8_t* d_ll = io.in(low_leaf, n * 96);
+    const uint8_t* d_or = io.in_fe(old_root, n * 32);
+    const uint8_t* d_ll = io.in_fe(low_leaf, n * 96);
     const uint64_t* d_li = (const uint64_t*)io.in(low_index, n * 8);
-    const uint8_t* d_ls = io.in(low_sib, (size_t)depth * n * 32);
-    const uint8_t* d_nr = io.in(new_root, n * 32);
-    const uint8_t* d_nl = io.in(new_leaf, n * 96);
+    const uint8_t* d_ls = io.in_fe(low_sib, (size_t)depth * n * 32);
+    const uint8_t* d_nr = io.in_fe(new_root, n * 32);
+    const uint8_t* d_nl = io.in_fe(new_leaf, n * 96);
     const uint64_t* d_ni = (const uint64_t*)io.in(new_index, n * 8);
     const uint64_t* d_np = new_path_index ? (const uint64_t*)io.in(new_path_index, n * 8) : d_ni;
-    const uint8_t* d_ns = io.in(new_sib, (size_t)depth * n * 32);
+    const uint8_t* d_ns = io.in_fe(new_sib, (size_t)depth * n * 32);
     const uint8_t* d_lg = io.in(is_largest, n);
     uint8_t* d_fail = io.out(fail_out, n);
     const unsigned fmt = flags & IMT_FMT_MASK;
-    uint8_t* d_trace_user = io.out(trace_out, 7 * n * 32);
+    uint8_t* d_trace_user = io.out_fe(trace_out, 7 * n * 32);
     uint8_t* d_trace = (d_trace_user && fmt == IMT_FMT_DEVICE) ? d_trace_user : io.temp(7 * n * 32);
     if (io.rc) return io.rc;
     launch::insert_witness(c->stream, d_or, d_ll, d_li, d_ls, d_nr, d_nl, d_ni, d_np, d_ns, sib_layout(flags, depth, n),
@@ -720,7 +729,7 @@ extern "C" int imt_zero_hashes(imt_ctx* c, unsigned depth, void* out, unsigned f
     if (depth > IMT_MAX_DEPTH) return c->fail(IMT_ERR_RANGE, "depth %u > %d", depth, IMT_MAX_DEPTH);
     if (!out) return c->fail(IMT_ERR_ARG, "null buffer");
     Io io(c, flags);
-    uint8_t* d = io.out(out, (size_t)(depth + 1) * 32);
+    uint8_t* d = io.out_fe(out, (size_t)(depth + 1) * 32);
     if (io.rc) return io.rc;
     launch::convert(c->stream, c->d_zero, d, depth + 1, IMT_FMT_DEVICE, flags & IMT_FMT_MASK, c->d_err);
     return io.finish();
@@ -736,8 +745,8 @@ extern "C" int imt_combine_subtree_roots(imt_ctx* c, const void* sub_roots, size
     while (((size_t)1 << k) < n_roots) k++;
     if (depth > IMT_MAX_DEPTH || sub_height + k > depth) return c->fail(IMT_ERR_RANGE, "sub_height + log2(n_roots) > depth");
     Io io(c, flags);
-    const uint8_t* d_in = io.in(sub_roots, n_roots * 32);
-    uint8_t* d_out = io.out(root, 32);
+    const uint8_t* d_in = io.in_fe(sub_roots, n_roots * 32);
+    uint8_t* d_out = io.out_fe(root, 32);
     uint8_t* a = io.temp(n_roots * 32);
     uint8_t* b = io.temp(n_roots * 32);
     if (io.rc) return io.rc;

@@ -14,7 +14,9 @@
 #include <array>
 #include <chrono>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
+#include <initializer_list>
 #include <new>
 #include <numeric>
 
@@ -45,6 +47,19 @@ inline void put_pre(uint8_t* dst, const U256& val, const U256& next_val, uint64_
     std::memcpy(dst + 32, next_val.data(), 32);
     std::memset(dst + 64, 0, 32);
     std::memcpy(dst + 64, &next_idx, 8);
+}
+
+// include/imt.h: every field-element row a DEVICE pointer refers to must be 16-byte aligned (the kernels move an
+// element as two 16-byte words).  A misaligned one is refused here as an argument error instead of faulting there.
+int check_fe_ptrs(imt_ctx* c, bool dev, std::initializer_list<const void*> ps) {
+    if (!dev) return IMT_OK;
+    for (const void* p : ps)
+        if (p && ((uintptr_t)p & 15u)) return c->fail(IMT_ERR_ARG, "device pointer %p to field elements is not 16-byte aligned", p);
+    return IMT_OK;
+}
+int check_out_ptrs(imt_ctx* c, bool dev, const imt_insert_out* o) {
+    if (!o) return IMT_OK;
+    return check_fe_ptrs(c, dev, {o->low_leaf, o->old_root, o->interim_root, o->new_root, o->new_leaf, o->low_sib, o->new_sib});
 }
 
 unsigned ceil_log2(uint64_t x) {
@@ -409,6 +424,7 @@ extern "C" int imt_itree_root(imt_itree* t, void* root, unsigned flags) {
     imt_ctx* c = t->ctx;
     int rc = c->set_device();
     if (rc) return rc;
+    if ((rc = check_fe_ptrs(c, flags & IMT_DEVICE_PTRS, {root}))) return rc;
     if ((rc = join_top(t))) return rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     const uint8_t* src = t->d_nodes + t->h_off[t->depth] * 32;
@@ -431,6 +447,7 @@ extern "C" int imt_itree_root_lagged(imt_itree* t, unsigned lag, void* root, uns
     int rc = c->set_device();
     if (rc) return rc;
     if (t->batch_no <= lag) return c->fail(IMT_ERR_RANGE, "no batch %u calls ago", lag);
+    if ((rc = check_fe_ptrs(c, flags & IMT_DEVICE_PTRS, {root}))) return rc;
     const PlanSet& P = t->plan[(t->cur + 2 * imt_itree::NSETS - 1 - (int)lag) % imt_itree::NSETS];
     if (!P.has_root) return c->fail(IMT_ERR_INTERNAL, "batch root not recorded");
     IMT_HIP(c, hipStreamWaitEvent(c->stream, P.done, 0));
@@ -505,6 +522,7 @@ extern "C" int imt_itree_find_low_batch(imt_itree* t, const void* vals, size_t n
     if (!vals || !low_index) return c->fail(IMT_ERR_ARG, "null buffer");
     int rc = c->set_device();
     if (rc) return rc;
+    if ((rc = check_fe_ptrs(c, flags & IMT_DEVICE_PTRS, {vals}))) return rc;
     if ((rc = ensure_mirror(t))) return rc;
     std::vector<U256> v;
     rc = fetch_canonical(c, c->stream, vals, n, flags, v);
@@ -568,6 +586,7 @@ extern "C" int imt_itree_get_proof_batch(imt_itree* t, const uint64_t* index, si
     int rc = c->set_device();
     if (rc) return rc;
     const bool dev = flags & IMT_DEVICE_PTRS;
+    if ((rc = check_fe_ptrs(c, dev, {sib}))) return rc;
     if (!dev)
         for (size_t i = 0; i < n; i++)
             if (index[i] - t->index_base >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
@@ -604,6 +623,7 @@ extern "C" int imt_itree_non_membership_witness(imt_itree* t, const void* vals, 
     if (n > ((size_t)1 << 31)) return c->fail(IMT_ERR_RANGE, "batch too large");
     int rc = c->set_device();
     if (rc) return rc;
+    if ((rc = check_fe_ptrs(c, flags & IMT_DEVICE_PTRS, {vals, low_leaf, low_sib}))) return rc;
     if ((rc = ensure_device_index(t))) return rc;
     if ((rc = join_top(t))) return rc;
     const bool dev = flags & IMT_DEVICE_PTRS;
@@ -1014,6 +1034,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     int rc = c->set_device();
     if (rc) return rc;
     const bool dev = flags & IMT_DEVICE_PTRS;
+    if ((rc = check_fe_ptrs(c, dev, {vals})) || (rc = check_out_ptrs(c, dev, out))) return rc;
     const bool gpu_prep = (flags & IMT_HOST_PREP) == 0;
     const unsigned fmt = flags & IMT_FMT_MASK;
     const uint64_t M = t->size;
@@ -1251,6 +1272,7 @@ extern "C" int imt_itree_batch_begin(imt_itree* t, const void* vals, size_t n, u
     if ((rc = join_top(t))) return rc;
     if ((rc = ensure_device_index(t))) return rc;
     const bool dev = flags & IMT_DEVICE_PTRS;
+    if ((rc = check_fe_ptrs(c, dev, {vals}))) return rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     const size_t E = 2 * n;
     const unsigned L0 = std::min(ceil_log2(M + n), t->depth);
@@ -1323,6 +1345,7 @@ extern "C" int imt_itree_batch_begin(imt_itree* t, const void* vals, size_t n, u
 extern "C" int imt_itree_batch_leaves(imt_itree* t, void* val0, uint32_t k_begin, uint32_t k_count) {
     IMT_PENDING(t, c);
     if (!val0 || (size_t)k_begin + k_count > E) return c->fail(IMT_ERR_RANGE, "slot range outside the batch");
+    if (int rc = check_fe_ptrs(c, true, {val0})) return rc;
     launch::sweep_leaves(c->stream, P.d_pre, P.d_tab[0][1], (uint8_t*)val0, k_begin, k_count, IMT_FMT_CANONICAL, c->d_err,
                          c->coop_max_events);
     return IMT_OK;
@@ -1333,6 +1356,7 @@ extern "C" int imt_itree_batch_level(imt_itree* t, unsigned level, const void* v
     IMT_PENDING(t, c);
     if (level >= L0) return c->fail(IMT_ERR_RANGE, "level %u >= l0 %u", level, L0);
     if (!val_in || !val_out || (size_t)k_begin + k_count > E) return c->fail(IMT_ERR_RANGE, "slot range outside the batch");
+    if (int rc = check_fe_ptrs(c, true, {val_in, val_out})) return rc;
     const size_t o = (size_t)level * P.cap_events;
     launch::sweep_level(c->stream, (const uint8_t*)val_in, (uint8_t*)val_out, P.d_from + o, P.d_sibsrc + o, P.d_nodeb + o,
                         P.d_timen + o, t->d_nodes + t->h_off[level] * 32, t->h_len[level], c->d_zero + (size_t)level * 32,
@@ -1346,6 +1370,7 @@ extern "C" int imt_itree_batch_top(imt_itree* t, const void* val_l0, uint32_t e_
     IMT_PENDING(t, c);
     if (!val_l0 || !roots || !top_path || (size_t)e_begin + e_count > E)
         return c->fail(IMT_ERR_RANGE, "event range outside the batch");
+    if (int rc = check_fe_ptrs(c, true, {val_l0, roots, top_path})) return rc;
     // levels [L0, depth) for this rank's events, ping-ponging through the plan's value scratch; the rank whose range
     // holds the last event fills top_path with that event's node at every level >= L0
     const uint8_t* vin = (const uint8_t*)val_l0;
@@ -1369,6 +1394,10 @@ extern "C" int imt_itree_batch_extract(imt_itree* t, const void* const* val_leve
     if (!(flags & IMT_DEVICE_PTRS)) return c->fail(IMT_ERR_ARG, "imt_itree_batch_extract takes device pointers");
     if ((size_t)ins_begin + ins_count > t->pending.n) return c->fail(IMT_ERR_RANGE, "insertion range outside the batch");
     if (ins_count == 0) return IMT_OK;
+    if (int rc = check_fe_ptrs(c, true, {roots})) return rc;
+    if (int rc = check_out_ptrs(c, true, out)) return rc;
+    for (unsigned l = 0; l <= L0; l++)
+        if (int rc = check_fe_ptrs(c, true, {val_levels[l]})) return rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     hipStream_t s = c->stream;
     IMT_HIP(c, hipMemcpyAsync(P.d_valptr, val_levels, (size_t)(L0 + 1) * sizeof(void*), hipMemcpyHostToDevice, s));
@@ -1420,6 +1449,9 @@ extern "C" int imt_itree_batch_abort(imt_itree* t) {
 extern "C" int imt_itree_batch_end(imt_itree* t, const void* const* val_levels, const void* top_path) {
     IMT_PENDING(t, c);
     if (!val_levels || !top_path) return c->fail(IMT_ERR_ARG, "null argument");
+    if (int rc = check_fe_ptrs(c, true, {top_path})) return rc;
+    for (unsigned l = 0; l < L0; l++)
+        if (int rc = check_fe_ptrs(c, true, {val_levels[l]})) return rc;
     hipStream_t s = c->stream;
     for (unsigned l = 0; l < L0; l++) {
         const size_t o = (size_t)l * P.cap_events;
@@ -1505,6 +1537,7 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
     int rc = c->set_device();
     if (rc) return rc;
     if ((rc = ensure_device_index(t))) return rc;
+    if ((rc = check_fe_ptrs(c, true, {vals})) || (rc = check_out_ptrs(c, true, out))) return rc;
     const unsigned fmt = flags & IMT_FMT_MASK;
     const int set = t->cur;
     PlanSet& P = t->plan[set];
@@ -1618,6 +1651,7 @@ extern "C" int imt_itree_slice_unit(imt_itree* t, int slice, unsigned unit, void
     if (unit != P.slice_next_unit) return c->fail(IMT_ERR_ARG, "slice unit %u out of order (next is %u)", unit, P.slice_next_unit);
     int rc = c->set_device();
     if (rc) return rc;
+    if ((rc = check_fe_ptrs(c, true, {payload}))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const size_t n = P.slice_n, E = 2 * n;
     const unsigned L0 = P.l0, depth = t->depth, fmt = P.slice_fmt;
@@ -1690,6 +1724,7 @@ extern "C" int imt_itree_slice_apply(imt_itree* t, uint64_t size_before, size_t 
     if (unit == 0) return IMT_OK;          // leaf hashes: nothing is stored yet
     int rc = c->set_device();
     if (rc) return rc;
+    if ((rc = check_fe_ptrs(c, true, {payload}))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const size_t E = 2 * n;
     const unsigned depth = t->depth, l = unit - 1;
@@ -1769,6 +1804,7 @@ extern "C" int imt_itree_lift_batch(imt_itree* t, const void* roots_before, cons
     const bool dev = flags & IMT_DEVICE_PTRS;
     const unsigned fmt = flags & IMT_FMT_MASK;
     hipStream_t s = c->stream;
+    if ((rc = check_fe_ptrs(c, dev, {roots_before, roots_after})) || (rc = check_out_ptrs(c, dev, out))) return rc;
     if (!dev && (rc = c->clear_err())) return rc;
     size_t slot = 2;
     auto scratch = [&](size_t bytes) { return (uint8_t*)c->dev_scratch(slot++, bytes); };

@@ -87,13 +87,30 @@ for xs in ([0, 0, 0], [1, 2], [1, 2, 3], vals[36:38], vals[38:41]):
                                   provenance="oracle-trace"))
 h = O.sparse_new(32, 64)
 run = []
-for v in oracle_lib.synth_values(40, 0x494D5402):
+big = []
+R256 = 1 << 256
+for i, v in enumerate(oracle_lib.synth_values(40, 0x494D5402)):
     r = O.sparse_insert(h, 32, v)
     assert r["rc"] == 0
     run.append(dict(val=str(v), low_idx=r["low"], largest=r["largest"], interim_root=str(r["interim_root"]),
                     new_root=str(r["new_root"])))
+    if i >= 38:
+        # BASELINE config 5 at the size a circuit assigns: the whole witness trace of this insert_leaf call at depth
+        # 32 (3 + 128 hashes, 158 251 rows), and of its verify_non_inclusion part alone (the low leaf's hash + path)
+        low3 = oracle_lib.arr_ints(r["low_leaf"])
+        new3 = oracle_lib.arr_ints(O.sparse_preimage(h, i + 1))
+        rows, roots = oracle_lib.insert_leaf_trace(O, low3, r["low"], r["low_proof"], new3, i + 1, r["new_proof"], 32)
+        assert roots[1] == roots[2] == r["interim_root"] and roots[3] == r["new_root"]
+        assert roots[0] == (int(run[-2]["new_root"]) if i else 0)
+        mont = oracle_lib.ints_to_arr([x * R256 % P for x in oracle_lib.arr_ints(rows)])
+        nm = 1209 + 32 * 1208
+        big.append(dict(insertion=i, n_rows=int(rows.shape[0]), sha256_rows=hashlib.sha256(rows.tobytes()).hexdigest(),
+                        sha256_rows_mont256=hashlib.sha256(mont.tobytes()).hexdigest(),
+                        non_inclusion_rows=nm, sha256_non_inclusion_rows=hashlib.sha256(rows[:nm].tobytes()).hexdigest(),
+                        provenance="oracle-trace"))
 O.sparse_free(h)
 vec["insert_run_depth32"] = dict(provenance="oracle", seed="0x494D5402", rounds=run)
+vec["insert_trace_depth32"] = big
 
 out = os.path.join(os.path.dirname(__file__), "vectors.json")
 with open(out, "w") as f:

@@ -44,6 +44,40 @@ for name, (res, args) in _ffi.SIGNATURES.items():
         print(f"CALL {name} {label}", flush=True)
         rc = fn(*hostile(args, handle, flags))
         print(f"RC {name} {label} {rc}", flush=True)
+# Every pointer a valid, device-addressable address that is NOT 16-byte aligned (8 bytes into a page-locked buffer),
+# IMT_DEVICE_PTRS set: the entry points that take field elements must refuse it (IMT_ERR_ARG, include/imt.h "16-byte
+# aligned") instead of handing it to a kernel.  Pointers that are not data are left out: a stream, a pointer to free.
+NOT_DATA = {"imt_ctx_set_stream", "imt_host_free", "imt_itree_slice_unit", "imt_itree_slice_apply",
+            "imt_itree_slice_apply_gathered", "imt_itree_batch_extract", "imt_itree_batch_end"}
+buf = ctx.host_alloc(1 << 20)
+odd = buf.ctypes.data + 8
+
+
+FLAGS_AT = {"imt_tree_new": 3, "imt_itree_batch_begin": 3, "imt_itree_slice_prepare": 6}     # flags not the last argument
+
+
+def misaligned(argtypes, handle, flags_at):
+    out = [handle]
+    for i, t in enumerate(argtypes[1:], start=1):
+        if t is ctypes.c_void_p or hasattr(t, "contents") or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            out.append(ctypes.cast(ctypes.c_void_p(odd), t) if t is not ctypes.c_void_p else odd)
+        elif i == flags_at:
+            out.append(_ffi.DEVICE_PTRS)
+        else:
+            out.append(1)
+    return out
+
+
+for name, (res, args) in _ffi.SIGNATURES.items():
+    if res is not ctypes.c_int or name in SKIP or name in NOT_DATA:
+        continue
+    flags_at = FLAGS_AT.get(name, len(args) - 1 if len(args) and args[-1] is ctypes.c_uint else None)
+    if flags_at is None:
+        continue                          # no flags argument: host pointers or device-only calls covered elsewhere
+    print(f"CALL {name} odd-offset", flush=True)
+    rc = getattr(lib, name)(*misaligned(args, handle_for(name), flags_at))
+    print(f"RC {name} odd-offset {rc}", flush=True)
+ctx.sync()
 # the handles still work afterwards
 assert imt_amd.to_int(ctx.hash2(imt_amd.to_bytes([[1, 2]]))[0]) > 0
 itree.insert_batch([5, 9])

@@ -221,6 +221,45 @@ class Oracle:
         return out
 
 
+def arr_ints(a):
+    return [int.from_bytes(x.tobytes(), "little") for x in np.asarray(a, dtype=np.uint8).reshape(-1, 32)]
+
+
+def path_trace(orc, start, leaf3, index, proof, depth):
+    """The witness rows of every hash_fix_len_array call of one compute_merkle_root
+    (/root/reference/src/indexed_merkle_tree.rs:78-96), in call order: the 3-input leaf hash first when `leaf3` is given
+    (:193-194), else the chain starts from the value `start`; then one hash per level with the (left, right) pair
+    dual_mux selects (:47-63).  Returns (rows uint8 [k, 32] canonical, root)."""
+    parts = []
+    if leaf3 is not None:
+        parts.append(orc.hash_trace(leaf3)["witness"])
+        cur = orc.hash(leaf3)
+    else:
+        cur = start
+    sib = arr_ints(proof)
+    for l in range(depth):
+        pair = [sib[l], cur] if (index >> l) & 1 else [cur, sib[l]]
+        parts.append(orc.hash_trace(pair)["witness"])
+        cur = orc.hash(pair)
+    return (np.concatenate(parts) if parts else np.zeros((0, 32), np.uint8)), cur
+
+
+def insert_leaf_trace(orc, low_leaf3, low_index, low_proof, new_leaf3, new_index, new_proof, depth):
+    """All 3 + 4 * depth hash traces of one insert_leaf call (:231-314) in the order the circuit reaches
+    hash_fix_len_array: low leaf + path (:193-204), rewritten low leaf {low.val, new.val, new_index} + the same path
+    (:265-284), the zero leaf's path at the new slot (:286-294; the zero-leaf hash is a constant, no trace), new leaf +
+    path (:299-312).  Returns (rows uint8 [3*1209 + 4*depth*1208, 32], [old_root, interim_root, interim_root', new_root])."""
+    new_low = [low_leaf3[0], new_leaf3[0], new_index]
+    chains = [(None, low_leaf3, low_index, low_proof), (None, new_low, low_index, low_proof),
+              (orc.hash([0, 0, 0]), None, new_index, new_proof), (None, new_leaf3, new_index, new_proof)]
+    rows, roots = [], []
+    for start, leaf3, idx, proof in chains:
+        r, root = path_trace(orc, start, leaf3, idx, proof, depth)
+        rows.append(r)
+        roots.append(root)
+    return np.concatenate(rows), roots
+
+
 _cached = None
 
 

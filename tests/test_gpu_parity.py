@@ -756,6 +756,15 @@ def test_c_abi_survives_null_and_nonsense_arguments(imt):
     assert rcs[("imt_itree_insert_batch", "null-args")] == imt._ffi.ERR["ARG"]
     assert rcs[("imt_hash2_batch", "bad-format")] == imt._ffi.ERR["ARG"]
     assert rcs[("imt_tree_new", "null-args")] == imt._ffi.ERR["ARG"]
+    # device pointers to field elements that are not 16-byte aligned are an argument error, not a GPU fault
+    for name in ("imt_hash2_batch", "imt_hash3_batch", "imt_permute_batch", "imt_hash_trace_batch", "imt_path_trace_batch",
+                 "imt_insert_trace_batch", "imt_tree_new", "imt_tree_build", "imt_tree_get_root", "imt_tree_get_proof_batch",
+                 "imt_path_root_batch", "imt_compute_merkle_root_batch", "imt_verify_proof_batch", "imt_non_membership_batch",
+                 "imt_split128_batch", "imt_insert_witness_batch", "imt_itree_root", "imt_itree_insert_batch",
+                 "imt_itree_get_proof_batch", "imt_itree_non_membership_witness", "imt_itree_find_low_batch",
+                 "imt_combine_subtree_roots", "imt_zero_hashes", "imt_itree_batch_begin",
+                 "imt_itree_slice_prepare"):
+        assert rcs[(name, "odd-offset")] == imt._ffi.ERR["ARG"], (name, rcs[(name, "odd-offset")])
 
 
 def test_reference_tests_in_cpp(imt, oracle, tmp_path):
@@ -871,8 +880,11 @@ def test_path_trace_is_the_trace_of_every_hash_on_the_path(imt, ctx, oracle):
             cur = oracle.hash(pair)
             off += 1208
         assert ints(roots[i]) == [cur]
-    tim, _ = ctx.path_trace(index, imt.to_bytes(sib), depth, leaf3=imt.to_bytes(leaf3), item_major=True)
-    assert (tim.transpose(1, 0, 2) == tr).all()
+    # item-major trace = item-major siblings too (one flag bit, as in imt_insert_trace_batch): n > 1 and depth > 1 tell
+    # sib[item][level] from sib[level][item]
+    sib_im = imt.to_bytes(sib).transpose(1, 0, 2).copy()
+    tim, rim = ctx.path_trace(index, sib_im, depth, leaf3=imt.to_bytes(leaf3), item_major=True)
+    assert (tim.transpose(1, 0, 2) == tr).all() and (rim == roots).all()
     leaf = [rng.randrange(P) for _ in range(n)]
     tr2, roots2 = ctx.path_trace(index, imt.to_bytes(sib), depth, leaf=imt.to_bytes(leaf))
     assert tr2.shape == (depth * 1208, n, 32)
@@ -915,6 +927,45 @@ def test_insert_trace_is_what_the_circuit_would_assign(imt, ctx, oracle):
     tim = ctx.insert_trace(r["low_leaf"], r["low_index"], r["low_sib"].transpose(1, 0, 2).copy(), r["new_leaf"],
                            r["new_index"], r["new_sib"].transpose(1, 0, 2).copy(), depth, item_major=True)
     assert (tim.transpose(1, 0, 2) == tr).all()
+    t.close()
+
+
+def test_insert_trace_at_depth_32_every_row(imt, ctx, oracle):
+    """BASELINE config 5 at the size a k=17 circuit assigns: imt_insert_trace_batch at depth 32 for two REAL insertions
+    (158 251 rows each: the call sites src/indexed_merkle_tree.rs:92, :194, :271-275, :299-303) and imt_path_trace_batch
+    for their verify_non_inclusion part (:193-204), every row against the oracle's trace of the same hashes, in
+    canonical form and in halo2curves' Montgomery form; digests as committed in tests/golden/vectors.json."""
+    import hashlib
+    depth = 32
+    gold = {g["insertion"]: g for g in GOLD["insert_trace_depth32"]}
+    vals = oracle_lib.synth_values(40, 0x494D5402)
+    t = imt.IndexedTree(ctx, depth, 64)
+    t.insert_batch(vals[:38])
+    r = t.insert_batch(vals[38:40])
+    n = 2
+    tr = ctx.insert_trace(r["low_leaf"], r["low_index"], r["low_sib"], r["new_leaf"], r["new_index"], r["new_sib"], depth)
+    assert tr.shape == (158251, n, 32)
+    R = 1 << 256
+    mont = lambda a: oracle_lib.ints_to_arr([x * R % P for x in ints(a)]).reshape(np.asarray(a).shape)
+    trm = ctx.insert_trace(mont(r["low_leaf"]), r["low_index"], mont(r["low_sib"]), mont(r["new_leaf"]), r["new_index"],
+                           mont(r["new_sib"]), depth, fmt=imt._ffi.FMT_MONT256)
+    nm_rows = 1209 + depth * 1208
+    ptr, proots = ctx.path_trace(r["low_index"], r["low_sib"], depth, leaf3=r["low_leaf"])
+    assert ptr.shape == (nm_rows, n, 32) and (proots == r["old_root"]).all()
+    for i in range(n):
+        low3, new3 = ints(r["low_leaf"][i]), ints(r["new_leaf"][i])
+        want, roots = oracle_lib.insert_leaf_trace(oracle, low3, int(r["low_index"][i]), r["low_sib"][:, i], new3,
+                                                   int(r["new_index"][i]), r["new_sib"][:, i], depth)
+        assert want.shape == (158251, 32)
+        assert (tr[:, i] == want).all(), f"insertion {38 + i}: a trace row differs from the oracle's"
+        assert roots == [ints(r["old_root"][i])[0], ints(r["interim_root"][i])[0], ints(r["interim_root"][i])[0],
+                         ints(r["new_root"][i])[0]]
+        g = gold[38 + i]
+        assert hashlib.sha256(np.ascontiguousarray(tr[:, i]).tobytes()).hexdigest() == g["sha256_rows"]
+        assert hashlib.sha256(np.ascontiguousarray(trm[:, i]).tobytes()).hexdigest() == g["sha256_rows_mont256"]
+        assert (trm[:, i] == oracle_lib.ints_to_arr([x * R % P for x in ints(want)])).all()
+        assert (ptr[:, i] == want[:nm_rows]).all()
+        assert hashlib.sha256(np.ascontiguousarray(ptr[:, i]).tobytes()).hexdigest() == g["sha256_non_inclusion_rows"]
     t.close()
 
 

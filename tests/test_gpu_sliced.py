@@ -210,3 +210,40 @@ def test_two_processes_over_gloo_equal_one_gpu_tree(imt, ctx):
                 w = np.asarray(want[r][k])
                 w = w[:, rank * P_BATCH:(rank + 1) * P_BATCH] if k.endswith("_sib") else w[rank * P_BATCH:(rank + 1) * P_BATCH]
                 assert (res[r][k] == w).all(), (rank, r, k)
+
+
+def test_slice_calls_refuse_bad_arguments(imt, ctx):
+    """the C entry points directly: misaligned payloads / values, units out of order, a second preparation of too many
+    slices, a placed tree -- documented codes, nothing reaches a kernel"""
+    import ctypes
+    F, lib = imt._ffi, imt.lib
+    t = imt.IndexedTree(ctx, 32, 1 << 10)
+    vals = torch.from_numpy(oracle_lib.ints_to_arr(oracle_lib.synth_values(64, 0x494D5471))).cuda()
+    pay = torch.zeros(int(lib.imt_itree_slice_payload_bytes(16)) + 64, dtype=torch.uint8, device="cuda")
+    sl = ctypes.c_int(-1)
+    P_ = lambda x, off=0: ctypes.c_void_p(x.data_ptr() + off)
+    assert lib.imt_itree_slice_prepare(t.h, P_(vals, 8), 0, 16, 0, None, F.DEVICE_PTRS, ctypes.byref(sl), None) == F.ERR["ARG"]
+    assert lib.imt_itree_slice_prepare(t.h, P_(vals), 0, 16, 0, None, 0, ctypes.byref(sl), None) == F.ERR["ARG"]      # host pointers
+    assert lib.imt_itree_slice_prepare(t.h, P_(vals), 0, 0, 16, None, F.DEVICE_PTRS, ctypes.byref(sl), None) == F.ERR["ARG"]
+    assert lib.imt_itree_slice_prepare(t.h, P_(vals), 600, 16, 600, None, F.DEVICE_PTRS, ctypes.byref(sl), None) == F.ERR["FULL"]
+    assert t.size == 1
+    assert lib.imt_itree_slice_prepare(t.h, P_(vals), 0, 16, 0, None, F.DEVICE_PTRS, ctypes.byref(sl), None) == 0
+    assert t.size == 17
+    assert lib.imt_itree_slice_unit(t.h, sl.value, 1, P_(pay), None) == F.ERR["ARG"]          # unit 0 comes first
+    assert lib.imt_itree_slice_unit(t.h, sl.value, 0, P_(pay, 8), None) == F.ERR["ARG"]       # misaligned payload
+    assert lib.imt_itree_slice_unit(t.h, 7, 0, P_(pay), None) == F.ERR["ARG"]
+    for q in range(33):
+        assert lib.imt_itree_slice_unit(t.h, sl.value, q, P_(pay), None) == 0
+    assert lib.imt_itree_slice_unit(t.h, sl.value, 33, P_(pay), None) == F.ERR["ARG"]         # the slice is closed
+    assert lib.imt_itree_slice_apply(t.h, 1, 16, 5, P_(pay, 8), None) == F.ERR["ARG"]
+    assert lib.imt_itree_slice_apply(t.h, 1, 16, 40, P_(pay), None) == F.ERR["RANGE"]
+    assert lib.imt_itree_slice_apply(t.h, 1 << 10, 16, 5, P_(pay), None) == F.ERR["RANGE"]
+    ctx.sync()
+    ref = imt.IndexedTree(ctx, 32, 1 << 10)
+    ref.insert_batch(oracle_lib.synth_values(64, 0x494D5471)[:16])
+    assert t.root() == ref.root()          # one slice alone on the context's stream = an ordinary batch
+    placed = imt.IndexedTree(ctx, 31, 1 << 10)
+    placed.set_placement(32, 1)
+    assert lib.imt_itree_slice_prepare(placed.h, P_(vals), 0, 16, 0, None, F.DEVICE_PTRS, ctypes.byref(sl), None) == F.ERR["ARG"]
+    for x in (t, ref, placed):
+        x.close()

@@ -179,3 +179,28 @@ def test_relation_checker_detects_failures(oracle):
     assert oracle.sparse_insert(sp, depth, 20)["rc"] == -10    # duplicate
     assert oracle.sparse_insert(sp, depth, 0)["rc"] == -10     # zero
     oracle.sparse_free(sp)
+
+
+def test_insert_trace_depth32_golden(oracle):
+    """BASELINE config 5 at the size a circuit assigns: the 158 251-row witness trace of insert_leaf at depth 32
+    (src/indexed_merkle_tree.rs:92, :194, :271-275, :299-303 are its hash_fix_len_array call sites) for insertions 38 and
+    39 of the seeded run, recomputed from the oracle: digests as committed, every vertical gate of a sample holds
+    through the chain ends (roots)."""
+    import hashlib
+    gold = {g["insertion"]: g for g in GOLD["insert_trace_depth32"]}
+    h = oracle.sparse_new(32, 64)
+    prev_root = None
+    for i, v in enumerate(oracle_lib.synth_values(40, 0x494D5402)):
+        r = oracle.sparse_insert(h, 32, v)
+        assert r["rc"] == 0
+        if i in gold:
+            low3 = oracle_lib.arr_ints(r["low_leaf"])
+            new3 = oracle_lib.arr_ints(oracle.sparse_preimage(h, i + 1))
+            rows, roots = oracle_lib.insert_leaf_trace(oracle, low3, r["low"], r["low_proof"], new3, i + 1, r["new_proof"], 32)
+            g = gold[i]
+            assert rows.shape == (g["n_rows"], 32) and g["n_rows"] == 3 * 1209 + 4 * 32 * 1208
+            assert hashlib.sha256(rows.tobytes()).hexdigest() == g["sha256_rows"]
+            assert hashlib.sha256(rows[:g["non_inclusion_rows"]].tobytes()).hexdigest() == g["sha256_non_inclusion_rows"]
+            assert roots == [prev_root, r["interim_root"], r["interim_root"], r["new_root"]]
+        prev_root = r["new_root"]
+    oracle.sparse_free(h)
