@@ -1270,6 +1270,55 @@ def test_subtree_lift_matches_dense_replay(imt, ctx, oracle, world, depth):
         b.tree.close(); b.ctx.close()
 
 
+def test_montgomery_inputs_ready_with_lagged_lift(imt, ctx):
+    """halo2curves' format + IMT_INPUTS_READY + IMT_PIPELINE through the sharded driver with the lift one step behind
+    (bench.py's N > 1 schedule): the canonical copy of a batch's values is made on the side stream, unordered behind the
+    context's stream on which the previous step's imt_itree_lift_batch still runs -- it must not share scratch with it
+    (it has the plan's own buffer).  Many small steps back to back; everything equals the canonical-format run."""
+    import torch
+    sharded = _load_sharded()
+    depth, world, n_step, steps_n = 32, 2, 96, 12
+    R = 1 << 256
+    raw = oracle_lib.synth_values(n_step * steps_n * 3, 0x494D5447)
+    runs = {}
+    for fmt in (0, imt._ffi.FMT_MONT256):
+        outs = []
+        trees = []
+        for g in range(world):
+            vals = [v for v in raw if v % world == g][:n_step * steps_n]
+            be = sharded.GpuBackend(imt, 0, depth, world, g, 1 << 12, n_step, pipeline=True, inputs_ready=True, nbuf=3, fmt=fmt)
+            trees.append((be, vals))
+        # one process stands in for both ranks: the "all-gather" is a stack of the two lagged roots
+        prev = torch.stack([trees[0][0].initial_root()] * world)
+        pending = None
+        for st in range(steps_n + 1):
+            slots = None
+            if st < steps_n:
+                slots = []
+                for be, vals in trees:
+                    chunk = vals[st * n_step:(st + 1) * n_step]
+                    arr = oracle_lib.ints_to_arr([v * R % P for v in chunk] if fmt else chunk)
+                    slots.append(be.insert(torch.from_numpy(arr).cuda()))
+            if pending is not None:
+                lag = 1 if st < steps_n else 0
+                after = torch.stack([be.root_after(lag).clone() for be, _ in trees])
+                for (be, _), slot in zip(trees, pending):
+                    be.lift(slot, prev, after)
+                    be.sync()
+                    o = be.outputs(slot)
+                    outs.append({k: o[k].cpu().numpy().copy() for k in ("old_root", "new_root", "low_sib", "low_leaf")})
+                prev = after
+            pending = slots
+        runs[fmt] = outs
+        for be, _ in trees:
+            be.tree.close(); be.ctx.close()
+    unmont = lambda a: [x * pow(R, -1, P) % P for x in ints(a)]
+    assert len(runs[0]) == world * steps_n
+    for a, b in zip(runs[0], runs[imt._ffi.FMT_MONT256]):
+        for k in a:
+            assert ints(a[k]) == unmont(b[k]), k
+
+
 def test_lift_batch_host_pointers_and_item_major(imt, ctx, oracle):
     """imt_itree_lift_batch with host pointers, both sibling layouts, equal to the device-pointer path; a
     placed tree's low-leaf queries speak global indices."""

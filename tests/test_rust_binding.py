@@ -113,3 +113,43 @@ def test_lib_rs_keeps_the_reference_signatures():
         assert sig in flat, sig
     # no Drop on the borrowed-hasher type: the reference's tests re-borrow the hasher before they reassign the tree
     assert "impl<'a, F: ScalarField, const T: usize, const RATE: usize> Drop for IndexedMerkleTree" not in flat
+
+
+def test_mockprover_rs_names_only_what_src_defines():
+    """bindings/rust/tests/mockprover.rs (the run that pins the trace order and config 5, for someone with cargo) must
+    not drift from src/: every `imt_hip::` path it imports, every method it calls on the chip / hasher / gpu module and
+    every witness field it reads exists in lib.rs / chip.rs / gpu.rs under that name; the Cargo feature it is gated on
+    exists."""
+    t = open(os.path.join(ROOT, "bindings", "rust", "tests", "mockprover.rs")).read()
+    chip = open(os.path.join(ROOT, "bindings", "rust", "src", "chip.rs")).read()
+    gpu = open(os.path.join(ROOT, "bindings", "rust", "src", "gpu.rs")).read()
+    cargo = open(os.path.join(ROOT, "bindings", "rust", "Cargo.toml")).read()
+    code = re.sub(r"//.*", "", t)
+    # imports
+    m = re.search(r"use imt_hip::chip::\{([^}]*)\};", code)
+    for name in [x.strip() for x in m.group(1).split(",")]:
+        assert re.search(rf"pub (struct|trait) {name}\b", chip), name
+    assert "use imt_hip::gpu;" in code and "pub mod gpu;" in LIB and "pub mod chip;" in LIB
+    # gpu:: functions
+    for name in set(re.findall(r"\bgpu::([a-z_]+)", code)):
+        assert re.search(rf"pub fn {name}\b", gpu), f"gpu::{name}"
+    # methods on chip / hasher objects
+    for name in set(re.findall(r"\b(?:chip|hasher)\.([a-z_]+)\(", code)) - {"initialize_consts"}:     # halo2-base's own hasher
+        assert re.search(rf"(pub )?fn {name}\b", chip), name
+    for name in ("new",):
+        assert re.search(r"impl IndexedMerkleTreeChip \{\s*pub fn new\(depth: usize, capacity: u64\)", chip)
+        assert re.search(r"pub fn new\(ctx: &mut Context<F>\) -> Self", chip)
+    # fields of AssignedInsert (`a.`) and of the witnesses (`w.`)
+    assigned = re.search(r"pub struct AssignedInsert<F: BigPrimeField> \{(.*?)\}", chip, flags=re.S).group(1)
+    for name in set(re.findall(r"\ba\.([a-z_]+)", code)):
+        assert re.search(rf"pub {name}:", assigned), f"AssignedInsert.{name}"
+    ni = re.search(r"pub struct NonInclusionWitness<F> \{(.*?)\}", gpu, flags=re.S).group(1)
+    for name in set(re.findall(r"\bw\.([a-z_]+)", code)) - {"clone"}:
+        assert re.search(rf"pub {name}:", ni), f"NonInclusionWitness.{name}"
+    assert 'feature = "reference-gadget"' in t and "reference-gadget = [" in cargo
+    # the reference's gadget is called with its own argument order (src/indexed_merkle_tree.rs:231-245, :127-137)
+    flat = re.sub(r"\s+", " ", code)
+    assert ("insert_leaf::<Fr, T, RATE>( ctx, range, &hasher, &a.old_root, &low_leaf, &a.low_leaf_proof, "
+            "&a.low_leaf_proof_helper, &a.new_root, &new_leaf, &a.new_leaf_index, &a.new_leaf_proof, "
+            "&a.new_leaf_proof_helper, &a.is_new_leaf_largest, )") in flat
+    assert "verify_non_inclusion::<Fr, T, RATE>(ctx, range, &hasher, &root, &leaf, &proof, &helper, &value, &largest)" in flat
