@@ -141,10 +141,11 @@ def test_mockprover_rs_names_only_what_src_defines():
         assert re.search(r"pub fn new\(ctx: &mut Context<F>\) -> Self", chip)
     # fields of AssignedInsert (`a.`) and of the witnesses (`w.`)
     assigned = re.search(r"pub struct AssignedInsert<F: BigPrimeField> \{(.*?)\}", chip, flags=re.S).group(1)
-    for name in set(re.findall(r"\ba\.([a-z_]+)", code)):
+    for name in set(re.findall(r"&a\.([a-z_]+)|\(a\.([a-z_]+)\[", code)):
+        name = name[0] or name[1]
         assert re.search(rf"pub {name}:", assigned), f"AssignedInsert.{name}"
     ni = re.search(r"pub struct NonInclusionWitness<F> \{(.*?)\}", gpu, flags=re.S).group(1)
-    for name in set(re.findall(r"\bw\.([a-z_]+)", code)) - {"clone"}:
+    for name in set(re.findall(r"\bw\.([a-z_]+)\b(?!\()", code)):
         assert re.search(rf"pub {name}:", ni), f"NonInclusionWitness.{name}"
     assert 'feature = "reference-gadget"' in t and "reference-gadget = [" in cargo
     # the reference's gadget is called with its own argument order (src/indexed_merkle_tree.rs:231-245, :127-137)
