@@ -41,6 +41,14 @@ using namespace dev;
 #ifndef IMT_HASH_WAVES
 #define IMT_HASH_WAVES __attribute__((amdgpu_waves_per_eu(5, 5)))
 #endif
+// The latency forms of the PATH kernels (a quad of lanes per item, imt_coop_device.hpp) run with at most one wave per
+// SIMD by construction -- the launcher picks them only while the launch leaves the chip mostly empty -- so registers are
+// free: with the 96 of the throughput kernels the two inlined copies of the quad hash plus the loop-carried path state
+// spilled 13-88 VGPRs inside the 33-hash chain; with up to 256 nothing spills.  (k_sweep_coop and k_hash_batch_coop
+// fit 96 without spills and keep it: they run up to 16 384 events, where a second wave per SIMD still pays.)
+#ifndef IMT_COOP_WAVES
+#define IMT_COOP_WAVES __attribute__((amdgpu_waves_per_eu(1, 2)))
+#endif
 constexpr int BLOCK = IMT_BLOCK;   // 256 = 4 waves = one per SIMD of a CU
 
 __device__ __forceinline__ size_t gtid() { return (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
@@ -273,7 +281,7 @@ __global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_path_pairs(launch::Pat
 }
 
 // the same for few paths: a quad of lanes per path (imt_coop_device.hpp); lane 1 holds the left input, lane 2 the right
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_path_pairs_coop(launch::PathChains a) {
+__global__ IMT_COOP_WAVES void __launch_bounds__(BLOCK) k_path_pairs_coop(launch::PathChains a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ uint32_t tab[coop::TAB_DWORDS];
     coop::tab_fill(tab, g_pc);
@@ -358,7 +366,7 @@ k_path_root(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3,
 // `depth` (+1) hashes one after the other in one thread -- 13 ms at depth 32 with one thread per path however few
 // paths there are (the reference calls verify_proof one proof at a time, src/indexed_merkle_tree.rs:397-400); this
 // form takes 0.6x that.  Lane 1 of a quad ends up with every hash and hands it to its neighbours for the next level.
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
+__global__ IMT_COOP_WAVES void __launch_bounds__(BLOCK)
 k_path_root_coop(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3, const uint64_t* __restrict__ index,
                  int is_helper, const uint8_t* __restrict__ sib, launch::SibLayout lay, unsigned depth, size_t n,
                  uint8_t* __restrict__ root_out, const uint8_t* __restrict__ expect, unsigned expect_stride,
@@ -418,7 +426,19 @@ k_non_membership(const uint8_t* __restrict__ root, unsigned root_stride, const u
     if (i >= n) return;
     bool ok = true;
     unsigned fail = 0;
-    {   // the range predicates first: their operands are dead before the hashing starts
+    // The hash chain first, the range predicates after it: every value that is live across a call of the shared hash
+    // function is saved to scratch by the caller (the callee owns the registers), so nothing but `ok` is kept over
+    // the 33 calls (the other order carried the failure bits and spilled 23 VGPRs).
+    Fe cur;
+    leaf_hash(cur, low_leaf + i * 96, fmt_in, ok);                  // :193-194
+    hash_chain(cur, low_index[i], sib, lay, i, depth, fmt_in, ok);  // :196-204
+    {
+        Fe rt;
+        ok &= load_fe(g_pc, rt, root + i * (size_t)root_stride, fmt_in);
+        if (!fe_eq(cur, rt)) fail |= 0x02;
+    }
+    if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
+    {
         Fe v, nx, nv, nvi, lvi, lni;
         ok &= load_fe(g_pc, v, low_leaf + (i * 3 + 0) * 32, fmt_in);
         ok &= load_fe(g_pc, nx, low_leaf + (i * 3 + 1) * 32, fmt_in);
@@ -431,22 +451,13 @@ k_non_membership(const uint8_t* __restrict__ root, unsigned root_stride, const u
         if (!(s ? is_zero : next_gr)) fail |= 0x01;                 // :182-191
         if (!int_lt(lvi, nvi)) fail |= 0x04;                        // :206-228
     }
-    Fe cur;
-    leaf_hash(cur, low_leaf + i * 96, fmt_in, ok);                  // :193-194
-    hash_chain(cur, low_index[i], sib, lay, i, depth, fmt_in, ok);  // :196-204
-    {
-        Fe rt;
-        ok &= load_fe(g_pc, rt, root + i * (size_t)root_stride, fmt_in);
-        if (!fe_eq(cur, rt)) fail |= 0x02;
-    }
     fail_out[i] = (uint8_t)fail;
-    if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
     flag_err(err, ok);
 }
 
 // the same for few items: a quad of lanes per item (imt_coop_device.hpp) -- one verify_non_inclusion call is a chain of
 // 33 dependent hashes, which is all its time
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
+__global__ IMT_COOP_WAVES void __launch_bounds__(BLOCK)
 k_non_membership_coop(const uint8_t* __restrict__ root, unsigned root_stride, const uint8_t* __restrict__ low_leaf,
                       const uint64_t* __restrict__ low_index, const uint8_t* __restrict__ sib, launch::SibLayout lay,
                       unsigned depth, const uint8_t* __restrict__ new_val, const uint8_t* __restrict__ is_largest,
@@ -570,7 +581,7 @@ k_insert_chains(const uint8_t* __restrict__ low_leaf, const uint64_t* __restrict
 }
 
 // the same for few items: a quad of lanes per (item, chain)
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK)
+__global__ IMT_COOP_WAVES void __launch_bounds__(BLOCK)
 k_insert_chains_coop(const uint8_t* __restrict__ low_leaf, const uint64_t* __restrict__ low_index,
                      const uint8_t* __restrict__ low_sib, const uint8_t* __restrict__ new_leaf,
                      const uint64_t* __restrict__ new_index, const uint64_t* __restrict__ new_path_index,
