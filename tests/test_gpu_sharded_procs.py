@@ -233,6 +233,29 @@ def test_bench_gpus2_as_typed_rehearsal():
     assert r2.returncode != 0 and "does not match WORLD_SIZE" in (r2.stdout + r2.stderr)
 
 
+def test_bench_gpus4_as_typed_rehearsal():
+    """`python3 bench.py --gpus 4 --steps 1 --warmup 1`, four ranks as children sharing device 0 over gloo: the largest
+    multi-PROCESS rehearsal a one-GPU box allows (its process guard admits six GPU processes; eight ranks run as
+    eight replicas in ONE process instead: test_gpu_sliced.py::test_local_world_equals_one_gpu_tree[8-...], and as eight
+    gloo processes without a GPU: test_sliced_schedule.py::test_gloo_ranks_line_up[8-32-None]).  A rank that fails makes
+    the launcher exit non-zero."""
+    import json
+    import subprocess
+    env = dict(os.environ, IMT_BENCH_DEVICE="0", IMT_BENCH_COLLECTIVE="gloo", IMT_BENCH_NO_TRACE="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 4 and res["ranks_seen"] == 4 and res["verified"] is True
+    assert res["modes"]["single_list"]["verified"] is True and res["modes"]["subtrees"]["verified"] is True
+    assert res["modes"]["single_list"]["schedule"]["lag_levels"] == 3
+    # a rank that dies takes the launcher's exit status with it (here: every rank refuses a world size it cannot shard)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], capture_output=True, text=True,
+                         timeout=120, env=env, cwd=ROOT)
+    assert bad.returncode != 0
+
+
 def test_bench_rccl_calls_with_one_rank():
     """The driver's N > 1 form (torch.distributed.run around bench.py, backend "nccl" = RCCL) needs one GPU per
     rank, so a one-GPU box can run it with ONE rank only: IMT_BENCH_FORCE_DIST makes that rank go through the
