@@ -130,6 +130,44 @@ impl<F: BigPrimeField> FixLenHasher<F> for TracedPoseidonHasher<F> {
     }
 }
 
+/// The ONE extra constraint a circuit needs when the tree behind the root is the SUBTREE layout (`sharded.py`,
+/// `bench.py --gpus N` mode "subtrees": `world = 2^k` sorted lists, list `g` = the values with `v mod world == g`, stored
+/// under leaf indices `[g << (d - k), (g + 1) << (d - k))`).  The reference's `verify_non_inclusion` (`:127-229`) and
+/// `insert_leaf` (`:231-314`) never tie a leaf's POSITION to a VALUE -- with one list they need not.  With `world` lists
+/// under one root they must: a low leaf taken from a list that does not own `v` (for instance another list's sentinel
+/// `{0, w, idx}` with `w > v`) satisfies every constraint of `verify_non_inclusion` for a `v` that IS stored in its own
+/// list, and `insert_leaf` would accept `v` a second time.  So, next to every `verify_non_inclusion(.., low_leaf_proof_helper,
+/// new_leaf_value, ..)` and for both paths of every `insert_leaf`, also call
+///
+/// ```ignore
+/// constrain_owner_subtree(ctx, range, &new_leaf_value, &low_leaf_proof_helper, k);   // the low leaf's list owns v
+/// constrain_owner_subtree(ctx, range, &new_leaf.val,   &new_leaf_proof_helper, k);   // insert_leaf: v lands in its own list
+/// ```
+///
+/// It constrains `v mod 2^k` (a `div_mod` by `2^k`: one 254-bit range decomposition) to equal the subtree number the
+/// path's top `k` helper bits spell (`helper = 1` means "left child", `src/utils.rs:79`, so bit `j` of the subtree number
+/// is `1 - helper[d - k + j]`).  The single-list layout (`sliced.py`, `bench.py`'s `value`) needs none of this.
+pub fn constrain_owner_subtree<F: BigPrimeField>(
+    ctx: &mut Context<F>,
+    range: &halo2_base::gates::RangeChip<F>,
+    value: &AssignedValue<F>,
+    proof_helper: &[AssignedValue<F>],
+    k: usize,
+) {
+    use halo2_base::gates::RangeInstructions;
+    if k == 0 {
+        return;
+    }
+    let gate = range.gate();
+    let d = proof_helper.len();
+    assert!(k <= d, "more subtree bits than tree levels");
+    let (_, residue) = range.div_mod(ctx, *value, num_bigint::BigUint::from(1u64) << k, F::NUM_BITS as usize);
+    let bits: Vec<AssignedValue<F>> = proof_helper[d - k..].iter().map(|h| gate.not(ctx, *h)).collect();
+    let weights = (0..k).map(|j| Constant(F::from(1u64 << j)));
+    let subtree = gate.inner_product(ctx, bits, weights);
+    ctx.constrain_equal(&residue, &subtree);
+}
+
 /// insert / update / non-membership in one object (the names `north_star` uses).  `assign_insert` loads one
 /// [`InsertWitness`] into the circuit and calls the reference's own `insert_leaf` through the closure the caller
 /// passes (the function is private to the reference's module, `src/indexed_merkle_tree.rs:231`), with a
