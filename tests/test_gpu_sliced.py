@@ -90,6 +90,51 @@ def test_local_world_equals_one_gpu_tree(imt, ctx, world, batch, rounds):
         be.ctx.close()
 
 
+def test_local_world_at_bench_size(imt, ctx):
+    """the size bench.py runs (BASELINE configs[1]: 2^16 insertions per GPU and step, depth 32): two replicas, three
+    steps, the default lag -- every witness byte of both ranks against imt_itree_insert_batch over the same 2^17 values
+    per step, compared on the GPU"""
+    sl = load_sliced()
+    depth, world, batch, rounds = 32, 2, 1 << 16, 3
+    cap = 1 << 19
+    import bench
+    vals = torch.from_numpy(bench.synth_values(world * batch * rounds, 0, 1, 0x494D5491)).cuda()
+    ref = imt.IndexedTree(ctx, depth, cap)
+    u8 = dict(dtype=torch.uint8, device="cuda")
+    gb = world * batch
+    want = []
+    F = imt._ffi
+    for r in range(rounds):
+        o = dict(low_index=torch.empty(gb, dtype=torch.int64, device="cuda"), low_leaf=torch.empty((gb, 3, 32), **u8),
+                 is_largest=torch.empty(gb, **u8), old_root=torch.empty((gb, 32), **u8), interim_root=torch.empty((gb, 32), **u8),
+                 new_root=torch.empty((gb, 32), **u8), new_leaf=torch.empty((gb, 3, 32), **u8),
+                 low_sib=torch.empty((depth, gb, 32), **u8), new_sib=torch.empty((depth, gb, 32), **u8))
+        st = F.InsertOut(**{k: t.data_ptr() for k, t in o.items()})
+        import ctypes
+        ctx._check(imt.lib.imt_itree_insert_batch(ref.h, ctypes.c_void_p(vals[r * gb:(r + 1) * gb].data_ptr()), gb, ctypes.byref(st),
+                                                  F.DEVICE_PTRS))
+        want.append(o)
+    ctx.sync()
+    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch) for _ in range(world)]
+    w = sl.LocalWorld(bes)
+    assert w.sched.lag == 6
+    for r in range(rounds):
+        w.step([vals[r * gb:(r + 1) * gb]] * world)
+    w.flush()
+    for r in range(rounds):
+        for rk in w.ranks:
+            got = rk.outputs(r)
+            lo, hi = rk.rank * batch, (rk.rank + 1) * batch
+            for k in FIELDS:
+                a = want[r][k][:, lo:hi] if k.endswith("_sib") else want[r][k][lo:hi]
+                assert bool((got[k] == a).all()), (r, rk.rank, k)
+    assert all(be.tree.root() == ref.root() for be in bes)
+    ref.close()
+    for be in bes:
+        be.tree.close()
+        be.ctx.close()
+
+
 def test_local_world_fills_a_small_tree_to_its_last_level(imt, ctx):
     """depth 8, 4 replicas: l0 reaches the depth (no empty-subtree levels left), the root travels in the payload"""
     sl = load_sliced()
