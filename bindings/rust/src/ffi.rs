@@ -174,6 +174,7 @@ extern "C" {
 
     // ---- e: one tree on several GPUs, single sorted list, time-sliced
     pub fn imt_itree_slice_payload_bytes(n: usize) -> usize;
+    pub fn imt_itree_slice_unit_bytes(t: *const imt_itree, size_before: u64, n: usize, unit: c_uint) -> usize;
     pub fn imt_itree_slice_prepare(t: *mut imt_itree, vals: *const c_void, n_before: usize, n_own: usize, n_after: usize, out: *const imt_insert_out, flags: c_uint, slice_out: *mut c_int, l0_out: *mut u32) -> c_int;
     pub fn imt_itree_slice_unit(t: *mut imt_itree, slice: c_int, unit: c_uint, payload: *mut c_void, hip_stream: *mut c_void) -> c_int;
     pub fn imt_itree_slice_apply(t: *mut imt_itree, size_before: u64, n: usize, unit: c_uint, payload: *const c_void, hip_stream: *mut c_void) -> c_int;

@@ -416,7 +416,7 @@ int imt_itree_batch_abort(imt_itree *t);
  * insertion, and writes the witnesses of its own insertions directly -- and every GPU keeps a replica of the
  * stored tree and of the sorted index.  A slice is hashed unit by unit (unit 0 = its leaf hashes, unit 1 + l = level
  * l -> l + 1) on a stream the caller names; each unit leaves a PAYLOAD -- the nodes it wrote back to level l of the
- * stored tree -- which the caller all-gathers (RCCL) and applies on the other replicas.  Correctness rule, kept by
+ * stored tree as packed (node, value) pairs -- which the caller all-gathers (RCCL) and applies on the other replicas.  Correctness rule, kept by
  * the caller's schedule (sharded.py: SlicedIndexedTree; slice k of the global sequence runs its unit u no earlier
  * than slice k - 1's unit u has been applied here): a slice's level l sees the level-l write-backs of every earlier
  * slice and of no later one.  Device pointers only.
@@ -432,7 +432,11 @@ int imt_itree_batch_abort(imt_itree *t);
  *   apply   : enqueue another GPU's payload for (slice of n insertions into a tree of size_before leaves, unit) on
  *             hip_stream: writes that unit's nodes into this replica.
  * After the last apply the caller synchronises the streams it passed before any other call on the tree. */
-size_t imt_itree_slice_payload_bytes(size_t n);
+size_t imt_itree_slice_payload_bytes(size_t n);   /* the largest payload of a slice of n insertions (buffer size) */
+/* bytes the payload of `unit` of a slice of n insertions into a tree of size_before leaves actually uses (<= the above):
+ * 128 B of header + one (node, value) pair per node the level can hold under the leaves in use, at most one per
+ * event -- what an all-gather of that unit has to move.  The same on every GPU (it depends on sizes only). */
+size_t imt_itree_slice_unit_bytes(const imt_itree *t, uint64_t size_before, size_t n, unsigned unit);
 int imt_itree_slice_prepare(imt_itree *t, const void *vals /*[n_before + n_own + n_after][32]*/, size_t n_before,
                             size_t n_own, size_t n_after, const imt_insert_out *out, unsigned flags, int *slice_out,
                             uint32_t *l0_out);

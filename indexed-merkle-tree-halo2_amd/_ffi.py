@@ -122,6 +122,7 @@ SIGNATURES = {
     "imt_itree_batch_end": (c_int, [c_void_p, P(c_void_p), c_void_p]),
     "imt_itree_batch_abort": (c_int, [c_void_p]),
     "imt_itree_slice_payload_bytes": (c_size_t, [c_size_t]),
+    "imt_itree_slice_unit_bytes": (c_size_t, [c_void_p, c_u64, c_size_t, c_uint]),
     "imt_itree_slice_prepare": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, P(InsertOut), c_uint, P(c_int),
                                         P(ctypes.c_uint32)]),
     "imt_itree_slice_unit": (c_int, [c_void_p, c_int, c_uint, c_void_p, c_void_p]),

@@ -106,6 +106,7 @@ struct PlanSet {
     imt_insert_out slice_out = {};
     unsigned slice_fmt = 0;
     unsigned slice_next_unit = 0;
+    uint64_t slice_size_before = 0;      // leaves in the tree before this slice (its own first new leaf)
     launch::SibLayout slice_lay = {0, 0};
 };
 
@@ -1486,7 +1487,23 @@ extern "C" int imt_itree_batch_end(imt_itree* t, const void* const* val_levels, 
 // SlicedIndexedTree) guarantees both.  The values other GPUs hash only enter this replica's index (sort + merge, no
 // events, no hashing).
 namespace {
-constexpr size_t SLICE_HDR = 128;      // payload header: node at l0 (32 B), node above (32 B), root (32 B), pad
+constexpr size_t SLICE_HDR = 128;      // payload header: node at l0 (32 B), node above (32 B), root (32 B), count (4 B), pad
+constexpr size_t SLICE_COUNT_AT = 96;
+
+// (node, value) pairs a slice of n insertions into a tree of size_before leaves can write back at level l: one per
+// event at most, and no more than the level has nodes under the leaves in use
+inline size_t slice_pairs(uint64_t size_before, size_t n, unsigned l) {
+    const uint64_t nodes = l < 63 ? ((size_before + n - 1) >> l) + 1 : 1;
+    return (size_t)std::min<uint64_t>(2 * (uint64_t)n, nodes);
+}
+// bytes of the payload of unit 1 + l: header, values, node ids, rounded to 16
+inline size_t slice_unit_bytes(uint64_t size_before, size_t n, unsigned unit, unsigned depth) {
+    if (unit == 0) return SLICE_HDR;
+    const unsigned l = unit - 1;
+    const unsigned L0 = std::min(ceil_log2(size_before + n), depth);
+    if (l >= L0) return SLICE_HDR;
+    return (SLICE_HDR + 36 * slice_pairs(size_before, n, l) + 15) & ~(size_t)15;
+}
 
 int fws_reserve(imt_itree* t, size_t n) {
     imt_ctx* c = t->ctx;
@@ -1519,7 +1536,12 @@ int fws_reserve(imt_itree* t, size_t n) {
 }
 }  // namespace
 
-extern "C" size_t imt_itree_slice_payload_bytes(size_t n) { return SLICE_HDR + 80 * n; }
+extern "C" size_t imt_itree_slice_payload_bytes(size_t n) { return (SLICE_HDR + 72 * n + 15) & ~(size_t)15; }
+
+extern "C" size_t imt_itree_slice_unit_bytes(const imt_itree* t, uint64_t size_before, size_t n, unsigned unit) {
+    if (!t || n == 0 || unit > t->depth) return 0;
+    return slice_unit_bytes(size_before, n, unit, t->depth);
+}
 
 extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_before, size_t n_own, size_t n_after,
                                        const imt_insert_out* out, unsigned flags, int* slice_out, uint32_t* l0_out) {
@@ -1633,6 +1655,7 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
     P.slice_out = out ? *out : imt_insert_out{};
     P.slice_fmt = fmt;
     P.slice_next_unit = 0;
+    P.slice_size_before = M_own;
     P.slice_lay = (flags & IMT_SIB_ITEM_MAJOR) ? launch::SibLayout{1, t->depth} : launch::SibLayout{n_own, 1};
     P.l0 = L0;
     P.has_root = false;
@@ -1678,10 +1701,11 @@ extern "C" int imt_itree_slice_unit(imt_itree* t, int slice, unsigned unit, void
         c->prof_end(pf, s);
         pf = c->prof_begin(IMT_PROF_WRITEBACK, s);
         launch::writeback(s, vin, P.d_from + off, P.d_nodeb + off, t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
-        if (pl) {       // what the other replicas need to write the same nodes back
-            IMT_HIP(c, hipMemcpyAsync(pl + SLICE_HDR, vin, E * 32, hipMemcpyDeviceToDevice, s));
-            IMT_HIP(c, hipMemcpyAsync(pl + SLICE_HDR + E * 32, P.d_from + off, E * 4, hipMemcpyDeviceToDevice, s));
-            IMT_HIP(c, hipMemcpyAsync(pl + SLICE_HDR + E * 36, P.d_nodeb + off, E * 4, hipMemcpyDeviceToDevice, s));
+        if (pl) {       // what the other replicas need to write the same nodes back: (node, value) pairs, packed
+            const size_t cap = slice_pairs(P.slice_size_before, n, l);
+            IMT_HIP(c, hipMemsetAsync(pl + SLICE_COUNT_AT, 0, 4, s));
+            launch::pack_writeback(s, vin, P.d_from + off, P.d_nodeb + off, (uint32_t)E, pl + SLICE_HDR,
+                                   (uint32_t*)(pl + SLICE_HDR + cap * 32), (uint32_t*)(pl + SLICE_COUNT_AT), (uint32_t)cap);
         }
         c->prof_end(pf, s);
     } else {
@@ -1726,13 +1750,13 @@ extern "C" int imt_itree_slice_apply(imt_itree* t, uint64_t size_before, size_t 
     if (rc) return rc;
     if ((rc = check_fe_ptrs(c, true, {payload}))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    const size_t E = 2 * n;
     const unsigned depth = t->depth, l = unit - 1;
     const unsigned L0 = std::min(ceil_log2(size_before + n), depth);
     const uint8_t* pl = (const uint8_t*)payload;
     if (l < L0) {
-        launch::writeback(s, pl + SLICE_HDR, (const uint32_t*)(pl + SLICE_HDR + E * 32), (const uint32_t*)(pl + SLICE_HDR + E * 36),
-                          t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
+        const size_t cap = slice_pairs(size_before, n, l);
+        launch::apply_packed(s, pl + SLICE_HDR, (const uint32_t*)(pl + SLICE_HDR + cap * 32), (const uint32_t*)(pl + SLICE_COUNT_AT),
+                             (uint32_t)cap, t->d_nodes + t->h_off[l] * 32, t->h_len[l]);
     } else {
         if (l == L0) IMT_HIP(c, hipMemcpyAsync(t->d_nodes + t->h_off[l] * 32, pl, 32, hipMemcpyDeviceToDevice, s));
         IMT_HIP(c, hipMemcpyAsync(t->d_nodes + t->h_off[l + 1] * 32, pl + 32, 32, hipMemcpyDeviceToDevice, s));

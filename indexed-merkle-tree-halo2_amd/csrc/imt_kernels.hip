@@ -1078,6 +1078,41 @@ __global__ void __launch_bounds__(BLOCK) k_extract(ExtractArgs a) {
     store_fe(g_pc, dst + ((uint64_t)l * a.lay.level_stride + (uint64_t)i_local * a.lay.item_stride) * 32, x, a.fmt_out);
 }
 
+// ---- time-sliced single list (imt_itree_slice_*): a level's write-back as a compact payload -----------------
+// What k_writeback writes -- the last version of every node the slice touched at this level -- as (node, value) pairs,
+// packed: level l has at most min(events, nodes of level l) of them, so the payloads the GPUs exchange shrink by half
+// per level once a level has fewer nodes than the slice has events.  Order is whatever the atomic counter gives; the
+// nodes are distinct.
+__global__ void __launch_bounds__(BLOCK)
+k_pack_writeback(const uint8_t* __restrict__ val_l, const uint32_t* __restrict__ from, const uint32_t* __restrict__ node_below,
+                 uint32_t total, uint8_t* __restrict__ out_vals, uint32_t* __restrict__ out_nodes, uint32_t* counter,
+                 uint32_t cap) {
+    const size_t kp = gtid();
+    if (kp >= total) return;
+    const uint32_t f = from[kp];
+    if (!(f & sweep::LAST_BIT)) return;
+    const uint32_t i = atomicAdd(counter, 1u);
+    if (i >= cap) return;                 // cannot happen: cap bounds the nodes of the level (kept as a fence)
+    const Word4* s = reinterpret_cast<const Word4*>(val_l + (size_t)(f & ~sweep::LAST_BIT) * 32);
+    Word4* d = reinterpret_cast<Word4*>(out_vals + (size_t)i * 32);
+    d[0] = s[0];
+    d[1] = s[1];
+    out_nodes[i] = node_below[kp];
+}
+__global__ void __launch_bounds__(BLOCK)
+k_apply_packed(const uint8_t* __restrict__ vals, const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ counter,
+               uint32_t cap, uint8_t* __restrict__ tree_l, uint64_t len_l) {
+    const size_t i = gtid();
+    const uint32_t n = *counter < cap ? *counter : cap;
+    if (i >= n) return;
+    const uint64_t node = nodes[i];
+    if (node >= len_l) return;            // a well-formed payload never names a node outside the stored level
+    const Word4* s = reinterpret_cast<const Word4*>(vals + i * 32);
+    Word4* d = reinterpret_cast<Word4*>(tree_l + node * 32);
+    d[0] = s[0];
+    d[1] = s[1];
+}
+
 __global__ void k_store_top_path(const uint8_t* __restrict__ top_path, uint8_t* __restrict__ tree_nodes,
                                  const uint64_t* __restrict__ tree_off, unsigned l0, unsigned depth) {
     const unsigned l = l0 + threadIdx.x;
@@ -1334,6 +1369,17 @@ void extract(hipStream_t s, const ExtractParams& p) {
                   p.new_sib, p.lay, p.fmt_out};
     const size_t threads = (size_t)p.ins_count * 2 * ((size_t)p.depth + 1);
     hipLaunchKernelGGL(k_extract, dim3(nblk(threads)), dim3(BLOCK), 0, s, a);
+}
+void pack_writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const uint32_t* node_below, uint32_t total,
+                    uint8_t* out_vals, uint32_t* out_nodes, uint32_t* counter, uint32_t cap) {
+    if (!total) return;
+    hipLaunchKernelGGL(k_pack_writeback, dim3(nblk(total)), dim3(BLOCK), 0, s, val_l, from, node_below, total, out_vals,
+                       out_nodes, counter, cap);
+}
+void apply_packed(hipStream_t s, const uint8_t* vals, const uint32_t* nodes, const uint32_t* counter, uint32_t cap,
+                  uint8_t* tree_l, uint64_t len_l) {
+    if (!cap) return;
+    hipLaunchKernelGGL(k_apply_packed, dim3(nblk(cap)), dim3(BLOCK), 0, s, vals, nodes, counter, cap, tree_l, len_l);
 }
 void store_top_path(hipStream_t s, const uint8_t* top_path, uint8_t* tree_nodes, const uint64_t* tree_off, unsigned l0,
                     unsigned depth) {

@@ -24,8 +24,11 @@ A later slice's level l does not exist yet when an earlier one reads it.  Stream
 tick orders round R's units AND its applies behind round R - 1's writes to the same level (two rounds' write-backs to
 one node must land in slice order).
 
-Per step and rank: depth + 1 + (world - 1) lag all-gathers of world x imt_itree_slice_payload_bytes(batch) bytes
-(5.2 MB per rank at batch 2^16), issued asynchronously and consumed `lag` ticks later.
+Per step and rank: depth + 1 + (world - 1) lag all-gathers, issued asynchronously and consumed `lag` ticks later.  A
+payload is the packed (node, value) pairs of a level's write-back: one per event at the bottom of the tree (36 B x 2^17 =
+4.7 MB at batch 2^16), half as many per level once a level has fewer nodes than the slice has events, 128 bytes above
+l0; every all-gather moves world x the largest payload of its tick (imt_itree_slice_unit_bytes: the same arithmetic on
+every rank).
 
 The compute backend is pluggable like sharded.py's: `SliceGpuBackend` (libimt_hip.so) or, in CPU tests, a symbolic one.
 Transports: `DistTransport` (torch.distributed: device tensors with "nccl" = RCCL, pinned host staging with gloo) and
@@ -131,6 +134,10 @@ class SliceGpuBackend:
         self.ctx._check(rc)
         return sl.value
 
+    def unit_bytes(self, size_before, n, q):
+        """bytes the payload of unit q of a slice (n insertions into a tree of size_before leaves) uses"""
+        return int(self.lib.imt_itree_slice_unit_bytes(self.tree.h, size_before, n, q))
+
     def unit(self, slice_id, q, payload, stream):
         self.ctx._check(self.lib.imt_itree_slice_unit(self.tree.h, slice_id, q, ctypes.c_void_p(payload.data_ptr()),
                                                       ctypes.c_void_p(stream.cuda_stream)))
@@ -169,7 +176,8 @@ class DistTransport:
         self.bytes_moved, self.collectives = 0, 0
 
     def all_gather(self, rk, slot, ring, stream):
-        out, inp = rk.recv[slot][ring], rk.send[slot][ring]
+        S = rk.gather_bytes[slot][ring]
+        out, inp = rk.recv[slot][ring][:S * rk.world], rk.send[slot][ring][:S]
         self.collectives += 1
         self.bytes_moved += out.numel()
         if not self.via_host:
@@ -194,7 +202,7 @@ class SlicedIndexedTree:
         S, D = SliceSchedule.STREAMS, self.sched.lag
         self.ring = D + 1
         pb = backend.payload_bytes
-        self.stride = pb
+        self.gather_bytes = [[pb] * self.ring for _ in range(S)]     # per collective in flight: bytes per rank
         self.send = [[backend.make_buffer(pb) for _ in range(self.ring)] for _ in range(S)]
         self.recv = [[backend.make_buffer(pb * world) for _ in range(self.ring)] for _ in range(S)]
         self.work = [[None] * self.ring for _ in range(S)]
@@ -226,8 +234,8 @@ class SlicedIndexedTree:
                     # (they run on different streams): behind that round's tick max(unit) + world * lag
                     st.wait_event(self.tick_ev[(R - 1) % sc.STREAMS][max(units) + sc.period])
                 b = rd["n"]
-                self.be.apply_gathered(self.recv[slot][ring], self.stride, [rd["size_before"] + g * b for g in range(self.world)],
-                                       [b] * self.world, units, st)
+                self.be.apply_gathered(self.recv[slot][ring], self.gather_bytes[slot][ring],
+                                       [rd["size_before"] + g * b for g in range(self.world)], [b] * self.world, units, st)
 
     def phase_compute(self, R, rt):
         sc = self.sched
@@ -252,6 +260,10 @@ class SlicedIndexedTree:
         with self.be.stream_ctx(st):
             if sc.has_gather(rt):
                 ring = rt % self.ring
+                rd = self.rounds[R]
+                # every rank contributes as many bytes as the largest payload of this tick needs
+                self.gather_bytes[slot][ring] = max(self.be.unit_bytes(rd["size_before"] + g * rd["n"], rd["n"], q)
+                                                    for g, q in enumerate(sc.payload_units(rt)) if q >= 0)
                 self.work[slot][ring] = self.tp.all_gather(self, slot, ring, st)
             self.tick_ev[slot][rt].record(st)
 
@@ -318,14 +330,15 @@ class LocalWorld:
 
         def all_gather(self, rk, slot, ring, stream):
             # every rank has recorded packed[slot][ring][rank] by now (LocalWorld drives the phases in lockstep)
+            S = rk.gather_bytes[slot][ring]
             for h, peer in enumerate(self.peers):
                 if h == rk.rank:
                     continue
                 stream.wait_event(self.packed[slot][ring][h])
-                rk.recv[slot][ring][h * rk.stride:(h + 1) * rk.stride].copy_(peer.send[slot][ring], non_blocking=True)
+                rk.recv[slot][ring][h * S:(h + 1) * S].copy_(peer.send[slot][ring][0:S], non_blocking=True)
             self.copied[slot][ring][rk.rank].record(stream)
             self.collectives += 1
-            self.bytes_moved += rk.stride * self.world
+            self.bytes_moved += S * self.world
             return LocalWorld._Work(self.copied[slot][ring], stream)
 
     def __init__(self, backends, lag=None):

@@ -56,7 +56,7 @@ class Buffer:
         self.is_cuda = False
 
     def __getitem__(self, sl):
-        return Buffer(self.sim, self.a[sl.start // 8:sl.stop // 8])
+        return Buffer(self.sim, self.a[(sl.start or 0) // 8:sl.stop // 8])
 
     def copy_(self, src, non_blocking=False):
         dst, s = self.a, src.a
@@ -152,6 +152,10 @@ class SymbolicBackend:
 
     def _words(self, buf):
         return buf.view(torch.int64) if torch.is_tensor(buf) else buf.a
+
+    def unit_bytes(self, size_before, n, q):
+        # like the product: smaller payloads higher up (here: the full 32 bytes for the lower half of the units, 24 above)
+        return self.payload_bytes if q <= self.units // 2 else 24
 
     def unit(self, slice_id, q, payload, stream):
         sl = self.slices[slice_id]

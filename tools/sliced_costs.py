@@ -39,22 +39,21 @@ for world in worlds:
         ts.append((time.perf_counter() - t0) * 1e3)
         # run the slice so that the plan set frees up (single stream, no exchange: timing only)
         st = be.streams[0]
-        pay = be.make_buffer(be.payload_bytes)
+        pay, pay5 = be.make_buffer(be.payload_bytes), be.make_buffer(be.payload_bytes)
+        size5 = be.size() - world * BATCH
         for q in range(DEPTH + 1):
-            be.unit(sl, q, pay, st)
+            be.unit(sl, q, pay5 if q == 5 else pay, st)     # keep one real payload (level 4: 2^17 pairs) for the apply timing
         st.synchronize()
     print(f"world {world}: slice_prepare (rank 0: own 2^16 + {world - 1} x 2^16 foreign) {np.median(ts[1:]):.2f} ms "
           f"(per round; first {ts[0]:.1f})", flush=True)
     # ---- apply of one gathered level (world - 1 remote payloads below l0)
     if world > 1:
-        g = be.make_buffer(be.payload_bytes * world)
-        # a well-formed payload: `from` without LAST bits (nothing is written), node_below zeros
-        size_before = [be.size() + k * BATCH for k in range(world)]
+        # the last round's real level-4 payload in every remote slot, applied to a second replica
+        g = pay5.repeat(world)
         units = [-1] + [5] * (world - 1)
         st = be.streams[0]
-        # sizes beyond capacity are refused: use a fresh backend's numbers
         be2 = sliced.SliceGpuBackend(imt_amd, 0, DEPTH, cap, BATCH)
-        size_before = [1 + k * BATCH for k in range(world)]
+        size_before = [size5] * world
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         be2.apply_gathered(g, be.payload_bytes, size_before, [BATCH] * world, units, st)
         e0.record(st)
@@ -62,7 +61,7 @@ for world in worlds:
             be2.apply_gathered(g, be.payload_bytes, size_before, [BATCH] * world, units, st)
         e1.record(st)
         st.synchronize()
-        print(f"world {world}: apply of one gathered level ({world - 1} payloads x 2^17 events) "
+        print(f"world {world}: apply of one gathered level ({world - 1} payloads x 2^17 (node, value) pairs) "
               f"{e0.elapsed_time(e1) / 20:.3f} ms", flush=True)
         be2.tree.close(); be2.ctx.close()
     be.tree.close(); be.ctx.close()
