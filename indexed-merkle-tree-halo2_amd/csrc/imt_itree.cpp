@@ -1700,12 +1700,14 @@ extern "C" int imt_itree_slice_unit(imt_itree* t, int slice, unsigned unit, void
                             (uint8_t*)o.low_sib, (uint8_t*)o.new_sib, P.slice_lay, l, fmt, c->coop_max_events);
         c->prof_end(pf, s);
         pf = c->prof_begin(IMT_PROF_WRITEBACK, s);
-        launch::writeback(s, vin, P.d_from + off, P.d_nodeb + off, t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
-        if (pl) {       // what the other replicas need to write the same nodes back: (node, value) pairs, packed
+        if (pl) {       // the write-back, and what the other replicas need to repeat it: (node, value) pairs, packed
             const size_t cap = slice_pairs(P.slice_size_before, n, l);
             IMT_HIP(c, hipMemsetAsync(pl + SLICE_COUNT_AT, 0, 4, s));
-            launch::pack_writeback(s, vin, P.d_from + off, P.d_nodeb + off, (uint32_t)E, pl + SLICE_HDR,
-                                   (uint32_t*)(pl + SLICE_HDR + cap * 32), (uint32_t*)(pl + SLICE_COUNT_AT), (uint32_t)cap);
+            launch::pack_writeback(s, vin, P.d_from + off, P.d_nodeb + off, (uint32_t)E, t->d_nodes + t->h_off[l] * 32,
+                                   pl + SLICE_HDR, (uint32_t*)(pl + SLICE_HDR + cap * 32), (uint32_t*)(pl + SLICE_COUNT_AT),
+                                   (uint32_t)cap);
+        } else {
+            launch::writeback(s, vin, P.d_from + off, P.d_nodeb + off, t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
         }
         c->prof_end(pf, s);
     } else {

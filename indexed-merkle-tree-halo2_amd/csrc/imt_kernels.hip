@@ -1078,26 +1078,40 @@ __global__ void __launch_bounds__(BLOCK) k_extract(ExtractArgs a) {
     store_fe(g_pc, dst + ((uint64_t)l * a.lay.level_stride + (uint64_t)i_local * a.lay.item_stride) * 32, x, a.fmt_out);
 }
 
-// ---- time-sliced single list (imt_itree_slice_*): a level's write-back as a compact payload -----------------
-// What k_writeback writes -- the last version of every node the slice touched at this level -- as (node, value) pairs,
+// ---- time-sliced single list (imt_itree_slice_*): a level's write-back AND the same as a compact payload ----
+// What k_writeback writes -- the last version of every node the slice touched at this level -- goes to the stored tree
+// and, as (node, value) pairs, into the payload the other replicas apply (one kernel, one pass over the tables),
 // packed: level l has at most min(events, nodes of level l) of them, so the payloads the GPUs exchange shrink by half
 // per level once a level has fewer nodes than the slice has events.  Order is whatever the atomic counter gives; the
 // nodes are distinct.
 __global__ void __launch_bounds__(BLOCK)
 k_pack_writeback(const uint8_t* __restrict__ val_l, const uint32_t* __restrict__ from, const uint32_t* __restrict__ node_below,
-                 uint32_t total, uint8_t* __restrict__ out_vals, uint32_t* __restrict__ out_nodes, uint32_t* counter,
-                 uint32_t cap) {
+                 uint32_t total, uint8_t* __restrict__ tree_l, uint8_t* __restrict__ out_vals,
+                 uint32_t* __restrict__ out_nodes, uint32_t* counter, uint32_t cap) {
     const size_t kp = gtid();
-    if (kp >= total) return;
-    const uint32_t f = from[kp];
-    if (!(f & sweep::LAST_BIT)) return;
-    const uint32_t i = atomicAdd(counter, 1u);
-    if (i >= cap) return;                 // cannot happen: cap bounds the nodes of the level (kept as a fence)
+    const uint32_t f = kp < total ? from[kp] : 0u;
+    const bool last = (f & sweep::LAST_BIT) != 0;
+    // one atomic per wavefront, not per pair: 2^17 increments of one address would serialise in L2 (tens of
+    // microseconds per level); the wave's leader reserves a run of slots and every lane takes its rank in the ballot
+    const uint64_t mask = __ballot(last);
+    if (!last) return;
+    const unsigned lane = __lane_id();
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    const uint32_t i = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     const Word4* s = reinterpret_cast<const Word4*>(val_l + (size_t)(f & ~sweep::LAST_BIT) * 32);
+    const Word4 lo = s[0], hi = s[1];
+    const uint32_t node = node_below[kp];
+    Word4* t = reinterpret_cast<Word4*>(tree_l + (size_t)node * 32);     // this replica's own write-back (k_writeback)
+    t[0] = lo;
+    t[1] = hi;
+    if (i >= cap) return;                 // cannot happen: cap bounds the nodes of the level (kept as a fence)
     Word4* d = reinterpret_cast<Word4*>(out_vals + (size_t)i * 32);
-    d[0] = s[0];
-    d[1] = s[1];
-    out_nodes[i] = node_below[kp];
+    d[0] = lo;
+    d[1] = hi;
+    out_nodes[i] = node;
 }
 __global__ void __launch_bounds__(BLOCK)
 k_apply_packed(const uint8_t* __restrict__ vals, const uint32_t* __restrict__ nodes, const uint32_t* __restrict__ counter,
@@ -1371,10 +1385,10 @@ void extract(hipStream_t s, const ExtractParams& p) {
     hipLaunchKernelGGL(k_extract, dim3(nblk(threads)), dim3(BLOCK), 0, s, a);
 }
 void pack_writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const uint32_t* node_below, uint32_t total,
-                    uint8_t* out_vals, uint32_t* out_nodes, uint32_t* counter, uint32_t cap) {
+                    uint8_t* tree_l, uint8_t* out_vals, uint32_t* out_nodes, uint32_t* counter, uint32_t cap) {
     if (!total) return;
-    hipLaunchKernelGGL(k_pack_writeback, dim3(nblk(total)), dim3(BLOCK), 0, s, val_l, from, node_below, total, out_vals,
-                       out_nodes, counter, cap);
+    hipLaunchKernelGGL(k_pack_writeback, dim3(nblk(total)), dim3(BLOCK), 0, s, val_l, from, node_below, total, tree_l,
+                       out_vals, out_nodes, counter, cap);
 }
 void apply_packed(hipStream_t s, const uint8_t* vals, const uint32_t* nodes, const uint32_t* counter, uint32_t cap,
                   uint8_t* tree_l, uint64_t len_l) {

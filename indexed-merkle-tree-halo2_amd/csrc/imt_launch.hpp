@@ -210,7 +210,7 @@ void extract(hipStream_t s, const ExtractParams& p);
 // time-sliced single list: the (node, value) pairs k_writeback would write, packed behind an atomic counter (at most
 // `cap` of them), and their application to a replica's stored level
 void pack_writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const uint32_t* node_below, uint32_t total,
-                    uint8_t* out_vals, uint32_t* out_nodes, uint32_t* counter, uint32_t cap);
+                    uint8_t* tree_l, uint8_t* out_vals, uint32_t* out_nodes, uint32_t* counter, uint32_t cap);
 void apply_packed(hipStream_t s, const uint8_t* vals, const uint32_t* nodes, const uint32_t* counter, uint32_t cap,
                   uint8_t* tree_l, uint64_t len_l);
 void store_top_path(hipStream_t s, const uint8_t* top_path, uint8_t* tree_nodes, const uint64_t* tree_off, unsigned l0,
