@@ -491,6 +491,7 @@ def bench_single_list(env):
     for g in range(world):
         ok = ok and bool((allends[g, 2] == allends[world - 1, 1]).all())
     verified = env.all_true(ok)
+    tree.close()
     kern, pipe_ms = sweep_lines(prof, args.steps)
     sc = tree.sched
     return {"mode": "single-list", "value": args.steps * gb / dt, "ms_per_step": dt / args.steps * 1e3, "verified": verified,

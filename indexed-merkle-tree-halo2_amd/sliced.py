@@ -169,11 +169,39 @@ class SliceGpuBackend:
 class DistTransport:
     """all-gather of one payload per rank through torch.distributed.  backend "nccl" (= RCCL over xGMI): device
     tensors, asynchronous, waited for `lag` ticks later on the round's stream.  Anything else (gloo: rehearsal on a
-    box without one GPU per rank, CPU tests): through host memory, synchronous."""
+    box without one GPU per rank, CPU tests): through host memory -- for device buffers on a helper thread with its
+    own gloo group and copy stream, so that the host-staged gather overlaps the hashing like the RCCL one does."""
+
+    class _HostWork:
+        def __init__(self, issued, done_event, stream):
+            self.issued, self.done_event, self.stream = issued, done_event, stream
+
+        def wait(self):
+            self.issued.wait()                       # the helper has enqueued the copy back to the device ...
+            self.stream.wait_event(self.done_event)  # ... and the round's stream runs behind it
 
     def __init__(self, dist, via_host):
         self.dist, self.via_host = dist, via_host
         self.bytes_moved, self.collectives = 0, 0
+        self._jobs = self._thread = self._group = None
+        self._staging = {}
+
+    def _helper(self, device):
+        torch.cuda.set_device(device)
+        copy_stream = torch.cuda.Stream(device=device)
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            packed, inp, out, h, o, issued, done = job
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(packed)
+                h.copy_(inp, non_blocking=True)
+                copy_stream.synchronize()
+                self.dist.all_gather_into_tensor(o, h, group=self._group)
+                out.copy_(o, non_blocking=True)
+                done.record(copy_stream)
+            issued.set()
 
     def all_gather(self, rk, slot, ring, stream):
         S = rk.gather_bytes[slot][ring]
@@ -182,13 +210,35 @@ class DistTransport:
         self.bytes_moved += out.numel()
         if not self.via_host:
             return self.dist.all_gather_into_tensor(out, inp, async_op=True)
-        if inp.is_cuda:
-            stream.synchronize()
-        h = inp.cpu()
-        o = torch.empty(out.numel(), dtype=torch.uint8)
-        self.dist.all_gather_into_tensor(o, h)
-        out.copy_(o.to(out.device), non_blocking=False)
-        return None
+        if not inp.is_cuda:                          # CPU tests: nothing to overlap
+            o = torch.empty(out.numel(), dtype=torch.uint8)
+            self.dist.all_gather_into_tensor(o, inp)
+            out.copy_(o)
+            return None
+        import queue
+        import threading
+        if self._thread is None:                     # every rank reaches this at its first gather: new_group is collective
+            self._group = self.dist.new_group(backend="gloo")
+            self._jobs = queue.Queue()
+            self._thread = threading.Thread(target=self._helper, args=(inp.device,), daemon=True)
+            self._thread.start()
+        key = (slot, ring)
+        if key not in self._staging:
+            cap = rk.send[slot][ring].numel()
+            self._staging[key] = (torch.empty(cap, dtype=torch.uint8, pin_memory=True),
+                                  torch.empty(cap * rk.world, dtype=torch.uint8, pin_memory=True),
+                                  torch.cuda.Event(), torch.cuda.Event())
+        h, o, packed, done = self._staging[key]
+        packed.record(stream)
+        issued = threading.Event()
+        self._jobs.put((packed, inp, out, h[:S], o[:S * rk.world], issued, done))
+        return self._HostWork(issued, done, stream)
+
+    def close(self):
+        if self._thread is not None:
+            self._jobs.put(None)
+            self._thread.join()
+            self._thread = None
 
 
 class SlicedIndexedTree:
@@ -299,6 +349,10 @@ class SlicedIndexedTree:
         if self.rounds:
             self._run_ticks(self.starts[-1] + self.sched.round_ticks)
         self.be.sync()
+
+    def close(self):
+        if hasattr(self.tp, "close"):
+            self.tp.close()
 
     def outputs(self, R):
         d = self.be.outputs(self.rounds[R]["out_slot"])

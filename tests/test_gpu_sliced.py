@@ -225,6 +225,7 @@ def _worker(rank, world, port, q):
     tree.flush()
     for r in range(max(0, P_ROUNDS - 3), P_ROUNDS):
         res.append({k: v.cpu().numpy().copy() for k, v in tree.outputs(r).items() if torch.is_tensor(v)})
+    tree.close()
     q.put((rank, res, be.tree.root(), tree.tp.collectives, tree.tp.bytes_moved))
     dist.barrier()
     dist.destroy_process_group()
