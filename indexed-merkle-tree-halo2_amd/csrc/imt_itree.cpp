@@ -368,6 +368,14 @@ extern "C" int imt_itree_new(imt_ctx* c, unsigned depth, uint64_t capacity, imt_
     return IMT_OK;
 }
 
+// a slice between imt_itree_slice_prepare and its last unit owns its plan set and has moved the index ahead of the
+// stored tree: the batch calls wait until it is finished
+static bool slice_open(const imt_itree* t) {
+    for (const auto& pl : t->plan)
+        if (pl.open) return true;
+    return false;
+}
+
 // order the context's stream behind every pipelined batch still in flight
 static int join_top(imt_itree* t) {
     if (!t->pipe_pending) return IMT_OK;
@@ -695,6 +703,7 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
     if (!preimages || n == 0) return c->fail(IMT_ERR_ARG, "null / empty snapshot");
     if (n > t->cap) return c->fail(IMT_ERR_FULL, "snapshot has %llu leaves, capacity is %llu", (unsigned long long)n,
                                    (unsigned long long)t->cap);
+    if (slice_open(t)) return c->fail(IMT_ERR_ARG, "a slice is open (issue its remaining units first)");
     int rc = c->set_device();
     if (rc) return rc;
     if ((rc = join_top(t))) return rc;
@@ -1032,6 +1041,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
     if (n > ((size_t)1 << 30)) return c->fail(IMT_ERR_RANGE, "batch too large");
     if (t->pending.active) return c->fail(IMT_ERR_ARG, "a sharded batch is open (imt_itree_batch_end first)");
+    if (slice_open(t)) return c->fail(IMT_ERR_ARG, "a slice is open (issue its remaining units first)");
     int rc = c->set_device();
     if (rc) return rc;
     const bool dev = flags & IMT_DEVICE_PTRS;
@@ -1265,6 +1275,7 @@ extern "C" int imt_itree_batch_begin(imt_itree* t, const void* vals, size_t n, u
     if (!vals || n == 0) return c->fail(IMT_ERR_ARG, "null / empty batch");
     if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
     if (t->pending.active) return c->fail(IMT_ERR_ARG, "a sharded batch is already open");
+    if (slice_open(t)) return c->fail(IMT_ERR_ARG, "a slice is open (issue its remaining units first)");
     if (n > ((size_t)1 << 30)) return c->fail(IMT_ERR_RANGE, "batch too large");
     int rc = c->set_device();
     if (rc) return rc;

@@ -275,6 +275,8 @@ def test_slice_calls_refuse_bad_arguments(imt, ctx):
     assert t.size == 1
     assert lib.imt_itree_slice_prepare(t.h, P_(vals), 0, 16, 0, None, F.DEVICE_PTRS, ctypes.byref(sl), None) == 0
     assert t.size == 17
+    with pytest.raises(imt.ImtError):                                                         # a slice is open: batch calls wait
+        t.insert_batch([12345])
     assert lib.imt_itree_slice_unit(t.h, sl.value, 1, P_(pay), None) == F.ERR["ARG"]          # unit 0 comes first
     assert lib.imt_itree_slice_unit(t.h, sl.value, 0, P_(pay, 8), None) == F.ERR["ARG"]       # misaligned payload
     assert lib.imt_itree_slice_unit(t.h, 7, 0, P_(pay), None) == F.ERR["ARG"]
