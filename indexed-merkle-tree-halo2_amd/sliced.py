@@ -173,17 +173,18 @@ class DistTransport:
     own gloo group and copy stream, so that the host-staged gather overlaps the hashing like the RCCL one does."""
 
     class _HostWork:
-        def __init__(self, issued, done_event, stream):
-            self.issued, self.done_event, self.stream = issued, done_event, stream
+        def __init__(self, tp, issued, done_event, stream):
+            self.tp, self.issued, self.done_event, self.stream = tp, issued, done_event, stream
 
         def wait(self):
-            self.issued.wait()                       # the helper has enqueued the copy back to the device ...
+            if not self.issued.wait(timeout=600) or self.tp._failure is not None:   # the helper has enqueued the copy back ...
+                raise RuntimeError(f"host-staged all-gather failed: {self.tp._failure or 'timed out'}")
             self.stream.wait_event(self.done_event)  # ... and the round's stream runs behind it
 
     def __init__(self, dist, via_host):
         self.dist, self.via_host = dist, via_host
         self.bytes_moved, self.collectives = 0, 0
-        self._jobs = self._thread = self._group = None
+        self._jobs = self._thread = self._group = self._failure = None
         self._staging = {}
 
     def _helper(self, device):
@@ -194,13 +195,16 @@ class DistTransport:
             if job is None:
                 return
             packed, inp, out, h, o, issued, done = job
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(packed)
-                h.copy_(inp, non_blocking=True)
-                copy_stream.synchronize()
-                self.dist.all_gather_into_tensor(o, h, group=self._group)
-                out.copy_(o, non_blocking=True)
-                done.record(copy_stream)
+            try:
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(packed)
+                    h.copy_(inp, non_blocking=True)
+                    copy_stream.synchronize()
+                    self.dist.all_gather_into_tensor(o, h, group=self._group)
+                    out.copy_(o, non_blocking=True)
+                    done.record(copy_stream)
+            except Exception as e:                   # reported by the next wait() on the main thread
+                self._failure = f"{type(e).__name__}: {e}"
             issued.set()
 
     def all_gather(self, rk, slot, ring, stream):
@@ -232,7 +236,7 @@ class DistTransport:
         packed.record(stream)
         issued = threading.Event()
         self._jobs.put((packed, inp, out, h[:S], o[:S * rk.world], issued, done))
-        return self._HostWork(issued, done, stream)
+        return self._HostWork(self, issued, done, stream)
 
     def close(self):
         if self._thread is not None:
