@@ -386,4 +386,44 @@ private:
     imt_itree* t_ = nullptr;
 };
 
+// ---- several GPUs, the single sorted list (imt_itree_slice_*): the schedule ------------------------------------------
+// The arithmetic a host needs to drive time-sliced insertion with its own collective library (RCCL's ncclAllGather):
+// which unit a rank runs at which tick, what each all-gather carries, when it is consumed.  It is the schedule of
+// indexed-merkle-tree-halo2_amd/sliced.py (SliceSchedule; tests/test_host_logic.py compares the two):
+//   round R = the `world` slices of step R; unit q of a slice: 0 = leaf hashes, 1 + l = level l -> l + 1;
+//   round tick rt: rank g runs unit rt - g * lag; all ranks all-gather that tick's payloads (imt_itree_slice_unit ->
+//   payload, imt_itree_slice_unit_bytes = its size); the gather of tick rt is applied at tick rt + lag
+//   (imt_itree_slice_apply_gathered); consecutive rounds start world * lag ticks apart, at most four are in flight.
+// Ordering a host must keep: round R's unit q, and round R's applies of payloads for unit q, run behind round R - 1's
+// tick q + world * lag (every write-back round R - 1 makes to that level is in this replica by then).
+struct SliceSchedule {
+    static constexpr unsigned kRoundsInFlight = 4;
+    unsigned world, units, lag, period, gathers, round_ticks;
+    SliceSchedule(unsigned world_, unsigned units_, unsigned lag_ = 0) : world(world_), units(units_) {
+        if (world < 1 || units < 2) throw std::invalid_argument("world >= 1 and units >= 2");
+        const unsigned fit = (units + (kRoundsInFlight - 1) * world - 1) / ((kRoundsInFlight - 1) * world);
+        lag = lag_ ? lag_ : (fit > 2 ? fit : 2);
+        period = world * lag;
+        gathers = units + (world - 1) * lag;
+        round_ticks = gathers + lag;
+        if ((round_ticks + period - 1) / period > kRoundsInFlight) throw std::invalid_argument("lag keeps too many rounds in flight");
+    }
+    // unit rank `rank` computes at round tick rt, or -1
+    int unit_of(unsigned rank, unsigned rt) const {
+        const long q = (long)rt - (long)rank * (long)lag;
+        return q >= 0 && q < (long)units ? (int)q : -1;
+    }
+    // unit whose payload rank `rank` contributes to the all-gather of round tick rt, or -1 (unit 0 writes nothing back)
+    int payload_unit(unsigned rank, unsigned rt) const {
+        const int q = unit_of(rank, rt);
+        return q >= 1 ? q : -1;
+    }
+    bool has_gather(unsigned rt) const {
+        if (rt >= gathers) return false;
+        for (unsigned g = 0; g < world; g++)
+            if (payload_unit(g, rt) >= 0) return true;
+        return false;
+    }
+};
+
 }  // namespace imt
