@@ -135,6 +135,70 @@ def test_local_world_at_bench_size(imt, ctx):
         be.ctx.close()
 
 
+def test_config4_single_list_eight_slices_2pow22(imt, ctx):
+    """BASELINE config 4's size on the reference's data structure: 2^22 insertions into ONE depth-32 tree, 8 slices of
+    2^16 per step (8 replicas on this one GPU), 8 steps.  Size-independent properties at full size: every insertion's
+    witnesses pass every insert_leaf constraint at depth 32 with global leaf indices (imt_insert_witness_batch), the
+    roots chain insertion to insertion, slice to slice and step to step, all replicas end in the same root, and that
+    root is the one-GPU tree's over the same 2^22 values."""
+    import ctypes
+    import bench
+    sl = load_sliced()
+    depth, world, batch, rounds = 32, 8, 1 << 16, 8
+    cap = 1 << 23
+    gb = world * batch
+    vals = torch.from_numpy(bench.synth_values(gb * rounds, 0, 1, 0x494D5404)).cuda()
+    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch) for _ in range(world)]
+    w = sl.LocalWorld(bes)
+    F, lib = imt._ffi, imt.lib
+    P_ = lambda x: ctypes.c_void_p(x.data_ptr())
+    fail = torch.empty(batch, dtype=torch.uint8, device="cuda")
+    prev_last = None
+    checked = 0
+
+    def check(r):
+        nonlocal prev_last
+        for rk in w.ranks:
+            o = rk.outputs(r)
+            first = o["first_insertion"]
+            assert first == 1 + r * gb + rk.rank * batch
+            new_index = torch.arange(first, first + batch, dtype=torch.int64, device="cuda")
+            c = rk.be.ctx
+            c._check(lib.imt_insert_witness_batch(c.h, P_(o["old_root"]), P_(o["low_leaf"]), P_(o["low_index"]), P_(o["low_sib"]),
+                                                  P_(o["new_root"]), P_(o["new_leaf"]), P_(new_index), None, P_(o["new_sib"]),
+                                                  P_(o["is_largest"]), depth, batch, P_(fail), None, F.DEVICE_PTRS))
+            c.sync()
+            assert int(fail.max()) == 0, (r, rk.rank)
+            assert bool((o["old_root"][1:] == o["new_root"][:-1]).all())
+            if prev_last is not None:
+                assert bool((o["old_root"][0] == prev_last).all()), (r, rk.rank)      # slice to slice, step to step
+            prev_last = o["new_root"][-1].clone()
+
+    for r in range(rounds):
+        w.step([vals[r * gb:(r + 1) * gb]] * world)
+        while checked <= r - 3:
+            for rk in w.ranks:
+                rk.done_event(checked).synchronize()
+            check(checked)
+            checked += 1
+    w.flush()
+    while checked < rounds:
+        check(checked)
+        checked += 1
+    roots = {be.tree.root() for be in bes}
+    assert len(roots) == 1 and imt.to_int(prev_last.cpu().numpy()) in roots
+    for be in bes:
+        assert be.size() == 1 + gb * rounds
+        be.tree.close()
+        be.ctx.close()
+    ref = imt.IndexedTree(ctx, depth, cap)
+    for r in range(rounds):
+        ctx._check(lib.imt_itree_insert_batch(ref.h, P_(vals[r * gb:(r + 1) * gb]), gb, None, F.DEVICE_PTRS | F.PIPELINE))
+    ctx.sync()
+    assert ref.root() in roots
+    ref.close()
+
+
 def test_local_world_fills_a_small_tree_to_its_last_level(imt, ctx):
     """depth 8, 4 replicas: l0 reaches the depth (no empty-subtree levels left), the root travels in the payload"""
     sl = load_sliced()
