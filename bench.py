@@ -355,19 +355,28 @@ def bench_subtrees(env):
     out_pinned = os.environ.get("IMT_BENCH_OUT") == "pinned"        # secondary measurement (PCIe note)
     gpu_prep = os.environ.get("IMT_BENCH_PREP", "gpu") == "gpu"     # low-leaf search + event build on the GPU
     pipelined = not os.environ.get("IMT_NO_PIPELINE")
-    # Two output sets: the batches in flight never share rows, and the set of a batch is rewritten only by the
-    # batch after next -- by then its lift (N > 1) has run.  The bench does not consume the outputs between steps, so
-    # the hash-free output buffers are idle when a batch starts (IMT_INPUTS_READY).
+    # Two rotating output sets: the batches in flight never share rows, and the set of a batch is rewritten only by
+    # the batch after next -- by then its lift (N > 1) has run.  The bench does not consume the outputs between steps, so
+    # the hash-free output buffers are idle when a batch starts (IMT_INPUTS_READY).  A THIRD set is written once, by the
+    # step in the middle of the timed region, and verified afterwards like the last step's: nothing is copied or
+    # synchronised inside the timed region for it.
     be = sharded.GpuBackend(env.imt, env.local_rank, DEPTH, world, rank, cap, BATCH, pipeline=pipelined,
-                            inputs_ready=True, nbuf=2, host_prep=not gpu_prep, pinned_outputs=out_pinned)
+                            inputs_ready=True, nbuf=3, host_prep=not gpu_prep, pinned_outputs=out_pinned)
+    mid_step = args.warmup + args.steps // 2 if args.steps >= 3 and not out_pinned else None
     ctx = be.ctx
     tree = sharded.ShardedIndexedTree(be, DEPTH, world, rank, dist, via_host=(env.backend != "nccl"))
     host_s = [0.0]
     last_slot = [None]
 
+    rot = [0]
+
     def step(i, flags=None):
         th = time.perf_counter()
         v = vals[i * BATCH:(i + 1) * BATCH]
+        if i == mid_step:
+            be.next_slot = 2
+        else:
+            be.next_slot, rot[0] = rot[0], rot[0] ^ 1
         if dist is None or flags is not None:
             last_slot[0] = be.insert(v, flags)
         else:
@@ -401,6 +410,10 @@ def bench_subtrees(env):
     # through the independent witness kernels with global leaf indices; its last new_root must be the tree's root.
     o = be.outputs(last_slot[0])
     verified = witness_check(env, ctx, o, o["first_new_index"], BATCH)
+    if mid_step is not None:        # a step from the middle of the timed region, kept in its own output set
+        om = be.outputs(2)
+        verified = verified and om["first_new_index"] == be.tree.index_base + 1 + mid_step * BATCH
+        verified = verified and witness_check(env, ctx, om, om["first_new_index"], BATCH)
     if dist is None:
         root_now = torch.from_numpy(env.imt.to_bytes(be.tree.root()))
         verified = verified and bool((o["new_root"][-1].cpu() == root_now).all())
@@ -580,9 +593,10 @@ def main():
                                    "proofs written to HBM; values resident in HBM",
                        "batch_per_gpu": BATCH, "depth": DEPTH, "parallelism": par,
                        "hashes_per_insertion": head["hashes_per_insertion"],
-                       "verified_how": "last timed step's outputs through imt_insert_witness_batch(depth=32, global "
-                                       "indices) + root chain (inside a batch, across ranks) + tree root, after the "
-                                       "timed region"},
+                       "verified_how": "outputs of the last timed step (and, for the one-tree / subtree leg, of the step in the "
+                                       "middle of the timed region, kept in its own buffer set) through "
+                                       "imt_insert_witness_batch(depth=32, global indices) + root chain (inside a batch, "
+                                       "across ranks) + tree root, after the timed region"},
             "roofline": roof, "valu": valu, "trace_roofline": trace_line,
             "kernels": head["kernels"], "gpu_kernel_ms_per_step": head["gpu_kernel_ms_per_step"],
             "host_call_ms_per_step": head["host_call_ms_per_step"],
