@@ -124,7 +124,7 @@ int imt_host_free(imt_ctx *ctx, void *ptr);
  * (one wave per SIMD); 0 = never.  Results are bit-identical either way. */
 #define IMT_OPT_COOP_MAX_EVENTS 1
 int imt_ctx_set_option(imt_ctx *ctx, int option, uint64_t value);
-/* ABI / build identification, e.g. "imt-hip gfx950 r2" */
+/* ABI / build identification, e.g. "imt-hip gfx950 r3" */
 const char *imt_version(void);
 /* Per-kernel timing with HIP events recorded on the context's stream around the launches of
  * imt_itree_insert_batch (used by bench.py for the roofline line; off by default).
