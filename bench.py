@@ -535,6 +535,66 @@ def mode_summary(r, world):
     return out
 
 
+def assemble_line(env, legs, failed, probes):
+    """rank 0's JSON line from the legs that finished; `failed` = why the single-list leg did not (or None)"""
+    args, world, dist = env.args, env.world, env.dist
+    mad_peak, copy_gbps, trace_line = probes
+    head = legs.get("single-list") or legs["subtrees"]
+    ok = all(r["verified"] for r in legs.values())
+    roof, valu = roofline_objects(head["ms_per_step"], head["alone_ms"], head["pipe_ms"], copy_gbps, mad_peak,
+                                  head["hashes_per_insertion"])
+    single = legs.get("subtrees") if dist is None else None
+    if world == 1 and dist is None:
+        par = "single tree"
+    elif head["mode"] == "single-list":
+        par = (f"ONE indexed tree (the reference's single sorted list) on {world} GPUs: a step's {world} x 2^16 "
+               f"insertions in {world} consecutive slices, one per rank; replicas kept equal by all-gathers (RCCL) of "
+               f"each slice's per-level write-backs, consumed {head['schedule']['lag_levels']} levels later")
+    else:
+        par = (f"{world} value-partitioned subtrees by leaf-index range; per step one RCCL all-gather of the "
+               f"subtree roots (one step behind) + lift of every witness to depth 32 on its own rank")
+    res = {
+        "metric": METRIC, "value": head["value"], "unit": "insertions/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "ranks_seen": env.ranks_seen,
+        "collective_backend": env.backend if dist is not None else None, "verified": ok,
+        "value_is": head["mode"] + (" (the reference's data structure, bit-exact with one GPU)"
+                                    if head["mode"] != "subtrees" else
+                                    " (N sorted lists under one root: needs one more circuit constraint per witness, INTEGRATION.md sec. 4)"),
+        "config": {"workload": "depth=32, 2^16 sequential-semantics insertions per step per GPU "
+                               "(BASELINE configs[1]); per insertion: old/interim/new depth-32 root + two 32-sibling "
+                               "proofs written to HBM; values resident in HBM",
+                   "batch_per_gpu": BATCH, "depth": DEPTH, "parallelism": par,
+                   "hashes_per_insertion": head["hashes_per_insertion"],
+                   "verified_how": "outputs of the last timed step (and, for the one-tree / subtree leg, of the step in the "
+                                   "middle of the timed region, kept in its own buffer set) through "
+                                   "imt_insert_witness_batch(depth=32, global indices) + root chain (inside a batch, "
+                                   "across ranks) + tree root, after the timed region"},
+        "roofline": roof, "valu": valu, "trace_roofline": trace_line,
+        "kernels": head["kernels"], "gpu_kernel_ms_per_step": head["gpu_kernel_ms_per_step"],
+        "host_call_ms_per_step": head["host_call_ms_per_step"],
+        "whole_step_algorithmic_GBps": head["value"] * BYTES_PER_INSERTION / 1e9,
+    }
+    if single is not None:
+        res["config"]["prepare"] = single["prepare"]
+        res["config"]["outputs"] = single["outputs"]
+        res["host_prepare_ms_per_step"] = single["host_prepare_ms_per_step"]
+    if dist is not None:
+        res["modes"] = {name.replace("-", "_"): mode_summary(r, world) for name, r in legs.items()}
+        if failed:
+            res["modes"]["single_list"] = {"error": failed}
+        res["collectives_per_step"] = head["collectives_per_step"]
+        res["bytes_gathered_per_step_per_rank"] = head["bytes_gathered_per_step_per_rank"]
+    if world == 1 and dist is None and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(single["vals_h"])
+        res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(single["vals_h"])
+    else:
+        res["cpu_baseline"] = None
+        res["cpu_baseline_why_null"] = ("measured on rank 0 at N = 1 only (contract)" if world > 1 or dist is not None
+                                        else "--no-cpu-baseline")
+    return res, ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -547,84 +607,53 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     env = Env(args)
-    world, rank, dist = env.world, env.rank, env.dist
+    rank, dist = env.rank, env.dist
     # N > 1: "both" (default; `value` = single-list), or one of "single-list" / "subtrees" alone
     mode = os.environ.get("IMT_BENCH_MODE", "both" if dist is not None else "subtrees")
     legs, failed = {}, None
     if mode in ("both", "subtrees") or dist is None:
         legs["subtrees"] = bench_subtrees(env)
     if dist is not None and mode in ("both", "single-list"):
+        watchdog = None
         if "subtrees" in legs:      # free the first leg's tree and buffers; keep its context for the probes
             legs["subtrees"]["be"].tree.close()
             legs["subtrees"]["be"].sets = legs["subtrees"]["be"].structs = None
             torch.cuda.empty_cache()
+            # The second leg's collectives have never run on more than one GPU in this builder's hands.  If they hang
+            # there, the first leg's measurement must not be lost with them: after the time limit every rank leaves, and
+            # rank 0 prints the line with what it has (no device probes: the device may be the thing that hangs).
+            import threading
+            limit = float(os.environ.get("IMT_BENCH_SINGLE_LIST_TIMEOUT", "240"))
+
+            def give_up():
+                if rank == 0:
+                    res, _ = assemble_line(env, legs, f"the single-list leg did not finish within {limit:.0f} s", (None, None, None))
+                    print(json.dumps(res), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(limit, give_up)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             legs["single-list"] = bench_single_list(env)
         except Exception as e:      # keep the leg that finished: the line says what happened
             if "subtrees" not in legs:
                 raise
             failed = f"{type(e).__name__}: {e}"
-    head = legs.get("single-list") or legs["subtrees"]
-    ok = all(r["verified"] for r in legs.values()) and failed is None
+        if watchdog is not None:
+            watchdog.cancel()
+    ok = True
     if rank == 0:
-        mad_peak, copy_gbps, trace_line = device_probes(env, head["ctx"])
-        roof, valu = roofline_objects(head["ms_per_step"], head["alone_ms"], head["pipe_ms"], copy_gbps, mad_peak,
-                                      head["hashes_per_insertion"])
-        single = legs.get("subtrees") if dist is None else None
-        if world == 1 and dist is None:
-            par = "single tree"
-        elif head["mode"] == "single-list":
-            par = (f"ONE indexed tree (the reference's single sorted list) on {world} GPUs: a step's {world} x 2^16 "
-                   f"insertions in {world} consecutive slices, one per rank; replicas kept equal by all-gathers (RCCL) of "
-                   f"each slice's per-level write-backs, consumed {head['schedule']['lag_levels']} levels later")
-        else:
-            par = (f"{world} value-partitioned subtrees by leaf-index range; per step one RCCL all-gather of the "
-                   f"subtree roots (one step behind) + lift of every witness to depth 32 on its own rank")
-        res = {
-            "metric": METRIC, "value": head["value"], "unit": "insertions/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "ranks_seen": env.ranks_seen,
-            "collective_backend": env.backend if dist is not None else None, "verified": ok,
-            "value_is": head["mode"] + (" (the reference's data structure, bit-exact with one GPU)"
-                                        if head["mode"] != "subtrees" else
-                                        " (N sorted lists under one root: needs one more circuit constraint per witness, INTEGRATION.md sec. 4)"),
-            "config": {"workload": "depth=32, 2^16 sequential-semantics insertions per step per GPU "
-                                   "(BASELINE configs[1]); per insertion: old/interim/new depth-32 root + two 32-sibling "
-                                   "proofs written to HBM; values resident in HBM",
-                       "batch_per_gpu": BATCH, "depth": DEPTH, "parallelism": par,
-                       "hashes_per_insertion": head["hashes_per_insertion"],
-                       "verified_how": "outputs of the last timed step (and, for the one-tree / subtree leg, of the step in the "
-                                       "middle of the timed region, kept in its own buffer set) through "
-                                       "imt_insert_witness_batch(depth=32, global indices) + root chain (inside a batch, "
-                                       "across ranks) + tree root, after the timed region"},
-            "roofline": roof, "valu": valu, "trace_roofline": trace_line,
-            "kernels": head["kernels"], "gpu_kernel_ms_per_step": head["gpu_kernel_ms_per_step"],
-            "host_call_ms_per_step": head["host_call_ms_per_step"],
-            "whole_step_algorithmic_GBps": head["value"] * BYTES_PER_INSERTION / 1e9,
-        }
-        if single is not None:
-            res["config"]["prepare"] = single["prepare"]
-            res["config"]["outputs"] = single["outputs"]
-            res["host_prepare_ms_per_step"] = single["host_prepare_ms_per_step"]
-        if dist is not None:
-            res["modes"] = {name.replace("-", "_"): mode_summary(r, world) for name, r in legs.items()}
-            if failed:
-                res["modes"]["single_list"] = {"error": failed}
-            res["collectives_per_step"] = head["collectives_per_step"]
-            res["bytes_gathered_per_step_per_rank"] = head["bytes_gathered_per_step_per_rank"]
-        if world == 1 and dist is None and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(single["vals_h"])
-            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(single["vals_h"])
-        else:
-            res["cpu_baseline"] = None
-            res["cpu_baseline_why_null"] = ("measured on rank 0 at N = 1 only (contract)" if world > 1 or dist is not None
-                                            else "--no-cpu-baseline")
+        head = legs.get("single-list") or legs["subtrees"]
+        res, ok = assemble_line(env, legs, failed, device_probes(env, head["ctx"]))
         print(json.dumps(res), flush=True)
-    if dist is not None:
+    ok = env.all_true(ok) if failed is None else ok
+    if dist is not None and failed is None:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
         sys.exit(1)
+    if failed is not None:
+        os._exit(0)                 # a process group that has failed is not torn down gracefully
 
 
 if __name__ == "__main__":

@@ -256,6 +256,25 @@ def test_bench_gpus4_as_typed_rehearsal():
     assert bad.returncode != 0
 
 
+def test_bench_keeps_the_first_leg_if_the_second_hangs():
+    """the single-list leg's collectives have never run on more than one GPU: if they hang, the subtree leg's
+    measurement must survive.  A time limit far below what the leg needs stands in for the hang: every rank leaves,
+    rank 0 prints the line with the subtree figures as `value` and says why, exit status 0."""
+    import json
+    import subprocess
+    env = dict(os.environ, IMT_BENCH_DEVICE="0", IMT_BENCH_COLLECTIVE="gloo", IMT_BENCH_NO_TRACE="1",
+               IMT_BENCH_SINGLE_LIST_TIMEOUT="0.3")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["value_is"].startswith("subtrees") and res["verified"] is True and res["value"] > 0
+    assert res["modes"]["subtrees"]["verified"] is True and "did not finish" in res["modes"]["single_list"]["error"]
+
+
 def test_bench_rccl_calls_with_one_rank():
     """The driver's N > 1 form (torch.distributed.run around bench.py, backend "nccl" = RCCL) needs one GPU per
     rank, so a one-GPU box can run it with ONE rank only: IMT_BENCH_FORCE_DIST makes that rank go through the
