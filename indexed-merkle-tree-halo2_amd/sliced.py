@@ -36,7 +36,6 @@ Transports: `DistTransport` (torch.distributed: device tensors with "nccl" = RCC
 """
 import ctypes
 
-import numpy as np
 import torch
 
 
