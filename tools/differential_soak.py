@@ -14,6 +14,7 @@ rng = random.Random(int(os.environ.get("SOAK_SEED", "2026")))
 budget = float(os.environ.get("SOAK_SECONDS", "60"))
 t0 = time.time()
 total = 0
+last_progress = t0
 case = 0
 forms = {}
 while time.time() - t0 < budget:
@@ -60,5 +61,8 @@ while time.time() - t0 < budget:
     t.close()
     total += n_total
     case += 1
+    if time.time() - last_progress > 30:          # a silent GPU job looks hung to the runner
+        last_progress = time.time()
+        print(f"... {case} trees, {total} insertions, {time.time() - t0:.0f} s", flush=True)
 print("differential soak: %d trees, %d insertions, every root and low index equal to the oracle (%.0f s); "
       "trees per IMT_OPT_COOP_MAX_EVENTS setting: %s" % (case, total, time.time() - t0, dict(sorted(forms.items()))))

@@ -23,6 +23,7 @@ rng = random.Random(int(os.environ.get("SOAK_SEED", "2027")))
 budget = float(os.environ.get("SOAK_SECONDS", "60"))
 t0 = time.time()
 cases = total = 0
+last_progress = t0
 seen = {}
 while time.time() - t0 < budget:
     depth = rng.choice([5, 9, 14, 32, 32])
@@ -95,5 +96,8 @@ while time.time() - t0 < budget:
     cases += 1
     total += n_total
     seen[world] = seen.get(world, 0) + 1
+    if time.time() - last_progress > 30:          # a silent GPU job looks hung to the runner
+        last_progress = time.time()
+        print(f"... {cases} runs, {total} insertions, {time.time() - t0:.0f} s", flush=True)
 print("sliced soak: %d runs, %d insertions, every witness of every rank and every replica's root equal to the sequential "
       "oracle (%.0f s); runs per world size: %s" % (cases, total, time.time() - t0, dict(sorted(seen.items()))))
