@@ -16,7 +16,8 @@ cp $O/verify_latency.txt $P/r03_verify_latency.txt
 grep check $O/witness_check_latency.txt > $P/r03_witness_check_latency.txt
 grep insert_trace $O/insert_trace_latency.txt > $P/r03_insert_trace_latency.txt
 cp $O/bench_aux.txt $P/r03_bench_aux.txt
-cp $O/differential_soak.txt $P/r03_differential_soak.txt
+grep "differential soak" $O/differential_soak.txt > $P/r03_differential_soak.txt
+[ -f $O/sliced_soak.txt ] && grep "sliced soak" $O/sliced_soak.txt > $P/r03_sliced_soak.txt
 grep -E "k_sweep|k_merge_level|k_writeback|k_events|k_insert" $O/pmc_bench_summary.txt > $P/r03_pmc_hbm_traffic_raw.txt
 { echo "# rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
   echo "# (tools/pmc_summary.py: mean per dispatch, summed over the 8 XCDs / 32 SEs of the device; kernels are serialised under --pmc)"

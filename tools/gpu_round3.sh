@@ -24,7 +24,8 @@ timeout -k 10 300 python tools/latency_vs_cpu.py > $O/latency_vs_cpu.txt 2>&1 &&
 timeout -k 10 300 python tools/verify_latency.py > $O/verify_latency.txt 2>&1 && echo "verify latency ok" &&
 timeout -k 10 300 python tools/witness_check_latency.py > $O/witness_check_latency.txt 2>&1 && timeout -k 10 300 python tools/insert_trace_latency.py > $O/insert_trace_latency.txt 2>&1 && echo "check / trace latency ok" &&
 timeout -k 10 300 python tools/bench_aux.py > $O/bench_aux.txt 2>&1 && echo "aux ok" &&
-SOAK_SECONDS=60 timeout -k 10 400 python tools/differential_soak.py > $O/differential_soak.txt 2>&1 && echo "soak ok"
+SOAK_SECONDS=60 timeout -k 10 400 python tools/differential_soak.py > $O/differential_soak.txt 2>&1 && echo "soak ok" &&
+SOAK_SECONDS=120 timeout -k 10 400 python tools/sliced_soak.py > $O/sliced_soak.txt 2>&1 && echo "sliced soak ok"
 echo "exit $?"
 # keep the merged output small: the raw traces are large
 find $O -name "*kernel_trace.csv" -size +8M -delete
