@@ -298,13 +298,14 @@ def test_header_is_plain_c_and_example_links():
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
                         os.path.join(ROOT, "include", "imt.h")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    exe = os.path.join(ROOT, "examples", "insert_demo")
-    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(ROOT, "include"),
-                        os.path.join(ROOT, "examples", "insert_demo.c"), "-L",
-                        os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc"), "-limt_hip",
-                        "-Wl,-rpath," + os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc"), "-o", exe],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    for name in ("insert_demo", "slice_demo"):
+        exe = os.path.join(ROOT, "examples", name)
+        r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "examples", name + ".c"), "-L",
+                            os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc"), "-limt_hip",
+                            "-Wl,-rpath," + os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc"), "-o", exe],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
 
 
 def test_cpp_host_side_builds_and_fails_loudly_without_a_gpu(tmp_path):
