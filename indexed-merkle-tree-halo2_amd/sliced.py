@@ -155,8 +155,13 @@ class SliceGpuBackend:
     def new_event(self):
         return torch.cuda.Event()
 
-    def outputs(self, slot):
-        return dict(self.sets[slot])
+    def outputs(self, slot, n=None):
+        """the slot's tensors; a slice shorter than `batch` fills a prefix (sibling rows are packed [depth][n])"""
+        d = dict(self.sets[slot])
+        if n is not None and n != self.batch:
+            for k, t in d.items():
+                d[k] = t.view(-1)[:self.depth * n * 32].view(self.depth, n, 32) if k.endswith("_sib") else t[:n]
+        return d
 
     def sync(self):
         for s in self.streams:
@@ -323,9 +328,9 @@ class SlicedIndexedTree:
     # ---- driving ----
     def _start_round(self, vals):
         R = len(self.rounds)
-        b = self.be.batch
-        if vals.shape[0] != b * self.world:
-            raise ValueError(f"a step is world x batch = {b * self.world} values")
+        b = vals.shape[0] // self.world
+        if vals.shape[0] != b * self.world or not 0 < b <= self.be.batch:
+            raise ValueError(f"a step is world x n values, 0 < n <= batch = {self.be.batch} (a shorter step has shorter slices)")
         size_before = self.be.size()
         out_slot = R % len(self.be.sets)
         sl = self.be.prepare(vals, self.rank * b, b, (self.world - 1 - self.rank) * b, out_slot)
@@ -358,8 +363,11 @@ class SlicedIndexedTree:
             self.tp.close()
 
     def outputs(self, R):
-        d = self.be.outputs(self.rounds[R]["out_slot"])
-        d["first_insertion"] = self.rounds[R]["size_before"] + self.rank * self.rounds[R]["n"]      # = first new leaf index
+        """this rank's witnesses of round R: rows [0, n) of every field (n = the round's slice length); sibling arrays
+        are [depth, n, 32]"""
+        rd = self.rounds[R]
+        d = self.be.outputs(rd["out_slot"], rd["n"])
+        d["first_insertion"] = rd["size_before"] + self.rank * rd["n"]      # = first new leaf index
         return d
 
     def done_event(self, R):

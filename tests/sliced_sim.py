@@ -140,7 +140,7 @@ class SymbolicBackend:
             _current[0] = prev
 
     def prepare(self, vals, n_before, n_own, n_after, out_slot):
-        assert n_before == self.rank * self.batch and n_own == self.batch
+        assert n_before == self.rank * n_own and n_own == self.batch
         k = (self._size - 1 + n_before) // self.batch
         assert (self._size - 1) % (self.batch * self.world) == 0
         sid = self.next_id % 5
@@ -189,7 +189,7 @@ class SymbolicBackend:
                 lvl.append(k)
         stream.push(("fn", run))
 
-    def outputs(self, slot):
+    def outputs(self, slot, n=None):
         return dict(self.sets[slot])
 
     def sync(self):

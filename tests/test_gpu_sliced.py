@@ -228,6 +228,38 @@ def test_local_world_fills_a_small_tree_to_its_last_level(imt, ctx):
         be.ctx.close()
 
 
+def test_local_world_ragged_steps(imt, ctx):
+    """steps shorter than the buffers were sized for (the last, ragged step of a stream of insertions): slices of 64,
+    10, 1 and 64 insertions per rank in consecutive steps"""
+    sl = load_sliced()
+    depth, cap, world, batch = 32, 1 << 10, 2, 64
+    sizes = [64, 10, 1, 64, 7]
+    vals = oracle_lib.synth_values(world * sum(sizes), 0x494D5481)
+    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch) for _ in range(world)]
+    w = sl.LocalWorld(bes)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    ref = imt.IndexedTree(ctx, depth, cap)
+    off = 0
+    for r, n in enumerate(sizes):
+        w.step([arr[off:off + world * n]] * world)
+        w.flush()                        # witness sets rotate: read each round before the fifth after it is prepared
+        want = ref.insert_batch(vals[off:off + world * n])
+        for rk in w.ranks:
+            got = rk.outputs(r)
+            assert got["low_sib"].shape == (depth, n, 32) and got["new_root"].shape == (n, 32)
+            check_round(want, got, rk.rank * n, (rk.rank + 1) * n)
+        off += world * n
+    with pytest.raises(ValueError):
+        w.ranks[0]._start_round(arr[:world * batch + world])      # longer than the buffers
+    with pytest.raises(ValueError):
+        w.ranks[0]._start_round(arr[:3])                          # not a multiple of the world size
+    assert all(be.tree.root() == ref.root() for be in bes)
+    ref.close()
+    for be in bes:
+        be.tree.close()
+        be.ctx.close()
+
+
 def test_local_world_montgomery_format_and_refused_values(imt, ctx):
     sl = load_sliced()
     depth, cap, world, batch = 32, 1 << 12, 2, 128
