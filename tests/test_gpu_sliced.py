@@ -85,6 +85,14 @@ def test_local_world_equals_one_gpu_tree(imt, ctx, world, batch, rounds):
     h = ctx.hash3(leaves)
     roots = ctx.path_root(h, idx, sib, depth)
     assert all(int.from_bytes(bytes(x), "little") == want_root for x in roots)
+    # non-membership (BASELINE config 3) on the replicated list needs no exchange: every replica holds the whole tree,
+    # so the candidates are simply split between the ranks; each witness verifies against the common root
+    cand = oracle_lib.synth_values(8 * world, 0x494D5499 + world)
+    for g, be in enumerate(bes):
+        mine = cand[g * 8:(g + 1) * 8]
+        low, leaves, nsib, largest = be.tree.non_membership_witness(mine)
+        fail = be.ctx.non_membership(imt.to_bytes(want_root), leaves, low, nsib, depth, imt.to_bytes(mine), largest)
+        assert not fail.any()
     for be in bes:
         be.tree.close()
         be.ctx.close()
