@@ -1745,6 +1745,7 @@ extern "C" int imt_itree_slice_unit(imt_itree* t, int slice, unsigned unit, void
         IMT_HIP(c, hipEventRecord(P.done, s));
         P.in_flight = true;
         P.pipelined = true;         // not on the context's stream: join_top orders that stream behind it
+        P.l0 = 0;                   // no per-level events were recorded: a pipelined batch that follows waits for `done`
         t->pipe_pending = true;
         P.open = false;
     }

@@ -362,6 +362,32 @@ def test_two_processes_over_gloo_equal_one_gpu_tree(imt, ctx):
                 assert (res[r][k] == w).all(), (rank, r, k)
 
 
+def test_batches_after_slices_on_one_tree(imt, ctx):
+    """a tree that has taken sliced steps goes on with ordinary pipelined batches (imt_itree_insert_batch with
+    IMT_PIPELINE, no synchronisation in between): the batch is ordered behind the slice's last kernel"""
+    import ctypes
+    sl = load_sliced()
+    depth, cap, batch = 32, 1 << 14, 2048
+    vals = oracle_lib.synth_values(4 * batch, 0x494D5483)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    be = sl.SliceGpuBackend(imt, 0, depth, cap, batch)
+    w = sl.LocalWorld([be])
+    w.step([arr[:batch]])
+    w.step([arr[batch:2 * batch]])
+    w._run_ticks(w.ranks[0].starts[-1] + w.sched.round_ticks)       # everything issued, nothing waited for
+    F = imt._ffi
+    for k in (2, 3):
+        be.ctx._check(imt.lib.imt_itree_insert_batch(be.tree.h, ctypes.c_void_p(arr[k * batch:(k + 1) * batch].data_ptr()), batch,
+                                                     None, F.DEVICE_PTRS | F.PIPELINE))
+    be.sync()
+    ref = imt.IndexedTree(ctx, depth, cap)
+    ref.insert_batch(vals)
+    assert be.tree.root() == ref.root()
+    ref.close()
+    be.tree.close()
+    be.ctx.close()
+
+
 def test_slice_calls_refuse_bad_arguments(imt, ctx):
     """the C entry points directly: misaligned payloads / values, units out of order, a second preparation of too many
     slices, a placed tree -- documented codes, nothing reaches a kernel"""
