@@ -335,8 +335,10 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_processes_over_gloo_equal_one_gpu_tree(imt, ctx):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_processes_over_gloo_equal_one_gpu_tree(imt, ctx, world):
+    """one PROCESS per rank on the one GPU (2 and 4: the box admits six GPU processes), torch.distributed over gloo, the
+    host-staged gather on its helper thread: every rank's witnesses and every replica's root equal the one-GPU tree"""
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     import socket
