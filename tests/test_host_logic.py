@@ -367,3 +367,17 @@ int main(int argc, char** argv) {
             want = ("1" if sc.has_gather(rt) else "0") + "".join(
                 f" {-1 if sc.unit_of(g, rt) is None else sc.unit_of(g, rt)}:{sc.payload_units(rt)[g]}" for g in range(world))
             assert out[1 + rt] == want, (world, units, lag, rt)
+
+
+def test_bench_synthetic_values_are_field_elements_of_the_right_residue():
+    """bench.synth_values (vectorised since round 3): 0 < v < p, v mod N == rank for the subtree leg, no repeats; the
+    helper the harness and the size-of-bench GPU tests share"""
+    import bench
+    for modulus, residue in ((1, 0), (2, 1), (8, 5)):
+        a = bench.synth_values(20000, residue, modulus, 7 + modulus)
+        assert a.shape == (20000, 32) and a.dtype == np.uint8
+        vals = [int.from_bytes(r.tobytes(), "little") for r in a]
+        assert all(0 < v < bench.P for v in vals) and all(v % modulus == residue for v in vals)
+        assert len(set(vals)) == len(vals)
+        assert max(vals) > bench.P // 2 and min(vals) < bench.P // 8          # spread over the field, not clustered
+    assert (bench.synth_values(100, 0, 1, 3) == bench.synth_values(100, 0, 1, 3)).all()       # seeded: every rank draws the same step
