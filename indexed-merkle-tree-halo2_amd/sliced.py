@@ -198,13 +198,19 @@ class DistTransport:
             job = self._jobs.get()
             if job is None:
                 return
-            packed, inp, out, h, o, issued, done = job
+            packed, inp, out, h, o, sizes, me, issued, done = job
             try:
                 with torch.cuda.stream(copy_stream):
                     copy_stream.wait_event(packed)
                     h.copy_(inp, non_blocking=True)
                     copy_stream.synchronize()
-                    self.dist.all_gather_into_tensor(o, h, group=self._group)
+                    # through the host every byte costs (gloo on the loopback: 1-2 GB/s): each rank broadcasts exactly
+                    # what its payload uses instead of all of them padding to the largest of the tick
+                    S = h.numel()
+                    for r, nbytes in enumerate(sizes):
+                        if nbytes:
+                            self.dist.broadcast(h[:nbytes] if r == me else o[r * S:r * S + nbytes], src=self._ranks[r],
+                                                group=self._group)
                     out.copy_(o, non_blocking=True)
                     done.record(copy_stream)
             except Exception as e:                   # reported by the next wait() on the main thread
@@ -215,9 +221,10 @@ class DistTransport:
         S = rk.gather_bytes[slot][ring]
         out, inp = rk.recv[slot][ring][:S * rk.world], rk.send[slot][ring][:S]
         self.collectives += 1
-        self.bytes_moved += out.numel()
         if not self.via_host:
+            self.bytes_moved += out.numel()
             return self.dist.all_gather_into_tensor(out, inp, async_op=True)
+        self.bytes_moved += sum(rk.gather_sizes[slot][ring])
         if not inp.is_cuda:                          # CPU tests: nothing to overlap
             o = torch.empty(out.numel(), dtype=torch.uint8)
             self.dist.all_gather_into_tensor(o, inp)
@@ -227,6 +234,7 @@ class DistTransport:
         import threading
         if self._thread is None:                     # every rank reaches this at its first gather: new_group is collective
             self._group = self.dist.new_group(backend="gloo")
+            self._ranks = list(range(self.dist.get_world_size()))
             self._jobs = queue.Queue()
             self._thread = threading.Thread(target=self._helper, args=(inp.device,), daemon=True)
             self._thread.start()
@@ -239,7 +247,7 @@ class DistTransport:
         h, o, packed, done = self._staging[key]
         packed.record(stream)
         issued = threading.Event()
-        self._jobs.put((packed, inp, out, h[:S], o[:S * rk.world], issued, done))
+        self._jobs.put((packed, inp, out, h[:S], o[:S * rk.world], list(rk.gather_sizes[slot][ring]), rk.rank, issued, done))
         return self._HostWork(self, issued, done, stream)
 
     def close(self):
@@ -261,6 +269,7 @@ class SlicedIndexedTree:
         self.ring = D + 1
         pb = backend.payload_bytes
         self.gather_bytes = [[pb] * self.ring for _ in range(S)]     # per collective in flight: bytes per rank
+        self.gather_sizes = [[[0] * world for _ in range(self.ring)] for _ in range(S)]    # ... and what each rank's payload uses
         self.send = [[backend.make_buffer(pb) for _ in range(self.ring)] for _ in range(S)]
         self.recv = [[backend.make_buffer(pb * world) for _ in range(self.ring)] for _ in range(S)]
         self.work = [[None] * self.ring for _ in range(S)]
@@ -320,8 +329,10 @@ class SlicedIndexedTree:
                 ring = rt % self.ring
                 rd = self.rounds[R]
                 # every rank contributes as many bytes as the largest payload of this tick needs
-                self.gather_bytes[slot][ring] = max(self.be.unit_bytes(rd["size_before"] + g * rd["n"], rd["n"], q)
-                                                    for g, q in enumerate(sc.payload_units(rt)) if q >= 0)
+                sizes = [self.be.unit_bytes(rd["size_before"] + g * rd["n"], rd["n"], q) if q >= 0 else 0
+                         for g, q in enumerate(sc.payload_units(rt))]
+                self.gather_sizes[slot][ring] = sizes
+                self.gather_bytes[slot][ring] = max(sizes)
                 self.work[slot][ring] = self.tp.all_gather(self, slot, ring, st)
             self.tick_ev[slot][rt].record(st)
 
