@@ -17,8 +17,8 @@ timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O
 ( export IMT_BENCH_NO_TRACE=1; timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_valu -o v -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_under_pmc_valu.json 2> $O/pmc_valu.err ) && echo "pmc valu (pipelined) ok" &&
 ( export IMT_NO_PIPELINE=1 IMT_BENCH_NO_ATTRIBUTION=1 IMT_BENCH_NO_TRACE=1; timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_valu_alone -o v -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_valu_alone.err ) && echo "pmc valu (alone) ok" &&
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/pmc_bench_summary.txt && python tools/pmc_summary.py $O/pmc_valu > $O/pmc_valu_summary.txt && python tools/pmc_summary.py $O/pmc_valu_alone > $O/pmc_valu_alone_summary.txt &&
-( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo; timeout -k 10 400 python3 bench.py --gpus 2 --steps 6 --warmup 2 > $O/bench_2rank_rehearsal.json 2> $O/bench_2rank.err ) && echo "2-rank ok" &&
-( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo; timeout -k 10 600 python3 bench.py --gpus 4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_4rank_rehearsal.json 2> $O/bench_4rank.err ) && echo "4-rank ok" &&
+( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo; timeout -k 10 400 python3 bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2rank_rehearsal.json 2> $O/bench_2rank.err ) && echo "2-rank ok" &&
+( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo; timeout -k 10 600 python3 bench.py --gpus 4 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_4rank_rehearsal.json 2> $O/bench_4rank.err ) && echo "4-rank ok" &&
 timeout -k 10 400 python tools/sliced_costs.py 1 2 4 8 > $O/sliced_costs.txt 2>&1 && echo "sliced costs ok" &&
 timeout -k 10 300 python tools/latency_vs_cpu.py > $O/latency_vs_cpu.txt 2>&1 && echo "latency vs cpu ok" &&
 timeout -k 10 300 python tools/verify_latency.py > $O/verify_latency.txt 2>&1 && echo "verify latency ok" &&
