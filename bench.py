@@ -17,7 +17,7 @@ N > 1 runs BOTH multi-GPU modes in one invocation and reports both (`modes`); `v
   single-list  ONE indexed tree, the reference's data structure (one sorted list, update_idx_leaf's sequential
                semantics), bit-exact with one GPU at any N.  A step's N x 2^16 insertions are cut into N consecutive
                slices; rank g hashes slice g; every rank keeps a replica; what a slice writes back to the stored tree
-               travels level by level (RCCL all-gather, asynchronous, consumed two levels later): a systolic chain
+               travels level by level (RCCL all-gather, asynchronous, consumed `lag` levels later): a systolic chain
                (indexed-merkle-tree-halo2_amd/sliced.py, imt_itree_slice_*).
   subtrees     north_star's layout: the value space partitioned by v mod N, rank g owns leaf-index range
                [g*2^(32-k), (g+1)*2^(32-k)) as an indexed subtree with its own sentinel; per step ONE all-gather of the
