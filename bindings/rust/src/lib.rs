@@ -11,6 +11,8 @@
 //!   (`:417`), which only type-checks when dropping the tree does not touch its `&'a mut` field.
 //! * [`gpu`] — batched entry points over the process-wide GPU context (hashes, path roots, non-membership,
 //!   insert-witness checks, the stateful depth-32 [`gpu::IndexedTree`]).
+//! * [`sliced`] — several GPUs, the single sorted list: the time-slice schedule and raw wrappers of `imt_itree_slice_*`
+//!   for a host that brings its own RCCL calls.
 //! * [`chip`] — circuit side: `TracedPoseidonHasher::hash_fix_len_array` assigns the GPU's witness trace instead of
 //!   recomputing Poseidon, and `IndexedMerkleTreeChip` is the insert / update / non-membership sugar `north_star`
 //!   names (the reference itself only has the free functions `insert_leaf` / `verify_non_inclusion`).
@@ -21,6 +23,7 @@
 pub mod chip;
 pub mod ffi;
 pub mod gpu;
+pub mod sliced;
 
 use halo2_base::utils::ScalarField;
 use pse_poseidon::Poseidon;

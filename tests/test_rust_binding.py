@@ -154,3 +154,42 @@ def test_mockprover_rs_names_only_what_src_defines():
             "&a.low_leaf_proof_helper, &a.new_root, &new_leaf, &a.new_leaf_index, &a.new_leaf_proof, "
             "&a.new_leaf_proof_helper, &a.is_new_leaf_largest, )") in flat
     assert "verify_non_inclusion::<Fr, T, RATE>(ctx, range, &hasher, &root, &leaf, &proof, &helper, &value, &largest)" in flat
+
+
+def test_sliced_rs_uses_the_ffi_as_declared_and_the_same_schedule():
+    """bindings/rust/src/sliced.rs (source only): every imt_* it calls is declared in ffi.rs with that many arguments,
+    and its SliceSchedule::new computes what sliced.SliceSchedule computes (the formulae are compared as text against
+    values from the Python class)"""
+    src = open(os.path.join(ROOT, "bindings", "rust", "src", "sliced.rs")).read()
+    code = re.sub(r"//.*", "", src)
+    protos = rust_prototypes()
+    for m in re.finditer(r"\b(imt_[a-z0-9_]+)\(([^;]*?)\)\s*[;}\n]", code):
+        name, args = m.group(1), m.group(2)
+        assert name in protos, name
+        depth, n, cur = 0, 0, ""
+        for ch in args:
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            if ch == "," and depth == 0:
+                n += 1
+                cur = ""
+            else:
+                cur += ch
+        n += 1 if cur.strip() else 0
+        assert n == len(protos[name][1]), (name, n, protos[name][1])
+    assert "pub mod sliced;" in LIB
+    # the default lag, the period and the tick counts: the Rust expressions, evaluated here, against the Python schedule
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_sliced_schedule import load_sliced
+    sl = load_sliced()
+    assert "let fit = (units + (ROUNDS_IN_FLIGHT - 1) * world - 1) / ((ROUNDS_IN_FLIGHT - 1) * world);" in src
+    assert "let lag = lag.unwrap_or(fit.max(2));" in src and "let period = world * lag;" in src
+    assert "let gathers = units + (world - 1) * lag;" in src and "let round_ticks = gathers + lag;" in src
+    for world in (1, 2, 4, 8, 16):
+        sc = sl.SliceSchedule(world, 33)
+        fit = (33 + 3 * world - 1) // (3 * world)
+        lag = max(fit, 2)
+        assert (sc.lag, sc.period, sc.gathers, sc.round_ticks) == (lag, world * lag, 33 + (world - 1) * lag, 33 + (world - 1) * lag + lag)
