@@ -1327,6 +1327,56 @@ def test_montgomery_inputs_ready_with_lagged_lift(imt, ctx):
             assert ints(a[k]) == unmont(b[k]), k
 
 
+def test_subtree_layout_needs_the_owner_constraint(imt, ctx, oracle):
+    """The soundness note of DESIGN.md 8b / INTEGRATION.md sec. 4 as an executable fact.  Two value-partitioned subtrees
+    under one depth-32 root: 10 (even) is stored in subtree 0, 11 (odd) in subtree 1.  A non-inclusion witness for 10
+    built from subtree 1's SENTINEL {0, 11, idx} passes every constraint of the reference's verify_non_inclusion
+    (src/indexed_merkle_tree.rs:127-229: range predicates, low leaf in root) although 10 is in the tree -- the reference's
+    circuit never ties a leaf's position to a value.  The library refuses to PRODUCE that witness; the extra constraint
+    `low_index >> (32 - k) == v mod 2^k` (chip.rs::constrain_owner_subtree) rejects it; the honest witness from subtree
+    0 cannot exist (10 is present).  In the single-list layout (sliced.py) none of this arises."""
+    import ctypes
+    depth, k = 32, 1
+    sub = depth - k
+    trees = []
+    for g in range(2):
+        t = imt.IndexedTree(ctx, sub, 64)
+        t.set_placement(depth, g)
+        ctx._check(imt.lib.imt_itree_set_value_partition(t.h, 2, g))
+        trees.append(t)
+    trees[0].insert_batch([10, 1000])
+    trees[1].insert_batch([11, 1001])
+    roots = ints_to_arr([trees[0].root(), trees[1].root()])
+    global_root = ctx.combine_subtree_roots(roots, sub, depth)
+    # the library: a candidate of the other residue has no witness in this list
+    with pytest.raises(ValueError, match="another subtree"):
+        trees[1].non_membership_witness([10], subtree_roots=roots)
+    with pytest.raises(ValueError):
+        trees[0].non_membership_witness([10], subtree_roots=roots)         # present in its own list
+    # the forged witness: subtree 1's sentinel as the low leaf, its proof lifted to the global root by hand
+    base1 = 1 << sub
+    idx = np.array([base1], dtype=np.uint64)
+    leaf = trees[1].get_leaves(idx)
+    assert ints(leaf[0]) == [0, 11, base1 + 1]
+    sib = np.zeros((depth, 1, 32), np.uint8)
+    sib[:sub] = trees[1].get_proof_batch(idx)
+    out = imt._ffi.InsertOut(low_sib=sib.ctypes.data)
+    ctx._check(imt.lib.imt_itree_lift_batch(trees[1].h, roots.ctypes.data_as(ctypes.c_void_p), roots.ctypes.data_as(ctypes.c_void_p),
+                                            2, 1, ctypes.byref(out), 0))
+    fail = ctx.non_membership(global_root, leaf, idx, sib, depth, imt.to_bytes([10]), [0])
+    assert int(fail[0]) == 0, "the reference's constraints alone reject it after all?"
+    # the oracle's restatement of verify_non_inclusion agrees: satisfied
+    helper = ints_to_arr([1 - ((base1 >> l) & 1) for l in range(depth)])
+    assert oracle.verify_non_inclusion(int.from_bytes(bytes(global_root), "little"), ints(leaf[0]), sib[:, 0].copy(), helper, 10, 0)[0] == 0
+    # the owner constraint a circuit over this layout must add
+    assert (int(idx[0]) >> sub) != 10 % 2          # violated by the forged witness ...
+    low, leaves, hsib, largest = trees[1].non_membership_witness([13], subtree_roots=roots)
+    assert (int(low[0]) >> sub) == 13 % 2          # ... and satisfied by an honest one
+    assert not ctx.non_membership(global_root, leaves, low, hsib, depth, imt.to_bytes([13]), largest).any()
+    for t in trees:
+        t.close()
+
+
 def test_lift_batch_host_pointers_and_item_major(imt, ctx, oracle):
     """imt_itree_lift_batch with host pointers, both sibling layouts, equal to the device-pointer path; a
     placed tree's low-leaf queries speak global indices."""
