@@ -121,3 +121,33 @@ def test_gloo_ranks_line_up(world, depth, lag):
         assert p.exitcode == 0
     assert all(ok for _, ok, _, _ in res)
     assert len({c for _, _, c, _ in res}) == 1          # the same number of collectives on every rank
+
+
+def test_small_schedules_exhaustively():
+    """every admissible (world <= 8, depth in 1..8, lag in 1..7) schedule, with flushes at changing places, under the
+    adversarial stream scheduler: the corner cases of the tick arithmetic (a world larger than the tree is deep, a lag
+    longer than a slice, rounds that overlap four deep or not at all)"""
+    import sliced_sim
+    sl = load_sliced()
+    done = 0
+    for world in range(1, 9):
+        for depth in (1, 2, 3, 5, 8):
+            for lag in (1, 2, 3, 4, 7):
+                try:
+                    sl.SliceSchedule(world, depth + 1, lag)
+                except ValueError:
+                    continue
+                sim = sliced_sim.Sim(immediate=False, seed=world * 100 + depth * 10 + lag)
+                bes = [sliced_sim.SymbolicBackend(sim, depth, 2, world, g) for g in range(world)]
+                w = sl.LocalWorld(bes, lag)
+                rounds = 6
+                for r in range(rounds):
+                    w.step([FakeVals(2 * world)] * world)
+                    if (r + lag) % 3 == 0:
+                        w.flush()
+                w.flush()
+                for be in bes:
+                    assert sorted(be.computed) == [(r * world + be.rank, q) for r in range(rounds) for q in range(depth + 1)]
+                    assert all(lvl == list(range(rounds * world)) for lvl in be.levels), (world, depth, lag)
+                done += 1
+    assert done > 150
