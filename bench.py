@@ -457,7 +457,10 @@ def bench_single_list(env):
     steps_total = args.warmup + args.steps
     gb = BATCH * world
     cap = 1 << (steps_total * gb).bit_length()
-    be = sliced.SliceGpuBackend(env.imt, env.local_rank, DEPTH, cap, BATCH)
+    # one witness set per round when that fits comfortably (0.29 GB each): rounds from the middle of the timed region can
+    # then be verified afterwards as they were written, nothing is rewritten
+    nbuf = steps_total if steps_total <= 40 else sliced.SliceSchedule.STREAMS + 1
+    be = sliced.SliceGpuBackend(env.imt, env.local_rank, DEPTH, cap, BATCH, nbuf=nbuf)
     ctx = be.ctx
     tp = sliced.DistTransport(dist, via_host=(env.backend != "nccl"))
     lag = int(os.environ["IMT_BENCH_LAG"]) if os.environ.get("IMT_BENCH_LAG") else None
@@ -493,6 +496,9 @@ def bench_single_list(env):
     R = steps_total - 1
     o = tree.outputs(R)
     ok = witness_check(env, ctx, o, o["first_insertion"], BATCH)
+    if nbuf == steps_total and args.steps >= 3:       # ... and a round from the middle of the timed region
+        om = tree.outputs(args.warmup + args.steps // 2)
+        ok = ok and witness_check(env, ctx, om, om["first_insertion"], BATCH)
     ends = torch.stack([o["old_root"][0], o["new_root"][-1], torch.from_numpy(env.imt.to_bytes(be.tree.root())).to(env.dev)])
     if dist is not None and world > 1:
         allends = torch.empty((world,) + tuple(ends.shape), dtype=torch.uint8, device=env.red_dev)
