@@ -573,8 +573,8 @@ def assemble_line(env, legs, failed, probes):
                                "proofs written to HBM; values resident in HBM",
                    "batch_per_gpu": BATCH, "depth": DEPTH, "parallelism": par,
                    "hashes_per_insertion": head["hashes_per_insertion"],
-                   "verified_how": "outputs of the last timed step (and, for the one-tree / subtree leg, of the step in the "
-                                   "middle of the timed region, kept in its own buffer set) through "
+                   "verified_how": "outputs of the last timed step and of the step in the middle of the timed region (kept in "
+                                   "their own buffer sets) through "
                                    "imt_insert_witness_batch(depth=32, global indices) + root chain (inside a batch, "
                                    "across ranks) + tree root, after the timed region"},
         "roofline": roof, "valu": valu, "trace_roofline": trace_line,
