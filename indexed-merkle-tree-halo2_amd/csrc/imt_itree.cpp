@@ -1785,12 +1785,47 @@ extern "C" int imt_itree_slice_apply_gathered(imt_itree* t, const void* gathered
                                               void* hip_stream) {
     if (!t) return IMT_ERR_ARG;
     if (!gathered || !size_before || !n || !unit) return t->ctx->fail(IMT_ERR_ARG, "null argument");
+    imt_ctx* c = t->ctx;
+    int rc = c->set_device();
+    if (rc) return rc;
+    if ((rc = check_fe_ptrs(c, true, {gathered})) || (stride & 15u))
+        return rc ? rc : c->fail(IMT_ERR_ARG, "payload stride must be a multiple of 16 bytes");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const unsigned depth = t->depth;
+    launch::ApplyJobs jobs{};
     for (size_t r = 0; r < count; r++) {
         if (unit[r] < 0) continue;
-        const int rc = imt_itree_slice_apply(t, size_before[r], (size_t)n[r], (unsigned)unit[r],
-                                             (const uint8_t*)gathered + r * stride, hip_stream);
-        if (rc) return rc;
+        if ((unsigned)unit[r] > depth) return c->fail(IMT_ERR_RANGE, "unit %d beyond depth %u", unit[r], depth);
+        if (n[r] == 0 || size_before[r] + n[r] > t->cap) return c->fail(IMT_ERR_RANGE, "slice outside the tree's capacity");
+        if (unit[r] == 0) continue;
+        const unsigned l = (unsigned)unit[r] - 1;
+        const unsigned L0 = std::min(ceil_log2(size_before[r] + n[r]), depth);
+        launch::ApplyJobs::Job& j = jobs.j[jobs.n_jobs++];
+        j = launch::ApplyJobs::Job{};
+        j.payload = (const uint8_t*)gathered + r * stride;
+        if (l < L0) {
+            j.pairs = 1;
+            j.cap = (uint32_t)slice_pairs(size_before[r], (size_t)n[r], l);
+            j.tree_l = t->d_nodes + t->h_off[l] * 32;
+            j.len_l = t->h_len[l];
+        } else {
+            if (l == L0) j.node_in = t->d_nodes + t->h_off[l] * 32;
+            j.node_out = t->d_nodes + t->h_off[l + 1] * 32;
+        }
+        if (l + 1 == depth && L0 == depth) {
+            if (j.pairs) {      // pairs and the root from one payload: the root goes as a job of its own
+                if (jobs.n_jobs == 16) { launch::apply_gathered(s, jobs); jobs.n_jobs = 0; }
+                launch::ApplyJobs::Job& k = jobs.j[jobs.n_jobs++];
+                k = launch::ApplyJobs::Job{};
+                k.payload = (const uint8_t*)gathered + r * stride;
+                k.root = t->d_nodes + t->h_off[depth] * 32;
+            } else {
+                j.root = t->d_nodes + t->h_off[depth] * 32;
+            }
+        }
+        if (jobs.n_jobs >= 15) { launch::apply_gathered(s, jobs); jobs.n_jobs = 0; }
     }
+    launch::apply_gathered(s, jobs);
     return IMT_OK;
 }
 

@@ -1127,6 +1127,34 @@ k_apply_packed(const uint8_t* __restrict__ vals, const uint32_t* __restrict__ no
     d[1] = s[1];
 }
 
+// all payloads of one all-gather in ONE launch (blockIdx.y = payload): below its slice's l0 a payload is a list of
+// (node, value) pairs for one stored level; at and above l0 it is the one or two nodes the level's launch stored
+// (node at l0, node above) and, when the tree is full to its depth, the root
+__global__ void __launch_bounds__(BLOCK) k_apply_gathered(launch::ApplyJobs a) {
+    const launch::ApplyJobs::Job j = a.j[blockIdx.y];
+    const size_t i = gtid();
+    if (j.pairs) {
+        const uint32_t* counter = reinterpret_cast<const uint32_t*>(j.payload + 96);
+        const uint32_t n = *counter < j.cap ? *counter : j.cap;
+        if (i >= n) return;
+        const uint32_t* nodes = reinterpret_cast<const uint32_t*>(j.payload + 128 + (size_t)j.cap * 32);
+        const uint64_t node = nodes[i];
+        if (node >= j.len_l) return;
+        const Word4* s = reinterpret_cast<const Word4*>(j.payload + 128 + i * 32);
+        Word4* d = reinterpret_cast<Word4*>(j.tree_l + node * 32);
+        d[0] = s[0];
+        d[1] = s[1];
+        return;
+    }
+    if (i >= 3) return;
+    uint8_t* dst = i == 0 ? j.node_in : (i == 1 ? j.node_out : j.root);
+    if (!dst) return;
+    const Word4* s = reinterpret_cast<const Word4*>(j.payload + i * 32);
+    Word4* d = reinterpret_cast<Word4*>(dst);
+    d[0] = s[0];
+    d[1] = s[1];
+}
+
 __global__ void k_store_top_path(const uint8_t* __restrict__ top_path, uint8_t* __restrict__ tree_nodes,
                                  const uint64_t* __restrict__ tree_off, unsigned l0, unsigned depth) {
     const unsigned l = l0 + threadIdx.x;
@@ -1394,6 +1422,13 @@ void apply_packed(hipStream_t s, const uint8_t* vals, const uint32_t* nodes, con
                   uint8_t* tree_l, uint64_t len_l) {
     if (!cap) return;
     hipLaunchKernelGGL(k_apply_packed, dim3(nblk(cap)), dim3(BLOCK), 0, s, vals, nodes, counter, cap, tree_l, len_l);
+}
+void apply_gathered(hipStream_t s, const ApplyJobs& a) {
+    if (!a.n_jobs) return;
+    uint32_t widest = 3;
+    for (int k = 0; k < a.n_jobs; k++)
+        if (a.j[k].pairs && a.j[k].cap > widest) widest = a.j[k].cap;
+    hipLaunchKernelGGL(k_apply_gathered, dim3(nblk(widest), a.n_jobs), dim3(BLOCK), 0, s, a);
 }
 void store_top_path(hipStream_t s, const uint8_t* top_path, uint8_t* tree_nodes, const uint64_t* tree_off, unsigned l0,
                     unsigned depth) {

@@ -213,6 +213,19 @@ void pack_writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, c
                     uint8_t* tree_l, uint8_t* out_vals, uint32_t* out_nodes, uint32_t* counter, uint32_t cap);
 void apply_packed(hipStream_t s, const uint8_t* vals, const uint32_t* nodes, const uint32_t* counter, uint32_t cap,
                   uint8_t* tree_l, uint64_t len_l);
+// every payload of one all-gather applied by one launch (imt_itree_slice_apply_gathered)
+struct ApplyJobs {
+    struct Job {
+        const uint8_t* payload;          // header 128 B | values [cap][32] | node ids [cap]
+        int pairs;                       // 1: (node, value) pairs for stored level tree_l; 0: the header's nodes
+        uint32_t cap;
+        uint8_t* tree_l;
+        uint64_t len_l;
+        uint8_t *node_in, *node_out, *root;     // header targets (any may be NULL)
+    } j[16];
+    int n_jobs;
+};
+void apply_gathered(hipStream_t s, const ApplyJobs& a);
 void store_top_path(hipStream_t s, const uint8_t* top_path, uint8_t* tree_nodes, const uint64_t* tree_off, unsigned l0,
                     unsigned depth);
 
