@@ -260,28 +260,33 @@ def sweep_lines(prof, steps):
 
 def roofline_objects(ms_per_batch, alone_ms, pipe_ms, copy_gbps, mad_peak, hashes_per_insertion):
     """The dominant kernel is k_sweep: LAUNCHES_PER_STEP launches per 2^16-insertion batch, each hashing 2 x 2^16 events
-    up one level.  `avg_launch_ms` is the TIMED REGION's: wall time per batch / launches per batch -- under the batch
-    pipeline up to four launches overlap, so a single launch's own HIP-event duration (`pipelined`) is longer than its
-    share of the wall clock, and the kernel alone on the GPU (`alone`) is a different schedule again; both stay as
-    secondary fields."""
+    up one level.  `achieved` = algorithmic bytes of one launch / the KERNEL's own average duration, measured live with
+    HIP events on the stream the kernel runs on: `kernel_ms.alone` (the kernel with the GPU to itself, the attribution pass
+    right after the timed region -- the figure rocprofv3 --kernel-trace --stats reproduces, profiles/*alone_kernel_stats.csv).
+    Inside the timed region up to four launches share the SIMDs: a launch's own duration there is `kernel_ms.pipelined`
+    (longer), while its share of the wall clock, `wall_ms_per_launch_slot` = wall time per batch / 33, is shorter and is
+    NOT a kernel duration; both are reported with their own GB/s so that nothing has to be inferred."""
     alg_bytes = 2 * BATCH * BYTES_PER_PATH_LEVEL
     eff_ms = ms_per_batch / LAUNCHES_PER_STEP
 
     def gbps(ms):
-        return alg_bytes / (ms * 1e-3) / 1e9
-    roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": gbps(eff_ms), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": gbps(eff_ms) / HBM_PEAK_GBPS, "traffic": None, "traffic_static": PMC_TRAFFIC_SWEEP_LEVEL,
-            "peak_copy_measured": copy_gbps, "avg_launch_ms": eff_ms, "algorithmic_bytes_per_launch": alg_bytes,
-            "launches_per_batch": LAUNCHES_PER_STEP,
-            "duration_source": "timed region: wall time of a 2^16-insertion batch on one GPU / its 33 k_sweep launches",
-            "alone": None if not alone_ms else {
-                "avg_launch_ms": alone_ms, "achieved": gbps(alone_ms), "frac": gbps(alone_ms) / HBM_PEAK_GBPS,
-                "what": "HIP events around the level launches of two un-pipelined batches after the timed region: the "
-                        "kernel alone on the GPU (2 waves per SIMD); rocprofv3 of this: profiles/*alone_kernel_stats.csv"},
-            "pipelined": None if not pipe_ms else {
-                "avg_launch_ms": pipe_ms, "achieved": gbps(pipe_ms), "frac": gbps(pipe_ms) / HBM_PEAK_GBPS,
-                "what": "HIP events around the same launches inside the timed region, where up to four of them share "
-                        "the SIMDs; rocprofv3 of this: profiles/*pipelined_kernel_stats.csv"},
+        return alg_bytes / (ms * 1e-3) / 1e9 if ms else None
+    dur, src = (alone_ms, "kernel_ms.alone") if alone_ms else (pipe_ms, "kernel_ms.pipelined") if pipe_ms else \
+        (eff_ms, "wall_ms_per_launch_slot (no per-kernel timing in this run)")
+    roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": gbps(dur), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": gbps(dur) / HBM_PEAK_GBPS, "traffic": None, "traffic_static": PMC_TRAFFIC_SWEEP_LEVEL,
+            "peak_copy_measured": copy_gbps, "duration_source": src,
+            "kernel_ms": {"alone": alone_ms or None, "pipelined": pipe_ms or None,
+                          "what": "k_sweep's own duration by HIP events on its stream: alone on the GPU (two un-pipelined "
+                                  "batches right after the timed region) / inside the timed region with up to four "
+                                  "launches sharing the SIMDs (rocprofv3: profiles/)"},
+            "wall_ms_per_launch_slot": eff_ms,
+            "algorithmic_bytes_per_launch": alg_bytes, "launches_per_batch": LAUNCHES_PER_STEP,
+            "pipelined": None if not pipe_ms else {"kernel_ms": pipe_ms, "achieved": gbps(pipe_ms),
+                                                   "frac": gbps(pipe_ms) / HBM_PEAK_GBPS},
+            "wall_share": {"ms": eff_ms, "achieved": gbps(eff_ms), "frac": gbps(eff_ms) / HBM_PEAK_GBPS,
+                           "what": "timed region: wall time of a 2^16-insertion batch / its 33 k_sweep launches -- what "
+                                   "the whole job delivers per launch slot, not a kernel duration"},
             "note": "declared HBM per the contract; the kernel is integer-VALU bound, see valu"}
     hps = 2 * BATCH / (eff_ms * 1e-3)
     valu = {"bound": "v_mad_u64_u32 issue", "kernel": "k_sweep", "peak_gmads_measured_now": mad_peak,
@@ -333,7 +338,7 @@ def device_probes(env, ctx):
         torch.cuda.synchronize()
         tms = e0.elapsed_time(e1) / 5
         tgbps = nt * TRACE_ROWS * 32 / (tms * 1e-3) / 1e9
-        trace_line = {"kernel": "k_hash_trace", "bound": "hbm", "hashes_per_launch": nt, "avg_launch_ms": tms,
+        trace_line = {"kernel": "k_hash_trace", "bound": "hbm", "hashes_per_launch": nt, "kernel_ms": tms,
                       "hashes_per_s": nt / (tms * 1e-3), "achieved": tgbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": tgbps / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": nt * TRACE_ROWS * 32,
                       "traffic_static": {"write_bytes": 10135000000, "source": "profiles/r02_pmc_trace_traffic.txt"}}
@@ -529,12 +534,16 @@ def mode_summary(r, world):
     """what the line says about one multi-GPU mode"""
     ms_batch = r["ms_per_step"]             # every rank hashes one 2^16 batch per step in both modes
     eff = ms_batch / LAUNCHES_PER_STEP
-    gbps = 2 * BATCH * BYTES_PER_PATH_LEVEL / (eff * 1e-3) / 1e9
+    alg = 2 * BATCH * BYTES_PER_PATH_LEVEL
+    dur = r["pipe_ms"] or eff              # the kernel's own duration inside the timed region (HIP events), if timed
+    gbps = alg / (dur * 1e-3) / 1e9
     out = {k: r[k] for k in ("value", "ms_per_step", "verified", "hashes_per_insertion", "collectives_per_step",
                              "bytes_gathered_per_step_per_rank", "host_call_ms_per_step", "gpu_kernel_ms_per_step")}
     out["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                       "frac": gbps / HBM_PEAK_GBPS, "avg_launch_ms": eff, "traffic": None,
-                       "pipelined_avg_launch_ms": r["pipe_ms"]}
+                       "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                       "duration_source": "kernel_ms.pipelined" if r["pipe_ms"] else "wall_ms_per_launch_slot",
+                       "kernel_ms": {"pipelined": r["pipe_ms"]}, "wall_ms_per_launch_slot": eff,
+                       "wall_share_achieved": alg / (eff * 1e-3) / 1e9}
     out["valu_frac"] = r["value"] / world * r["hashes_per_insertion"] * MADS_PER_HASH / 1e9 / VALU_PEAK_GMADS
     out["cpu_baseline"] = None
     if "schedule" in r:
@@ -542,46 +551,68 @@ def mode_summary(r, world):
     return out
 
 
-def assemble_line(env, legs, failed, probes):
-    """rank 0's JSON line from the legs that finished; `failed` = why the single-list leg did not (or None)"""
+def headline_mode(dist, mode):
+    """the mode whose figure is `value`: the reference's single list wherever it was asked to run"""
+    if dist is None:
+        return "subtrees"           # N = 1: the single tree (bench_subtrees with world 1)
+    return "single-list" if mode in ("both", "single-list") else "subtrees"
+
+
+def assemble_line(env, legs, failed, probes, headline):
+    """rank 0's JSON line.  `headline` names the leg `value` belongs to; if that leg did not finish (`failed` says why)
+    or did not verify, `value` is null, `verified` false and the process exits non-zero -- another mode's figure never
+    stands in for it (it stays under `modes`)."""
     args, world, dist = env.args, env.world, env.dist
     mad_peak, copy_gbps, trace_line = probes
-    head = legs.get("single-list") or legs["subtrees"]
-    ok = all(r["verified"] for r in legs.values())
-    roof, valu = roofline_objects(head["ms_per_step"], head["alone_ms"], head["pipe_ms"], copy_gbps, mad_peak,
-                                  head["hashes_per_insertion"])
+    head = legs.get(headline)
+    head_ok = head is not None and bool(head["verified"])
+    ok = head_ok and all(r["verified"] for r in legs.values())
+    shown = head if head is not None else next(iter(legs.values()))      # for the static parts of the line only
+    if head is not None:
+        roof, valu = roofline_objects(head["ms_per_step"], head["alone_ms"], head["pipe_ms"], copy_gbps, mad_peak,
+                                      head["hashes_per_insertion"])
+    else:
+        roof = valu = None
     single = legs.get("subtrees") if dist is None else None
     if world == 1 and dist is None:
         par = "single tree"
-    elif head["mode"] == "single-list":
+    elif headline == "single-list":
+        lagtxt = f"{head['schedule']['lag_levels']} levels later" if head is not None else "`lag` levels later"
         par = (f"ONE indexed tree (the reference's single sorted list) on {world} GPUs: a step's {world} x 2^16 "
                f"insertions in {world} consecutive slices, one per rank; replicas kept equal by all-gathers (RCCL) of "
-               f"each slice's per-level write-backs, consumed {head['schedule']['lag_levels']} levels later")
+               f"each slice's per-level write-backs, consumed {lagtxt}")
     else:
         par = (f"{world} value-partitioned subtrees by leaf-index range; per step one RCCL all-gather of the "
                f"subtree roots (one step behind) + lift of every witness to depth 32 on its own rank")
     res = {
-        "metric": METRIC, "value": head["value"], "unit": "insertions/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "metric": METRIC, "value": head["value"] if head_ok else None, "unit": "insertions/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"] if head_ok else None,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "ranks_seen": env.ranks_seen,
         "collective_backend": env.backend if dist is not None else None, "verified": ok,
-        "value_is": head["mode"] + (" (the reference's data structure, bit-exact with one GPU)"
-                                    if head["mode"] != "subtrees" else
-                                    " (N sorted lists under one root: needs one more circuit constraint per witness, INTEGRATION.md sec. 4)"),
+        "value_is": headline + (" (the reference's data structure, bit-exact with one GPU)"
+                                if headline != "subtrees" or dist is None else
+                                " (N sorted lists under one root: needs one more circuit constraint per witness, INTEGRATION.md sec. 4)"),
         "config": {"workload": "depth=32, 2^16 sequential-semantics insertions per step per GPU "
                                "(BASELINE configs[1]); per insertion: old/interim/new depth-32 root + two 32-sibling "
                                "proofs written to HBM; values resident in HBM",
                    "batch_per_gpu": BATCH, "depth": DEPTH, "parallelism": par,
-                   "hashes_per_insertion": head["hashes_per_insertion"],
-                   "verified_how": "outputs of the last timed step and of the step in the middle of the timed region (kept in "
-                                   "their own buffer sets) through "
-                                   "imt_insert_witness_batch(depth=32, global indices) + root chain (inside a batch, "
-                                   "across ranks) + tree root, after the timed region"},
+                   "hashes_per_insertion": shown["hashes_per_insertion"],
+                   "verified_how": "SELF-CHECK BY INDEPENDENT KERNELS of this library, not an oracle run: the outputs of the "
+                                   "last timed step and of the step in the middle of the timed region (kept in their own "
+                                   "buffer sets) go through imt_insert_witness_batch (k_insert_chains: 3 leaf hashes + 4 "
+                                   "depth-32 path recomputes per insertion, every insert_leaf constraint, global indices) + "
+                                   "root chain (inside a batch, across ranks) + tree root, after the timed region.  Both "
+                                   "kernels are pinned to the CPU oracle by the -m gpu parity tests"},
         "roofline": roof, "valu": valu, "trace_roofline": trace_line,
-        "kernels": head["kernels"], "gpu_kernel_ms_per_step": head["gpu_kernel_ms_per_step"],
-        "host_call_ms_per_step": head["host_call_ms_per_step"],
-        "whole_step_algorithmic_GBps": head["value"] * BYTES_PER_INSERTION / 1e9,
     }
+    if head is not None:
+        res.update({"kernels": head["kernels"], "gpu_kernel_ms_per_step": head["gpu_kernel_ms_per_step"],
+                    "host_call_ms_per_step": head["host_call_ms_per_step"],
+                    "whole_step_algorithmic_GBps": head["value"] * BYTES_PER_INSERTION / 1e9 if head_ok else None})
+    if not head_ok:
+        res["value_failed"] = (failed or "the headline leg did not run") if head is None else \
+            f"the {headline} leg ran ({head['value']:.0f} insertions/s) but its outputs did not verify"
     if single is not None:
         res["config"]["prepare"] = single["prepare"]
         res["config"]["outputs"] = single["outputs"]
@@ -590,8 +621,9 @@ def assemble_line(env, legs, failed, probes):
         res["modes"] = {name.replace("-", "_"): mode_summary(r, world) for name, r in legs.items()}
         if failed:
             res["modes"]["single_list"] = {"error": failed}
-        res["collectives_per_step"] = head["collectives_per_step"]
-        res["bytes_gathered_per_step_per_rank"] = head["bytes_gathered_per_step_per_rank"]
+        if head is not None:
+            res["collectives_per_step"] = head["collectives_per_step"]
+            res["bytes_gathered_per_step_per_rank"] = head["bytes_gathered_per_step_per_rank"]
     if world == 1 and dist is None and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(single["vals_h"])
         res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(single["vals_h"])
@@ -617,6 +649,7 @@ def main():
     rank, dist = env.rank, env.dist
     # N > 1: "both" (default; `value` = single-list), or one of "single-list" / "subtrees" alone
     mode = os.environ.get("IMT_BENCH_MODE", "both" if dist is not None else "subtrees")
+    headline = headline_mode(dist, mode)
     legs, failed = {}, None
     if mode in ("both", "subtrees") or dist is None:
         legs["subtrees"] = bench_subtrees(env)
@@ -626,41 +659,42 @@ def main():
             legs["subtrees"]["be"].tree.close()
             legs["subtrees"]["be"].sets = legs["subtrees"]["be"].structs = None
             torch.cuda.empty_cache()
-            # The second leg's collectives have never run on more than one GPU in this builder's hands.  If they hang
-            # there, the first leg's measurement must not be lost with them: after the time limit every rank leaves, and
-            # rank 0 prints the line with what it has (no device probes: the device may be the thing that hangs).
-            import threading
-            limit = float(os.environ.get("IMT_BENCH_SINGLE_LIST_TIMEOUT", "240"))
+        # A leg whose collectives hang must not hang the job: after the time limit every rank leaves with status 1; rank
+        # 0 first prints the line -- `value` null, the reason, the other leg's figures under `modes` only (no device
+        # probes: the device may be the thing that hangs).
+        import threading
+        limit = float(os.environ.get("IMT_BENCH_SINGLE_LIST_TIMEOUT", "240"))
 
-            def give_up():
-                if rank == 0:
-                    res, _ = assemble_line(env, legs, f"the single-list leg did not finish within {limit:.0f} s", (None, None, None))
-                    print(json.dumps(res), flush=True)
-                os._exit(0)
-            watchdog = threading.Timer(limit, give_up)
-            watchdog.daemon = True
-            watchdog.start()
+        def give_up():
+            if rank == 0:
+                why = f"the single-list leg did not finish within {limit:.0f} s"
+                res, _ = assemble_line(env, legs, why, (None, None, None), headline) if legs else \
+                    ({"metric": METRIC, "value": None, "verified": False, "value_failed": why, "n_gpus": env.world}, False)
+                print(json.dumps(res), flush=True)
+            os._exit(1)
+        watchdog = threading.Timer(limit, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             legs["single-list"] = bench_single_list(env)
-        except Exception as e:      # keep the leg that finished: the line says what happened
+        except Exception as e:      # the line says what happened; the status says it failed
             if "subtrees" not in legs:
                 raise
             failed = f"{type(e).__name__}: {e}"
-        if watchdog is not None:
-            watchdog.cancel()
+        watchdog.cancel()
     ok = True
     if rank == 0:
-        head = legs.get("single-list") or legs["subtrees"]
-        res, ok = assemble_line(env, legs, failed, device_probes(env, head["ctx"]))
+        probe_leg = legs.get(headline) or next(iter(legs.values()))
+        res, ok = assemble_line(env, legs, failed, device_probes(env, probe_leg["ctx"]), headline)
         print(json.dumps(res), flush=True)
-    ok = env.all_true(ok) if failed is None else ok
-    if dist is not None and failed is None:
+    if failed is not None:
+        os._exit(1)                 # a process group that has failed is not torn down gracefully
+    ok = env.all_true(ok)
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
         sys.exit(1)
-    if failed is not None:
-        os._exit(0)                 # a process group that has failed is not torn down gracefully
 
 
 if __name__ == "__main__":

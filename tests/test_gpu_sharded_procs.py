@@ -257,9 +257,10 @@ def test_bench_gpus4_as_typed_rehearsal():
 
 
 def test_bench_keeps_the_first_leg_if_the_second_hangs():
-    """the single-list leg's collectives have never run on more than one GPU: if they hang, the subtree leg's
-    measurement must survive.  A time limit far below what the leg needs stands in for the hang: every rank leaves,
-    rank 0 prints the line with the subtree figures as `value` and says why, exit status 0."""
+    """A hung headline (single-list) leg must not look like a pass, and another mode's figure must never stand in for
+    it.  A time limit far below what the leg needs stands in for the hang: every rank leaves with a non-zero status,
+    rank 0 first prints the line with `value` null, `verified` false and the reason; the subtree leg's measurement
+    survives under `modes.subtrees` only."""
     import json
     import subprocess
     env = dict(os.environ, IMT_BENCH_DEVICE="0", IMT_BENCH_COLLECTIVE="gloo", IMT_BENCH_NO_TRACE="1",
@@ -267,12 +268,14 @@ def test_bench_keeps_the_first_leg_if_the_second_hangs():
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.returncode != 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     res = json.loads(lines[0])
-    assert res["value_is"].startswith("subtrees") and res["verified"] is True and res["value"] > 0
-    assert res["modes"]["subtrees"]["verified"] is True and "did not finish" in res["modes"]["single_list"]["error"]
+    assert res["value"] is None and res["verified"] is False and res["ms_per_step"] is None
+    assert res["value_is"].startswith("single-list") and "did not finish" in res["value_failed"]
+    assert res["modes"]["subtrees"]["verified"] is True and res["modes"]["subtrees"]["value"] > 0
+    assert "did not finish" in res["modes"]["single_list"]["error"]
 
 
 def test_bench_rccl_calls_with_one_rank():
