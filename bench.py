@@ -17,8 +17,8 @@ N > 1 runs BOTH multi-GPU modes in one invocation and reports both (`modes`); `v
   single-list  ONE indexed tree, the reference's data structure (one sorted list, update_idx_leaf's sequential
                semantics), bit-exact with one GPU at any N.  A step's N x 2^16 insertions are cut into N consecutive
                slices; rank g hashes slice g; every rank keeps a replica; what a slice writes back to the stored tree
-               travels level by level (RCCL all-gather, asynchronous, consumed `lag` levels later): a systolic chain
-               (indexed-merkle-tree-halo2_amd/sliced.py, imt_itree_slice_*).
+               travels level by level (RCCL all-gather, asynchronous, consumed `lag` levels later): a systolic chain,
+               scheduled inside libimt_hip.so (imt_sliced_step: one call per step; csrc/imt_sliced_sched.hpp).
   subtrees     north_star's layout: the value space partitioned by v mod N, rank g owns leaf-index range
                [g*2^(32-k), (g+1)*2^(32-k)) as an indexed subtree with its own sentinel; per step ONE all-gather of the
                N subtree roots + lift of every witness to depth 32.  Scales without data exchange, but the root commits
@@ -456,7 +456,10 @@ def bench_subtrees(env):
 
 
 def bench_single_list(env):
-    """N > 1 (or IMT_BENCH_FORCE_DIST): ONE depth-32 tree on all ranks, time-sliced (sliced.SlicedIndexedTree)."""
+    """N > 1 (or IMT_BENCH_FORCE_DIST): ONE depth-32 tree on all ranks, time-sliced, through the C ABI: imt_sliced_step per
+    step; the schedule, its streams / events and the all-gather (RCCL: ncclAllGather called by the library on its own
+    communicators) are inside libimt_hip.so.  torch.distributed only carries the bootstrap ids and the bench's own
+    reductions."""
     args, world, rank, dist, lib = env.args, env.world, env.rank, env.dist, env.lib
     sliced = load_module("sliced")
     steps_total = args.warmup + args.steps
@@ -464,38 +467,46 @@ def bench_single_list(env):
     cap = 1 << (steps_total * gb).bit_length()
     # one witness set per round when that fits comfortably (0.29 GB each): rounds from the middle of the timed region can
     # then be verified afterwards as they were written, nothing is rewritten
-    nbuf = steps_total if steps_total <= 40 else sliced.SliceSchedule.STREAMS + 1
-    be = sliced.SliceGpuBackend(env.imt, env.local_rank, DEPTH, cap, BATCH, nbuf=nbuf)
-    ctx = be.ctx
-    tp = sliced.DistTransport(dist, via_host=(env.backend != "nccl"))
+    nbuf = steps_total if steps_total <= 40 else 5
     lag = int(os.environ["IMT_BENCH_LAG"]) if os.environ.get("IMT_BENCH_LAG") else None
-    tree = sliced.SlicedIndexedTree(be, world, rank, tp, lag)
+    # transport: RCCL with backend "nccl" (the driver's runs); on a one-GPU rehearsal (IMT_BENCH_COLLECTIVE=gloo) the
+    # ranks share the device and exchange payloads by direct peer copies over HIP IPC handles
+    kind = os.environ.get("IMT_BENCH_SLICED_TRANSPORT", "rccl" if env.backend == "nccl" else ("ipc" if world > 1 else "local"))
+    boot = env.imt.Context(env.local_rank)
+    if kind == "rccl":
+        tp = sliced.rccl_transport(env.imt, boot, dist, world, rank, n_comms=int(os.environ.get("IMT_BENCH_RCCL_COMMS", "4")),
+                                   device=env.dev if env.backend == "nccl" else None)
+    elif kind == "ipc":
+        tp = sliced.ipc_transport(env.imt, boot, dist, world, rank, DEPTH, BATCH, lag, device=env.dev if env.backend == "nccl" else None)
+    else:
+        tp = sliced.local_transport(env.imt)
+    tree = sliced.SlicedTree(env.imt, env.local_rank, DEPTH, cap, BATCH, world, first_rank=rank, n_local=1, transport=tp,
+                             lag=lag, nbuf=nbuf)
+    ctx = tree.ctxs[0]
     # every rank sees the whole step: the same seed everywhere
     vals = torch.from_numpy(synth_values(steps_total * gb, 0, 1, 0x494D5403)).to(env.dev)
-
-    def sync():
-        be.sync()
-        env.barrier()
+    torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        tree.step(vals[i * gb:(i + 1) * gb])
+        tree.step(vals[i * gb:(i + 1) * gb], env.F.INPUTS_READY)
     tree.flush()                    # the timed region then holds exactly `steps` rounds, fill and drain included
-    sync()
-    c0, b0 = tp.collectives, tp.bytes_moved
+    env.barrier()
+    i0 = tree.info()
     lib.imt_profile_enable(ctx.h, 1)
     t0 = time.perf_counter()
     host_s = 0.0
     for i in range(args.warmup, steps_total):
         th = time.perf_counter()
-        tree.step(vals[i * gb:(i + 1) * gb])
+        tree.step(vals[i * gb:(i + 1) * gb], env.F.INPUTS_READY)
         host_s += time.perf_counter() - th
     tree.flush()
-    sync()
+    env.barrier()
     dt = time.perf_counter() - t0
     prof = (ctypes.c_double * 12)()
     lib.imt_profile_read(ctx.h, prof)
     lib.imt_profile_enable(ctx.h, 0)
     dt = env.max_over_ranks(dt)
+    i1 = tree.info()
     # ---- verification: the last round's witnesses of THIS rank's slice through the witness kernels; the slices chain
     # (rank g's first old root = rank g - 1's last new root); every replica holds the same root = the last new root
     R = steps_total - 1
@@ -504,7 +515,7 @@ def bench_single_list(env):
     if nbuf == steps_total and args.steps >= 3:       # ... and a round from the middle of the timed region
         om = tree.outputs(args.warmup + args.steps // 2)
         ok = ok and witness_check(env, ctx, om, om["first_insertion"], BATCH)
-    ends = torch.stack([o["old_root"][0], o["new_root"][-1], torch.from_numpy(env.imt.to_bytes(be.tree.root())).to(env.dev)])
+    ends = torch.stack([o["old_root"][0], o["new_root"][-1], torch.from_numpy(env.imt.to_bytes(tree.trees[0].root())).to(env.dev)])
     if dist is not None and world > 1:
         allends = torch.empty((world,) + tuple(ends.shape), dtype=torch.uint8, device=env.red_dev)
         dist.all_gather_into_tensor(allends.view(-1), ends.to(env.red_dev).reshape(-1))
@@ -516,18 +527,22 @@ def bench_single_list(env):
     for g in range(world):
         ok = ok and bool((allends[g, 2] == allends[world - 1, 1]).all())
     verified = env.all_true(ok)
-    tree.close()
     kern, pipe_ms = sweep_lines(prof, args.steps)
-    sc = tree.sched
+    rccl_lib = None
+    if kind == "rccl":
+        ver = ctypes.c_int(0)
+        rccl_lib = {"path": lib.imt_rccl_library(ctypes.byref(ver)).decode(), "version_code": ver.value}
     return {"mode": "single-list", "value": args.steps * gb / dt, "ms_per_step": dt / args.steps * 1e3, "verified": verified,
             "alone_ms": None, "pipe_ms": pipe_ms, "kernels": kern,
             "gpu_kernel_ms_per_step": sum(v["ms_total"] for n_, v in kern.items() if n_ != "host_prepare") / args.steps,
             "host_call_ms_per_step": host_s / args.steps * 1e3, "hashes_per_insertion": HASHES_PER_INSERTION,
-            "collectives_per_step": (tp.collectives - c0) / args.steps,
-            "bytes_gathered_per_step_per_rank": (tp.bytes_moved - b0) / args.steps,
-            "schedule": {"lag_levels": sc.lag, "round_period_ticks": sc.period, "gathers_per_round": sc.gathers,
-                         "rounds_in_flight": -(-sc.round_ticks // sc.period), "payload_bytes": be.payload_bytes},
-            "ctx": ctx, "be": be}
+            "collectives_per_step": (i1["collectives"] - i0["collectives"]) / args.steps,
+            "bytes_gathered_per_step_per_rank": (i1["bytes_gathered"] - i0["bytes_gathered"]) / args.steps,
+            "schedule": {"lag_levels": i1["lag"], "round_period_ticks": i1["period"], "gathers_per_round": i1["gathers_per_round"],
+                         "rounds_in_flight": i1["rounds_in_flight"], "payload_bytes": i1["payload_bytes"],
+                         "driver": "libimt_hip.so (imt_sliced_step: schedule, streams, events and the collective behind the C ABI)",
+                         "transport": kind, "rccl": rccl_lib},
+            "ctx": ctx, "be": tree}
 
 
 def mode_summary(r, world):

@@ -34,6 +34,41 @@ pub struct imt_insert_out {
     pub new_sib: *mut c_void,
 }
 
+#[repr(C)]
+pub struct imt_sliced {
+    _opaque: [u8; 0],
+}
+#[repr(C)]
+pub struct imt_transport {
+    _opaque: [u8; 0],
+}
+
+/// `imt_transport_ops`: a caller-supplied collective for `imt_sliced_*` (NCCL semantics, stream-ordered).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct imt_transport_ops {
+    pub self_: *mut c_void,
+    pub all_gather: Option<unsafe extern "C" fn(self_: *mut c_void, channel: c_int, buffer: c_int, send: *const c_void, recv: *mut c_void, bytes: usize, hip_stream: *mut c_void) -> c_int>,
+    pub destroy: Option<unsafe extern "C" fn(self_: *mut c_void)>,
+}
+
+/// `imt_sliced_info`
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct imt_sliced_info {
+    pub world: c_int,
+    pub n_local: c_int,
+    pub lag: c_int,
+    pub period: c_int,
+    pub gathers_per_round: c_int,
+    pub round_ticks: c_int,
+    pub rounds_in_flight: c_int,
+    pub payload_bytes: usize,
+    pub rounds: u64,
+    pub collectives: u64,
+    pub bytes_gathered: u64,
+}
+
 /// `imt_trace_cell`: one cell of the advice column of a hash (imt_hash_trace_layout).
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -88,6 +123,8 @@ pub const IMT_PROF_HOST: usize = 5;
 pub const IMT_PROF_CLASSES: usize = 6;
 
 pub const IMT_OPT_COOP_MAX_EVENTS: c_int = 1;
+pub const IMT_SLICED_ROUNDS: usize = 4;
+pub const IMT_RCCL_UNIQUE_ID_BYTES: usize = 128;
 
 pub const IMT_CELL_CONST: u8 = 0;
 pub const IMT_CELL_INPUT: u8 = 1;
@@ -172,7 +209,26 @@ extern "C" {
     pub fn imt_itree_batch_end(t: *mut imt_itree, val_levels: *const *const c_void, top_path: *const c_void) -> c_int;
     pub fn imt_itree_batch_abort(t: *mut imt_itree) -> c_int;
 
-    // ---- e: one tree on several GPUs, single sorted list, time-sliced
+    // ---- e: one tree on several GPUs, single sorted list, time-sliced: schedule + collective inside the library
+    pub fn imt_transport_custom_create(ops: *const imt_transport_ops, out: *mut *mut imt_transport) -> c_int;
+    pub fn imt_transport_local_create(out: *mut *mut imt_transport) -> c_int;
+    pub fn imt_rccl_get_unique_id(id: *mut c_void) -> c_int;
+    pub fn imt_transport_rccl_create(ctx: *mut imt_ctx, unique_ids: *const c_void, n_comms: c_int, world: c_int, rank: c_int, out: *mut *mut imt_transport) -> c_int;
+    pub fn imt_transport_rccl_adopt(nccl_comms: *const *mut c_void, n_comms: c_int, out: *mut *mut imt_transport) -> c_int;
+    pub fn imt_rccl_library(version_out: *mut c_int) -> *const c_char;
+    pub fn imt_transport_ipc_blob_bytes() -> usize;
+    pub fn imt_transport_ipc_create(ctx: *mut imt_ctx, world: c_int, rank: c_int, depth: c_uint, max_slice: usize, lag: c_int, out: *mut *mut imt_transport, blob_out: *mut c_void) -> c_int;
+    pub fn imt_transport_ipc_connect(tp: *mut imt_transport, all_blobs: *const c_void) -> c_int;
+    pub fn imt_transport_destroy(tp: *mut imt_transport);
+    pub fn imt_transport_last_error(tp: *const imt_transport) -> *const c_char;
+    pub fn imt_sliced_create(trees: *const *mut imt_itree, n_local: c_int, world: c_int, first_rank: c_int, tp: *mut imt_transport, max_slice: usize, lag: c_int, out: *mut *mut imt_sliced) -> c_int;
+    pub fn imt_sliced_step(w: *mut imt_sliced, vals: *const c_void, n: usize, outs: *const imt_insert_out, flags: c_uint, round_out: *mut u64) -> c_int;
+    pub fn imt_sliced_wait(w: *mut imt_sliced, local_rank: c_int, round: u64) -> c_int;
+    pub fn imt_sliced_flush(w: *mut imt_sliced) -> c_int;
+    pub fn imt_sliced_get_info(w: *const imt_sliced, out: *mut imt_sliced_info) -> c_int;
+    pub fn imt_sliced_last_error(w: *const imt_sliced) -> *const c_char;
+    pub fn imt_sliced_destroy(w: *mut imt_sliced);
+    // the building blocks (a host with its own scheduler)
     pub fn imt_itree_slice_payload_bytes(n: usize) -> usize;
     pub fn imt_itree_slice_unit_bytes(t: *const imt_itree, size_before: u64, n: usize, unit: c_uint) -> usize;
     pub fn imt_itree_slice_prepare(t: *mut imt_itree, vals: *const c_void, n_before: usize, n_own: usize, n_after: usize, out: *const imt_insert_out, flags: c_uint, slice_out: *mut c_int, l0_out: *mut u32) -> c_int;

@@ -1,114 +1,85 @@
-//! Several GPUs, the reference's single sorted list (`update_idx_leaf`, `src/indexed_merkle_tree.rs:632-660`), time-sliced:
-//! what a Rust host needs to drive `imt_itree_slice_*` with its own RCCL (`ncclAllGather`) calls.
+//! Several GPUs, the reference's single sorted list (`update_idx_leaf`, `src/indexed_merkle_tree.rs:632-660`; insertion i at
+//! leaf `size + i`, `:715`), bit-exact with one GPU: a step's `world * n` insertions are cut into `world` consecutive
+//! slices, GPU g hashes slice g and returns its witnesses, every GPU keeps a replica.
 //!
-//! A step's `world * n` insertions are cut into `world` consecutive slices; GPU g hashes slice g and returns its
-//! witnesses; every GPU keeps a replica; each level's write-back travels as a payload.  [`SliceSchedule`] is the
-//! arithmetic (the same as `indexed-merkle-tree-halo2_amd/sliced.py` and `imt::SliceSchedule` in `include/imt.hpp`):
-//! in round tick `rt` rank `g` runs unit `rt - g * lag` of its slice (0 = leaf hashes, 1 + l = level l -> l + 1), all
-//! ranks all-gather that tick's payloads, and the gather of tick `rt` is applied at tick `rt + lag`; consecutive steps
-//! (rounds) start `world * lag` ticks apart, at most four in flight, each on its own stream.
-//! Ordering the host must keep: round R's unit q, and round R's applies of payloads for unit q, run behind round
-//! R - 1's tick `q + world * lag`.
-//!
-//! All pointers here are DEVICE pointers (or `imt_host_alloc` memory); streams are `hipStream_t` as `*mut c_void`.
+//! The schedule, its streams and events and the RCCL all-gather live in libimt_hip.so (`imt_sliced_*`, include/imt.h): a
+//! host makes ONE call per step.  This file is the safe-ish face of those calls.
 //! NOT COMPILED in the repository this file ships in; `tests/test_rust_binding.py` checks the FFI names it uses.
 
 use crate::ffi::*;
 use std::os::raw::c_void;
 
-pub const ROUNDS_IN_FLIGHT: usize = 4;
-
-#[derive(Clone, Copy, Debug)]
-pub struct SliceSchedule {
-    pub world: usize,
-    pub units: usize,
-    pub lag: usize,
-    /// global ticks between the starts of consecutive rounds
-    pub period: usize,
-    /// round ticks that have a compute phase / a collective
-    pub gathers: usize,
-    /// + the ticks that only apply
-    pub round_ticks: usize,
-}
-
-impl SliceSchedule {
-    /// `units` = depth + 1; `lag` = None picks the smallest lag that keeps at most four rounds in flight (and >= 2, so
-    /// that a gather overlaps the next unit)
-    pub fn new(world: usize, units: usize, lag: Option<usize>) -> Option<Self> {
-        if world < 1 || units < 2 {
-            return None;
-        }
-        let fit = (units + (ROUNDS_IN_FLIGHT - 1) * world - 1) / ((ROUNDS_IN_FLIGHT - 1) * world);
-        let lag = lag.unwrap_or(fit.max(2));
-        if lag < 1 {
-            return None;
-        }
-        let period = world * lag;
-        let gathers = units + (world - 1) * lag;
-        let round_ticks = gathers + lag;
-        if (round_ticks + period - 1) / period > ROUNDS_IN_FLIGHT {
-            return None;
-        }
-        Some(SliceSchedule { world, units, lag, period, gathers, round_ticks })
-    }
-    /// unit rank `rank` computes at round tick `rt`
-    pub fn unit_of(&self, rank: usize, rt: usize) -> Option<usize> {
-        let q = rt.checked_sub(rank * self.lag)?;
-        if q < self.units { Some(q) } else { None }
-    }
-    /// unit whose payload rank `rank` contributes to the all-gather of round tick `rt` (unit 0 writes nothing back)
-    pub fn payload_unit(&self, rank: usize, rt: usize) -> Option<usize> {
-        self.unit_of(rank, rt).filter(|q| *q >= 1)
-    }
-    pub fn has_gather(&self, rt: usize) -> bool {
-        rt < self.gathers && (0..self.world).any(|g| self.payload_unit(g, rt).is_some())
-    }
-}
-
-/// One replica's tree as the slice calls see it.  The caller owns the `imt_itree` (e.g. `gpu::IndexedTree`) and the
-/// context's thread.
+/// One rank (one process per GPU) of a sliced tree over RCCL.
 pub struct SlicedTree {
-    pub tree: *mut imt_itree,
-    pub depth: usize,
+    w: *mut imt_sliced,
+    tp: *mut imt_transport,
 }
 
 impl SlicedTree {
-    /// bytes of the largest payload of a slice of n insertions (buffer size)
-    pub fn payload_bytes(n: usize) -> usize {
-        unsafe { imt_itree_slice_payload_bytes(n) }
+    /// rank 0 makes `n_comms` ids (1..=IMT_SLICED_ROUNDS) and the host broadcasts them by whatever means it has (MPI, a
+    /// socket, a file): the usual NCCL bootstrap
+    pub fn unique_ids(n_comms: usize) -> Result<Vec<u8>, i32> {
+        let mut ids = vec![0u8; n_comms * IMT_RCCL_UNIQUE_ID_BYTES];
+        for i in 0..n_comms {
+            let rc = unsafe { imt_rccl_get_unique_id(ids[i * IMT_RCCL_UNIQUE_ID_BYTES..].as_mut_ptr() as *mut c_void) };
+            if rc != IMT_OK {
+                return Err(rc);
+            }
+        }
+        Ok(ids)
     }
-    /// bytes the payload of `unit` actually uses: what every rank contributes to that tick's all-gather is the maximum
-    /// of this over the ranks that run a unit >= 1 in the tick
-    pub fn unit_bytes(&self, size_before: u64, n: usize, unit: usize) -> usize {
-        unsafe { imt_itree_slice_unit_bytes(self.tree, size_before, n, unit as u32) }
-    }
-    /// index work for the whole step (identical values on every GPU), events for the own slice; blocks until the values
-    /// are checked.  Returns the slice id.
+
+    /// collective: returns when every rank has joined.
     ///
     /// # Safety
-    /// `vals` must point to `(n_before + n_own + n_after) * 32` bytes of device memory; the pointers in `out` must stay
-    /// valid until the slice's last unit has run.
-    pub unsafe fn prepare(&self, vals: *const c_void, n_before: usize, n_own: usize, n_after: usize, out: &imt_insert_out, fmt: u32) -> Result<i32, i32> {
-        let mut slice = -1;
-        let rc = imt_itree_slice_prepare(self.tree, vals, n_before, n_own, n_after, out, IMT_DEVICE_PTRS | fmt, &mut slice, std::ptr::null_mut());
-        if rc == IMT_OK { Ok(slice) } else { Err(rc) }
+    /// `ctx` / `tree` are live handles of this process's GPU; `tree` is empty or equal on every rank.
+    pub unsafe fn new(ctx: *mut imt_ctx, tree: *mut imt_itree, ids: &[u8], world: usize, rank: usize, max_slice: usize) -> Result<Self, i32> {
+        let mut tp = std::ptr::null_mut();
+        let n_comms = (ids.len() / IMT_RCCL_UNIQUE_ID_BYTES) as i32;
+        let rc = imt_transport_rccl_create(ctx, ids.as_ptr() as *const c_void, n_comms, world as i32, rank as i32, &mut tp);
+        if rc != IMT_OK {
+            return Err(rc);
+        }
+        let mut w = std::ptr::null_mut();
+        let trees = [tree];
+        let rc = imt_sliced_create(trees.as_ptr(), 1, world as i32, rank as i32, tp, max_slice, 0, &mut w);
+        if rc != IMT_OK {
+            imt_transport_destroy(tp);
+            return Err(rc);
+        }
+        Ok(SlicedTree { w, tp })
     }
-    /// enqueue unit `unit` (0..=depth, in order) of an open slice on `stream`; `payload` receives `payload_bytes(n)` bytes
+
+    /// one step: `vals` = all `world * n` values (device memory, identical on every rank); `out` = where THIS rank's
+    /// witnesses (insertions `[rank * n, (rank + 1) * n)` of the step) go.  Returns the round number.
     ///
     /// # Safety
-    /// `payload` is a 16-byte aligned device pointer of that size; `stream` a valid `hipStream_t` or null.
-    pub unsafe fn unit(&self, slice: i32, unit: usize, payload: *mut c_void, stream: *mut c_void) -> Result<(), i32> {
-        let rc = imt_itree_slice_unit(self.tree, slice, unit as u32, payload, stream);
+    /// `vals` and every pointer in `out` stay valid and untouched until `wait(round)`.
+    pub unsafe fn step(&mut self, vals: *const c_void, n: usize, out: &imt_insert_out, flags: u32) -> Result<u64, i32> {
+        let mut round = 0u64;
+        let rc = imt_sliced_step(self.w, vals, n, out, flags, &mut round);
+        if rc == IMT_OK { Ok(round) } else { Err(rc) }
+    }
+    pub fn wait(&mut self, round: u64) -> Result<(), i32> {
+        let rc = unsafe { imt_sliced_wait(self.w, 0, round) };
         if rc == IMT_OK { Ok(()) } else { Err(rc) }
     }
-    /// apply the `world` payloads of one all-gather (payload r at `gathered + r * stride`; `units[r] < 0` = skip, e.g. the
-    /// own rank)
-    ///
-    /// # Safety
-    /// `gathered` holds `units.len() * stride` bytes of device memory produced by the peers' `unit` calls.
-    pub unsafe fn apply_gathered(&self, gathered: *const c_void, stride: usize, size_before: &[u64], n: &[u64], units: &[i32], stream: *mut c_void) -> Result<(), i32> {
-        assert!(size_before.len() == units.len() && n.len() == units.len());
-        let rc = imt_itree_slice_apply_gathered(self.tree, gathered, stride, units.len(), size_before.as_ptr(), n.as_ptr(), units.as_ptr(), stream);
+    pub fn flush(&mut self) -> Result<(), i32> {
+        let rc = unsafe { imt_sliced_flush(self.w) };
         if rc == IMT_OK { Ok(()) } else { Err(rc) }
+    }
+    pub fn info(&self) -> imt_sliced_info {
+        let mut o = imt_sliced_info::default();
+        unsafe { imt_sliced_get_info(self.w, &mut o) };
+        o
+    }
+}
+
+impl Drop for SlicedTree {
+    fn drop(&mut self) {
+        unsafe {
+            imt_sliced_destroy(self.w);
+            imt_transport_destroy(self.tp);
+        }
     }
 }

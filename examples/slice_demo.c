@@ -1,10 +1,9 @@
 /* slice_demo.c -- plain C against include/imt.h: the reference's ONE sorted list (update_idx_leaf's sequential
- * semantics, src/indexed_merkle_tree.rs:632-660) kept by TWO replicas that each hash half of every step
- * (imt_itree_slice_prepare / _unit / _apply), with the simplest legal schedule: the slices one after the other, every
- * unit's payload applied to the other replica before the next slice starts.  Buffers come from imt_host_alloc
- * (page-locked, device-addressable: valid wherever a device pointer is expected), so the "transport" between the
- * replicas is a pointer; a multi-GPU host puts ncclAllGather there and overlaps the slices as imt::SliceSchedule
- * (include/imt.hpp) says.  The replicas' roots must equal a third, ordinary tree's over the same values.  Build:
+ * semantics, src/indexed_merkle_tree.rs:632-660) kept by TWO replicas that each hash half of every step, through
+ * imt_sliced_create / imt_sliced_step / imt_sliced_flush: the schedule, its streams and events and the exchange of each
+ * slice's per-level write-backs are the library's business; the host makes one call per step.  Both replicas live in
+ * this process on one GPU (the local transport); one process per GPU passes imt_transport_rccl_create's handle instead
+ * and nothing else changes.  The replicas' roots must equal a third, ordinary tree's over the same values.  Build:
  *   gcc -std=c11 -I include examples/slice_demo.c -L indexed-merkle-tree-halo2_amd/csrc -limt_hip -o slice_demo
  */
 #include <stdio.h>
@@ -42,39 +41,24 @@ int main(void) {
         memcpy(vals[i] + 4, &state, 4);
         vals[i][20] = (unsigned char)(state >> 9);
     }
-    /* per replica: the roots of its slice (the other outputs work the same way) and one payload buffer */
+    /* per replica and step: the new roots of its slice (the other outputs work the same way) */
     unsigned char(*new_root[WORLD])[32];
-    unsigned char *payload[WORLD];
-    const size_t pay_bytes = imt_itree_slice_payload_bytes(SLICE);
-    for (int g = 0; g < WORLD; g++) {
-        CHECK(imt_host_alloc(ctx[g], SLICE * 32, (void **)&new_root[g]));
-        CHECK(imt_host_alloc(ctx[g], pay_bytes, (void **)&payload[g]));
-    }
+    for (int g = 0; g < WORLD; g++) CHECK(imt_host_alloc(ctx[g], (size_t)STEPS * SLICE * 32, (void **)&new_root[g]));
+    imt_transport *tp = NULL;
+    imt_sliced *world = NULL;
+    CHECK(imt_transport_local_create(&tp));
+    CHECK(imt_sliced_create(tree, WORLD, WORLD, 0, tp, SLICE, 0, &world));
     for (int s = 0; s < STEPS; s++) {
-        const unsigned char(*step_vals)[32] = (const unsigned char(*)[32])vals[s * WORLD * SLICE];
-        const uint64_t size_before = imt_itree_size(tree[0]);
-        int slice[WORLD];
-        /* every replica sees the whole step: index work for all of it, events for its own slice */
-        for (int g = 0; g < WORLD; g++) {
-            imt_insert_out out;
-            memset(&out, 0, sizeof out);
-            out.new_root = new_root[g];
-            CHECK(imt_itree_slice_prepare(tree[g], step_vals, (size_t)g * SLICE, SLICE, (size_t)(WORLD - 1 - g) * SLICE, &out,
-                                          IMT_DEVICE_PTRS, &slice[g], NULL));
-        }
-        /* the slices in insertion order; a unit's payload reaches the other replica before anything later runs */
-        for (int g = 0; g < WORLD; g++)
-            for (unsigned q = 0; q <= DEPTH; q++) {
-                CHECK(imt_itree_slice_unit(tree[g], slice[g], q, payload[g], NULL));
-                CHECK(imt_ctx_sync(ctx[g]));
-                if (imt_itree_slice_unit_bytes(tree[g], size_before + (uint64_t)g * SLICE, SLICE, q) > pay_bytes) return 2;
-                for (int h = 0; h < WORLD; h++)
-                    if (h != g) {
-                        CHECK(imt_itree_slice_apply(tree[h], size_before + (uint64_t)g * SLICE, SLICE, q, payload[g], NULL));
-                        CHECK(imt_ctx_sync(ctx[h]));
-                    }
-            }
+        imt_insert_out outs[WORLD];
+        memset(outs, 0, sizeof outs);
+        for (int g = 0; g < WORLD; g++) outs[g].new_root = new_root[g][s * SLICE];
+        uint64_t round = 0;
+        int rc = imt_sliced_step(world, vals[s * WORLD * SLICE], SLICE, outs, 0, &round);
+        if (rc || round != (uint64_t)s) { fprintf(stderr, "imt_sliced_step: %d %s\n", rc, imt_sliced_last_error(world)); return 1; }
     }
+    CHECK(imt_sliced_flush(world));
+    imt_sliced_info info;
+    CHECK(imt_sliced_get_info(world, &info));
     /* the ordinary tree over the same values */
     CHECK(imt_itree_insert_batch(tree[WORLD], vals, (size_t)STEPS * WORLD * SLICE, NULL, IMT_DEVICE_PTRS));
     CHECK(imt_ctx_sync(ctx[WORLD]));
@@ -85,12 +69,12 @@ int main(void) {
     printf("\n");
     int same = 1;
     for (int g = 0; g < WORLD; g++) same &= memcmp(root[g], root[WORLD], 32) == 0;
-    same &= memcmp(new_root[WORLD - 1][SLICE - 1], root[WORLD], 32) == 0;      /* the last slice's last new root */
-    printf("replicas %s the one-GPU tree (%llu leaves)\n", same ? "equal" : "DIFFER FROM", (unsigned long long)imt_itree_size(tree[0]));
-    for (int g = 0; g < WORLD; g++) {
-        imt_host_free(ctx[g], new_root[g]);
-        imt_host_free(ctx[g], payload[g]);
-    }
+    same &= memcmp(new_root[WORLD - 1][STEPS * SLICE - 1], root[WORLD], 32) == 0;      /* the last slice's last new root */
+    printf("replicas %s the one-GPU tree (%llu leaves; lag %d, %llu all-gathers)\n", same ? "equal" : "DIFFER FROM",
+           (unsigned long long)imt_itree_size(tree[0]), info.lag, (unsigned long long)info.collectives);
+    imt_sliced_destroy(world);
+    imt_transport_destroy(tp);
+    for (int g = 0; g < WORLD; g++) imt_host_free(ctx[g], new_root[g]);
     imt_host_free(ctx[0], vals);
     for (int g = 0; g <= WORLD; g++) {
         imt_itree_free(tree[g]);

@@ -124,7 +124,7 @@ int imt_host_free(imt_ctx *ctx, void *ptr);
  * (one wave per SIMD); 0 = never.  Results are bit-identical either way. */
 #define IMT_OPT_COOP_MAX_EVENTS 1
 int imt_ctx_set_option(imt_ctx *ctx, int option, uint64_t value);
-/* ABI / build identification, e.g. "imt-hip gfx950 r3" */
+/* ABI / build identification, e.g. "imt-hip gfx950 r4" */
 const char *imt_version(void);
 /* Per-kernel timing with HIP events recorded on the context's stream around the launches of
  * imt_itree_insert_batch (used by bench.py for the roofline line; off by default).
@@ -409,29 +409,116 @@ int imt_itree_batch_end(imt_itree *t, const void *const *val_levels, const void 
 /* gives up an open batch (after a failed collective, say): the tree is as it was before imt_itree_batch_begin */
 int imt_itree_batch_abort(imt_itree *t);
 
-/* ---- e: one tree on several GPUs, sequential semantics, TIME-SLICED ---------------------------
- * The reference's single sorted list (update_idx_leaf, src/indexed_merkle_tree.rs:632-660) at any number of GPUs,
- * bit-exact with one GPU.  A step's insertions are cut into consecutive slices, one per GPU, in insertion order:
- * GPU g hashes slice g -- low-leaf rewrites, new leaves, every node version up to the root, 2 + 2 * depth hashes per
- * insertion, and writes the witnesses of its own insertions directly -- and every GPU keeps a replica of the
- * stored tree and of the sorted index.  A slice is hashed unit by unit (unit 0 = its leaf hashes, unit 1 + l = level
+/* ---- e: ONE tree on several GPUs, sequential semantics, TIME-SLICED ------------------------------
+ * The reference's single sorted list (update_idx_leaf, src/indexed_merkle_tree.rs:632-660; insertion i at leaf
+ * size + i, :715) at any number of GPUs, bit-exact with one GPU.  A step's world x n insertions are cut into `world`
+ * consecutive slices in insertion order: GPU g hashes slice g -- low-leaf rewrites, new leaves, every node version up to
+ * the root, 2 + 2 * depth hashes per insertion -- and writes the witnesses of its own insertions directly; every GPU
+ * keeps a replica of the stored tree and of the sorted index (all ranks see all values of a step; the index work is
+ * hash-free).  What crosses GPUs is what a slice WRITES BACK to the stored tree, level by level, as packed (node,
+ * value) pairs: the ranks form a systolic chain `lag` levels apart, the pairs of a tick are all-gathered
+ * asynchronously and applied `lag` ticks later, and up to IMT_SLICED_ROUNDS steps overlap.
+ *
+ * THE SCHEDULE, ITS STREAMS AND EVENTS AND THE COLLECTIVE LIVE IN THE LIBRARY: a host calls imt_sliced_step once per
+ * step and imt_sliced_wait / imt_sliced_flush to read results.  Correctness (a slice's level l sees the level-l
+ * write-backs of every earlier slice and of no later one) does not depend on anything the caller orders.
+ *
+ * One imt_sliced drives the ranks of THIS process: one (a distributed world, one process per GPU: the production form,
+ * transport = RCCL) or all of them (all replicas in one process: tests and the one-GPU rehearsal, transport = local).
+ * Every rank of a world must make the same sequence of imt_sliced_step / imt_sliced_flush calls with the same values. */
+#define IMT_SLICED_ROUNDS 4
+typedef struct imt_sliced imt_sliced;
+typedef struct imt_transport imt_transport;    /* how the payloads of one tick meet: an all-gather */
+
+/* A caller-supplied collective (MPI, a test double, ...).  all_gather is enqueued on hip_stream and must be complete, in
+ * stream order, when the stream gets past it (NCCL semantics): recv[r * bytes, (r + 1) * bytes) = rank r's send[0, bytes)
+ * for every rank r of the world.  Calls with different `channel` (0 .. IMT_SLICED_ROUNDS - 1) come from different streams
+ * and may overlap; calls on one channel are issued in the same order on every rank.  `buffer` (0 .. lag) tells which of
+ * the channel's buffer pairs is in use: the (send, recv) pointers of a (channel, buffer) never change. */
+typedef struct imt_transport_ops {
+    void *self;
+    int (*all_gather)(void *self, int channel, int buffer, const void *send, void *recv, size_t bytes, void *hip_stream);
+    void (*destroy)(void *self);       /* may be NULL */
+} imt_transport_ops;
+int imt_transport_custom_create(const imt_transport_ops *ops, imt_transport **out);
+/* all ranks in this process (any devices that can copy to each other): device-to-device copies ordered by events */
+int imt_transport_local_create(imt_transport **out);
+/* RCCL over xGMI: ncclAllGather on communicators of this library's own (n_comms of them, 1 .. IMT_SLICED_ROUNDS: the
+ * rounds in flight use different communicators, so their gathers do not queue behind each other).  Bootstrap like any
+ * NCCL program: rank 0 calls imt_rccl_get_unique_id n_comms times, the host broadcasts the ids by whatever means it has,
+ * every rank calls imt_transport_rccl_create (collective: it returns when all ranks have joined). */
+#define IMT_RCCL_UNIQUE_ID_BYTES 128
+int imt_rccl_get_unique_id(void *id /*[IMT_RCCL_UNIQUE_ID_BYTES]*/);
+int imt_transport_rccl_create(imt_ctx *ctx, const void *unique_ids /*[n_comms][IMT_RCCL_UNIQUE_ID_BYTES]*/, int n_comms,
+                              int world, int rank, imt_transport **out);
+/* the same over communicators the host owns (ncclComm_t handles of this device; not destroyed by the library) */
+int imt_transport_rccl_adopt(void *const *nccl_comms, int n_comms, imt_transport **out);
+/* RCCL is bound at run time: the copy the process already holds (a host that has loaded one), else librccl.so.1 from
+ * the library's RUNPATH.  Returns the path of the bound library (or why none was found); *version_out = its
+ * NCCL_VERSION_CODE.  IMT_ERR_NO_DEVICE from the calls above when there is none. */
+const char *imt_rccl_library(int *version_out);
+/* Direct peer copies between processes of one node (HIP IPC memory + event handles; xGMI point-to-point reads when the
+ * ranks sit on different GPUs, plain device copies when they share one: the one-GPU rehearsal of a multi-process run).
+ * create writes this rank's handle blob (imt_transport_ipc_blob_bytes() bytes); the host all-gathers the blobs by
+ * whatever means it has and every rank passes all of them, in rank order, to connect.  depth / max_slice / lag as given
+ * to imt_sliced_create. */
+size_t imt_transport_ipc_blob_bytes(void);
+int imt_transport_ipc_create(imt_ctx *ctx, int world, int rank, unsigned depth, size_t max_slice, int lag,
+                             imt_transport **out, void *blob_out);
+int imt_transport_ipc_connect(imt_transport *tp, const void *all_blobs /*[world][blob_bytes]*/);
+void imt_transport_destroy(imt_transport *tp);   /* after every imt_sliced that uses it */
+const char *imt_transport_last_error(const imt_transport *tp);
+
+/* trees[k] = the replica of rank first_rank + k (each on its own context; empty or with the same contents on every rank;
+ * not placed, not partitioned); n_local = 1, or = world with the local transport.  max_slice = the largest n of a step.
+ * lag = 0: the default max(2, ceil((depth + 1) / (3 * world))) (6, 3, 2 at 2, 4, 8 GPUs for depth 32).
+ * IMT_ERR_RANGE if (world, depth, lag) would keep more than IMT_SLICED_ROUNDS steps in flight. */
+int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first_rank, imt_transport *tp,
+                      size_t max_slice, int lag, imt_sliced **out);
+/* One step: vals = ALL world x n values of the step in insertion order (device pointer, identical contents on every
+ * rank; format per flags), outs[k] = where local rank k's witnesses of ITS slice (insertions [rank * n, (rank + 1) * n)
+ * of the step, n rows; sibling arrays [depth][n] or item-major per flags) are written; both stay untouched by the caller
+ * until imt_sliced_wait for that round.  Enqueues the step's preparation and advances the schedule by one round
+ * period; returns without waiting for the GPU (except for the values check: IMT_ERR_VALUE / IMT_ERR_NONCANONICAL /
+ * IMT_ERR_FULL exactly as imt_itree_insert_batch, the same verdict on every rank, nothing changed).  *round_out = the
+ * step's number.  flags: IMT_FMT_*, IMT_SIB_ITEM_MAJOR, IMT_INPUTS_READY. */
+int imt_sliced_step(imt_sliced *w, const void *vals /*[world * n][32]*/, size_t n, const imt_insert_out *outs /*[n_local]*/,
+                    unsigned flags, uint64_t *round_out);
+/* host waits until local rank k's witnesses of `round` are complete (issues what is left of that slice first) */
+int imt_sliced_wait(imt_sliced *w, int local_rank, uint64_t round);
+/* issues everything that is left of the steps in flight and waits for it: all replicas then hold the same tree, and the
+ * trees may be used through the ordinary imt_itree_* calls again (roots, proofs, non-membership witnesses: every replica
+ * holds the whole list, so such queries need no exchange).  Between imt_sliced_step and imt_sliced_flush only
+ * imt_sliced_* calls may touch the trees. */
+int imt_sliced_flush(imt_sliced *w);
+typedef struct imt_sliced_info {
+    int world, n_local, lag, period, gathers_per_round, round_ticks, rounds_in_flight;
+    size_t payload_bytes;            /* size of one send buffer */
+    uint64_t rounds, collectives, bytes_gathered;    /* since creation; collectives / bytes per local rank summed */
+} imt_sliced_info;
+int imt_sliced_get_info(const imt_sliced *w, imt_sliced_info *out);
+const char *imt_sliced_last_error(const imt_sliced *w);
+void imt_sliced_destroy(imt_sliced *w);          /* flushes first */
+
+/* The building blocks imt_sliced_* is made of (kept exported for hosts that bring their own scheduler; a host that calls
+ * them owns the ordering rule above).  A slice is hashed unit by unit (unit 0 = its leaf hashes, unit 1 + l = level
  * l -> l + 1) on a stream the caller names; each unit leaves a PAYLOAD -- the nodes it wrote back to level l of the
- * stored tree as packed (node, value) pairs -- which the caller all-gathers (RCCL) and applies on the other replicas.  Correctness rule, kept by
- * the caller's schedule (sharded.py: SlicedIndexedTree; slice k of the global sequence runs its unit u no earlier
- * than slice k - 1's unit u has been applied here): a slice's level l sees the level-l write-backs of every earlier
- * slice and of no later one.  Device pointers only.
+ * stored tree as packed (node, value) pairs.  Device pointers only.
  *   prepare : vals = the step's values for the slices before this GPU's, its own, and those after, in step order
  *             (identical on every GPU).  Index work for all of them on the tree's side stream (sort, low-leaf
  *             search, merge into the sorted index), events + level tables for the own slice only; the hash-free
  *             outputs (low_index, is_largest, low_leaf, new_leaf) are written now.  Blocks until the values are
  *             checked: IMT_ERR_VALUE / IMT_ERR_NONCANONICAL / IMT_ERR_FULL as imt_itree_insert_batch, the same
  *             verdict on every GPU, tree and index unchanged.  On success the index holds the whole step and
- *             *slice_out names the slice (up to 4 may be open).  `out` pointers are kept until the last unit.
+ *             *slice_out names the slice (up to 4 may be open).  `out` pointers are kept until the last unit.  The
+ *             slice's units are ordered behind every ordinary batch (imt_itree_insert_batch, pipelined or not) issued
+ *             on the tree before.
  *   unit    : enqueue unit `unit` (0 .. depth, in order) of an open slice on hip_stream; payload (NULL = none
  *             wanted) receives imt_itree_slice_payload_bytes(n_own) bytes, stream-ordered.
  *   apply   : enqueue another GPU's payload for (slice of n insertions into a tree of size_before leaves, unit) on
  *             hip_stream: writes that unit's nodes into this replica.
- * After the last apply the caller synchronises the streams it passed before any other call on the tree. */
+ * After the last apply the caller synchronises the streams it passed before any other call on the tree.
+ * imt_itree_root_lagged does not see slices (a slice's own last root is a mid-step root on every rank but the last). */
 size_t imt_itree_slice_payload_bytes(size_t n);   /* the largest payload of a slice of n insertions (buffer size) */
 /* bytes the payload of `unit` of a slice of n insertions into a tree of size_before leaves actually uses (<= the above):
  * 128 B of header + one (node, value) pair per node the level can hold under the leaves in use, at most one per
@@ -443,7 +530,8 @@ int imt_itree_slice_prepare(imt_itree *t, const void *vals /*[n_before + n_own +
 int imt_itree_slice_unit(imt_itree *t, int slice, unsigned unit, void *payload, void *hip_stream);
 int imt_itree_slice_apply(imt_itree *t, uint64_t size_before, size_t n, unsigned unit, const void *payload,
                           void *hip_stream);
-/* the same for the `count` payloads of one all-gather (payload r at gathered + r * stride); unit[r] < 0 = skip */
+/* the same for the `count` payloads of one all-gather (payload r at gathered + r * stride, stride >= the bytes
+ * imt_itree_slice_unit_bytes gives for every r that is not skipped); unit[r] < 0 = skip */
 int imt_itree_slice_apply_gathered(imt_itree *t, const void *gathered, size_t stride, size_t count,
                                    const uint64_t *size_before /*[count]*/, const uint64_t *n /*[count]*/,
                                    const int32_t *unit /*[count]*/, void *hip_stream);

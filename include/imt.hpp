@@ -386,44 +386,56 @@ private:
     imt_itree* t_ = nullptr;
 };
 
-// ---- several GPUs, the single sorted list (imt_itree_slice_*): the schedule ------------------------------------------
-// The arithmetic a host needs to drive time-sliced insertion with its own collective library (RCCL's ncclAllGather):
-// which unit a rank runs at which tick, what each all-gather carries, when it is consumed.  It is the schedule of
-// indexed-merkle-tree-halo2_amd/sliced.py (SliceSchedule; tests/test_host_logic.py compares the two):
-//   round R = the `world` slices of step R; unit q of a slice: 0 = leaf hashes, 1 + l = level l -> l + 1;
-//   round tick rt: rank g runs unit rt - g * lag; all ranks all-gather that tick's payloads (imt_itree_slice_unit ->
-//   payload, imt_itree_slice_unit_bytes = its size); the gather of tick rt is applied at tick rt + lag
-//   (imt_itree_slice_apply_gathered); consecutive rounds start world * lag ticks apart, at most four are in flight.
-// Ordering a host must keep: round R's unit q, and round R's applies of payloads for unit q, run behind round R - 1's
-// tick q + world * lag (every write-back round R - 1 makes to that level is in this replica by then).
-struct SliceSchedule {
-    static constexpr unsigned kRoundsInFlight = 4;
-    unsigned world, units, lag, period, gathers, round_ticks;
-    SliceSchedule(unsigned world_, unsigned units_, unsigned lag_ = 0) : world(world_), units(units_) {
-        if (world < 1 || units < 2) throw std::invalid_argument("world >= 1 and units >= 2");
-        const unsigned fit = (units + (kRoundsInFlight - 1) * world - 1) / ((kRoundsInFlight - 1) * world);
-        lag = lag_ ? lag_ : (fit > 2 ? fit : 2);
-        period = world * lag;
-        gathers = units + (world - 1) * lag;
-        round_ticks = gathers + lag;
-        if ((round_ticks + period - 1) / period > kRoundsInFlight) throw std::invalid_argument("lag keeps too many rounds in flight");
+// ---- several GPUs, the single sorted list: imt_sliced_* --------------------------------------------------------------
+// The reference's ONE sorted list (update_idx_leaf, src/indexed_merkle_tree.rs:632-660) on `world` GPUs, bit-exact with
+// one: the schedule, its streams and events and the all-gather live in the library; a host makes one call per step.
+// This wrapper owns the imt_sliced handle and (optionally) its transport.
+class Sliced {
+public:
+    // all `world` replicas in this process (tests, the one-GPU rehearsal): the in-process transport
+    static Sliced local(const std::vector<imt_itree*>& trees, size_t max_slice, int lag = 0) {
+        imt_transport* tp = nullptr;
+        if (int rc = imt_transport_local_create(&tp)) throw Error(rc, "imt_transport_local_create failed");
+        return Sliced(trees, (int)trees.size(), 0, tp, true, max_slice, lag);
     }
-    // unit rank `rank` computes at round tick rt, or -1
-    int unit_of(unsigned rank, unsigned rt) const {
-        const long q = (long)rt - (long)rank * (long)lag;
-        return q >= 0 && q < (long)units ? (int)q : -1;
+    // one rank of a distributed world over a transport the caller made (imt_transport_rccl_create, ..._ipc_create)
+    Sliced(imt_itree* tree, int world, int rank, imt_transport* tp, size_t max_slice, int lag = 0)
+        : Sliced(std::vector<imt_itree*>{tree}, world, rank, tp, false, max_slice, lag) {}
+    Sliced(Sliced&& o) noexcept : w_(o.w_), tp_(o.tp_), own_tp_(o.own_tp_) { o.w_ = nullptr; o.tp_ = nullptr; }
+    Sliced(const Sliced&) = delete;
+    ~Sliced() {
+        if (w_) imt_sliced_destroy(w_);
+        if (tp_ && own_tp_) imt_transport_destroy(tp_);
     }
-    // unit whose payload rank `rank` contributes to the all-gather of round tick rt, or -1 (unit 0 writes nothing back)
-    int payload_unit(unsigned rank, unsigned rt) const {
-        const int q = unit_of(rank, rt);
-        return q >= 1 ? q : -1;
+    // vals: all world x n values of the step (device memory); outs[k]: local rank k's witness buffers
+    uint64_t step(const void* vals, size_t n, const imt_insert_out* outs, unsigned flags = 0) {
+        uint64_t round = 0;
+        check(imt_sliced_step(w_, vals, n, outs, flags, &round));
+        return round;
     }
-    bool has_gather(unsigned rt) const {
-        if (rt >= gathers) return false;
-        for (unsigned g = 0; g < world; g++)
-            if (payload_unit(g, rt) >= 0) return true;
-        return false;
+    void wait(uint64_t round, int local_rank = 0) { check(imt_sliced_wait(w_, local_rank, round)); }
+    void flush() { check(imt_sliced_flush(w_)); }
+    imt_sliced_info info() const {
+        imt_sliced_info o{};
+        imt_sliced_get_info(w_, &o);
+        return o;
     }
+
+private:
+    Sliced(const std::vector<imt_itree*>& trees, int world, int first_rank, imt_transport* tp, bool own, size_t max_slice, int lag)
+        : tp_(tp), own_tp_(own) {
+        const int rc = imt_sliced_create(trees.data(), (int)trees.size(), world, first_rank, tp, max_slice, lag, &w_);
+        if (rc) {
+            if (own) imt_transport_destroy(tp);
+            throw Error(rc, "imt_sliced_create failed");
+        }
+    }
+    void check(int rc) const {
+        if (rc) throw Error(rc, imt_sliced_last_error(w_));
+    }
+    imt_sliced* w_ = nullptr;
+    imt_transport* tp_ = nullptr;
+    bool own_tp_ = false;
 };
 
 }  // namespace imt

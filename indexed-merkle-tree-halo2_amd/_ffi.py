@@ -23,7 +23,9 @@ def _preload_torch_hip_runtime():
     both.  If this library came first, a later `import torch` would run on a runtime it was not built
     with and report "No HIP GPUs are available".  So when torch is installed, its runtime is loaded
     first -- without importing torch itself -- and libimt_hip.so binds to it, which is the order
-    bench.py and the GPU tests have always run in."""
+    bench.py and the GPU tests have always run in.  The same holds for RCCL (librccl.so.1: the library
+    calls ncclAllGather itself, imt_sliced_rccl.cpp): one copy per process, torch's when torch is there,
+    so that torch.distributed and this library never run two RCCL builds over one HIP runtime."""
     import importlib.util
     try:
         spec = importlib.util.find_spec("torch")
@@ -49,6 +51,19 @@ P = ctypes.POINTER
 
 class TraceCell(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_uint8), ("gate", ctypes.c_uint8), ("region", ctypes.c_uint16), ("index", ctypes.c_uint32)]
+
+
+class TransportOps(ctypes.Structure):
+    ALL_GATHER = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_size_t, ctypes.c_void_p)
+    DESTROY = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+    _fields_ = [("self", ctypes.c_void_p), ("all_gather", ALL_GATHER), ("destroy", DESTROY)]
+
+
+class SlicedInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("world", "n_local", "lag", "period", "gathers_per_round", "round_ticks",
+                                            "rounds_in_flight")] + \
+               [("payload_bytes", ctypes.c_size_t)] + [(n, ctypes.c_uint64) for n in ("rounds", "collectives", "bytes_gathered")]
 
 
 class InsertOut(ctypes.Structure):
@@ -129,6 +144,24 @@ SIGNATURES = {
     "imt_itree_slice_apply": (c_int, [c_void_p, c_u64, c_size_t, c_uint, c_void_p, c_void_p]),
     "imt_itree_slice_apply_gathered": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, P(c_u64), P(c_u64),
                                                P(ctypes.c_int32), c_void_p]),
+    "imt_transport_custom_create": (c_int, [P(TransportOps), P(c_void_p)]),
+    "imt_transport_local_create": (c_int, [P(c_void_p)]),
+    "imt_rccl_get_unique_id": (c_int, [c_void_p]),
+    "imt_transport_rccl_create": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, P(c_void_p)]),
+    "imt_transport_rccl_adopt": (c_int, [P(c_void_p), c_int, P(c_void_p)]),
+    "imt_rccl_library": (ctypes.c_char_p, [P(c_int)]),
+    "imt_transport_ipc_blob_bytes": (c_size_t, []),
+    "imt_transport_ipc_create": (c_int, [c_void_p, c_int, c_int, c_uint, c_size_t, c_int, P(c_void_p), c_void_p]),
+    "imt_transport_ipc_connect": (c_int, [c_void_p, c_void_p]),
+    "imt_transport_destroy": (None, [c_void_p]),
+    "imt_transport_last_error": (ctypes.c_char_p, [c_void_p]),
+    "imt_sliced_create": (c_int, [P(c_void_p), c_int, c_int, c_int, c_void_p, c_size_t, c_int, P(c_void_p)]),
+    "imt_sliced_step": (c_int, [c_void_p, c_void_p, c_size_t, P(InsertOut), c_uint, P(c_u64)]),
+    "imt_sliced_wait": (c_int, [c_void_p, c_int, c_u64]),
+    "imt_sliced_flush": (c_int, [c_void_p]),
+    "imt_sliced_get_info": (c_int, [c_void_p, P(SlicedInfo)]),
+    "imt_sliced_last_error": (ctypes.c_char_p, [c_void_p]),
+    "imt_sliced_destroy": (None, [c_void_p]),
     "imt_itree_set_placement": (c_int, [c_void_p, c_uint, c_u64]),
     "imt_itree_set_value_partition": (c_int, [c_void_p, ctypes.c_uint32, ctypes.c_uint32]),
     "imt_itree_lift_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, P(InsertOut), c_uint]),
@@ -154,3 +187,5 @@ F_RANGE_PRED, F_LOW_IN_ROOT, F_LOW_LT_NEW, F_ZERO_SLOT, F_NEXT_VAL, F_NEXT_IDX, 
 CELL_CONST, CELL_INPUT, CELL_INIT, CELL_WITNESS, CELL_COPY = 0, 1, 2, 3, 4
 TRACE_ITEM_MAJOR = SIB_ITEM_MAJOR
 OPT_COOP_MAX_EVENTS = 1
+SLICED_ROUNDS = 4
+RCCL_UNIQUE_ID_BYTES = 128

@@ -155,7 +155,7 @@ extern "C" int imt_ctx_set_option(imt_ctx* c, int option, uint64_t value) {
     }
 }
 
-extern "C" const char* imt_version(void) { return "imt-hip gfx950 r3"; }
+extern "C" const char* imt_version(void) { return "imt-hip gfx950 r4"; }
 
 extern "C" int imt_ctx_create(int device, imt_ctx** out) {
     if (!out) return IMT_ERR_ARG;

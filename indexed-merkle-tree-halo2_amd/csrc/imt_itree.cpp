@@ -102,6 +102,7 @@ struct PlanSet {
     // a time slice of a multi-GPU step (imt_itree_slice_*): prepared here, hashed unit by unit on the caller's streams
     hipEvent_t prep_done = nullptr;      // recorded on the side stream behind the slice's preparation and index phase
     bool open = false;                   // prepared, last unit not yet issued
+    bool sliced = false;                 // the set's last user was a slice (imt_itree_slice_prepare), not an ordinary batch
     size_t slice_n = 0;
     imt_insert_out slice_out = {};
     unsigned slice_fmt = 0;
@@ -427,6 +428,10 @@ static int ensure_device_index(imt_itree* t) {
 }
 
 extern "C" uint64_t imt_itree_size(const imt_itree* t) { return t ? t->size : 0; }
+// internal (imt_itree_internal.hpp): what imt_sliced.cpp needs to know about a tree
+imt_ctx* imt_itree_ctx(const imt_itree* t) { return t ? t->ctx : nullptr; }
+unsigned imt_itree_depth(const imt_itree* t) { return t ? t->depth : 0; }
+bool imt_itree_is_plain(const imt_itree* t) { return t && !t->index_base && t->part_mod <= 1 && !t->pending.active; }
 
 extern "C" int imt_itree_root(imt_itree* t, void* root, unsigned flags) {
     if (!t || !root) return IMT_ERR_ARG;
@@ -458,7 +463,9 @@ extern "C" int imt_itree_root_lagged(imt_itree* t, unsigned lag, void* root, uns
     if (t->batch_no <= lag) return c->fail(IMT_ERR_RANGE, "no batch %u calls ago", lag);
     if ((rc = check_fe_ptrs(c, flags & IMT_DEVICE_PTRS, {root}))) return rc;
     const PlanSet& P = t->plan[(t->cur + 2 * imt_itree::NSETS - 1 - (int)lag) % imt_itree::NSETS];
-    if (!P.has_root) return c->fail(IMT_ERR_INTERNAL, "batch root not recorded");
+    if (!P.has_root)
+        return c->fail(P.sliced ? IMT_ERR_ARG : IMT_ERR_INTERNAL,
+                       P.sliced ? "imt_itree_root_lagged does not see slices: imt_sliced_flush, then imt_itree_root" : "batch root not recorded");
     IMT_HIP(c, hipStreamWaitEvent(c->stream, P.done, 0));
     const unsigned fmt = flags & IMT_FMT_MASK;
     if (flags & IMT_DEVICE_PTRS) {
@@ -1184,6 +1191,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     P.has_root = true;
     IMT_HIP(c, hipEventRecord(P.done, s));
     P.pipelined = pipelined;
+    P.sliced = false;
     P.l0 = L0;
     P.in_flight = true;
     t->cur = (t->cur + 1) % imt_itree::NSETS;
@@ -1651,6 +1659,12 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
         if (out->low_leaf) launch::convert(ps, (uint8_t*)out->low_leaf, (uint8_t*)out->low_leaf, n_own * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
         if (out->new_leaf) launch::convert(ps, (uint8_t*)out->new_leaf, (uint8_t*)out->new_leaf, n_own * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
     }
+    // The slice's units run on streams the caller names and read / write the stored levels: they must come behind
+    // every ORDINARY batch still in flight on this tree (pipelined or on the context's stream), whose sweeps write the
+    // same levels.  Unit 0 waits for prep_done, so ordering the side stream behind those batches orders the units.
+    // Earlier slices are not waited for here: the sliced schedule orders slices among themselves level by level.
+    for (auto& pl : t->plan)
+        if (&pl != &P && pl.in_flight && !pl.sliced) IMT_HIP(c, hipStreamWaitEvent(ps, pl.done, 0));
     IMT_HIP(c, hipEventRecord(P.prep_done, ps));
     IMT_HIP(c, hipStreamSynchronize(ps));
     const int perr = *t->h_err_pin;      // the same verdict on every GPU: they all see all values of the step
@@ -1662,6 +1676,7 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
     t->size = M0 + n_all;
     t->mirror_valid = false;
     P.open = true;
+    P.sliced = true;
     P.slice_n = n_own;
     P.slice_out = out ? *out : imt_insert_out{};
     P.slice_fmt = fmt;
@@ -1740,8 +1755,7 @@ extern "C" int imt_itree_slice_unit(imt_itree* t, int slice, unsigned unit, void
         launch::emit_roots(s, P.d_val[depth & 1], 0, (uint32_t)E, (uint32_t)E, g_old, (uint8_t*)o.interim_root,
                            (uint8_t*)o.new_root, fmt, nullptr, L0 == depth ? root_node : nullptr);
         if (pl && L0 == depth) IMT_HIP(c, hipMemcpyAsync(pl + 64, root_node, 32, hipMemcpyDeviceToDevice, s));
-        IMT_HIP(c, hipMemcpyAsync(P.d_root, root_node, 32, hipMemcpyDeviceToDevice, s));
-        P.has_root = true;
+        P.has_root = false;         // the root after THIS slice is a mid-step root on every rank but the last: not offered
         IMT_HIP(c, hipEventRecord(P.done, s));
         P.in_flight = true;
         P.pipelined = true;         // not on the context's stream: join_top orders that stream behind it
@@ -1798,6 +1812,11 @@ extern "C" int imt_itree_slice_apply_gathered(imt_itree* t, const void* gathered
         if ((unsigned)unit[r] > depth) return c->fail(IMT_ERR_RANGE, "unit %d beyond depth %u", unit[r], depth);
         if (n[r] == 0 || size_before[r] + n[r] > t->cap) return c->fail(IMT_ERR_RANGE, "slice outside the tree's capacity");
         if (unit[r] == 0) continue;
+        // the kernel reads the counter and the node ids at offsets computed from (size_before, n, unit): a payload
+        // slot shorter than that would make it read the neighbouring payload
+        if (count > 1 && stride < slice_unit_bytes(size_before[r], (size_t)n[r], (unsigned)unit[r], depth))
+            return c->fail(IMT_ERR_ARG, "payload stride %zu is smaller than the %zu bytes unit %d of slot %zu uses", stride,
+                           slice_unit_bytes(size_before[r], (size_t)n[r], (unsigned)unit[r], depth), unit[r], r);
         const unsigned l = (unsigned)unit[r] - 1;
         const unsigned L0 = std::min(ceil_log2(size_before[r] + n[r]), depth);
         launch::ApplyJobs::Job& j = jobs.j[jobs.n_jobs++];

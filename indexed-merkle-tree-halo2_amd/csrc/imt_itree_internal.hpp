@@ -1,0 +1,7 @@
+// imt_itree_internal.hpp -- what other translation units of the library may know about an imt_itree (imt_itree.cpp).
+#pragma once
+#include "imt_ctx.hpp"
+
+imt_ctx* imt_itree_ctx(const imt_itree* t);
+unsigned imt_itree_depth(const imt_itree* t);
+bool imt_itree_is_plain(const imt_itree* t);     // not placed, not partitioned, no sharded batch open

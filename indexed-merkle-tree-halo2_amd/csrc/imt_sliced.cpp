@@ -1,0 +1,492 @@
+// imt_sliced.cpp -- imt_sliced_* (include/imt.h): the multi-GPU single-list mode behind one call per step.
+//
+// The schedule is imt_sliced_sched.hpp (HIP-free, tested on the CPU over a symbolic backend); this file gives it HIP
+// streams, events and buffers, the slice calls of one replica (imt_itree_slice_* in imt_itree.cpp), and the transports
+// that do not need RCCL: in-process copies, a caller-supplied vtable, and direct peer copies between processes over HIP
+// IPC handles.  The RCCL transport is imt_sliced_rccl.cpp.  The data structure is the reference's ONE sorted list
+// (/root/reference/src/indexed_merkle_tree.rs:632-660, insertion i at leaf size + i: :715).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <thread>
+#include "imt_itree_internal.hpp"
+#include "imt_sliced_sched.hpp"
+#include "imt_sliced_transport.hpp"
+
+using namespace imt::sliced;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- one replica over HIP
+struct HipBackend : Backend {
+    imt_itree* tree;
+    imt_ctx* ctx;
+    hipStream_t rs[ROUNDS] = {}, cs[ROUNDS] = {};
+    int n_comm = ROUNDS;
+
+    explicit HipBackend(imt_itree* t) : tree(t), ctx(imt_itree_ctx(t)) {}
+    int init() {
+        int rc = ctx->set_device();
+        if (rc) return rc;
+        if (const char* e = getenv("IMT_SLICED_COMM_STREAMS")) n_comm = std::max(1, std::min(ROUNDS, atoi(e)));
+        // different priorities for the round streams, like the batch pipeline's: the runtime may otherwise map them to
+        // one hardware queue, which serialises them
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+        for (int i = 0; i < ROUNDS; i++) {
+            const int prio = std::max(greatest, std::min(least, 0 - i));
+            IMT_HIP(ctx, hipStreamCreateWithPriority(&rs[i], hipStreamNonBlocking, prio));
+            ctx->side_streams.push_back(rs[i]);
+        }
+        for (int i = 0; i < n_comm; i++) {
+            IMT_HIP(ctx, hipStreamCreateWithPriority(&cs[i], hipStreamNonBlocking, greatest));
+            ctx->side_streams.push_back(cs[i]);
+        }
+        return IMT_OK;
+    }
+    ~HipBackend() override {
+        if (ctx->set_device()) return;
+        auto& ss = ctx->side_streams;
+        for (hipStream_t* arr : {rs, cs})
+            for (int i = 0; i < ROUNDS; i++)
+                if (arr[i]) {
+                    hipStreamSynchronize(arr[i]);
+                    ss.erase(std::remove(ss.begin(), ss.end(), arr[i]), ss.end());
+                    hipStreamDestroy(arr[i]);
+                }
+    }
+    Stream round_stream(int slot) override { return rs[slot]; }
+    Stream comm_stream(int slot) override { return cs[slot % n_comm]; }
+    int new_event(Event* out) override {
+        hipEvent_t e;
+        IMT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        *out = e;
+        return IMT_OK;
+    }
+    void free_event(Event e) override { hipEventDestroy((hipEvent_t)e); }
+    int record(Event e, Stream s) override {
+        IMT_HIP(ctx, hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+        return IMT_OK;
+    }
+    int wait(Stream s, Event e) override {
+        IMT_HIP(ctx, hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0));
+        return IMT_OK;
+    }
+    int event_sync(Event e) override {
+        IMT_HIP(ctx, hipEventSynchronize((hipEvent_t)e));
+        return IMT_OK;
+    }
+    int alloc(size_t bytes, Buffer* out) override {
+        void* p = nullptr;
+        IMT_HIP(ctx, hipMalloc(&p, bytes));
+        IMT_HIP(ctx, hipMemset(p, 0, bytes));
+        *out = p;
+        return IMT_OK;
+    }
+    void free_buffer(Buffer b) override { hipFree(b); }
+    int copy(Buffer dst, size_t doff, Buffer src, size_t soff, size_t bytes, Stream s) override {
+        IMT_HIP(ctx, hipMemcpyAsync((uint8_t*)dst + doff, (const uint8_t*)src + soff, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+        return IMT_OK;
+    }
+    uint64_t tree_size() override { return imt_itree_size(tree); }
+    size_t payload_bytes(size_t n) override { return imt_itree_slice_payload_bytes(n); }
+    size_t unit_bytes(uint64_t sb, size_t n, unsigned q) override { return imt_itree_slice_unit_bytes(tree, sb, n, q); }
+    int prepare(const void* vals, size_t nb, size_t no, size_t na, const imt_insert_out* out, unsigned flags, int* slice) override {
+        return imt_itree_slice_prepare(tree, vals, nb, no, na, out, flags | IMT_DEVICE_PTRS, slice, nullptr);
+    }
+    int unit(int slice, unsigned q, Buffer payload, Stream s) override { return imt_itree_slice_unit(tree, slice, q, payload, s); }
+    int apply_gathered(Buffer g, size_t stride, int count, const uint64_t* sb, const uint64_t* n, const int32_t* units,
+                       Stream s) override {
+        return imt_itree_slice_apply_gathered(tree, g, stride, (size_t)count, sb, n, units, s);
+    }
+    int sync() override {
+        int rc = ctx->set_device();
+        if (rc) return rc;
+        for (hipStream_t* arr : {rs, cs})
+            for (int i = 0; i < ROUNDS; i++)
+                if (arr[i]) IMT_HIP(ctx, hipStreamSynchronize(arr[i]));
+        return imt_ctx_sync(ctx);
+    }
+};
+
+// ------------------------------------------------------------------------------------- a caller-supplied collective
+struct CustomTransport : Transport {
+    imt_transport_ops ops;
+    explicit CustomTransport(const imt_transport_ops& o) : ops(o) {}
+    ~CustomTransport() override {
+        if (ops.destroy) ops.destroy(ops.self);
+    }
+    int all_gather(Rank& rk, int slot, int r, size_t bytes, Stream st) override {
+        const int i = rk.at(slot, r);
+        return ops.all_gather(ops.self, slot, r, rk.send[i], rk.recv[i], bytes, st);
+    }
+};
+
+// ------------------------------------------------------------------------------ direct peer copies between processes
+// Every rank exports ONE allocation holding all its send buffers (hipIpcMemHandle) and, per (slot, ring), two
+// interprocess events: `packed` (my payload is in my send buffer) and `copied` (I have copied every peer's payload of
+// this gather).  A gather = wait for each peer's `packed`, copy its payload out of its memory, record `copied`; the fence
+// = wait for every peer's `copied` before the send buffer is rewritten.  HIP's cross-process rule is the in-process one
+// (a wait captures the latest record ISSUED before it), so the hosts also keep sequence numbers in a small POSIX
+// shared-memory page each: a rank waits on the host until the peer has ISSUED record number k, then enqueues the wait.
+constexpr int IPC_RING_MAX = 12;
+constexpr int IPC_NEV = ROUNDS * IPC_RING_MAX;
+
+struct IpcBlob {
+    hipIpcMemHandle_t mem;
+    hipIpcEventHandle_t packed[IPC_NEV], copied[IPC_NEV];
+    char shm_name[64];
+    uint64_t arena_bytes;
+    int32_t rank, world, ring, pid;
+};
+struct IpcShm {
+    std::atomic<uint64_t> packed_seq[IPC_NEV], copied_seq[IPC_NEV];
+};
+
+struct IpcTransport : Transport {
+    imt_ctx* ctx;
+    int world, rank, ring = 0;
+    size_t payload_cap = 0;
+    uint8_t* arena = nullptr;                    // [ROUNDS][ring][payload_cap]
+    hipEvent_t ev_packed[IPC_NEV] = {}, ev_copied[IPC_NEV] = {};
+    IpcShm* my_shm = nullptr;
+    std::string shm_name;
+    uint64_t seq[IPC_NEV] = {};                  // gathers issued per (slot, ring): the same on every rank
+    struct Peer {
+        uint8_t* arena = nullptr;
+        hipEvent_t packed[IPC_NEV] = {}, copied[IPC_NEV] = {};
+        IpcShm* shm = nullptr;
+    };
+    std::vector<Peer> peers;
+    bool connected = false;
+    double timeout_s = 120.0;
+
+    IpcTransport(imt_ctx* c, int w, int r) : ctx(c), world(w), rank(r) {}
+    static int ei(int slot, int r) { return slot * IPC_RING_MAX + r; }
+
+    int create(unsigned depth, size_t max_slice, int lag, IpcBlob* blob) {
+        Schedule sc;
+        if (!sc.init(world, (int)depth + 1, lag)) return ctx->fail(IMT_ERR_RANGE, "not a schedule: world %d depth %u lag %d", world, depth, lag);
+        ring = sc.lag + 1;
+        if (ring > IPC_RING_MAX) return ctx->fail(IMT_ERR_RANGE, "lag %d too large for the IPC transport (max %d)", sc.lag, IPC_RING_MAX - 1);
+        int rc = ctx->set_device();
+        if (rc) return rc;
+        if (const char* e = getenv("IMT_IPC_TIMEOUT_S")) timeout_s = atof(e);
+        payload_cap = imt_itree_slice_payload_bytes(max_slice);
+        const size_t bytes = (size_t)ROUNDS * ring * payload_cap;
+        IMT_HIP(ctx, hipMalloc((void**)&arena, bytes));
+        IMT_HIP(ctx, hipMemset(arena, 0, bytes));
+        std::memset(blob, 0, sizeof *blob);
+        IMT_HIP(ctx, hipIpcGetMemHandle(&blob->mem, arena));
+        for (int slot = 0; slot < ROUNDS; slot++)
+            for (int r = 0; r < ring; r++) {
+                const int i = ei(slot, r);
+                IMT_HIP(ctx, hipEventCreateWithFlags(&ev_packed[i], hipEventDisableTiming | hipEventInterprocess));
+                IMT_HIP(ctx, hipEventCreateWithFlags(&ev_copied[i], hipEventDisableTiming | hipEventInterprocess));
+                IMT_HIP(ctx, hipIpcGetEventHandle(&blob->packed[i], ev_packed[i]));
+                IMT_HIP(ctx, hipIpcGetEventHandle(&blob->copied[i], ev_copied[i]));
+            }
+        char name[64];
+        snprintf(name, sizeof name, "/imt_ipc_%d_%d_%llx", (int)getpid(), rank,
+                 (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+        shm_name = name;
+        const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, sizeof(IpcShm)) != 0) {
+            if (fd >= 0) close(fd);
+            return ctx->fail(IMT_ERR_ALLOC, "shm_open(%s) failed", name);
+        }
+        my_shm = (IpcShm*)mmap(nullptr, sizeof(IpcShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (my_shm == MAP_FAILED) {
+            my_shm = nullptr;
+            return ctx->fail(IMT_ERR_ALLOC, "mmap of the sequence page failed");
+        }
+        new (my_shm) IpcShm();
+        snprintf(blob->shm_name, sizeof blob->shm_name, "%s", name);
+        blob->arena_bytes = bytes;
+        blob->rank = rank;
+        blob->world = world;
+        blob->ring = ring;
+        blob->pid = (int)getpid();
+        return IMT_OK;
+    }
+    int connect(const IpcBlob* all) {
+        int rc = ctx->set_device();
+        if (rc) return rc;
+        peers.assign(world, Peer());
+        for (int h = 0; h < world; h++) {
+            if (h == rank) continue;
+            const IpcBlob& b = all[h];
+            if (b.rank != h || b.world != world || b.ring != ring)
+                return ctx->fail(IMT_ERR_ARG, "IPC blob %d does not describe rank %d of this world", h, h);
+            if (b.pid == (int)getpid()) return ctx->fail(IMT_ERR_ARG, "the IPC transport joins PROCESSES; ranks of one process use the local transport");
+            Peer& p = peers[h];
+            IMT_HIP(ctx, hipIpcOpenMemHandle((void**)&p.arena, b.mem, hipIpcMemLazyEnablePeerAccess));
+            for (int slot = 0; slot < ROUNDS; slot++)
+                for (int r = 0; r < ring; r++) {
+                    const int i = ei(slot, r);
+                    IMT_HIP(ctx, hipIpcOpenEventHandle(&p.packed[i], b.packed[i]));
+                    IMT_HIP(ctx, hipIpcOpenEventHandle(&p.copied[i], b.copied[i]));
+                }
+            const int fd = shm_open(b.shm_name, O_RDWR, 0600);
+            if (fd < 0) return ctx->fail(IMT_ERR_ARG, "shm_open(%s) of rank %d failed", b.shm_name, h);
+            p.shm = (IpcShm*)mmap(nullptr, sizeof(IpcShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (p.shm == MAP_FAILED) {
+                p.shm = nullptr;
+                return ctx->fail(IMT_ERR_ALLOC, "mmap of rank %d's sequence page failed", h);
+            }
+        }
+        connected = true;
+        return IMT_OK;
+    }
+    ~IpcTransport() override {
+        if (ctx->set_device()) return;
+        for (auto& p : peers) {
+            for (int i = 0; i < IPC_NEV; i++) {
+                if (p.packed[i]) hipEventDestroy(p.packed[i]);
+                if (p.copied[i]) hipEventDestroy(p.copied[i]);
+            }
+            if (p.arena) hipIpcCloseMemHandle(p.arena);
+            if (p.shm) munmap(p.shm, sizeof(IpcShm));
+        }
+        for (int i = 0; i < IPC_NEV; i++) {
+            if (ev_packed[i]) hipEventDestroy(ev_packed[i]);
+            if (ev_copied[i]) hipEventDestroy(ev_copied[i]);
+        }
+        if (arena) hipFree(arena);
+        if (my_shm) munmap(my_shm, sizeof(IpcShm));
+        if (!shm_name.empty()) shm_unlink(shm_name.c_str());
+    }
+    int attach(Rank& rk) override {
+        if (!connected) return ctx->fail(IMT_ERR_ARG, "imt_transport_ipc_connect first");
+        if (rk.world != world || rk.rank != rank || rk.ring != ring || rk.payload_cap != payload_cap)
+            return ctx->fail(IMT_ERR_ARG, "the IPC transport was created for another world / depth / max_slice / lag");
+        return IMT_OK;
+    }
+    Buffer provide_send(Rank&, int slot, int r, size_t) override { return arena + ((size_t)slot * ring + r) * payload_cap; }
+    // host: wait until the peer has ISSUED its record number k
+    int await_seq(const std::atomic<uint64_t>& a, uint64_t k, int peer, const char* what) {
+        if (a.load(std::memory_order_acquire) >= k) return IMT_OK;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++) {
+            if (a.load(std::memory_order_acquire) >= k) return IMT_OK;
+            if ((spins & 1023) == 1023) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+                    return ctx->fail(IMT_ERR_INTERNAL, "IPC transport: rank %d did not issue its %s record %llu within %.0f s", peer, what,
+                                     (unsigned long long)k, timeout_s);
+                std::this_thread::yield();
+            }
+        }
+    }
+    int all_gather(Rank& rk, int slot, int r, size_t bytes, Stream st_) override {
+        hipStream_t st = (hipStream_t)st_;
+        const int i = ei(slot, r);
+        const uint64_t k = ++seq[i];
+        // st is already behind the unit that packed my send buffer
+        IMT_HIP(ctx, hipEventRecord(ev_packed[i], st));
+        my_shm->packed_seq[i].store(k, std::memory_order_release);
+        uint8_t* recv = (uint8_t*)rk.recv[rk.at(slot, r)];
+        const size_t off = ((size_t)slot * ring + r) * payload_cap;
+        for (int d = 1; d < world; d++) {              // start with the next rank: spread the reads over the peers
+            const int h = (rank + d) % world;
+            Peer& p = peers[h];
+            int rc = await_seq(p.shm->packed_seq[i], k, h, "packed");
+            if (rc) return rc;
+            IMT_HIP(ctx, hipStreamWaitEvent(st, p.packed[i], 0));
+            IMT_HIP(ctx, hipMemcpyAsync(recv + (size_t)h * bytes, p.arena + off, bytes, hipMemcpyDeviceToDevice, st));
+        }
+        IMT_HIP(ctx, hipEventRecord(ev_copied[i], st));
+        my_shm->copied_seq[i].store(k, std::memory_order_release);
+        return IMT_OK;
+    }
+    int fence(Rank&, int slot, int r, Stream st_) override {
+        const int i = ei(slot, r);
+        for (int h = 0; h < world; h++) {
+            if (h == rank) continue;
+            int rc = await_seq(peers[h].shm->copied_seq[i], seq[i], h, "copied");
+            if (rc) return rc;
+            IMT_HIP(ctx, hipStreamWaitEvent((hipStream_t)st_, peers[h].copied[i], 0));
+        }
+        return IMT_OK;
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------- the handles
+imt_transport* imt_transport_wrap(Transport* t, imt_ctx* ctx) {
+    imt_transport* h = new (std::nothrow) imt_transport();
+    if (!h) {
+        delete t;
+        return nullptr;
+    }
+    h->impl.reset(t);
+    h->ctx = ctx;
+    return h;
+}
+
+struct imt_sliced {
+    World w;
+    std::vector<std::unique_ptr<HipBackend>> bes;
+    std::vector<std::unique_ptr<Rank>> ranks;
+    imt_transport* tp = nullptr;
+    size_t max_slice = 0;
+    std::string error;
+};
+
+extern "C" {
+
+int imt_transport_custom_create(const imt_transport_ops* ops, imt_transport** out) {
+    if (!ops || !ops->all_gather || !out) return IMT_ERR_ARG;
+    *out = imt_transport_wrap(new (std::nothrow) CustomTransport(*ops), nullptr);
+    return *out ? IMT_OK : IMT_ERR_ALLOC;
+}
+
+int imt_transport_local_create(imt_transport** out) {
+    if (!out) return IMT_ERR_ARG;
+    *out = imt_transport_wrap(new (std::nothrow) LocalTransport(), nullptr);
+    return *out ? IMT_OK : IMT_ERR_ALLOC;
+}
+
+size_t imt_transport_ipc_blob_bytes(void) { return sizeof(IpcBlob); }
+
+int imt_transport_ipc_create(imt_ctx* ctx, int world, int rank, unsigned depth, size_t max_slice, int lag, imt_transport** out,
+                             void* blob_out) {
+    if (!ctx || !out || !blob_out) return IMT_ERR_ARG;
+    *out = nullptr;
+    if (world < 2 || rank < 0 || rank >= world || max_slice == 0) return ctx->fail(IMT_ERR_ARG, "IPC transport: world >= 2, 0 <= rank < world");
+    IpcTransport* t = new (std::nothrow) IpcTransport(ctx, world, rank);
+    if (!t) return ctx->fail(IMT_ERR_ALLOC, "out of host memory");
+    int rc = t->create(depth, max_slice, lag, (IpcBlob*)blob_out);
+    if (rc) {
+        delete t;
+        return rc;
+    }
+    *out = imt_transport_wrap(t, ctx);
+    return *out ? IMT_OK : IMT_ERR_ALLOC;
+}
+
+int imt_transport_ipc_connect(imt_transport* tp, const void* all_blobs) {
+    if (!tp || !all_blobs) return IMT_ERR_ARG;
+    IpcTransport* t = dynamic_cast<IpcTransport*>(tp->impl.get());
+    if (!t) return IMT_ERR_ARG;
+    return t->connect((const IpcBlob*)all_blobs);
+}
+
+void imt_transport_destroy(imt_transport* tp) { delete tp; }
+
+const char* imt_transport_last_error(const imt_transport* tp) {
+    if (!tp) return "";
+    if (!tp->error.empty()) return tp->error.c_str();
+    return tp->ctx ? tp->ctx->last_error.c_str() : "";
+}
+
+void imt_sliced_destroy(imt_sliced* s) {
+    if (!s) return;
+    if (!s->ranks.empty() && s->w.n_rounds) s->w.flush();
+    for (auto& be : s->bes) be->sync();
+    for (auto& r : s->ranks) r->destroy();
+    if (s->tp) s->tp->users--;
+    delete s;
+}
+
+int imt_sliced_create(imt_itree* const* trees, int n_local, int world, int first_rank, imt_transport* tp, size_t max_slice,
+                      int lag, imt_sliced** out) {
+    if (!out) return IMT_ERR_ARG;
+    *out = nullptr;
+    if (!trees || !tp || n_local < 1 || !trees[0]) return IMT_ERR_ARG;
+    imt_ctx* c0 = imt_itree_ctx(trees[0]);
+    if (world < 1 || first_rank < 0 || first_rank + n_local > world || max_slice == 0 || (n_local != 1 && n_local != world))
+        return c0->fail(IMT_ERR_ARG, "imt_sliced_create: n_local is 1 or world, 0 <= first_rank, first_rank + n_local <= world");
+    const unsigned depth = imt_itree_depth(trees[0]);
+    for (int k = 0; k < n_local; k++) {
+        if (!trees[k]) return c0->fail(IMT_ERR_ARG, "null tree");
+        if (imt_itree_depth(trees[k]) != depth || !imt_itree_is_plain(trees[k]))
+            return c0->fail(IMT_ERR_ARG, "replicas have one depth and are not placed / partitioned");
+        for (int j = 0; j < k; j++)
+            if (trees[j] == trees[k] || imt_itree_ctx(trees[j]) == imt_itree_ctx(trees[k]))
+                return c0->fail(IMT_ERR_ARG, "every replica needs its own tree on its own context");
+    }
+    if (n_local == world && world > 1 && !dynamic_cast<LocalTransport*>(tp->impl.get()))
+        return c0->fail(IMT_ERR_ARG, "all ranks in one process use the local transport");
+    if (n_local == 1 && world > 1 && dynamic_cast<LocalTransport*>(tp->impl.get()))
+        return c0->fail(IMT_ERR_ARG, "the local transport needs every rank in this process (n_local = world)");
+    std::unique_ptr<imt_sliced> s(new (std::nothrow) imt_sliced());
+    if (!s) return c0->fail(IMT_ERR_ALLOC, "out of host memory");
+    if (!s->w.sc.init(world, (int)depth + 1, lag))
+        return c0->fail(IMT_ERR_RANGE, "world %d, depth %u, lag %d would keep more than %d steps in flight (or is no schedule)", world, depth,
+                        lag, ROUNDS);
+    s->tp = tp;
+    s->max_slice = max_slice;
+    tp->users++;
+    for (int k = 0; k < n_local; k++) {
+        s->bes.emplace_back(new (std::nothrow) HipBackend(trees[k]));
+        s->ranks.emplace_back(new (std::nothrow) Rank());
+        HipBackend* be = s->bes.back().get();
+        Rank* rk = s->ranks.back().get();
+        int rc;
+        if (!be || !rk) rc = IMT_ERR_ALLOC;
+        else if (!(rc = be->init()) && !(rc = rk->init(be, tp->impl.get(), world, first_rank + k, max_slice)))
+            rc = rk->build(s->w.sc);
+        if (rc) {
+            imt_sliced_destroy(s.release());
+            return rc;
+        }
+        s->w.ranks.push_back(rk);
+    }
+    *out = s.release();
+    return IMT_OK;
+}
+
+int imt_sliced_step(imt_sliced* s, const void* vals, size_t n, const imt_insert_out* outs, unsigned flags, uint64_t* round_out) {
+    if (!s) return IMT_ERR_ARG;
+    imt_ctx* c0 = s->bes[0]->ctx;
+    if (!vals) return c0->fail(IMT_ERR_ARG, "null vals");
+    if (n == 0 || n > s->max_slice) return c0->fail(IMT_ERR_RANGE, "a step is world x n values with 0 < n <= max_slice = %zu", s->max_slice);
+    if (flags & ~(IMT_FMT_MASK | IMT_SIB_ITEM_MAJOR | IMT_INPUTS_READY | IMT_DEVICE_PTRS))
+        return c0->fail(IMT_ERR_ARG, "imt_sliced_step takes IMT_FMT_*, IMT_SIB_ITEM_MAJOR, IMT_INPUTS_READY");
+    return s->w.step(vals, n, outs, flags, round_out);
+}
+
+int imt_sliced_wait(imt_sliced* s, int local_rank, uint64_t round) {
+    if (!s || local_rank < 0) return IMT_ERR_ARG;
+    return s->w.wait_round((size_t)local_rank, round);
+}
+
+int imt_sliced_flush(imt_sliced* s) { return s ? s->w.flush() : IMT_ERR_ARG; }
+
+int imt_sliced_get_info(const imt_sliced* s, imt_sliced_info* o) {
+    if (!s || !o) return IMT_ERR_ARG;
+    const Schedule& sc = s->w.sc;
+    o->world = sc.world;
+    o->n_local = (int)s->ranks.size();
+    o->lag = sc.lag;
+    o->period = sc.period;
+    o->gathers_per_round = sc.gathers;
+    o->round_ticks = sc.round_ticks;
+    o->rounds_in_flight = (sc.round_ticks + sc.period - 1) / sc.period;
+    o->payload_bytes = s->ranks[0]->payload_cap;
+    o->rounds = s->w.n_rounds;
+    o->collectives = s->tp->impl->collectives;
+    o->bytes_gathered = s->tp->impl->bytes_moved;
+    return IMT_OK;
+}
+
+const char* imt_sliced_last_error(const imt_sliced* s) {
+    if (!s) return "";
+    for (auto& be : s->bes)
+        if (!be->ctx->last_error.empty()) return be->ctx->last_error.c_str();
+    return imt_transport_last_error(s->tp);
+}
+
+}  // extern "C"

@@ -1,0 +1,432 @@
+// imt_sliced_sched.hpp -- the systolic schedule of the multi-GPU single-list mode (imt_sliced_*, include/imt.h), free of
+// HIP: everything that is not hashing.  The reference's data structure is ONE sorted list with update_idx_leaf's
+// sequential semantics (/root/reference/src/indexed_merkle_tree.rs:632-660), insertion i at leaf size + i (:715); a step
+// of world x n insertions is cut into `world` consecutive SLICES in insertion order, rank g hashes slice g (its 2 + 2 *
+// depth hashes per insertion, its witnesses), every rank keeps a replica, and what a slice WRITES BACK to the stored tree
+// crosses ranks level by level:
+//
+//     round R = the world slices of step R.         unit q of a slice: q = 0 leaf hashes, q = 1 + l level l -> l + 1
+//     round tick rt = 0, 1, ...:  rank g runs unit q = rt - g * lag of its slice      (units = depth + 1)
+//                                 all ranks all-gather the payloads of that tick      (the collective)
+//                                 payloads gathered at tick rt are applied at tick rt + lag
+//     global tick T: round R is at round tick T - R * world * lag, so consecutive rounds overlap (up to ROUNDS in flight,
+//     each on its own stream).
+//
+// Why it is right: rank g computes (R, q) at round tick q + g lag; the payload of an earlier slice (R, g' < g, q) was
+// gathered at q + g' lag and applied by q + g' lag + lag <= q + g lag; round R - 1's last payload for unit q (rank world - 1)
+// is applied at its round tick q + world * lag = the global tick at which (R, 0, q) runs, older rounds first.  A later
+// slice's level l does not exist yet when an earlier one reads it.  Two ordering rules between rounds (different streams):
+// round R's unit q runs behind round R - 1's tick q + world * lag, and round R's APPLIES of unit q run behind that tick
+// too (two rounds' write-backs to one node must land in slice order).  Within a round everything is on one stream.
+//
+// The classes here drive an abstract Backend (streams, events, buffers, the slice calls of one replica) and an abstract
+// Transport (the all-gather).  The product instantiates them over HIP (imt_sliced.cpp: imt_itree_slice_*, RCCL / IPC /
+// in-process transports); tests/native/sliced_sym.cpp instantiates the SAME code over a symbolic backend whose streams
+// are FIFO queues drained by an adversarial scheduler (tests/test_sliced_schedule.py), so a missing event or an early
+// buffer reuse fails on the CPU.
+#pragma once
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+#include "../../include/imt.h"
+
+namespace imt {
+namespace sliced {
+
+constexpr int ROUNDS = 4;            // rounds in flight = slices a tree keeps open (its plan sets minus one)
+
+// Test hook (tests/test_sliced_schedule.py::test_the_simulator_catches_planted_mutations): a build with
+// -DIMT_SCHED_MUTATION=k drops one ordering rule, and the adversarial simulator must notice.  0 in every product build.
+#ifndef IMT_SCHED_MUTATION
+#define IMT_SCHED_MUTATION 0
+#endif
+
+struct Schedule {
+    int world = 0, units = 0, lag = 0;
+    int period = 0;                  // global ticks between two rounds' starts
+    int gathers = 0;                 // round ticks with a compute phase / a collective
+    int round_ticks = 0;             // + the ticks that only apply
+
+    // the smallest lag that keeps ROUNDS rounds in flight; >= 2 so that a gather overlaps the next unit
+    static int default_lag(int world, int units) { return std::max(2, (units + (ROUNDS - 1) * world - 1) / ((ROUNDS - 1) * world)); }
+    // false: not a schedule (world < 1, units < 2, lag < 1, or more than ROUNDS rounds in flight)
+    bool init(int world_, int units_, int lag_) {
+        if (world_ < 1 || units_ < 2) return false;
+        world = world_;
+        units = units_;
+        lag = lag_ > 0 ? lag_ : default_lag(world_, units_);
+        if (lag < 1) return false;
+        period = world * lag;
+        gathers = units + (world - 1) * lag;
+        round_ticks = gathers + lag;
+        return (round_ticks + period - 1) / period <= ROUNDS;
+    }
+    int unit_of(int rank, int rt) const {            // unit `rank` computes at round tick rt, or -1
+        const int q = rt - rank * lag;
+        return (q >= 0 && q < units) ? q : -1;
+    }
+    // [unit or -1 per rank] carried by the collective of round tick rt (unit 0 carries nothing); true if any
+    bool payload_units(int rt, int32_t* out) const {
+        bool any = false;
+        for (int g = 0; g < world; g++) {
+            const int q = unit_of(g, rt);
+            out[g] = q >= 1 ? q : -1;
+            any = any || q >= 1;
+        }
+        return any;
+    }
+    bool has_gather(int rt) const {
+        if (rt < 0 || rt >= gathers) return false;
+        for (int g = 0; g < world; g++)
+            if (unit_of(g, rt) >= 1) return true;
+        return false;
+    }
+};
+
+typedef void* Stream;
+typedef void* Event;
+typedef void* Buffer;
+
+// One rank's replica and its device objects.  Every call returns IMT_OK or an IMT_ERR_* code.
+struct Backend {
+    virtual ~Backend() {}
+    virtual Stream round_stream(int slot) = 0;      // the stream round R runs on, slot = R % ROUNDS
+    virtual Stream comm_stream(int slot) = 0;       // the stream its collectives are enqueued on
+    virtual int new_event(Event* out) = 0;
+    virtual void free_event(Event e) = 0;
+    virtual int record(Event e, Stream s) = 0;
+    virtual int wait(Stream s, Event e) = 0;        // HIP semantics: the latest record ISSUED before this call
+    virtual int event_sync(Event e) = 0;            // host waits
+    virtual int alloc(size_t bytes, Buffer* out) = 0;
+    virtual void free_buffer(Buffer b) = 0;
+    // src may belong to another rank of the same process (the in-process transport)
+    virtual int copy(Buffer dst, size_t dst_off, Buffer src, size_t src_off, size_t bytes, Stream s) = 0;
+    virtual uint64_t tree_size() = 0;
+    virtual size_t payload_bytes(size_t n) = 0;     // imt_itree_slice_payload_bytes
+    virtual size_t unit_bytes(uint64_t size_before, size_t n, unsigned unit) = 0;
+    virtual int prepare(const void* vals, size_t n_before, size_t n_own, size_t n_after, const imt_insert_out* out,
+                        unsigned flags, int* slice) = 0;
+    virtual int unit(int slice, unsigned q, Buffer payload, Stream s) = 0;
+    virtual int apply_gathered(Buffer gathered, size_t stride, int count, const uint64_t* size_before, const uint64_t* n,
+                               const int32_t* units, Stream s) = 0;
+    virtual int sync() = 0;                         // host waits for everything this rank has enqueued
+};
+
+struct Rank;
+
+// How the payloads of one tick meet.  all_gather is stream-ordered on `st` (the rank's comm stream, already behind the
+// unit that packed the send buffer); fence makes `st` wait until the gather last issued on (slot, ring) is complete for
+// everyone who reads this rank's send buffer (nothing to do for a collective with NCCL semantics).
+struct Transport {
+    virtual ~Transport() {}
+    virtual int attach(Rank& rk) { (void)rk; return IMT_OK; }
+    virtual void detach(Rank& rk) { (void)rk; }
+    // a transport that exports its send buffers to other processes owns them; nullptr = the rank allocates
+    virtual Buffer provide_send(Rank& rk, int slot, int ring, size_t bytes) { (void)rk; (void)slot; (void)ring; (void)bytes; return nullptr; }
+    virtual int all_gather(Rank& rk, int slot, int ring, size_t bytes, Stream st) = 0;
+    virtual int fence(Rank& rk, int slot, int ring, Stream st) { (void)rk; (void)slot; (void)ring; (void)st; return IMT_OK; }
+    uint64_t collectives = 0, bytes_moved = 0;
+};
+
+struct Round {
+    int slice = -1;
+    uint64_t size_before = 0;        // leaves in the tree before the round (the same on every rank)
+    size_t n = 0;                    // insertions per slice
+    uint64_t start = 0;              // global tick of the round's tick 0
+};
+
+// One rank of the sliced tree: the three phases of (round R, round tick rt).
+struct Rank {
+    Backend* be = nullptr;
+    Transport* tp = nullptr;
+    Schedule sc;
+    int world = 0, rank = 0, ring = 0;
+    size_t max_n = 0, payload_cap = 0;
+    std::vector<Buffer> send, recv;             // [ROUNDS][ring]
+    std::vector<char> send_owned;
+    std::vector<size_t> gather_bytes;           // [ROUNDS][ring] bytes per rank of the collective in flight
+    std::vector<char> pending;                  // [ROUNDS][ring] a collective has been issued and not yet consumed
+    std::vector<Event> tick_ev;                 // [ROUNDS][round_ticks]
+    std::vector<Event> packed_ev, gathered_ev;  // [ROUNDS][ring]
+    Event done_ev[ROUNDS] = {};
+    Round rounds[ROUNDS + 1];                   // round R at R % (ROUNDS + 1)
+    uint64_t n_rounds = 0;
+    std::vector<int32_t> w_units;
+    std::vector<uint64_t> w_sb, w_n;
+
+    Round& round(uint64_t R) { return rounds[R % (ROUNDS + 1)]; }
+    int at(int slot, int r) const { return slot * ring + r; }
+
+    int init(Backend* be_, Transport* tp_, int world_, int rank_, size_t max_n_) {
+        be = be_;
+        tp = tp_;
+        world = world_;
+        rank = rank_;
+        max_n = max_n_;
+        return (rank < 0 || rank >= world || max_n == 0) ? IMT_ERR_ARG : IMT_OK;
+    }
+    // buffers and events; after the schedule is known
+    int build(const Schedule& s) {
+        sc = s;
+        ring = sc.lag + 1;
+        payload_cap = be->payload_bytes(max_n);
+        const int nb = ROUNDS * ring;
+        send.assign(nb, nullptr);
+        recv.assign(nb, nullptr);
+        send_owned.assign(nb, 0);
+        gather_bytes.assign(nb, payload_cap);
+        pending.assign(nb, 0);
+        packed_ev.assign(nb, nullptr);
+        gathered_ev.assign(nb, nullptr);
+        tick_ev.assign((size_t)ROUNDS * sc.round_ticks, nullptr);
+        w_units.resize(world);
+        w_sb.resize(world);
+        w_n.resize(world);
+        int rc = tp->attach(*this);
+        if (rc) return rc;
+        for (int slot = 0; slot < ROUNDS; slot++)
+            for (int r = 0; r < ring; r++) {
+                const int i = at(slot, r);
+                send[i] = tp->provide_send(*this, slot, r, payload_cap);
+                if (!send[i]) {
+                    if ((rc = be->alloc(payload_cap, &send[i]))) return rc;
+                    send_owned[i] = 1;
+                }
+                if ((rc = be->alloc(payload_cap * world, &recv[i]))) return rc;
+                if ((rc = be->new_event(&packed_ev[i])) || (rc = be->new_event(&gathered_ev[i]))) return rc;
+            }
+        for (auto& e : tick_ev)
+            if ((rc = be->new_event(&e))) return rc;
+        for (auto& e : done_ev)
+            if ((rc = be->new_event(&e))) return rc;
+        return IMT_OK;
+    }
+    void destroy() {
+        if (!be) return;
+        if (tp) tp->detach(*this);
+        for (size_t i = 0; i < send.size(); i++) {
+            if (send[i] && send_owned[i]) be->free_buffer(send[i]);
+            if (recv[i]) be->free_buffer(recv[i]);
+            if (packed_ev[i]) be->free_event(packed_ev[i]);
+            if (gathered_ev[i]) be->free_event(gathered_ev[i]);
+        }
+        for (auto e : tick_ev)
+            if (e) be->free_event(e);
+        for (auto e : done_ev)
+            if (e) be->free_event(e);
+        send.clear();
+        recv.clear();
+        tick_ev.clear();
+        be = nullptr;
+    }
+
+    // gathered payloads of tick rt - lag -> this replica
+    int phase_apply(uint64_t R, int rt) {
+        const int src = rt - sc.lag;
+        if (src < 0 || !sc.has_gather(src)) return IMT_OK;
+        const int slot = (int)(R % ROUNDS), i = at(slot, src % ring);
+        Stream st = be->round_stream(slot);
+        const Round& rd = round(R);
+        int rc;
+        if (pending[i]) {           // the round's stream waits for the collective; the host does not
+            if ((rc = be->wait(st, gathered_ev[i])) || (IMT_SCHED_MUTATION != 3 && (rc = tp->fence(*this, slot, src % ring, st)))) return rc;
+            pending[i] = 0;
+        }
+        sc.payload_units(src, w_units.data());
+        w_units[rank] = -1;         // own write-backs are already in this replica
+        int top = -1;
+        for (int g = 0; g < world; g++) top = std::max(top, (int)w_units[g]);
+        if (top < 0) return IMT_OK;
+        if (R >= 1 && IMT_SCHED_MUTATION != 2)
+            // a write-back of round R lands on a node after every write-back round R - 1 made to that level (they run
+            // on different streams): behind that round's tick max(unit) + world * lag
+            if ((rc = be->wait(st, tick_ev[(size_t)((R - 1) % ROUNDS) * sc.round_ticks + top + sc.period]))) return rc;
+        for (int g = 0; g < world; g++) {
+            w_sb[g] = rd.size_before + (uint64_t)g * rd.n;
+            w_n[g] = rd.n;
+        }
+        return be->apply_gathered(recv[i], gather_bytes[i], world, w_sb.data(), w_n.data(), w_units.data(), st);
+    }
+
+    // this rank's unit of the tick, packed into the tick's send buffer
+    int phase_compute(uint64_t R, int rt) {
+        const int q = sc.unit_of(rank, rt);
+        const int slot = (int)(R % ROUNDS);
+        Stream st = be->round_stream(slot);
+        int rc;
+        if (q >= 0) {
+            if (q >= 1 && R >= 1 && IMT_SCHED_MUTATION != 1)
+                // level q - 1 of every slice of round R - 1 must be in this replica: applied (others) or written back
+                // (own) by the end of that round's tick q + world * lag
+                if ((rc = be->wait(st, tick_ev[(size_t)((R - 1) % ROUNDS) * sc.round_ticks + q + sc.period]))) return rc;
+            if ((rc = be->unit(round(R).slice, (unsigned)q, send[at(slot, rt % ring)], st))) return rc;
+            if (q == sc.units - 1 && (rc = be->record(done_ev[slot], st))) return rc;
+        }
+        if (sc.has_gather(rt) && (rc = be->record(packed_ev[at(slot, rt % ring)], st))) return rc;
+        return IMT_OK;
+    }
+
+    // the tick's collective (asynchronous, consumed `lag` ticks later) and the tick's event
+    int phase_send(uint64_t R, int rt) {
+        const int slot = (int)(R % ROUNDS);
+        Stream st = be->round_stream(slot);
+        int rc;
+        if (sc.has_gather(rt)) {
+            const int r = rt % ring, i = at(slot, r);
+            const Round& rd = round(R);
+            // every rank contributes as many bytes as the largest payload of this tick needs (sizes only: the same
+            // arithmetic on every rank)
+            sc.payload_units(rt, w_units.data());
+            size_t mx = 0;
+            for (int g = 0; g < world; g++)
+                if (w_units[g] >= 0) mx = std::max(mx, be->unit_bytes(rd.size_before + (uint64_t)g * rd.n, rd.n, (unsigned)w_units[g]));
+            gather_bytes[i] = mx;
+            Stream cs = be->comm_stream(slot);
+            if ((rc = be->wait(cs, packed_ev[i])) || (rc = tp->all_gather(*this, slot, r, mx, cs)) ||
+                (rc = be->record(gathered_ev[i], cs)))
+                return rc;
+            pending[i] = 1;
+            tp->collectives++;
+            tp->bytes_moved += mx * (uint64_t)world;
+        }
+        return be->record(tick_ev[(size_t)slot * sc.round_ticks + rt], st);
+    }
+};
+
+// The ranks this process drives, in lockstep: one for a distributed world, all of them for an in-process one.
+struct World {
+    std::vector<Rank*> ranks;
+    Schedule sc;
+    uint64_t T = 0;                  // next global tick to issue
+    uint64_t n_rounds = 0;
+    uint64_t starts[ROUNDS + 1] = {};
+
+    uint64_t& start_of(uint64_t R) { return starts[R % (ROUNDS + 1)]; }
+
+    int run_ticks(uint64_t upto) {
+        int rc;
+        for (; T < upto; T++) {
+            const uint64_t first = n_rounds > (uint64_t)ROUNDS ? n_rounds - ROUNDS : 0;
+            for (uint64_t R = first; R < n_rounds; R++) {        // oldest first
+                if (T < start_of(R) || T - start_of(R) >= (uint64_t)sc.round_ticks) continue;
+                const int rt = (int)(T - start_of(R));
+                for (Rank* rk : ranks)
+                    if ((rc = rk->phase_apply(R, rt))) return rc;
+                for (Rank* rk : ranks)
+                    if ((rc = rk->phase_compute(R, rt))) return rc;
+                for (Rank* rk : ranks)
+                    if ((rc = rk->phase_send(R, rt))) return rc;
+            }
+        }
+        return IMT_OK;
+    }
+
+    // Starts round R = n_rounds with vals = the WHOLE step (world x n values, identical on every rank) and advances the
+    // global schedule by one round period.  outs[k] = witness buffers of local rank k (kept until its last unit).
+    // A refused step (IMT_ERR_VALUE / NONCANONICAL / FULL: the same verdict on every rank) changes nothing.
+    int step(const void* vals, size_t n, const imt_insert_out* outs, unsigned flags, uint64_t* round_out) {
+        if (ranks.empty() || !vals) return IMT_ERR_ARG;
+        if (n == 0 || n > ranks[0]->max_n) return IMT_ERR_RANGE;
+        const uint64_t R = n_rounds;
+        const uint64_t size_before = ranks[0]->be->tree_size();
+        // the plan set of round R - ROUNDS - 1 is reused by round R: its slice closed long ago (its last unit was issued
+        // ROUNDS rounds back); nothing to wait for on the host
+        std::vector<int> slices(ranks.size(), -1);
+        for (size_t k = 0; k < ranks.size(); k++) {
+            Rank* rk = ranks[k];
+            if (rk->be->tree_size() != size_before) return IMT_ERR_INTERNAL;
+            int rc = rk->be->prepare(vals, (size_t)rk->rank * n, n, (size_t)(rk->world - 1 - rk->rank) * n,
+                                     outs ? &outs[k] : nullptr, flags, &slices[k]);
+            if (rc) return k == 0 ? rc : IMT_ERR_INTERNAL;       // replicas that disagree about a step are broken
+        }
+        const uint64_t start = n_rounds == 0 ? T : std::max<uint64_t>(T, start_of(R - 1) + sc.period);
+        start_of(R) = start;
+        for (size_t k = 0; k < ranks.size(); k++) {
+            Round& rd = ranks[k]->round(R);
+            rd.slice = slices[k];
+            rd.size_before = size_before;
+            rd.n = n;
+            rd.start = start;
+            ranks[k]->n_rounds = R + 1;
+        }
+        n_rounds = R + 1;
+        if (round_out) *round_out = R;
+        return run_ticks(start + sc.period);
+    }
+
+    // issue everything that is left of the rounds in flight and wait for it
+    int flush() {
+        int rc;
+        if (n_rounds && (rc = run_ticks(start_of(n_rounds - 1) + sc.round_ticks))) return rc;
+        for (Rank* rk : ranks)
+            if ((rc = rk->be->sync())) return rc;
+        return IMT_OK;
+    }
+
+    // host waits for local rank k's witnesses of round R (its slice's last unit)
+    int wait_round(size_t k, uint64_t R) {
+        if (k >= ranks.size() || R >= n_rounds) return IMT_ERR_RANGE;
+        Rank* rk = ranks[k];
+        // its stream slot has been taken over by a later round, whose tick 0 was recorded on the same stream behind it
+        if (R + ROUNDS < n_rounds) return rk->be->event_sync(rk->tick_ev[(size_t)(R % ROUNDS) * sc.round_ticks]);
+        // the last unit is issued at round tick units - 1 + rank * lag: make sure the schedule has got there
+        int rc = run_ticks(std::max<uint64_t>(T, start_of(R) + sc.units + (uint64_t)rk->rank * sc.lag));
+        if (rc) return rc;
+        return rk->be->event_sync(rk->done_ev[R % ROUNDS]);
+    }
+};
+
+// All ranks in ONE process: the gather is a set of device-to-device copies between the replicas' buffers, ordered by
+// events (the one-GPU rehearsal and test form, and the reference point for what a collective has to guarantee).
+struct LocalTransport : Transport {
+    std::vector<Rank*> peers;
+    std::vector<Event> copied;       // [world][ROUNDS][ring]: rank g has copied everything of the gather (slot, ring)
+    int ring = 0;
+
+    int attach(Rank& rk) override {
+        if ((int)peers.size() < rk.world) peers.resize(rk.world, nullptr);
+        peers[rk.rank] = &rk;
+        ring = rk.ring;
+        if (copied.empty()) copied.assign((size_t)rk.world * ROUNDS * ring, nullptr);
+        for (int i = 0; i < ROUNDS * ring; i++) {
+            int rc = rk.be->new_event(&copied[(size_t)rk.rank * ROUNDS * ring + i]);
+            if (rc) return rc;
+        }
+        return IMT_OK;
+    }
+    void detach(Rank& rk) override {
+        if (copied.empty()) return;
+        for (int i = 0; i < ROUNDS * ring; i++) {
+            Event& e = copied[(size_t)rk.rank * ROUNDS * ring + i];
+            if (e) rk.be->free_event(e);
+            e = nullptr;
+        }
+        if (rk.rank < (int)peers.size()) peers[rk.rank] = nullptr;
+    }
+    int all_gather(Rank& rk, int slot, int r, size_t bytes, Stream st) override {
+        // every rank has recorded packed_ev[slot][r] by now: the world drives the phases in lockstep
+        int rc;
+        const int i = rk.at(slot, r);
+        for (int h = 0; h < rk.world; h++) {
+            if (h == rk.rank) continue;
+            Rank* p = peers[h];
+            if ((rc = rk.be->wait(st, p->packed_ev[i])) ||
+                (rc = rk.be->copy(rk.recv[i], (size_t)h * bytes, p->send[i], 0, bytes, st)))
+                return rc;
+        }
+        return rk.be->record(copied[(size_t)rk.rank * ROUNDS * ring + i], st);
+    }
+    int fence(Rank& rk, int slot, int r, Stream st) override {      // nobody still reads my send buffer
+        const int i = rk.at(slot, r);
+        for (int h = 0; h < rk.world; h++) {
+            if (h == rk.rank) continue;
+            int rc = rk.be->wait(st, copied[(size_t)h * ROUNDS * ring + i]);
+            if (rc) return rc;
+        }
+        return IMT_OK;
+    }
+};
+
+}  // namespace sliced
+}  // namespace imt

@@ -1,13 +1,18 @@
-"""GPU (MI355X): the multi-GPU single-list mode (indexed-merkle-tree-halo2_amd/sliced.py over imt_itree_slice_*)
-against the ONE-GPU tree (imt_itree_insert_batch) on the same value sequence -- which is itself pinned to the CPU
-oracle's sequential update_idx_leaf + rebuild (/root/reference/src/indexed_merkle_tree.rs:632-671, :715-735) by
-tests/test_gpu_parity.py.  Bit-exact: every low index, preimage, flag, old / interim / new root and both proofs of
-every insertion, and the stored tree of every replica.
+"""GPU (MI355X): the multi-GPU single-list mode BEHIND THE C ABI (imt_sliced_create / _step / _wait / _flush: the schedule,
+its streams and events and the all-gather live in libimt_hip.so; indexed-merkle-tree-halo2_amd/sliced.py only owns buffers)
 
- * LocalWorld: world = 1, 2, 4, 8 replicas in this process on the one GPU (device-to-device copies as the all-gather)
- * two processes over gloo (host-staged all-gather): tests the torch.distributed transport with real kernels
- * small depth where the tree fills up to its last level (l0 == depth), halo2curves' Montgomery format, refused values
+ * directly against the CPU oracle's sequential update_idx_leaf + rebuild
+   (/root/reference/src/indexed_merkle_tree.rs:632-671, :715-735): every low index, flag, preimage, interim / new root and
+   both proofs of every rank, world 2, 4 and 8, depth 32, a flush in the middle;
+ * against the ONE-GPU tree (imt_itree_insert_batch, itself pinned to the oracle by tests/test_gpu_parity.py) on longer
+   sequences: world = 1, 2, 4, 8 replicas in this process (the local transport: device-to-device copies as the
+   all-gather), BASELINE config 2's and config 4's sizes;
+ * two and four PROCESSES sharing the GPU over the IPC transport (peer copies through HIP IPC handles), one rank alone
+   through the RCCL transport (ncclAllGather called by the library), a caller-supplied transport vtable;
+ * small depth where the tree fills up to its last level (l0 == depth), halo2curves' Montgomery format, refused values,
+   ordinary batches before and after slices, bad arguments.
 """
+import ctypes
 import os
 import sys
 
@@ -22,10 +27,17 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib  # noqa: E402
-from test_sliced_schedule import load_sliced  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 FIELDS = ("low_index", "low_leaf", "is_largest", "old_root", "interim_root", "new_root", "new_leaf", "low_sib", "new_sib")
+
+
+def load_sliced():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("imt_sliced", os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "sliced.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def reference_run(imt, ctx, depth, cap, vals, per_call):
@@ -47,55 +59,93 @@ def check_round(want, got, lo, hi):
         assert (g == w).all(), k
 
 
+@pytest.mark.parametrize("world,batch,rounds", [(2, 167, 6), (4, 84, 6), (8, 40, 7)])
+def test_sliced_world_against_the_sequential_oracle(imt, world, batch, rounds):
+    """>= 2000 insertions at depth 32, a flush in the middle: every rank's every witness against oracle.sparse_insert"""
+    sl = load_sliced()
+    depth, cap = 32, 1 << 12
+    n_total = world * batch * rounds
+    assert n_total >= 2000
+    vals = oracle_lib.synth_values(n_total, 0x494D5439 + world)
+    orc = oracle_lib.load()
+    oh = orc.sparse_new(depth, cap)
+    empty_root = orc.sparse_root(oh)
+    rows = [orc.sparse_insert(oh, depth, v) for v in vals]
+    assert all(r["rc"] == 0 for r in rows)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world, nbuf=rounds)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    gb = world * batch
+    for r in range(rounds):
+        assert t.step(arr[r * gb:(r + 1) * gb]) == r
+        if r == rounds // 2:
+            t.flush()
+    t.flush()
+    for r in range(rounds):
+        for k in range(world):
+            o = {f: v.cpu().numpy() for f, v in t.outputs(r, k).items() if torch.is_tensor(v)}
+            base = r * gb + k * batch
+            assert t.outputs(r, k)["first_insertion"] == 1 + base
+            for j in range(batch):
+                e = rows[base + j]
+                assert imt.to_int(o["new_root"][j]) == e["new_root"] and imt.to_int(o["interim_root"][j]) == e["interim_root"], (r, k, j)
+                assert imt.to_int(o["old_root"][j]) == (rows[base + j - 1]["new_root"] if base + j else empty_root)
+                assert int(o["low_index"][j]) == e["low"] and int(o["is_largest"][j]) == e["largest"], (r, k, j)
+                assert (o["low_sib"][:, j] == e["low_proof"]).all() and (o["new_sib"][:, j] == e["new_proof"]).all(), (r, k, j)
+                assert (o["low_leaf"][j] == e["low_leaf"]).all(), (r, k, j)
+    want_root = orc.sparse_root(oh)
+    orc.sparse_free(oh)
+    assert all(tr.root() == want_root for tr in t.trees)
+    info = t.info()
+    assert info["world"] == world and info["rounds"] == rounds and info["collectives"] > 0
+    t.close()
+
+
 @pytest.mark.parametrize("world,batch,rounds", [(1, 256, 6), (2, 256, 6), (4, 192, 6), (8, 64, 7), (2, 8192, 3)])
 def test_local_world_equals_one_gpu_tree(imt, ctx, world, batch, rounds):
     sl = load_sliced()
     depth, cap = 32, 1 << 17
     vals = oracle_lib.synth_values(world * batch * rounds, 0x494D5431 + world)
     want, want_root = reference_run(imt, ctx, depth, cap, vals, world * batch)
-    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch) for _ in range(world)]
-    w = sl.LocalWorld(bes)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world)
     arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
-    # witnesses must be read before their rotating buffer set is reused: check a round once it is `nbuf - 1` rounds old
+    # witnesses must be read before their rotating buffer set is reused: check a round once it is `nbuf - 2` rounds old
     checked = 0
     for r in range(rounds):
         step = arr[r * world * batch:(r + 1) * world * batch]
-        assert w.step([step] * world) == r
+        assert t.step(step) == r
         if r == 2 and world != 4:
-            w.flush()                    # run the schedule dry in the middle and go on (bench.py after its warm-up)
+            t.flush()                    # run the schedule dry in the middle and go on (bench.py after its warm-up)
         while checked <= r - 3:
-            for rk in w.ranks:
-                rk.done_event(checked).synchronize()
-                check_round(want[checked], rk.outputs(checked), rk.rank * batch, (rk.rank + 1) * batch)
+            for k in range(world):
+                t.wait(checked, k)
+                check_round(want[checked], t.outputs(checked, k), k * batch, (k + 1) * batch)
             checked += 1
-    w.flush()
+    t.flush()
     while checked < rounds:
-        for rk in w.ranks:
-            check_round(want[checked], rk.outputs(checked), rk.rank * batch, (rk.rank + 1) * batch)
+        for k in range(world):
+            check_round(want[checked], t.outputs(checked, k), k * batch, (k + 1) * batch)
         checked += 1
-    for be in bes:                       # every replica is the same tree
-        assert be.tree.root() == want_root
-        assert be.size() == 1 + world * batch * rounds
+    for tr in t.trees:                   # every replica is the same tree
+        assert tr.root() == want_root
+        assert tr.size == 1 + world * batch * rounds
     if world > 1:
-        assert w.tp.collectives > 0
+        assert t.info()["collectives"] > 0 and t.info()["bytes_gathered"] > 0
     # the replicas stay usable through the ordinary calls: a proof from replica 0 verifies against the root
     idx = np.array([1, 5, world * batch * rounds], dtype=np.uint64)
-    sib = bes[0].tree.get_proof_batch(idx)
-    leaves = bes[-1].tree.get_leaves(idx)
+    sib = t.trees[0].get_proof_batch(idx)
+    leaves = t.trees[-1].get_leaves(idx)
     h = ctx.hash3(leaves)
     roots = ctx.path_root(h, idx, sib, depth)
     assert all(int.from_bytes(bytes(x), "little") == want_root for x in roots)
     # non-membership (BASELINE config 3) on the replicated list needs no exchange: every replica holds the whole tree,
     # so the candidates are simply split between the ranks; each witness verifies against the common root
     cand = oracle_lib.synth_values(8 * world, 0x494D5499 + world)
-    for g, be in enumerate(bes):
+    for g, (tr, c) in enumerate(zip(t.trees, t.ctxs)):
         mine = cand[g * 8:(g + 1) * 8]
-        low, leaves, nsib, largest = be.tree.non_membership_witness(mine)
-        fail = be.ctx.non_membership(imt.to_bytes(want_root), leaves, low, nsib, depth, imt.to_bytes(mine), largest)
+        low, leaves, nsib, largest = tr.non_membership_witness(mine)
+        fail = c.non_membership(imt.to_bytes(want_root), leaves, low, nsib, depth, imt.to_bytes(mine), largest)
         assert not fail.any()
-    for be in bes:
-        be.tree.close()
-        be.ctx.close()
+    t.close()
 
 
 def test_local_world_at_bench_size(imt, ctx):
@@ -118,29 +168,25 @@ def test_local_world_at_bench_size(imt, ctx):
                  new_root=torch.empty((gb, 32), **u8), new_leaf=torch.empty((gb, 3, 32), **u8),
                  low_sib=torch.empty((depth, gb, 32), **u8), new_sib=torch.empty((depth, gb, 32), **u8))
         st = F.InsertOut(**{k: t.data_ptr() for k, t in o.items()})
-        import ctypes
         ctx._check(imt.lib.imt_itree_insert_batch(ref.h, ctypes.c_void_p(vals[r * gb:(r + 1) * gb].data_ptr()), gb, ctypes.byref(st),
                                                   F.DEVICE_PTRS))
         want.append(o)
     ctx.sync()
-    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch) for _ in range(world)]
-    w = sl.LocalWorld(bes)
-    assert w.sched.lag == 6
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world)
+    assert t.info()["lag"] == 6
     for r in range(rounds):
-        w.step([vals[r * gb:(r + 1) * gb]] * world)
-    w.flush()
+        t.step(vals[r * gb:(r + 1) * gb])
+    t.flush()
     for r in range(rounds):
-        for rk in w.ranks:
-            got = rk.outputs(r)
-            lo, hi = rk.rank * batch, (rk.rank + 1) * batch
-            for k in FIELDS:
-                a = want[r][k][:, lo:hi] if k.endswith("_sib") else want[r][k][lo:hi]
-                assert bool((got[k] == a).all()), (r, rk.rank, k)
-    assert all(be.tree.root() == ref.root() for be in bes)
+        for k in range(world):
+            got = t.outputs(r, k)
+            lo, hi = k * batch, (k + 1) * batch
+            for f in FIELDS:
+                a = want[r][f][:, lo:hi] if f.endswith("_sib") else want[r][f][lo:hi]
+                assert bool((got[f] == a).all()), (r, k, f)
+    assert all(tr.root() == ref.root() for tr in t.trees)
     ref.close()
-    for be in bes:
-        be.tree.close()
-        be.ctx.close()
+    t.close()
 
 
 def test_config4_single_list_eight_slices_2pow22(imt, ctx):
@@ -149,15 +195,13 @@ def test_config4_single_list_eight_slices_2pow22(imt, ctx):
     witnesses pass every insert_leaf constraint at depth 32 with global leaf indices (imt_insert_witness_batch), the
     roots chain insertion to insertion, slice to slice and step to step, all replicas end in the same root, and that
     root is the one-GPU tree's over the same 2^22 values."""
-    import ctypes
     import bench
     sl = load_sliced()
     depth, world, batch, rounds = 32, 8, 1 << 16, 8
     cap = 1 << 23
     gb = world * batch
     vals = torch.from_numpy(bench.synth_values(gb * rounds, 0, 1, 0x494D5404)).cuda()
-    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch) for _ in range(world)]
-    w = sl.LocalWorld(bes)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world)
     F, lib = imt._ffi, imt.lib
     P_ = lambda x: ctypes.c_void_p(x.data_ptr())
     fail = torch.empty(batch, dtype=torch.uint8, device="cuda")
@@ -166,39 +210,37 @@ def test_config4_single_list_eight_slices_2pow22(imt, ctx):
 
     def check(r):
         nonlocal prev_last
-        for rk in w.ranks:
-            o = rk.outputs(r)
+        for k in range(world):
+            o = t.outputs(r, k)
             first = o["first_insertion"]
-            assert first == 1 + r * gb + rk.rank * batch
+            assert first == 1 + r * gb + k * batch
             new_index = torch.arange(first, first + batch, dtype=torch.int64, device="cuda")
-            c = rk.be.ctx
+            c = t.ctxs[k]
             c._check(lib.imt_insert_witness_batch(c.h, P_(o["old_root"]), P_(o["low_leaf"]), P_(o["low_index"]), P_(o["low_sib"]),
                                                   P_(o["new_root"]), P_(o["new_leaf"]), P_(new_index), None, P_(o["new_sib"]),
                                                   P_(o["is_largest"]), depth, batch, P_(fail), None, F.DEVICE_PTRS))
             c.sync()
-            assert int(fail.max()) == 0, (r, rk.rank)
+            assert int(fail.max()) == 0, (r, k)
             assert bool((o["old_root"][1:] == o["new_root"][:-1]).all())
             if prev_last is not None:
-                assert bool((o["old_root"][0] == prev_last).all()), (r, rk.rank)      # slice to slice, step to step
+                assert bool((o["old_root"][0] == prev_last).all()), (r, k)      # slice to slice, step to step
             prev_last = o["new_root"][-1].clone()
 
     for r in range(rounds):
-        w.step([vals[r * gb:(r + 1) * gb]] * world)
+        t.step(vals[r * gb:(r + 1) * gb])
         while checked <= r - 3:
-            for rk in w.ranks:
-                rk.done_event(checked).synchronize()
+            for k in range(world):
+                t.wait(checked, k)
             check(checked)
             checked += 1
-    w.flush()
+    t.flush()
     while checked < rounds:
         check(checked)
         checked += 1
-    roots = {be.tree.root() for be in bes}
+    roots = {tr.root() for tr in t.trees}
     assert len(roots) == 1 and imt.to_int(prev_last.cpu().numpy()) in roots
-    for be in bes:
-        assert be.size() == 1 + gb * rounds
-        be.tree.close()
-        be.ctx.close()
+    assert all(tr.size == 1 + gb * rounds for tr in t.trees)
+    t.close()
     ref = imt.IndexedTree(ctx, depth, cap)
     for r in range(rounds):
         ctx._check(lib.imt_itree_insert_batch(ref.h, P_(vals[r * gb:(r + 1) * gb]), gb, None, F.DEVICE_PTRS | F.PIPELINE))
@@ -214,16 +256,15 @@ def test_local_world_fills_a_small_tree_to_its_last_level(imt, ctx):
     rounds = 4                               # 1 + 240 leaves of 256
     vals = oracle_lib.synth_values(world * batch * rounds, 0x494D5441)
     want, want_root = reference_run(imt, ctx, depth, cap, vals, world * batch)
-    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch) for _ in range(world)]
-    w = sl.LocalWorld(bes)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world)
     arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
     for r in range(rounds):
-        w.step([arr[r * world * batch:(r + 1) * world * batch]] * world)
-    w.flush()
+        t.step(arr[r * world * batch:(r + 1) * world * batch])
+    t.flush()
     for r in range(rounds):
-        for rk in w.ranks:
-            check_round(want[r], rk.outputs(r), rk.rank * batch, (rk.rank + 1) * batch)
-    assert all(be.tree.root() == want_root for be in bes)
+        for k in range(world):
+            check_round(want[r], t.outputs(r, k), k * batch, (k + 1) * batch)
+    assert all(tr.root() == want_root for tr in t.trees)
     # the oracle's sequential insertion agrees on the final root (depth 8 is cheap on the CPU)
     orc = oracle_lib.load()
     h = orc.sparse_new(depth, cap)
@@ -231,9 +272,7 @@ def test_local_world_fills_a_small_tree_to_its_last_level(imt, ctx):
         assert orc.sparse_insert(h, depth, v)["rc"] == 0
     assert orc.sparse_root(h) == want_root
     orc.sparse_free(h)
-    for be in bes:
-        be.tree.close()
-        be.ctx.close()
+    t.close()
 
 
 def test_local_world_ragged_steps(imt, ctx):
@@ -243,29 +282,29 @@ def test_local_world_ragged_steps(imt, ctx):
     depth, cap, world, batch = 32, 1 << 10, 2, 64
     sizes = [64, 10, 1, 64, 7]
     vals = oracle_lib.synth_values(world * sum(sizes), 0x494D5481)
-    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch) for _ in range(world)]
-    w = sl.LocalWorld(bes)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world)
     arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
     ref = imt.IndexedTree(ctx, depth, cap)
     off = 0
     for r, n in enumerate(sizes):
-        w.step([arr[off:off + world * n]] * world)
-        w.flush()                        # witness sets rotate: read each round before the fifth after it is prepared
+        t.step(arr[off:off + world * n])
+        t.flush()                        # witness sets rotate: read each round before the fifth after it is prepared
         want = ref.insert_batch(vals[off:off + world * n])
-        for rk in w.ranks:
-            got = rk.outputs(r)
+        for k in range(world):
+            got = t.outputs(r, k)
             assert got["low_sib"].shape == (depth, n, 32) and got["new_root"].shape == (n, 32)
-            check_round(want, got, rk.rank * n, (rk.rank + 1) * n)
+            check_round(want, got, k * n, (k + 1) * n)
         off += world * n
     with pytest.raises(ValueError):
-        w.ranks[0]._start_round(arr[:world * batch + world])      # longer than the buffers
+        t.step(arr[:world * batch + world])      # longer than the buffers
     with pytest.raises(ValueError):
-        w.ranks[0]._start_round(arr[:3])                          # not a multiple of the world size
-    assert all(be.tree.root() == ref.root() for be in bes)
+        t.step(arr[:3])                          # not a multiple of the world size
+    F = imt._ffi
+    assert imt.lib.imt_sliced_step(t.h, ctypes.c_void_p(arr.data_ptr()), batch + 1, None, 0, None) == F.ERR["RANGE"]
+    assert imt.lib.imt_sliced_step(t.h, None, 4, None, 0, None) == F.ERR["ARG"]
+    assert all(tr.root() == ref.root() for tr in t.trees)
     ref.close()
-    for be in bes:
-        be.tree.close()
-        be.ctx.close()
+    t.close()
 
 
 def test_local_world_montgomery_format_and_refused_values(imt, ctx):
@@ -273,72 +312,74 @@ def test_local_world_montgomery_format_and_refused_values(imt, ctx):
     depth, cap, world, batch = 32, 1 << 12, 2, 128
     vals = oracle_lib.synth_values(world * batch * 2, 0x494D5451)
     F = imt._ffi
-    bes = [sl.SliceGpuBackend(imt, 0, depth, cap, batch, fmt=F.FMT_MONT256) for _ in range(world)]
-    w = sl.LocalWorld(bes)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world, fmt=F.FMT_MONT256)
     R = 1 << 256
     mont = torch.from_numpy(oracle_lib.ints_to_arr([v * R % oracle_lib.P for v in vals])).cuda()
-    w.step([mont[:world * batch]] * world)
-    # a step with a duplicate (of a stored value, in the second rank's slice) is refused by EVERY rank, nothing changes
+    t.step(mont[:world * batch])
+    # a step with a duplicate (of a stored value, in the second rank's slice) is refused, nothing changes on any replica
     bad = mont[world * batch:].clone()
     bad[batch + 3] = mont[5]
-    for rk in w.ranks:
-        with pytest.raises(ValueError):
-            rk._start_round(bad)
-        assert rk.be.size() == 1 + world * batch
-    w.step([mont[world * batch:]] * world)
-    w.flush()
+    with pytest.raises(ValueError):
+        t.step(bad)
+    assert all(tr.size == 1 + world * batch for tr in t.trees)
+    t.step(mont[world * batch:])
+    t.flush()
     ref = imt.IndexedTree(ctx, depth, cap)
     for r in range(2):
         want = ref.insert_batch(vals[r * world * batch:(r + 1) * world * batch])
-        for rk in w.ranks:
-            got = rk.outputs(r)
-            lo, hi = rk.rank * batch, (rk.rank + 1) * batch
-            for k in ("old_root", "interim_root", "new_root"):
-                g = [int.from_bytes(bytes(x), "little") for x in got[k].cpu().numpy()]
-                assert g == [int.from_bytes(bytes(x), "little") * R % oracle_lib.P for x in want[k][lo:hi]], k
+        for k in range(world):
+            got = t.outputs(r, k)
+            lo, hi = k * batch, (k + 1) * batch
+            for f in ("old_root", "interim_root", "new_root"):
+                g = [int.from_bytes(bytes(x), "little") for x in got[f].cpu().numpy()]
+                assert g == [int.from_bytes(bytes(x), "little") * R % oracle_lib.P for x in want[f][lo:hi]], f
             assert (got["low_index"].cpu().numpy() == want["low_index"][lo:hi]).all()
             g = [int.from_bytes(bytes(x), "little") for x in got["low_sib"].cpu().numpy()[:, 7]]
             assert g == [int.from_bytes(bytes(x), "little") * R % oracle_lib.P for x in want["low_sib"][:, lo + 7]]
-    assert all(be.tree.root() == ref.root() for be in bes)
+    assert all(tr.root() == ref.root() for tr in t.trees)
     ref.close()
-    for be in bes:
-        be.tree.close()
-        be.ctx.close()
+    t.close()
 
 
-# ---------------------------------------------------------------- two processes, gloo
+# ---------------------------------------------------------------- one process per rank, sharing the GPU: the IPC transport
 P_DEPTH, P_BATCH, P_ROUNDS = 32, 384, 5
 
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # carries the IPC handle blobs, nothing else
     import imt_amd
     sl = load_sliced()
-    be = sl.SliceGpuBackend(imt_amd, 0, P_DEPTH, 1 << 13, P_BATCH)
-    tree = sl.SlicedIndexedTree(be, world, rank, sl.DistTransport(dist, via_host=True))
+    boot = imt_amd.Context(0)
+    tp = sl.ipc_transport(imt_amd, boot, dist, world, rank, P_DEPTH, P_BATCH)
+    tree = sl.SlicedTree(imt_amd, 0, P_DEPTH, 1 << 13, P_BATCH, world, first_rank=rank, n_local=1, transport=tp)
     vals = oracle_lib.synth_values(world * P_BATCH * P_ROUNDS, 0x494D5461)
     arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
     res = []
     for r in range(P_ROUNDS):
         tree.step(arr[r * world * P_BATCH:(r + 1) * world * P_BATCH])
         if r >= 3:                      # read a finished round while later ones are in flight
-            tree.done_event(r - 3).synchronize()
+            tree.wait(r - 3)
             res.append({k: v.cpu().numpy().copy() for k, v in tree.outputs(r - 3).items() if torch.is_tensor(v)})
     tree.flush()
     for r in range(max(0, P_ROUNDS - 3), P_ROUNDS):
         res.append({k: v.cpu().numpy().copy() for k, v in tree.outputs(r).items() if torch.is_tensor(v)})
+    info = tree.info()
+    root = tree.trees[0].root()
+    dist.barrier()                      # nobody closes its exported buffers while a peer may still read them
     tree.close()
-    q.put((rank, res, be.tree.root(), tree.tp.collectives, tree.tp.bytes_moved))
+    boot.close()
+    q.put((rank, res, root, info["collectives"], info["bytes_gathered"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_processes_over_gloo_equal_one_gpu_tree(imt, ctx, world):
-    """one PROCESS per rank on the one GPU (2 and 4: the box admits six GPU processes), torch.distributed over gloo, the
-    host-staged gather on its helper thread: every rank's witnesses and every replica's root equal the one-GPU tree"""
+def test_processes_over_ipc_equal_one_gpu_tree(imt, ctx, world):
+    """one PROCESS per rank on the one GPU (2 and 4: the box admits six GPU processes), payloads copied peer to peer
+    through HIP IPC memory handles, ordered by interprocess events: every rank's witnesses and every replica's root equal
+    the one-GPU tree"""
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     import socket
@@ -364,36 +405,97 @@ def test_processes_over_gloo_equal_one_gpu_tree(imt, ctx, world):
                 assert (res[r][k] == w).all(), (rank, r, k)
 
 
-def test_batches_after_slices_on_one_tree(imt, ctx):
-    """a tree that has taken sliced steps goes on with ordinary pipelined batches (imt_itree_insert_batch with
-    IMT_PIPELINE, no synchronisation in between): the batch is ordered behind the slice's last kernel"""
-    import ctypes
+def test_rccl_transport_with_one_rank(imt, ctx):
+    """the RCCL transport -- ncclCommInitRank and ncclAllGather called by the library on its own communicators and
+    streams -- needs one GPU per rank, so a one-GPU box runs it with a world of ONE: every tick's gather still goes
+    through RCCL (a one-rank all-gather is a copy of the send buffer into the receive buffer)"""
     sl = load_sliced()
-    depth, cap, batch = 32, 1 << 14, 2048
-    vals = oracle_lib.synth_values(4 * batch, 0x494D5483)
+    depth, cap, batch, rounds = 32, 1 << 12, 256, 5
+    F, lib = imt._ffi, imt.lib
+    ver = ctypes.c_int(0)
+    boot = imt.Context(0)
+    tp = sl.rccl_transport(imt, boot, None, 1, 0, n_comms=4)
+    path = lib.imt_rccl_library(ctypes.byref(ver)).decode()
+    assert "rccl" in path and ver.value >= 21000, (path, ver.value)
+    vals = oracle_lib.synth_values(batch * rounds, 0x494D5463)
+    want, want_root = reference_run(imt, ctx, depth, cap, vals, batch)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, 1, transport=tp)
     arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
-    be = sl.SliceGpuBackend(imt, 0, depth, cap, batch)
-    w = sl.LocalWorld([be])
-    w.step([arr[:batch]])
-    w.step([arr[batch:2 * batch]])
-    w._run_ticks(w.ranks[0].starts[-1] + w.sched.round_ticks)       # everything issued, nothing waited for
+    for r in range(rounds):
+        t.step(arr[r * batch:(r + 1) * batch])
+    t.flush()
+    for r in range(rounds):
+        check_round(want[r], t.outputs(r), 0, batch)
+    assert t.trees[0].root() == want_root
+    assert t.info()["collectives"] == rounds * depth          # unit 0 carries nothing; one gather per level
+    t.close()
+    boot.close()
+
+
+def test_custom_transport_vtable(imt, ctx):
+    """a caller-supplied collective through imt_transport_custom_create: here a world of one, whose all-gather is a
+    device-to-device copy issued on the stream the library hands over"""
+    sl = load_sliced()
+    F, lib = imt._ffi, imt.lib
+    calls = []
+    hip = ctypes.CDLL("libamdhip64.so.7")       # the HIP runtime this process already holds
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+
+    def all_gather(self_, channel, buffer, send, recv, nbytes, stream):
+        calls.append((channel, buffer, nbytes))
+        return 0 if hip.hipMemcpyAsync(recv, send, nbytes, 3, stream) == 0 else F.ERR["HIP"]
+
+    ops = F.TransportOps(None, F.TransportOps.ALL_GATHER(all_gather), F.TransportOps.DESTROY())
+    tp = ctypes.c_void_p()
+    assert lib.imt_transport_custom_create(ctypes.byref(ops), ctypes.byref(tp)) == 0
+    depth, cap, batch = 32, 1 << 10, 64
+    vals = oracle_lib.synth_values(3 * batch, 0x494D5467)
+    want, want_root = reference_run(imt, ctx, depth, cap, vals, batch)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, 1, transport=tp)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    for r in range(3):
+        t.step(arr[r * batch:(r + 1) * batch])
+    t.flush()
+    for r in range(3):
+        check_round(want[r], t.outputs(r), 0, batch)
+    assert t.trees[0].root() == want_root and len(calls) == 3 * depth
+    assert {c[0] for c in calls} == {0, 1, 2} and all(0 <= c[1] <= t.info()["lag"] for c in calls)
+    t.close()
+
+
+def test_batches_before_and_after_slices_on_one_tree(imt, ctx):
+    """a tree goes from ordinary pipelined batches (imt_itree_insert_batch with IMT_PIPELINE) to sliced steps and back
+    with no synchronisation by the caller in between: slices are ordered behind the batches in flight (the sweep of a
+    batch and a slice's units touch the same stored levels), and a batch behind the slices' last kernels"""
+    sl = load_sliced()
+    depth, cap, batch = 32, 1 << 15, 2048
+    vals = oracle_lib.synth_values(8 * batch, 0x494D5483)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, 1)
+    tr, c = t.trees[0], t.ctxs[0]
     F = imt._ffi
-    for k in (2, 3):
-        be.ctx._check(imt.lib.imt_itree_insert_batch(be.tree.h, ctypes.c_void_p(arr[k * batch:(k + 1) * batch].data_ptr()), batch,
-                                                     None, F.DEVICE_PTRS | F.PIPELINE))
-    be.sync()
+    P_ = lambda k: ctypes.c_void_p(arr[k * batch:(k + 1) * batch].data_ptr())
+    for k in (0, 1):        # pipelined batches first ...
+        c._check(imt.lib.imt_itree_insert_batch(tr.h, P_(k), batch, None, F.DEVICE_PTRS | F.PIPELINE))
+    t.step(arr[2 * batch:3 * batch])        # ... slices second, nothing waited for
+    t.step(arr[3 * batch:4 * batch])
+    t.flush()
+    for k in (4, 5):        # and back: batches behind the slices
+        c._check(imt.lib.imt_itree_insert_batch(tr.h, P_(k), batch, None, F.DEVICE_PTRS | F.PIPELINE))
+    t.step(arr[6 * batch:7 * batch])        # a slice right behind two pipelined batches
+    t.flush()
+    c._check(imt.lib.imt_itree_insert_batch(tr.h, P_(7), batch, None, F.DEVICE_PTRS | F.PIPELINE))
+    c.sync()
     ref = imt.IndexedTree(ctx, depth, cap)
     ref.insert_batch(vals)
-    assert be.tree.root() == ref.root()
+    assert tr.root() == ref.root()
     ref.close()
-    be.tree.close()
-    be.ctx.close()
+    t.close()
 
 
 def test_slice_calls_refuse_bad_arguments(imt, ctx):
     """the C entry points directly: misaligned payloads / values, units out of order, a second preparation of too many
-    slices, a placed tree -- documented codes, nothing reaches a kernel"""
-    import ctypes
+    slices, a placed tree, a short payload stride, worlds that are no schedule -- documented codes, nothing reaches a kernel"""
     F, lib = imt._ffi, imt.lib
     t = imt.IndexedTree(ctx, 32, 1 << 10)
     vals = torch.from_numpy(oracle_lib.ints_to_arr(oracle_lib.synth_values(64, 0x494D5471))).cuda()
@@ -418,6 +520,11 @@ def test_slice_calls_refuse_bad_arguments(imt, ctx):
     assert lib.imt_itree_slice_apply(t.h, 1, 16, 5, P_(pay, 8), None) == F.ERR["ARG"]
     assert lib.imt_itree_slice_apply(t.h, 1, 16, 40, P_(pay), None) == F.ERR["RANGE"]
     assert lib.imt_itree_slice_apply(t.h, 1 << 10, 16, 5, P_(pay), None) == F.ERR["RANGE"]
+    # two payloads 256 bytes apart cannot hold unit 1 of a 16-insertion slice (128 + 36 * 17 bytes)
+    sb, nn, un = (ctypes.c_uint64 * 2)(17, 33), (ctypes.c_uint64 * 2)(16, 16), (ctypes.c_int32 * 2)(1, 1)
+    assert lib.imt_itree_slice_apply_gathered(t.h, P_(pay), 256, 2, sb, nn, un, None) == F.ERR["ARG"]
+    root = np.zeros(32, dtype=np.uint8)
+    assert lib.imt_itree_root_lagged(t.h, 0, root.ctypes.data_as(ctypes.c_void_p), 0) == F.ERR["ARG"]     # slices have no lagged root
     ctx.sync()
     ref = imt.IndexedTree(ctx, 32, 1 << 10)
     ref.insert_batch(oracle_lib.synth_values(64, 0x494D5471)[:16])
@@ -425,5 +532,17 @@ def test_slice_calls_refuse_bad_arguments(imt, ctx):
     placed = imt.IndexedTree(ctx, 31, 1 << 10)
     placed.set_placement(32, 1)
     assert lib.imt_itree_slice_prepare(placed.h, P_(vals), 0, 16, 0, None, F.DEVICE_PTRS, ctypes.byref(sl), None) == F.ERR["ARG"]
+    # imt_sliced_create: a placed tree, two ranks on one context, a lag that keeps 17 steps in flight, the wrong transport
+    tp, h = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.imt_transport_local_create(ctypes.byref(tp)) == 0
+    one = (ctypes.c_void_p * 1)(placed.h)
+    assert lib.imt_sliced_create(one, 1, 1, 0, tp, 16, 0, ctypes.byref(h)) == F.ERR["ARG"]
+    two = (ctypes.c_void_p * 2)(t.h, ref.h)
+    assert lib.imt_sliced_create(two, 2, 2, 0, tp, 16, 0, ctypes.byref(h)) == F.ERR["ARG"]      # one context for both
+    one = (ctypes.c_void_p * 1)(t.h)
+    assert lib.imt_sliced_create(one, 1, 1, 0, tp, 16, 2, ctypes.byref(h)) == F.ERR["RANGE"]
+    assert lib.imt_sliced_create(one, 1, 2, 0, tp, 16, 0, ctypes.byref(h)) == F.ERR["ARG"]      # local transport, one of two ranks
+    assert lib.imt_sliced_create(one, 1, 1, 0, None, 16, 0, ctypes.byref(h)) == F.ERR["ARG"]
+    lib.imt_transport_destroy(tp)
     for x in (t, ref, placed):
         x.close()

@@ -327,46 +327,36 @@ def test_cpp_host_side_builds_and_fails_loudly_without_a_gpu(tmp_path):
     assert "hash_zero" not in r.stdout
 
 
-def test_cpp_slice_schedule_equals_the_python_one(tmp_path):
-    """include/imt.hpp's SliceSchedule (for a compiled host that drives imt_itree_slice_* with its own RCCL calls) against
-    sliced.SliceSchedule, the one the tests simulate: same lag, period, gathers, same unit per rank and tick"""
+def test_cpp_sliced_wrapper_compiles_against_the_header(tmp_path):
+    """include/imt.hpp's imt::Sliced (RAII over imt_sliced_create / _step / _wait / _flush, the multi-GPU single list
+    behind one call per step) builds warning-free with g++ against imt.h and links against libimt_hip.so; without a GPU it
+    fails where the library says it has no CPU path.  (The schedule itself is tested in tests/test_sliced_schedule.py.)"""
     import subprocess
-    from test_sliced_schedule import load_sliced
-    sl = load_sliced()
-    src = tmp_path / "sched.cpp"
+    src = tmp_path / "sl.cpp"
     src.write_text('''#include "imt.hpp"
 #include <cstdio>
-#include <cstdlib>
-int main(int argc, char** argv) {
-    const unsigned world = std::atoi(argv[1]), units = std::atoi(argv[2]), lag = argc > 3 ? std::atoi(argv[3]) : 0;
+int main() {
     try {
-        imt::SliceSchedule s(world, units, lag);
-        std::printf("%u %u %u %u\\n", s.lag, s.period, s.gathers, s.round_ticks);
-        for (unsigned rt = 0; rt < s.round_ticks; rt++) {
-            std::printf("%d", s.has_gather(rt) ? 1 : 0);
-            for (unsigned g = 0; g < world; g++) std::printf(" %d:%d", s.unit_of(g, rt), s.payload_unit(g, rt));
-            std::printf("\\n");
-        }
-    } catch (const std::invalid_argument&) { std::printf("invalid\\n"); }
+        imt::Context c0(0), c1(0);
+        imt::IndexedTree a(c0, 32, 256), b(c1, 32, 256);
+        imt::Sliced w = imt::Sliced::local({a.get(), b.get()}, 8);
+        std::printf("lag %d period %d\\n", w.info().lag, w.info().period);
+        w.flush();
+    } catch (const imt::Error& e) { std::printf("imt::Error %d\\n", e.code()); return 2; }
     return 0;
 }
 ''')
-    exe = str(tmp_path / "sched")
+    exe = str(tmp_path / "sl")
+    csrc = os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc")
     r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
-                        str(src), "-o", exe], capture_output=True, text=True)
+                        str(src), "-L", csrc, "-limt_hip", "-Wl,-rpath," + csrc, "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    for world, units, lag in [(1, 33, 0), (2, 33, 0), (4, 33, 0), (8, 33, 0), (16, 33, 0), (3, 9, 0), (8, 33, 4), (2, 9, 5), (1, 33, 2)]:
-        out = subprocess.run([exe, str(world), str(units)] + ([str(lag)] if lag else []), capture_output=True, text=True).stdout.split("\n")
-        try:
-            sc = sl.SliceSchedule(world, units, lag or None)
-        except ValueError:
-            assert out[0] == "invalid", (world, units, lag)
-            continue
-        assert out[0] == f"{sc.lag} {sc.period} {sc.gathers} {sc.round_ticks}", (world, units, lag, out[0])
-        for rt in range(sc.round_ticks):
-            want = ("1" if sc.has_gather(rt) else "0") + "".join(
-                f" {-1 if sc.unit_of(g, rt) is None else sc.unit_of(g, rt)}:{sc.payload_units(rt)[g]}" for g in range(world))
-            assert out[1 + rt] == want, (world, units, lag, rt)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "lag 6 period 12" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 2 and "imt::Error -7" in r.stdout
 
 
 def test_bench_synthetic_values_are_field_elements_of_the_right_residue():

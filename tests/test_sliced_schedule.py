@@ -1,17 +1,21 @@
-"""CPU: the multi-GPU single-list driver (indexed-merkle-tree-halo2_amd/sliced.py) with a symbolic backend
-(tests/sliced_sim.py).  What is under test is everything that is not hashing: the systolic schedule, which payload is
-applied where and when, the events between rounds, buffer reuse, the line-up of the collectives across ranks.
+"""CPU: the multi-GPU single-list schedule of libimt_hip.so (csrc/imt_sliced_sched.hpp: Schedule, Rank, World,
+LocalTransport -- what imt_sliced_step / imt_sliced_flush run) compiled over a symbolic backend
+(tests/native/sliced_sym.cpp, tests/sliced_sim.py).  What is under test is everything that is not hashing: the systolic
+schedule, which payload is applied where and when, the events between rounds, buffer reuse, the line-up of the
+collectives across ranks.
 
- * LocalWorld, deferred execution in random interleavings (only stream order and event waits are respected): every
-   slice's every level must see exactly the slices before it -- the rule that makes the replicas equal the reference's
-   sequential list (src/indexed_merkle_tree.rs:632-660), at world 1..16, several depths, lags and seeds.
- * DistTransport over gloo with 2 and 4 processes: the same assertions, real collectives.
-The GPU tests (tests/test_gpu_sliced.py) run the same driver with the HIP backend against the one-GPU tree."""
+ * all ranks in one process, deferred execution in random interleavings (only stream order and event waits are
+   respected): every slice's every level must see exactly the slices before it -- the rule that makes the replicas equal
+   the reference's sequential list (src/indexed_merkle_tree.rs:632-660), at world 1..16, several depths, lags and seeds;
+ * three planted mutations of the schedule code (a dropped ordering rule each) must be caught;
+ * one rank per process over gloo with 2, 4 and 8 processes: the same assertions, real collectives.
+The GPU tests (tests/test_gpu_sliced.py) run the same classes over HIP against the one-GPU tree and the oracle."""
+import ctypes
 import os
+import subprocess
 import sys
 
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -19,22 +23,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-
-def load_sliced():
-    import importlib.util
-    path = os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "sliced.py")
-    spec = importlib.util.spec_from_file_location("imt_sliced", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)         # sliced.py itself does not need the HIP library
-    return mod
+import sliced_sim  # noqa: E402
 
 
-def test_schedule_arithmetic():
-    sl = load_sliced()
+@pytest.fixture(scope="module")
+def lib():
+    return sliced_sim.load()
+
+
+def test_schedule_arithmetic(lib):
     for world in (1, 2, 3, 4, 8, 16):
         for units in (4, 9, 33):
-            sc = sl.SliceSchedule(world, units)
-            assert -(-sc.round_ticks // sc.period) <= sc.STREAMS
+            sc = sliced_sim.Schedule(lib, world, units)
+            assert -(-sc.round_ticks // sc.period) <= sliced_sim.ROUNDS
             seen = set()
             for rt in range(sc.round_ticks):
                 for g in range(world):
@@ -49,57 +50,84 @@ def test_schedule_arithmetic():
             assert sorted(carried) == sorted((g, q) for g in range(world) for q in range(1, units))
             assert all(sc.has_gather(rt) == any(q >= 0 for q in sc.payload_units(rt)) for rt in range(sc.round_ticks))
     with pytest.raises(ValueError):
-        sl.SliceSchedule(1, 33, lag=2)       # 17 rounds in flight
-    sc = sl.SliceSchedule(8, 33)
+        sliced_sim.Schedule(lib, 1, 33, lag=2)       # 17 rounds in flight
+    sc = sliced_sim.Schedule(lib, 8, 33)
     assert (sc.lag, sc.period, sc.gathers) == (2, 16, 47)
+    assert [sliced_sim.Schedule(lib, w, 33).lag for w in (1, 2, 4)] == [11, 6, 3]
+
+
+def run_world(lib, world, depth, lag, seed, rounds=7, batch=4):
+    sim = sliced_sim.Sim(immediate=False, seed=seed)
+    w = sliced_sim.SymWorld(lib, sim, world, depth, batch, lag)
+    for r in range(rounds):
+        assert w.step() == r
+        if seed % 2 and r == 3:
+            sim.run()                    # a caller that synchronises in the middle
+        if seed % 4 == 2 and r in (1, 4):
+            w.flush()                    # ... or runs the schedule dry and goes on (bench.py: warm-up, then the timed region)
+        if seed % 4 == 3 and r >= 2:
+            w.wait(r % world, r - 2)     # ... or waits for one rank's witnesses of an older round
+    w.flush()
+    for rank, rp in w.reps.items():
+        assert sorted(rp.computed) == [(r * world + rank, q) for r in range(rounds) for q in range(depth + 1)]
+        for lvl in rp.levels:
+            assert lvl == list(range(rounds * world))      # every replica holds every slice's write-back, in order
+    assert w.collectives > 0 or world == 1
+    w.close()
 
 
 @pytest.mark.parametrize("world,depth,lag", [(1, 8, None), (2, 8, None), (2, 8, 5), (4, 8, None), (4, 32, None), (8, 32, None),
                                              (8, 32, 4), (3, 8, None), (16, 32, None), (8, 8, 1), (2, 3, 2)])
-def test_every_level_sees_exactly_the_earlier_slices(world, depth, lag):
-    import sliced_sim
-    sl = load_sliced()
+def test_every_level_sees_exactly_the_earlier_slices(lib, world, depth, lag):
     for seed in range(int(os.environ.get("IMT_SIM_SEEDS", "4"))):
-        sim = sliced_sim.Sim(immediate=False, seed=seed)
-        bes = [sliced_sim.SymbolicBackend(sim, depth, 4, world, g) for g in range(world)]
-        w = sl.LocalWorld(bes, lag)
-        rounds = 7
-        for r in range(rounds):
-            assert w.step([FakeVals(4 * world)] * world) == r
-            if seed % 2 and r == 3:
-                sim.run()                    # a caller that synchronises in the middle
-            if seed % 4 == 2 and r in (1, 4):
-                w.flush()                    # ... or runs the schedule dry and goes on (bench.py: warm-up, then the timed region)
-        w.flush()
-        for be in bes:
-            assert sorted(be.computed) == [(r * world + be.rank, q) for r in range(rounds) for q in range(depth + 1)]
-            for lvl in be.levels:
-                assert lvl == list(range(rounds * world))      # every replica holds every slice's write-back, in order
-        assert w.tp.collectives > 0 or world == 1
+        run_world(lib, world, depth, lag, seed)
 
 
-class FakeVals:
-    def __init__(self, n):
-        self.shape = (n, 32)
+def test_the_simulator_catches_planted_mutations(tmp_path):
+    """the schedule code rebuilt with one ordering rule dropped each time -- round R's units behind round R - 1's tick
+    (1), round R's applies behind it (2), the fence that keeps a send buffer until every peer has copied it (3) -- must
+    fail under the adversarial scheduler for some seed; the unmodified code passes the same runs"""
+    src = os.path.join(ROOT, "tests", "native", "sliced_sym.cpp")
+
+    def outcome(mutation):
+        so = str(tmp_path / f"libslicedsym_m{mutation}.so")
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", f"-DIMT_SCHED_MUTATION={mutation}", "-o", so, src],
+                       check=True)
+        mlib = ctypes.CDLL(so)
+        for name in ("sym_schedule", "sym_unit_of", "sym_payload_units", "sym_world_create", "sym_world_step", "sym_world_flush",
+                     "sym_world_run_all", "sym_world_wait", "sym_world_collectives", "sym_world_destroy"):
+            ref = getattr(sliced_sim.load(), name)
+            fn = getattr(mlib, name)
+            fn.argtypes, fn.restype = ref.argtypes, ref.restype
+        for world, depth, lag in ((2, 8, None), (4, 8, None), (8, 8, 1), (3, 5, 2)):
+            for seed in range(6):
+                try:
+                    run_world(mlib, world, depth, lag, seed)
+                except AssertionError:
+                    return "caught"
+        return "passed"
+
+    assert outcome(0) == "passed"
+    for m in (1, 2, 3):
+        assert outcome(m) == "caught", f"mutation {m} went unnoticed"
 
 
 def _worker(rank, world, port, depth, lag, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import sliced_sim
-    sl = load_sliced()
+    lib = sliced_sim.load()
     sim = sliced_sim.Sim(immediate=True)
-    be = sliced_sim.SymbolicBackend(sim, depth, 4, world, rank)
-    tree = sl.SlicedIndexedTree(be, world, rank, sl.DistTransport(dist, via_host=True), lag)
+    w = sliced_sim.SymWorld(lib, sim, world, depth, 4, lag, first_rank=rank, n_local=1, dist=dist)
     rounds = 6
     for r in range(rounds):
-        assert tree.step(FakeVals(4 * world)) == r
+        assert w.step() == r
         if r == 2:
-            tree.flush()
-    tree.flush()
-    ok = (sorted(be.computed) == [(r * world + rank, u) for r in range(rounds) for u in range(depth + 1)]
-          and all(lvl == list(range(rounds * world)) for lvl in be.levels))
-    q.put((rank, ok, tree.tp.collectives, tree.sched.gathers))
+            w.flush()
+    w.flush()
+    rp = w.reps[rank]
+    ok = (sorted(rp.computed) == [(r * world + rank, u) for r in range(rounds) for u in range(depth + 1)]
+          and all(lvl == list(range(rounds * world)) for lvl in rp.levels))
+    q.put((rank, ok, w.collectives, w.sched.gathers))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -107,6 +135,7 @@ def _worker(rank, world, port, depth, lag, q):
 @pytest.mark.parametrize("world,depth,lag", [(2, 8, None), (4, 6, 2), (8, 32, None)])
 def test_gloo_ranks_line_up(world, depth, lag):
     import socket
+    sliced_sim.build_lib()               # once, before the ranks race to build it
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -121,33 +150,32 @@ def test_gloo_ranks_line_up(world, depth, lag):
         assert p.exitcode == 0
     assert all(ok for _, ok, _, _ in res)
     assert len({c for _, _, c, _ in res}) == 1          # the same number of collectives on every rank
+    assert res[0][2] > 0
 
 
-def test_small_schedules_exhaustively():
+def test_small_schedules_exhaustively(lib):
     """every admissible (world <= 8, depth in 1..8, lag in 1..7) schedule, with flushes at changing places, under the
     adversarial stream scheduler: the corner cases of the tick arithmetic (a world larger than the tree is deep, a lag
     longer than a slice, rounds that overlap four deep or not at all)"""
-    import sliced_sim
-    sl = load_sliced()
     done = 0
     for world in range(1, 9):
         for depth in (1, 2, 3, 5, 8):
             for lag in (1, 2, 3, 4, 7):
                 try:
-                    sl.SliceSchedule(world, depth + 1, lag)
+                    sliced_sim.Schedule(lib, world, depth + 1, lag)
                 except ValueError:
                     continue
                 sim = sliced_sim.Sim(immediate=False, seed=world * 100 + depth * 10 + lag)
-                bes = [sliced_sim.SymbolicBackend(sim, depth, 2, world, g) for g in range(world)]
-                w = sl.LocalWorld(bes, lag)
+                w = sliced_sim.SymWorld(lib, sim, world, depth, 2, lag)
                 rounds = 6
                 for r in range(rounds):
-                    w.step([FakeVals(2 * world)] * world)
+                    w.step()
                     if (r + lag) % 3 == 0:
                         w.flush()
                 w.flush()
-                for be in bes:
-                    assert sorted(be.computed) == [(r * world + be.rank, q) for r in range(rounds) for q in range(depth + 1)]
-                    assert all(lvl == list(range(rounds * world)) for lvl in be.levels), (world, depth, lag)
+                for rank, rp in w.reps.items():
+                    assert sorted(rp.computed) == [(r * world + rank, q) for r in range(rounds) for q in range(depth + 1)]
+                    assert all(lvl == list(range(rounds * world)) for lvl in rp.levels), (world, depth, lag)
+                w.close()
                 done += 1
     assert done > 150

@@ -1,4 +1,4 @@
-"""Differential soak of the multi-GPU single-list mode (sliced.py, LocalWorld: N replicas on this one GPU): random
+"""Differential soak of the multi-GPU single-list mode (imt_sliced_* through sliced.SlicedTree: N replicas on this one GPU): random
 world sizes, slice sizes, depths, value patterns, lags, flushes in the middle -- every witness of every rank against the
 SEQUENTIAL CPU oracle (update_idx_leaf + rebuild, /root/reference/src/indexed_merkle_tree.rs:632-671).  Not part of the
 test suite; tests/test_gpu_sliced.py is the short version."""
@@ -56,42 +56,40 @@ while time.time() - t0 < budget:
     oroot = orc.sparse_root(oh)
     lag = rng.choice([None, None, 1, 2, 5]) if world > 1 else None
     try:
-        sliced.SliceSchedule(world, depth + 1, lag)
-    except ValueError:
-        lag = None
-    bes = [sliced.SliceGpuBackend(imt_amd, 0, depth, cap, batch) for _ in range(world)]
-    w = sliced.LocalWorld(bes, lag)
+        w = sliced.SlicedTree(imt_amd, 0, depth, cap, batch, world, n_local=world, lag=lag)
+    except imt_amd.ImtError:        # that lag keeps too many rounds in flight at this world / depth
+        w = sliced.SlicedTree(imt_amd, 0, depth, cap, batch, world, n_local=world)
     arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
     gb = world * batch
     checked = 0
 
     def check(r):
-        for rk in w.ranks:
-            o = {k: v.cpu().numpy() for k, v in rk.outputs(r).items() if torch.is_tensor(v)}
+        for k in range(world):
+            o = {f: v.cpu().numpy() for f, v in w.outputs(r, k).items() if torch.is_tensor(v)}
             for j in range(batch):
-                e = rows[r * gb + rk.rank * batch + j]
+                e = rows[r * gb + k * batch + j]
                 assert imt_amd.to_int(o["new_root"][j]) == e["new_root"] and imt_amd.to_int(o["interim_root"][j]) == e["interim_root"], \
-                    (cases, depth, world, batch, r, rk.rank, j)
+                    (cases, depth, world, batch, r, k, j)
                 assert int(o["low_index"][j]) == e["low"] and int(o["is_largest"][j]) == e["largest"]
                 assert (o["low_sib"][:, j] == e["low_proof"]).all() and (o["new_sib"][:, j] == e["new_proof"]).all()
                 assert (o["low_leaf"][j] == e["low_leaf"]).all()
 
     for r in range(rounds):
-        w.step([arr[r * gb:(r + 1) * gb]] * world)
+        w.step(arr[r * gb:(r + 1) * gb])
         if rng.random() < 0.2:
             w.flush()
         while checked <= r - 3:
-            for rk in w.ranks:
-                rk.done_event(checked).synchronize()
+            for k in range(world):
+                w.wait(checked, k)
             check(checked)
             checked += 1
     w.flush()
     while checked < rounds:
         check(checked)
         checked += 1
-    for be in bes:
-        assert be.tree.root() == oroot
-        be.tree.close(); be.ctx.close()
+    for tr in w.trees:
+        assert tr.root() == oroot
+    w.close()
     orc.sparse_free(oh)
     cases += 1
     total += n_total
