@@ -535,7 +535,9 @@ def bench_single_list(env):
     return {"mode": "single-list", "value": args.steps * gb / dt, "ms_per_step": dt / args.steps * 1e3, "verified": verified,
             "alone_ms": None, "pipe_ms": pipe_ms, "kernels": kern,
             "gpu_kernel_ms_per_step": sum(v["ms_total"] for n_, v in kern.items() if n_ != "host_prepare") / args.steps,
-            "host_call_ms_per_step": host_s / args.steps * 1e3, "hashes_per_insertion": HASHES_PER_INSERTION,
+            "host_call_ms_per_step": (i1["host_issue_ms"] - i0["host_issue_ms"]) / args.steps,
+            "host_wait_ms_per_step": (i1["host_wait_ms"] - i0["host_wait_ms"]) / args.steps,
+            "host_in_step_call_ms_per_step": host_s / args.steps * 1e3, "hashes_per_insertion": HASHES_PER_INSERTION,
             "collectives_per_step": (i1["collectives"] - i0["collectives"]) / args.steps,
             "bytes_gathered_per_step_per_rank": (i1["bytes_gathered"] - i0["bytes_gathered"]) / args.steps,
             "schedule": {"lag_levels": i1["lag"], "round_period_ticks": i1["period"], "gathers_per_round": i1["gathers_per_round"],
@@ -554,6 +556,8 @@ def mode_summary(r, world):
     gbps = alg / (dur * 1e-3) / 1e9
     out = {k: r[k] for k in ("value", "ms_per_step", "verified", "hashes_per_insertion", "collectives_per_step",
                              "bytes_gathered_per_step_per_rank", "host_call_ms_per_step", "gpu_kernel_ms_per_step")}
+    if "host_wait_ms_per_step" in r:        # single list: host_call = issuing the step's work; wait = blocked on the GPU
+        out["host_wait_ms_per_step"] = r["host_wait_ms_per_step"]
     out["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                        "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
                        "duration_source": "kernel_ms.pipelined" if r["pipe_ms"] else "wall_ms_per_launch_slot",
@@ -693,6 +697,8 @@ def main():
         try:
             legs["single-list"] = bench_single_list(env)
         except Exception as e:      # the line says what happened; the status says it failed
+            import traceback
+            print(f"[rank {rank}] the single-list leg failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
             if "subtrees" not in legs:
                 raise
             failed = f"{type(e).__name__}: {e}"

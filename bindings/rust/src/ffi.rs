@@ -67,6 +67,8 @@ pub struct imt_sliced_info {
     pub rounds: u64,
     pub collectives: u64,
     pub bytes_gathered: u64,
+    pub host_issue_ms: c_double,
+    pub host_wait_ms: c_double,
 }
 
 /// `imt_trace_cell`: one cell of the advice column of a hash (imt_hash_trace_layout).

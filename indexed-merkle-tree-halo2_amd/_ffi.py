@@ -63,7 +63,8 @@ class TransportOps(ctypes.Structure):
 class SlicedInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("world", "n_local", "lag", "period", "gathers_per_round", "round_ticks",
                                             "rounds_in_flight")] + \
-               [("payload_bytes", ctypes.c_size_t)] + [(n, ctypes.c_uint64) for n in ("rounds", "collectives", "bytes_gathered")]
+               [("payload_bytes", ctypes.c_size_t)] + [(n, ctypes.c_uint64) for n in ("rounds", "collectives", "bytes_gathered")] + \
+               [(n, ctypes.c_double) for n in ("host_issue_ms", "host_wait_ms")]
 
 
 class InsertOut(ctypes.Structure):

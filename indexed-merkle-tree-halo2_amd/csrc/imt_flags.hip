@@ -1,0 +1,44 @@
+// imt_flags.hip -- stream-ordered flags between PROCESSES (the IPC transport of imt_sliced_*, imt_sliced.cpp).
+//
+// A flag is a 64-bit counter in host memory both processes have mapped and registered with HIP (a POSIX shared-memory
+// page: uncached for the GPU, so coherent without any cache-scope reasoning).  k_flag_set publishes "everything before
+// me on this stream is done, for the k-th time"; k_flag_wait holds its stream until every flag of a set has reached k.
+// Counters only grow, so a wait never depends on the order in which the two hosts issue their work.  Every wave of
+// k_flag_wait reaches an exit: a flag that does not arrive within the time limit sets an error bit and the kernel
+// returns (the host reports it: a peer died or hangs), so the grid always drains.
+#include <hip/hip_runtime.h>
+#include "imt_flags.hpp"
+
+namespace {
+
+__global__ void k_flag_set(uint64_t* flag, uint64_t value) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_flag_wait(imt::launch::FlagWait w) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint64_t t0 = wall_clock64();
+    for (int i = 0; i < w.n; i++) {
+        while (__hip_atomic_load(w.flag[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < w.value) {
+            if (wall_clock64() - t0 > w.timeout_ticks) {      // the exit every wave reaches
+                __hip_atomic_fetch_or(w.err, 1u << (i & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+}
+
+}  // namespace
+
+namespace imt {
+namespace launch {
+
+void flag_set(hipStream_t s, uint64_t* flag, uint64_t value) { hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, s, flag, value); }
+
+void flag_wait(hipStream_t s, const FlagWait& w) {
+    if (w.n > 0) hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, s, w);
+}
+
+}  // namespace launch
+}  // namespace imt

@@ -164,6 +164,7 @@ struct imt_itree {
     uint8_t* d_canon_all = nullptr;
     size_t canon_all_cap = 0;
     uint32_t* d_sorted_extra = nullptr;      // third index buffer: a step's up to three merges never write the committed one
+    double slice_wait_ms = 0;                // host time spent waiting for the GPU inside imt_itree_slice_prepare
 };
 
 static void plan_free(PlanSet& p) {
@@ -431,6 +432,11 @@ extern "C" uint64_t imt_itree_size(const imt_itree* t) { return t ? t->size : 0;
 // internal (imt_itree_internal.hpp): what imt_sliced.cpp needs to know about a tree
 imt_ctx* imt_itree_ctx(const imt_itree* t) { return t ? t->ctx : nullptr; }
 unsigned imt_itree_depth(const imt_itree* t) { return t ? t->depth : 0; }
+double imt_itree_take_wait_ms(imt_itree* t) {
+    const double w = t ? t->slice_wait_ms : 0;
+    if (t) t->slice_wait_ms = 0;
+    return w;
+}
 bool imt_itree_is_plain(const imt_itree* t) { return t && !t->index_base && t->part_mod <= 1 && !t->pending.active; }
 
 extern "C" int imt_itree_root(imt_itree* t, void* root, unsigned flags) {
@@ -1584,7 +1590,9 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
     PlanSet& P = t->plan[set];
     if (P.open) return c->fail(IMT_ERR_ARG, "too many slices prepared ahead (%d plan sets)", imt_itree::NSETS);
     if (P.in_flight) {
+        const auto w0 = std::chrono::steady_clock::now();
         IMT_HIP(c, hipEventSynchronize(P.done));
+        t->slice_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
         P.in_flight = false;
     }
     if ((rc = plan_reserve(c, P, 2 * n_own, t->depth, t->cap))) return rc;
@@ -1666,7 +1674,11 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
     for (auto& pl : t->plan)
         if (&pl != &P && pl.in_flight && !pl.sliced) IMT_HIP(c, hipStreamWaitEvent(ps, pl.done, 0));
     IMT_HIP(c, hipEventRecord(P.prep_done, ps));
-    IMT_HIP(c, hipStreamSynchronize(ps));
+    {
+        const auto w0 = std::chrono::steady_clock::now();
+        IMT_HIP(c, hipStreamSynchronize(ps));
+        t->slice_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    }
     const int perr = *t->h_err_pin;      // the same verdict on every GPU: they all see all values of the step
     if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
     if (perr & prep::ERR_ZERO) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");

@@ -5,3 +5,6 @@
 imt_ctx* imt_itree_ctx(const imt_itree* t);
 unsigned imt_itree_depth(const imt_itree* t);
 bool imt_itree_is_plain(const imt_itree* t);     // not placed, not partitioned, no sharded batch open
+// milliseconds the host has spent waiting for the GPU inside imt_itree_slice_prepare (the values check, plan-set
+// back-pressure) since the last call; reset by the call
+double imt_itree_take_wait_ms(imt_itree* t);

@@ -18,6 +18,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include "imt_flags.hpp"
 #include "imt_itree_internal.hpp"
 #include "imt_sliced_sched.hpp"
 #include "imt_sliced_transport.hpp"
@@ -132,85 +133,96 @@ struct CustomTransport : Transport {
 };
 
 // ------------------------------------------------------------------------------ direct peer copies between processes
-// Every rank exports ONE allocation holding all its send buffers (hipIpcMemHandle) and, per (slot, ring), two
-// interprocess events: `packed` (my payload is in my send buffer) and `copied` (I have copied every peer's payload of
-// this gather).  A gather = wait for each peer's `packed`, copy its payload out of its memory, record `copied`; the fence
-// = wait for every peer's `copied` before the send buffer is rewritten.  HIP's cross-process rule is the in-process one
-// (a wait captures the latest record ISSUED before it), so the hosts also keep sequence numbers in a small POSIX
-// shared-memory page each: a rank waits on the host until the peer has ISSUED record number k, then enqueues the wait.
+// Every rank exports ONE device allocation holding all its send buffers (hipIpcMemHandle) and one page of POSIX shared
+// memory with two 64-bit counters per (slot, ring): `packed` (my payload number k is in my send buffer) and `copied` (I
+// have copied every peer's payload number k).  Both pages are registered with HIP in every process, so the counters are
+// written and polled BY THE GPUS, in stream order (imt_flags.hip): a gather = publish my `packed`, wait until every
+// peer's `packed` has reached k, copy each payload out of its owner's memory (a device-to-device copy: an xGMI
+// point-to-point read when the ranks sit on different GPUs), publish my `copied`; the fence = wait until every peer's
+// `copied` has reached k, then the send buffer may be rewritten.  Counters only grow, so nothing depends on the order in
+// which the hosts issue their work, and no host ever waits for another.  (A first version used HIP's interprocess
+// events; they failed after a few dozen records per event -- profiles/r04 notes -- and need a host-side handshake for
+// HIP's "latest record issued before the wait" rule.)  A peer that never arrives: the waiting kernel gives up after
+// IMT_IPC_TIMEOUT_S (default 60) and sets an error bit, reported by the next imt_sliced_wait / _flush.
 constexpr int IPC_RING_MAX = 12;
 constexpr int IPC_NEV = ROUNDS * IPC_RING_MAX;
 
 struct IpcBlob {
     hipIpcMemHandle_t mem;
-    hipIpcEventHandle_t packed[IPC_NEV], copied[IPC_NEV];
     char shm_name[64];
     uint64_t arena_bytes;
     int32_t rank, world, ring, pid;
 };
 struct IpcShm {
-    std::atomic<uint64_t> packed_seq[IPC_NEV], copied_seq[IPC_NEV];
+    uint64_t packed[IPC_NEV], copied[IPC_NEV];
+    uint32_t err;
 };
+constexpr size_t IPC_SHM_BYTES = (sizeof(IpcShm) + 4095) & ~(size_t)4095;
 
 struct IpcTransport : Transport {
     imt_ctx* ctx;
     int world, rank, ring = 0;
     size_t payload_cap = 0;
     uint8_t* arena = nullptr;                    // [ROUNDS][ring][payload_cap]
-    hipEvent_t ev_packed[IPC_NEV] = {}, ev_copied[IPC_NEV] = {};
-    IpcShm* my_shm = nullptr;
+    IpcShm *my_shm = nullptr, *my_shm_dev = nullptr;
     std::string shm_name;
     uint64_t seq[IPC_NEV] = {};                  // gathers issued per (slot, ring): the same on every rank
     struct Peer {
         uint8_t* arena = nullptr;
-        hipEvent_t packed[IPC_NEV] = {}, copied[IPC_NEV] = {};
-        IpcShm* shm = nullptr;
+        IpcShm *shm = nullptr, *shm_dev = nullptr;
     };
     std::vector<Peer> peers;
     bool connected = false;
-    double timeout_s = 120.0;
+    uint64_t timeout_ticks = 0;
 
     IpcTransport(imt_ctx* c, int w, int r) : ctx(c), world(w), rank(r) {}
     static int ei(int slot, int r) { return slot * IPC_RING_MAX + r; }
 
+    int map_page(const char* name, bool create, IpcShm** host, IpcShm** dev) {
+        const int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+        if (fd < 0 || (create && ftruncate(fd, (off_t)IPC_SHM_BYTES) != 0)) {
+            if (fd >= 0) close(fd);
+            return ctx->fail(IMT_ERR_ALLOC, "shm_open(%s) failed", name);
+        }
+        void* p = mmap(nullptr, IPC_SHM_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) return ctx->fail(IMT_ERR_ALLOC, "mmap of the flag page %s failed", name);
+        if (create) std::memset(p, 0, IPC_SHM_BYTES);
+        *host = (IpcShm*)p;
+        hipError_t e = hipHostRegister(p, IPC_SHM_BYTES, hipHostRegisterMapped | hipHostRegisterPortable);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)dev, p, 0);
+        if (e != hipSuccess) return ctx->hip_fail(e, "hipHostRegister(flag page)");
+        return IMT_OK;
+    }
+    void unmap_page(IpcShm* host) {
+        if (!host) return;
+        hipHostUnregister(host);
+        munmap(host, IPC_SHM_BYTES);
+    }
     int create(unsigned depth, size_t max_slice, int lag, IpcBlob* blob) {
         Schedule sc;
         if (!sc.init(world, (int)depth + 1, lag)) return ctx->fail(IMT_ERR_RANGE, "not a schedule: world %d depth %u lag %d", world, depth, lag);
         ring = sc.lag + 1;
         if (ring > IPC_RING_MAX) return ctx->fail(IMT_ERR_RANGE, "lag %d too large for the IPC transport (max %d)", sc.lag, IPC_RING_MAX - 1);
+        if (world - 1 > imt::launch::FLAG_WAIT_MAX) return ctx->fail(IMT_ERR_RANGE, "the IPC transport joins at most %d ranks", imt::launch::FLAG_WAIT_MAX + 1);
         int rc = ctx->set_device();
         if (rc) return rc;
-        if (const char* e = getenv("IMT_IPC_TIMEOUT_S")) timeout_s = atof(e);
+        int khz = 100000;                        // wall_clock64 ticks per millisecond (100 MHz on gfx9)
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
+        double limit_s = 60.0;
+        if (const char* e = getenv("IMT_IPC_TIMEOUT_S")) limit_s = atof(e);
+        timeout_ticks = (uint64_t)(limit_s * 1e3 * khz);
         payload_cap = imt_itree_slice_payload_bytes(max_slice);
         const size_t bytes = (size_t)ROUNDS * ring * payload_cap;
         IMT_HIP(ctx, hipMalloc((void**)&arena, bytes));
         IMT_HIP(ctx, hipMemset(arena, 0, bytes));
         std::memset(blob, 0, sizeof *blob);
         IMT_HIP(ctx, hipIpcGetMemHandle(&blob->mem, arena));
-        for (int slot = 0; slot < ROUNDS; slot++)
-            for (int r = 0; r < ring; r++) {
-                const int i = ei(slot, r);
-                IMT_HIP(ctx, hipEventCreateWithFlags(&ev_packed[i], hipEventDisableTiming | hipEventInterprocess));
-                IMT_HIP(ctx, hipEventCreateWithFlags(&ev_copied[i], hipEventDisableTiming | hipEventInterprocess));
-                IMT_HIP(ctx, hipIpcGetEventHandle(&blob->packed[i], ev_packed[i]));
-                IMT_HIP(ctx, hipIpcGetEventHandle(&blob->copied[i], ev_copied[i]));
-            }
         char name[64];
         snprintf(name, sizeof name, "/imt_ipc_%d_%d_%llx", (int)getpid(), rank,
                  (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+        if ((rc = map_page(name, true, &my_shm, &my_shm_dev))) return rc;
         shm_name = name;
-        const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0 || ftruncate(fd, sizeof(IpcShm)) != 0) {
-            if (fd >= 0) close(fd);
-            return ctx->fail(IMT_ERR_ALLOC, "shm_open(%s) failed", name);
-        }
-        my_shm = (IpcShm*)mmap(nullptr, sizeof(IpcShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        close(fd);
-        if (my_shm == MAP_FAILED) {
-            my_shm = nullptr;
-            return ctx->fail(IMT_ERR_ALLOC, "mmap of the sequence page failed");
-        }
-        new (my_shm) IpcShm();
         snprintf(blob->shm_name, sizeof blob->shm_name, "%s", name);
         blob->arena_bytes = bytes;
         blob->rank = rank;
@@ -231,20 +243,7 @@ struct IpcTransport : Transport {
             if (b.pid == (int)getpid()) return ctx->fail(IMT_ERR_ARG, "the IPC transport joins PROCESSES; ranks of one process use the local transport");
             Peer& p = peers[h];
             IMT_HIP(ctx, hipIpcOpenMemHandle((void**)&p.arena, b.mem, hipIpcMemLazyEnablePeerAccess));
-            for (int slot = 0; slot < ROUNDS; slot++)
-                for (int r = 0; r < ring; r++) {
-                    const int i = ei(slot, r);
-                    IMT_HIP(ctx, hipIpcOpenEventHandle(&p.packed[i], b.packed[i]));
-                    IMT_HIP(ctx, hipIpcOpenEventHandle(&p.copied[i], b.copied[i]));
-                }
-            const int fd = shm_open(b.shm_name, O_RDWR, 0600);
-            if (fd < 0) return ctx->fail(IMT_ERR_ARG, "shm_open(%s) of rank %d failed", b.shm_name, h);
-            p.shm = (IpcShm*)mmap(nullptr, sizeof(IpcShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-            close(fd);
-            if (p.shm == MAP_FAILED) {
-                p.shm = nullptr;
-                return ctx->fail(IMT_ERR_ALLOC, "mmap of rank %d's sequence page failed", h);
-            }
+            if ((rc = map_page(b.shm_name, false, &p.shm, &p.shm_dev))) return rc;
         }
         connected = true;
         return IMT_OK;
@@ -252,19 +251,11 @@ struct IpcTransport : Transport {
     ~IpcTransport() override {
         if (ctx->set_device()) return;
         for (auto& p : peers) {
-            for (int i = 0; i < IPC_NEV; i++) {
-                if (p.packed[i]) hipEventDestroy(p.packed[i]);
-                if (p.copied[i]) hipEventDestroy(p.copied[i]);
-            }
             if (p.arena) hipIpcCloseMemHandle(p.arena);
-            if (p.shm) munmap(p.shm, sizeof(IpcShm));
-        }
-        for (int i = 0; i < IPC_NEV; i++) {
-            if (ev_packed[i]) hipEventDestroy(ev_packed[i]);
-            if (ev_copied[i]) hipEventDestroy(ev_copied[i]);
+            unmap_page(p.shm);
         }
         if (arena) hipFree(arena);
-        if (my_shm) munmap(my_shm, sizeof(IpcShm));
+        unmap_page(my_shm);
         if (!shm_name.empty()) shm_unlink(shm_name.c_str());
     }
     int attach(Rank& rk) override {
@@ -274,49 +265,44 @@ struct IpcTransport : Transport {
         return IMT_OK;
     }
     Buffer provide_send(Rank&, int slot, int r, size_t) override { return arena + ((size_t)slot * ring + r) * payload_cap; }
-    // host: wait until the peer has ISSUED its record number k
-    int await_seq(const std::atomic<uint64_t>& a, uint64_t k, int peer, const char* what) {
-        if (a.load(std::memory_order_acquire) >= k) return IMT_OK;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 0;; spins++) {
-            if (a.load(std::memory_order_acquire) >= k) return IMT_OK;
-            if ((spins & 1023) == 1023) {
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-                    return ctx->fail(IMT_ERR_INTERNAL, "IPC transport: rank %d did not issue its %s record %llu within %.0f s", peer, what,
-                                     (unsigned long long)k, timeout_s);
-                std::this_thread::yield();
-            }
+    int wait_peers(hipStream_t st, int i, uint64_t k, bool copied) {
+        imt::launch::FlagWait w{};
+        for (int d = 1; d < world; d++) {
+            const int h = (rank + d) % world;
+            w.flag[w.n++] = copied ? &peers[h].shm_dev->copied[i] : &peers[h].shm_dev->packed[i];
         }
+        w.value = k;
+        w.timeout_ticks = timeout_ticks;
+        w.err = &my_shm_dev->err;
+        imt::launch::flag_wait(st, w);
+        IMT_HIP(ctx, hipGetLastError());
+        return IMT_OK;
     }
     int all_gather(Rank& rk, int slot, int r, size_t bytes, Stream st_) override {
         hipStream_t st = (hipStream_t)st_;
         const int i = ei(slot, r);
         const uint64_t k = ++seq[i];
         // st is already behind the unit that packed my send buffer
-        IMT_HIP(ctx, hipEventRecord(ev_packed[i], st));
-        my_shm->packed_seq[i].store(k, std::memory_order_release);
+        imt::launch::flag_set(st, &my_shm_dev->packed[i], k);
+        int rc = wait_peers(st, i, k, false);
+        if (rc) return rc;
         uint8_t* recv = (uint8_t*)rk.recv[rk.at(slot, r)];
         const size_t off = ((size_t)slot * ring + r) * payload_cap;
         for (int d = 1; d < world; d++) {              // start with the next rank: spread the reads over the peers
             const int h = (rank + d) % world;
-            Peer& p = peers[h];
-            int rc = await_seq(p.shm->packed_seq[i], k, h, "packed");
-            if (rc) return rc;
-            IMT_HIP(ctx, hipStreamWaitEvent(st, p.packed[i], 0));
-            IMT_HIP(ctx, hipMemcpyAsync(recv + (size_t)h * bytes, p.arena + off, bytes, hipMemcpyDeviceToDevice, st));
+            IMT_HIP(ctx, hipMemcpyAsync(recv + (size_t)h * bytes, peers[h].arena + off, bytes, hipMemcpyDeviceToDevice, st));
         }
-        IMT_HIP(ctx, hipEventRecord(ev_copied[i], st));
-        my_shm->copied_seq[i].store(k, std::memory_order_release);
+        imt::launch::flag_set(st, &my_shm_dev->copied[i], k);
+        IMT_HIP(ctx, hipGetLastError());
         return IMT_OK;
     }
     int fence(Rank&, int slot, int r, Stream st_) override {
         const int i = ei(slot, r);
-        for (int h = 0; h < world; h++) {
-            if (h == rank) continue;
-            int rc = await_seq(peers[h].shm->copied_seq[i], seq[i], h, "copied");
-            if (rc) return rc;
-            IMT_HIP(ctx, hipStreamWaitEvent((hipStream_t)st_, peers[h].copied[i], 0));
-        }
+        return wait_peers((hipStream_t)st_, i, seq[i], true);
+    }
+    int poll_error() override {
+        const uint32_t e = my_shm ? *(volatile uint32_t*)&my_shm->err : 0;
+        if (e) return ctx->fail(IMT_ERR_INTERNAL, "IPC transport: a peer's payload did not arrive in time (flag mask 0x%x): a rank died or hangs", e);
         return IMT_OK;
     }
 };
@@ -342,6 +328,7 @@ struct imt_sliced {
     imt_transport* tp = nullptr;
     size_t max_slice = 0;
     std::string error;
+    double host_issue_ms = 0, host_wait_ms = 0;      // wall time inside imt_sliced_step: issuing / waiting for the GPU
 };
 
 extern "C" {
@@ -455,7 +442,14 @@ int imt_sliced_step(imt_sliced* s, const void* vals, size_t n, const imt_insert_
     if (n == 0 || n > s->max_slice) return c0->fail(IMT_ERR_RANGE, "a step is world x n values with 0 < n <= max_slice = %zu", s->max_slice);
     if (flags & ~(IMT_FMT_MASK | IMT_SIB_ITEM_MAJOR | IMT_INPUTS_READY | IMT_DEVICE_PTRS))
         return c0->fail(IMT_ERR_ARG, "imt_sliced_step takes IMT_FMT_*, IMT_SIB_ITEM_MAJOR, IMT_INPUTS_READY");
-    return s->w.step(vals, n, outs, flags, round_out);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = s->w.step(vals, n, outs, flags, round_out);
+    const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    double waited = 0;
+    for (auto& be : s->bes) waited += imt_itree_take_wait_ms(be->tree);
+    s->host_wait_ms += waited;
+    s->host_issue_ms += total - waited;
+    return rc;
 }
 
 int imt_sliced_wait(imt_sliced* s, int local_rank, uint64_t round) {
@@ -479,6 +473,8 @@ int imt_sliced_get_info(const imt_sliced* s, imt_sliced_info* o) {
     o->rounds = s->w.n_rounds;
     o->collectives = s->tp->impl->collectives;
     o->bytes_gathered = s->tp->impl->bytes_moved;
+    o->host_issue_ms = s->host_issue_ms;
+    o->host_wait_ms = s->host_wait_ms;
     return IMT_OK;
 }
 

@@ -126,6 +126,7 @@ struct Transport {
     virtual Buffer provide_send(Rank& rk, int slot, int ring, size_t bytes) { (void)rk; (void)slot; (void)ring; (void)bytes; return nullptr; }
     virtual int all_gather(Rank& rk, int slot, int ring, size_t bytes, Stream st) = 0;
     virtual int fence(Rank& rk, int slot, int ring, Stream st) { (void)rk; (void)slot; (void)ring; (void)st; return IMT_OK; }
+    virtual int poll_error() { return IMT_OK; }    // after a host-side wait: did the transport give up on a peer?
     uint64_t collectives = 0, bytes_moved = 0;
 };
 
@@ -361,7 +362,7 @@ struct World {
         if (n_rounds && (rc = run_ticks(start_of(n_rounds - 1) + sc.round_ticks))) return rc;
         for (Rank* rk : ranks)
             if ((rc = rk->be->sync())) return rc;
-        return IMT_OK;
+        return ranks.empty() ? IMT_OK : ranks[0]->tp->poll_error();
     }
 
     // host waits for local rank k's witnesses of round R (its slice's last unit)
@@ -369,11 +370,15 @@ struct World {
         if (k >= ranks.size() || R >= n_rounds) return IMT_ERR_RANGE;
         Rank* rk = ranks[k];
         // its stream slot has been taken over by a later round, whose tick 0 was recorded on the same stream behind it
-        if (R + ROUNDS < n_rounds) return rk->be->event_sync(rk->tick_ev[(size_t)(R % ROUNDS) * sc.round_ticks]);
-        // the last unit is issued at round tick units - 1 + rank * lag: make sure the schedule has got there
-        int rc = run_ticks(std::max<uint64_t>(T, start_of(R) + sc.units + (uint64_t)rk->rank * sc.lag));
-        if (rc) return rc;
-        return rk->be->event_sync(rk->done_ev[R % ROUNDS]);
+        int rc;
+        if (R + ROUNDS < n_rounds) {
+            rc = rk->be->event_sync(rk->tick_ev[(size_t)(R % ROUNDS) * sc.round_ticks]);
+        } else {
+            // the last unit is issued at round tick units - 1 + rank * lag: make sure the schedule has got there
+            if ((rc = run_ticks(std::max<uint64_t>(T, start_of(R) + sc.units + (uint64_t)rk->rank * sc.lag)))) return rc;
+            rc = rk->be->event_sync(rk->done_ev[R % ROUNDS]);
+        }
+        return rc ? rc : rk->tp->poll_error();
     }
 };
 

@@ -14,6 +14,10 @@ leaves = imt_amd.to_bytes([1, 2, 3, 4])
 dense = imt_amd.IndexedMerkleTree.new(ctx, leaves)
 itree = imt_amd.IndexedTree(ctx, 4, 8)
 SKIP = {"imt_ctx_create"}                 # takes no handle; covered by test_no_cpu_fallback
+# the first argument of these is not an opaque handle (an ops table, an out-pointer, an id buffer the call WRITES): the
+# generic loop would hand them a context as scratch memory; they get their own hostile calls below
+SLICED = {n for n in _ffi.SIGNATURES if n.startswith(("imt_transport_", "imt_sliced_", "imt_rccl_"))}
+SKIP |= SLICED
 
 
 def handle_for(name):
@@ -77,6 +81,45 @@ for name, (res, args) in _ffi.SIGNATURES.items():
     print(f"CALL {name} odd-offset", flush=True)
     rc = getattr(lib, name)(*misaligned(args, handle_for(name), flags_at))
     print(f"RC {name} odd-offset {rc}", flush=True)
+# ---- imt_sliced_* / imt_transport_*: NULL everything, then valid handles with NULL / nonsense for the rest
+P, vp = ctypes.POINTER, ctypes.c_void_p
+calls = [
+    ("imt_transport_custom_create", (None, None)), ("imt_transport_custom_create", (ctypes.byref(_ffi.TransportOps()), None)),
+    ("imt_transport_local_create", (None,)), ("imt_rccl_get_unique_id", (None,)),
+    ("imt_transport_rccl_create", (None, None, 1, 1, 0, None)), ("imt_transport_rccl_create", (ctx.h, None, 1, 1, 0, ctypes.byref(vp()))),
+    ("imt_transport_rccl_create", (ctx.h, ctypes.create_string_buffer(128), 9, 1, 0, ctypes.byref(vp()))),
+    ("imt_transport_rccl_adopt", (None, 1, None)), ("imt_transport_rccl_adopt", ((vp * 1)(None), 1, ctypes.byref(vp()))),
+    ("imt_transport_ipc_create", (None, 2, 0, 32, 8, 0, None, None)), ("imt_transport_ipc_create", (ctx.h, 1, 0, 32, 8, 0, ctypes.byref(vp()), ctypes.create_string_buffer(1 << 14))),
+    ("imt_transport_ipc_create", (ctx.h, 2, 5, 32, 8, 0, ctypes.byref(vp()), ctypes.create_string_buffer(1 << 14))),
+    ("imt_transport_ipc_connect", (None, None)),
+    ("imt_sliced_create", (None, 1, 1, 0, None, 8, 0, None)), ("imt_sliced_create", ((vp * 1)(itree.h), 1, 1, 0, None, 8, 0, ctypes.byref(vp()))),
+    ("imt_sliced_step", (None, None, 1, None, 0, None)), ("imt_sliced_wait", (None, 0, 0)), ("imt_sliced_flush", (None,)),
+    ("imt_sliced_get_info", (None, None)),
+]
+for k, (name, args) in enumerate(calls):
+    print(f"CALL {name} hostile-{k}", flush=True)
+    rc = getattr(lib, name)(*args)
+    assert rc < 0, (name, rc)
+    print(f"RC {name} hostile-{k} {rc}", flush=True)
+tp, w = vp(), vp()
+assert lib.imt_transport_local_create(ctypes.byref(tp)) == 0
+assert lib.imt_transport_ipc_connect(tp, ctypes.create_string_buffer(64)) == _ffi.ERR["ARG"]      # not an IPC transport
+big = imt_amd.IndexedTree(ctx, 32, 64)
+assert lib.imt_sliced_create((vp * 1)(big.h), 1, 1, 0, tp, 8, 0, ctypes.byref(w)) == 0
+for k, (name, args) in enumerate((("imt_sliced_step", (w, None, 1, None, 0, None)), ("imt_sliced_step", (w, vp(odd), 1, None, _ffi.DEVICE_PTRS, None)),
+                   ("imt_sliced_step", (w, vp(buf.ctypes.data), 99, None, 0, None)), ("imt_sliced_step", (w, vp(buf.ctypes.data), 1, None, 0x4000, None)),
+                   ("imt_sliced_wait", (w, 3, 0)), ("imt_sliced_wait", (w, 0, 7)), ("imt_sliced_wait", (w, -1, 0)),
+                   ("imt_sliced_get_info", (w, None)))):
+    print(f"CALL {name} hostile-live-{k}", flush=True)
+    rc = getattr(lib, name)(*args)
+    assert rc < 0, (name, args, rc)
+    print(f"RC {name} hostile-live-{k} {rc}", flush=True)
+assert lib.imt_sliced_flush(w) == 0
+lib.imt_sliced_destroy(w)
+lib.imt_sliced_destroy(None)
+lib.imt_transport_destroy(tp)
+lib.imt_transport_destroy(None)
+big.close()
 ctx.sync()
 # the handles still work afterwards
 assert imt_amd.to_int(ctx.hash2(imt_amd.to_bytes([[1, 2]]))[0]) > 0

@@ -1,57 +1,133 @@
-"""One-off scale check: 2^20 insertions into a depth-32 tree as 4 pipelined batches of 2^18, all
-per-insertion outputs kept; every insert_leaf constraint re-checked by the witness kernels; final
-root against a bulk rebuild from the snapshot.  (Sizes above what the pytest suite uses.)"""
-import ctypes, os, sys, time
+#!/usr/bin/env python3
+"""The timed path on BIG trees: prefill a depth-32 tree with imt_itree_load to 2^k leaves (k from SCALE_SIZES, default
+20 24 26 27), then 50 pipelined batches of 2^16 insertions exactly as bench.py issues them (device pointers,
+IMT_PIPELINE | IMT_INPUTS_READY, every witness written), and report the rate, the per-class kernel times
+(imt_profile_read) and a correctness check at that size: the last batch's witnesses through imt_insert_witness_batch
+(every insert_leaf constraint at depth 32), the root chain, the tree's root.
+
+Above 2^22 leaves every level's sibling read is a random 32-byte access into an array of >= 128 MB and k_merge_level /
+k_writeback run for more levels (L0 = ceil(log2(size))): this is where a cliff would show.
+
+Prefill: leaf i holds v_i = (i << 64) + r_i (r_i random 64 bits), so leaf order = value order and the snapshot is
+{v_i, v_{i+1}, i+1} without a sort; the inserted values are (j << 64) + r with j uniform over the prefilled leaves, i.e.
+every insertion's low leaf is a uniformly random stored leaf -- random paths through the whole stored tree."""
+import ctypes
+import os
+import sys
+import time
+
 import numpy as np
 import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import imt_amd
-from imt_amd import _ffi
+import imt_amd  # noqa: E402
+from imt_amd import _ffi  # noqa: E402
+
 lib = imt_amd.lib
-ctx = imt_amd.Context(0)
-ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+DEPTH, BATCH = 32, 1 << 16
+STEPS, WARM = int(os.environ.get("SCALE_STEPS", "50")), 4
+sizes = [int(x) for x in os.environ.get("SCALE_SIZES", "20 24 26 27").split()]
 dev = torch.device("cuda", 0)
-depth, nb, bs = 32, 4, 1 << 18
-t = imt_amd.IndexedTree(ctx, depth, 1 << 21)
-rng = np.random.default_rng(5)
-raw = rng.integers(0, 256, size=(nb * bs, 32), dtype=np.uint8)
-raw[:, 31] &= 0x0f
-raw[:, 0] |= 1
-vals = torch.from_numpy(raw).to(dev)
-P = lambda x: ctypes.c_void_p(x.data_ptr())
-outs = []
-t0 = time.perf_counter()
-for b in range(nb):
-    o = dict(low_index=torch.empty(bs, dtype=torch.int64, device=dev), is_largest=torch.empty(bs, dtype=torch.uint8, device=dev),
-             low_leaf=torch.empty((bs, 3, 32), dtype=torch.uint8, device=dev), new_leaf=torch.empty((bs, 3, 32), dtype=torch.uint8, device=dev),
-             old_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev), interim_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
-             new_root=torch.empty((bs, 32), dtype=torch.uint8, device=dev),
-             low_sib=torch.empty((depth, bs, 32), dtype=torch.uint8, device=dev), new_sib=torch.empty((depth, bs, 32), dtype=torch.uint8, device=dev))
-    st = _ffi.InsertOut(**{k: v.data_ptr() for k, v in o.items()})
-    rc = lib.imt_itree_insert_batch(t.h, ctypes.c_void_p(vals.data_ptr() + b * bs * 32), bs, ctypes.byref(st),
-                                    _ffi.DEVICE_PTRS | _ffi.PIPELINE)
-    assert rc == 0, lib.imt_last_error(ctx.h)
-    outs.append(o)
-ctx.sync(); torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(f"inserted {nb * bs} in {dt * 1e3:.1f} ms = {nb * bs / dt / 1e6:.2f} M insertions/s (batches of 2^18)")
-prev = None
-for b, o in enumerate(outs):
-    new_index = torch.arange(1 + b * bs, 1 + (b + 1) * bs, dtype=torch.int64, device=dev)
-    fail = torch.empty(bs, dtype=torch.uint8, device=dev)
-    rc = lib.imt_insert_witness_batch(ctx.h, P(o["old_root"]), P(o["low_leaf"]), P(o["low_index"]), P(o["low_sib"]),
-                                      P(o["new_root"]), P(o["new_leaf"]), P(new_index), None, P(o["new_sib"]),
-                                      P(o["is_largest"]), depth, bs, P(fail), None, _ffi.DEVICE_PTRS)
-    assert rc == 0
+P_ = lambda x: ctypes.c_void_p(x.data_ptr())
+
+
+def avail_gb():
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            return int(line.split()[1]) / 1e6
+    return 0.0
+
+
+def snapshot(M, rng):
+    """[M][3][32] uint8: the sorted linked list of M leaves described above"""
+    pre = np.zeros((M, 3, 4), dtype=np.uint64)           # 4 x u64 little-endian limbs per element
+    r = rng.integers(1, 1 << 63, size=M, dtype=np.uint64)
+    r[0] = 0
+    idx = np.arange(M, dtype=np.uint64)
+    pre[:, 0, 0], pre[:, 0, 1] = r, idx                   # val = (i << 64) + r_i
+    pre[:-1, 1, 0], pre[:-1, 1, 1] = r[1:], idx[1:]       # next_val
+    pre[:-1, 2, 0] = idx[1:]                              # next_idx
+    return pre.view(np.uint8).reshape(M, 3, 32)
+
+
+def new_values(n, M, rng):
+    v = np.zeros((n, 4), dtype=np.uint64)
+    v[:, 0] = rng.integers(1, 1 << 63, size=n, dtype=np.uint64) | np.uint64(1 << 63)      # never equal to a stored r_i (< 2^63)
+    v[:, 1] = rng.integers(0, M, size=n, dtype=np.uint64)
+    # distinct inside the run with overwhelming probability; the library refuses a batch with a duplicate anyway
+    return v.view(np.uint8).reshape(n, 32)
+
+
+print(f"host memory available: {avail_gb():.0f} GB; steps {STEPS} x 2^16 after {WARM} warm-up batches", flush=True)
+for k in sizes:
+    M = 1 << k
+    need = M * 96 * 3.3 / 1e9         # snapshot + the library's canonical copy + host mirror
+    if need > 0.6 * avail_gb():
+        print(f"2^{k} leaves: skipped ({need:.0f} GB of host memory needed for imt_itree_load, {avail_gb():.0f} GB available)", flush=True)
+        continue
+    rng = np.random.default_rng(1000 + k)
+    total = (STEPS + WARM) * BATCH
+    cap = 1 << (M + total).bit_length()
+    ctx = imt_amd.Context(0)
+    tree = imt_amd.IndexedTree(ctx, DEPTH, cap)
+    t0 = time.perf_counter()
+    snap = snapshot(M, rng)
+    t1 = time.perf_counter()
+    ctx._check(lib.imt_itree_load(tree.h, snap.ctypes.data_as(ctypes.c_void_p), M, 0))
+    t2 = time.perf_counter()
+    del snap
+    vals = torch.from_numpy(new_values(total, M, rng)).to(dev)
+    u8 = dict(dtype=torch.uint8, device=dev)
+    sets = [dict(low_index=torch.empty(BATCH, dtype=torch.int64, device=dev), low_leaf=torch.empty((BATCH, 3, 32), **u8),
+                 is_largest=torch.empty(BATCH, **u8), old_root=torch.empty((BATCH, 32), **u8),
+                 interim_root=torch.empty((BATCH, 32), **u8), new_root=torch.empty((BATCH, 32), **u8),
+                 new_leaf=torch.empty((BATCH, 3, 32), **u8), low_sib=torch.empty((DEPTH, BATCH, 32), **u8),
+                 new_sib=torch.empty((DEPTH, BATCH, 32), **u8)) for _ in range(3)]
+    structs = [_ffi.InsertOut(**{f: t.data_ptr() for f, t in s.items()}) for s in sets]
+    flags = _ffi.DEVICE_PTRS | _ffi.PIPELINE | _ffi.INPUTS_READY
+    torch.cuda.synchronize()
+
+    def batch(i, slot):
+        ctx._check(lib.imt_itree_insert_batch(tree.h, ctypes.c_void_p(vals.data_ptr() + i * BATCH * 32), BATCH,
+                                              ctypes.byref(structs[slot]), flags))
+
+    tw = time.perf_counter()
+    for i in range(WARM):
+        batch(i, i & 1)
     ctx.sync()
-    assert int(fail.max()) == 0, b
-    assert bool((o["old_root"][1:] == o["new_root"][:-1]).all())
-    if prev is not None:
-        assert bool((o["old_root"][0] == prev).all())
-    prev = o["new_root"][-1].clone()
-print("all", nb * bs, "insert_leaf witnesses satisfied; root chain continuous")
-t2 = imt_amd.IndexedTree(ctx, depth, 1 << 21)
-t2.load(t.snapshot())
-assert t2.root() == t.root() == imt_amd.to_int(prev.cpu().numpy())
-print("bulk rebuild from snapshot gives the same root", hex(t.root()))
+    torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - tw) * 1e3          # includes the device index built from the loaded host mirror
+    lib.imt_profile_enable(ctx.h, 1)
+    t3 = time.perf_counter()
+    for i in range(WARM, WARM + STEPS):
+        batch(i, 2 if i == WARM + STEPS - 1 else (i & 1))
+    ctx.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t3
+    prof = (ctypes.c_double * 12)()
+    lib.imt_profile_read(ctx.h, prof)
+    lib.imt_profile_enable(ctx.h, 0)
+    names = ["k_sweep[leaves]", "k_merge_level", "k_sweep[l<l0]", "k_sweep[l>=l0]", "k_writeback", "host"]
+    per = {names[c]: (prof[2 * c] / STEPS, int(prof[2 * c + 1]) // STEPS) for c in range(6)}
+    # ---- the last batch, as it lies in HBM, through the independent witness kernels
+    o = sets[2]
+    first = M + (WARM + STEPS - 1) * BATCH
+    new_index = torch.arange(first, first + BATCH, dtype=torch.int64, device=dev)
+    fail = torch.empty(BATCH, dtype=torch.uint8, device=dev)
+    ctx._check(lib.imt_insert_witness_batch(ctx.h, P_(o["old_root"]), P_(o["low_leaf"]), P_(o["low_index"]), P_(o["low_sib"]),
+                                            P_(o["new_root"]), P_(o["new_leaf"]), P_(new_index), None, P_(o["new_sib"]),
+                                            P_(o["is_largest"]), DEPTH, BATCH, P_(fail), None, _ffi.DEVICE_PTRS))
+    ctx.sync()
+    ok = int(fail.max()) == 0 and bool((o["old_root"][1:] == o["new_root"][:-1]).all())
+    ok = ok and imt_amd.to_int(o["new_root"][-1].cpu().numpy()) == tree.root()
+    spread = int(o["low_index"].max()) - int(o["low_index"].min())
+    l0 = (M + total - 1).bit_length()
+    print(f"2^{k} leaves prefilled (snapshot {t1 - t0:.1f} s, imt_itree_load {t2 - t1:.1f} s, first {WARM} batches {first_ms:.0f} ms): "
+          f"{STEPS * BATCH / dt / 1e6:.3f} M insertions/s, {dt / STEPS * 1e3:.2f} ms per 2^16 batch, L0 = {l0}; "
+          f"verified {ok} (last batch: witness kernels + root chain + tree root; low leaves span {spread} positions)", flush=True)
+    print("    per batch: " + "; ".join(f"{n_} {ms:.2f} ms / {cnt} launches" for n_, (ms, cnt) in per.items()), flush=True)
+    del vals, sets, structs
+    tree.close()
+    ctx.close()
+    torch.cuda.empty_cache()

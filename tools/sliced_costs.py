@@ -45,6 +45,7 @@ for world in worlds:
           f"({dt / rounds * 1e3:.1f} ms per round of {world} x 2^16; lag {i1['lag']}, "
           f"{(i1['collectives'] - i0['collectives']) / rounds:.0f} gathers and "
           f"{(i1['bytes_gathered'] - i0['bytes_gathered']) / rounds / 1e9:.3f} GB copied per round); "
-          f"host inside imt_sliced_step {host / rounds * 1e3:.2f} ms per round (all {world} ranks' calls, prepare's value check included)",
+          f"host inside imt_sliced_step {host / rounds * 1e3:.2f} ms per round for all {world} ranks: "
+          f"{(i1['host_issue_ms'] - i0['host_issue_ms']) / rounds:.2f} ms issuing, {(i1['host_wait_ms'] - i0['host_wait_ms']) / rounds:.2f} ms waiting for the GPU",
           flush=True)
     t.close()
