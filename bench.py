@@ -712,6 +712,10 @@ def main():
         os._exit(1)                 # a process group that has failed is not torn down gracefully
     ok = env.all_true(ok)
     if dist is not None:
+        dist.barrier()              # nobody closes the buffers it exports while a peer may still read them
+    if "single-list" in legs:
+        legs["single-list"]["be"].close()
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:

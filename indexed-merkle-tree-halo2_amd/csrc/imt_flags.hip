@@ -7,6 +7,7 @@
 // k_flag_wait reaches an exit: a flag that does not arrive within the time limit sets an error bit and the kernel
 // returns (the host reports it: a peer died or hangs), so the grid always drains.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "imt_flags.hpp"
 
 namespace {
@@ -29,10 +30,24 @@ __global__ void k_flag_wait(imt::launch::FlagWait w) {
     }
 }
 
+// payload copy out of a peer's memory.  hipMemcpyAsync from an IPC-mapped pointer blocks the host until the stream has
+// drained (measured: 1.1 ms per call behind a waiting kernel, profiles/r04 notes), so the copy is a kernel of its own:
+// 16 bytes per lane and step, grid-stride, sizes are multiples of 16.
+__global__ void k_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace
 
 namespace imt {
 namespace launch {
+
+void copy16(hipStream_t s, void* dst, const void* src, size_t bytes) {
+    const size_t n16 = bytes / 16;
+    if (!n16) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, 512);
+    hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n16);
+}
 
 void flag_set(hipStream_t s, uint64_t* flag, uint64_t value) { hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, s, flag, value); }
 

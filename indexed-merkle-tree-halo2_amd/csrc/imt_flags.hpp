@@ -16,6 +16,8 @@ struct FlagWait {
 };
 void flag_set(hipStream_t s, uint64_t* flag, uint64_t value);
 void flag_wait(hipStream_t s, const FlagWait& w);
+// bytes: a multiple of 16; both pointers 16-byte aligned device-visible memory (a peer's IPC-mapped buffer included)
+void copy16(hipStream_t s, void* dst, const void* src, size_t bytes);
 
 }  // namespace launch
 }  // namespace imt

@@ -38,18 +38,30 @@ struct HipBackend : Backend {
     int init() {
         int rc = ctx->set_device();
         if (rc) return rc;
-        if (const char* e = getenv("IMT_SLICED_COMM_STREAMS")) n_comm = std::max(1, std::min(ROUNDS, atoi(e)));
-        // different priorities for the round streams, like the batch pipeline's: the runtime may otherwise map them to
-        // one hardware queue, which serialises them
+        // Measured on one MI355X with in-process replicas (profiles/r04_sliced_stream_matrix.txt): the four round streams
+        // at EQUAL priority (2.93-2.95 M insertions/s at world 1, 2.86 at world 2) beat the batch pipeline's scheme of one
+        // normal + three high (2.49-2.64 / 2.64-2.83) -- rounds are whole slices apart here, not one level, and a
+        // high-priority round starves the others; where the collectives are enqueued (the round's own stream, one or four
+        // extra streams, normal or high priority) moves the rate by < 2 % with equal round priorities.  Default: four
+        // normal-priority streams for the collectives, so that a gather never sits in front of a hash kernel.
+        // Knobs: IMT_SLICED_COMM_STREAMS (0 = enqueue a round's gathers on the round's own stream), IMT_SLICED_COMM_PRIO,
+        // IMT_SLICED_ROUND_PRIO=pipe.
+        if (const char* e = getenv("IMT_SLICED_COMM_STREAMS")) n_comm = std::max(0, std::min(ROUNDS, atoi(e)));
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+        const char* rp = getenv("IMT_SLICED_ROUND_PRIO");
+        const bool equal = !(rp && !strcmp(rp, "pipe"));
+        int comm_prio = std::max(greatest, std::min(least, 0));
+        if (const char* e = getenv("IMT_SLICED_COMM_PRIO")) comm_prio = std::max(greatest, std::min(least, atoi(e)));
         for (int i = 0; i < ROUNDS; i++) {
-            const int prio = std::max(greatest, std::min(least, 0 - i));
+            // different priorities for the round streams, like the batch pipeline's: the runtime may otherwise map them to
+            // one hardware queue, which serialises them
+            const int prio = equal ? 0 : std::max(greatest, std::min(least, 0 - i));
             IMT_HIP(ctx, hipStreamCreateWithPriority(&rs[i], hipStreamNonBlocking, prio));
             ctx->side_streams.push_back(rs[i]);
         }
         for (int i = 0; i < n_comm; i++) {
-            IMT_HIP(ctx, hipStreamCreateWithPriority(&cs[i], hipStreamNonBlocking, greatest));
+            IMT_HIP(ctx, hipStreamCreateWithPriority(&cs[i], hipStreamNonBlocking, comm_prio));
             ctx->side_streams.push_back(cs[i]);
         }
         return IMT_OK;
@@ -66,7 +78,7 @@ struct HipBackend : Backend {
                 }
     }
     Stream round_stream(int slot) override { return rs[slot]; }
-    Stream comm_stream(int slot) override { return cs[slot % n_comm]; }
+    Stream comm_stream(int slot) override { return n_comm ? cs[slot % n_comm] : rs[slot]; }
     int new_event(Event* out) override {
         hipEvent_t e;
         IMT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -159,8 +171,26 @@ struct IpcShm {
 };
 constexpr size_t IPC_SHM_BYTES = (sizeof(IpcShm) + 4095) & ~(size_t)4095;
 
+struct HostTimer {          // IMT_SLICED_TIMING=1: where the host's time inside the transport goes (printed at destroy)
+    double ms[6] = {0};
+    uint64_t n[6] = {0};
+    bool on = getenv("IMT_SLICED_TIMING") != nullptr;
+    struct Scope {
+        HostTimer& t;
+        int k;
+        std::chrono::steady_clock::time_point t0;
+        Scope(HostTimer& t_, int k_) : t(t_), k(k_), t0(std::chrono::steady_clock::now()) {}
+        ~Scope() {
+            if (!t.on) return;
+            t.ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            t.n[k]++;
+        }
+    };
+};
+
 struct IpcTransport : Transport {
     imt_ctx* ctx;
+    HostTimer ht;
     int world, rank, ring = 0;
     size_t payload_cap = 0;
     uint8_t* arena = nullptr;                    // [ROUNDS][ring][payload_cap]
@@ -249,6 +279,10 @@ struct IpcTransport : Transport {
         return IMT_OK;
     }
     ~IpcTransport() override {
+        if (ht.on)
+            fprintf(stderr, "[imt ipc rank %d] host ms (calls): flag_set %.1f (%llu)  wait packed %.1f (%llu)  memcpy %.1f (%llu)  wait copied %.1f (%llu)\n",
+                    rank, ht.ms[0], (unsigned long long)ht.n[0], ht.ms[1], (unsigned long long)ht.n[1], ht.ms[2], (unsigned long long)ht.n[2], ht.ms[3],
+                    (unsigned long long)ht.n[3]);
         if (ctx->set_device()) return;
         for (auto& p : peers) {
             if (p.arena) hipIpcCloseMemHandle(p.arena);
@@ -274,6 +308,7 @@ struct IpcTransport : Transport {
         w.value = k;
         w.timeout_ticks = timeout_ticks;
         w.err = &my_shm_dev->err;
+        HostTimer::Scope sc(ht, copied ? 3 : 1);
         imt::launch::flag_wait(st, w);
         IMT_HIP(ctx, hipGetLastError());
         return IMT_OK;
@@ -283,15 +318,20 @@ struct IpcTransport : Transport {
         const int i = ei(slot, r);
         const uint64_t k = ++seq[i];
         // st is already behind the unit that packed my send buffer
-        imt::launch::flag_set(st, &my_shm_dev->packed[i], k);
+        {
+            HostTimer::Scope sc(ht, 0);
+            imt::launch::flag_set(st, &my_shm_dev->packed[i], k);
+        }
         int rc = wait_peers(st, i, k, false);
         if (rc) return rc;
         uint8_t* recv = (uint8_t*)rk.recv[rk.at(slot, r)];
         const size_t off = ((size_t)slot * ring + r) * payload_cap;
         for (int d = 1; d < world; d++) {              // start with the next rank: spread the reads over the peers
             const int h = (rank + d) % world;
-            IMT_HIP(ctx, hipMemcpyAsync(recv + (size_t)h * bytes, peers[h].arena + off, bytes, hipMemcpyDeviceToDevice, st));
+            HostTimer::Scope sc(ht, 2);
+            imt::launch::copy16(st, recv + (size_t)h * bytes, peers[h].arena + off, bytes);
         }
+        HostTimer::Scope sc(ht, 0);
         imt::launch::flag_set(st, &my_shm_dev->copied[i], k);
         IMT_HIP(ctx, hipGetLastError());
         return IMT_OK;
@@ -380,6 +420,10 @@ const char* imt_transport_last_error(const imt_transport* tp) {
 
 void imt_sliced_destroy(imt_sliced* s) {
     if (!s) return;
+    if (getenv("IMT_SLICED_TIMING"))
+        fprintf(stderr, "[imt sliced rank %d] host ms over %llu rounds: apply %.1f  compute %.1f  send %.1f  (issue %.1f, waiting in prepare %.1f)\n",
+                s->ranks.empty() ? -1 : s->ranks[0]->rank, (unsigned long long)s->w.n_rounds, s->w.phase_ms[0], s->w.phase_ms[1], s->w.phase_ms[2],
+                s->host_issue_ms, s->host_wait_ms);
     if (!s->ranks.empty() && s->w.n_rounds) s->w.flush();
     for (auto& be : s->bes) be->sync();
     for (auto& r : s->ranks) r->destroy();

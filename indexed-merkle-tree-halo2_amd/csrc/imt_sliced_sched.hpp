@@ -26,6 +26,7 @@
 // buffer reuse fails on the CPU.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <vector>
@@ -299,6 +300,7 @@ struct Rank {
 struct World {
     std::vector<Rank*> ranks;
     Schedule sc;
+    double phase_ms[4] = {0, 0, 0, 0};      // host wall time in apply / compute / send / prepare (diagnostics)
     uint64_t T = 0;                  // next global tick to issue
     uint64_t n_rounds = 0;
     uint64_t starts[ROUNDS + 1] = {};
@@ -312,12 +314,19 @@ struct World {
             for (uint64_t R = first; R < n_rounds; R++) {        // oldest first
                 if (T < start_of(R) || T - start_of(R) >= (uint64_t)sc.round_ticks) continue;
                 const int rt = (int)(T - start_of(R));
+                const auto t0 = std::chrono::steady_clock::now();
                 for (Rank* rk : ranks)
                     if ((rc = rk->phase_apply(R, rt))) return rc;
+                const auto t1 = std::chrono::steady_clock::now();
                 for (Rank* rk : ranks)
                     if ((rc = rk->phase_compute(R, rt))) return rc;
+                const auto t2 = std::chrono::steady_clock::now();
                 for (Rank* rk : ranks)
                     if ((rc = rk->phase_send(R, rt))) return rc;
+                const auto t3 = std::chrono::steady_clock::now();
+                phase_ms[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+                phase_ms[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+                phase_ms[2] += std::chrono::duration<double, std::milli>(t3 - t2).count();
             }
         }
         return IMT_OK;
