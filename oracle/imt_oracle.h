@@ -148,6 +148,24 @@ int orc_hash_trace(const uint8_t *in /*[arity][32]*/, int arity, uint8_t *cells,
 void orc_trace_spec(uint8_t *start /*[5][3][32]*/, uint8_t *partial /*[57][32]*/, uint8_t *end /*[3][3][32]*/,
                     uint8_t *pre_sparse /*[9][32]*/, uint8_t *sp_row /*[57][3][32]*/, uint8_t *sp_col_hat /*[57][2][32]*/);
 
+/* ---- f3: the advice cells of insert_leaf OUTSIDE hash_fix_len_array (gadget.c) ----
+ * is_less_than (src/indexed_merkle_tree.rs:98-125) of two 256-bit values: its whole column (inputs 0..3 = a_q, a_r, b_q,
+ * b_r), 4 * (ceil(128 / lookup_bits) + 1) + 27 new witnesses; out_row = the row of the result. */
+size_t orc_less_than_trace_rows(unsigned lookup_bits);
+int orc_less_than_trace(const uint8_t a[32], const uint8_t b[32], unsigned lookup_bits, uint8_t *cells, orc_trace_cell *desc,
+                        size_t cap, size_t *n_cells, uint8_t *witness, size_t wcap, size_t *n_witness, uint32_t *out_row);
+/* every new witness of insert_leaf (:231-314) that is not inside a hash ("glue rows": is_equal, the limb loads, both
+ * is_less_than, select, load_witness + dual_mux of the four paths), in assignment order, and the segments -- glue rows
+ * (kind 0) / one hash_fix_len_array call (kind 1, rows of orc_hash_trace in imt_insert_trace_batch's order) -- that make
+ * up the column */
+typedef struct { uint32_t kind, arity; uint64_t first_row, n_rows; } orc_column_segment;
+size_t orc_insert_gadget_rows(size_t depth, unsigned lookup_bits);
+int orc_insert_gadget_trace(const uint8_t low_leaf[3][32], uint64_t low_index, const uint8_t *low_proof,
+                            const uint8_t new_leaf[3][32], uint64_t new_index, uint64_t new_path_index,
+                            const uint8_t *new_proof, int is_new_leaf_largest, size_t depth, unsigned lookup_bits,
+                            uint8_t *witness, size_t wcap, size_t *n_witness, orc_column_segment *segs, size_t seg_cap,
+                            size_t *n_segs);
+
 /* ---- indexed-list insertion of the test module (:632-671) */
 /* update_idx_leaf: linear scan, in place on preimages[n][3][32]; returns low idx in *low */
 int orc_update_idx_leaf(uint8_t *preimages, size_t n, const uint8_t new_val[32],
