@@ -71,6 +71,16 @@ pub struct imt_sliced_info {
     pub host_wait_ms: c_double,
 }
 
+/// `imt_column_segment`: a stretch of insert_leaf's advice column (imt_insert_column_segments).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct imt_column_segment {
+    pub kind: u32,
+    pub arity: u32,
+    pub first_row: u64,
+    pub n_rows: u64,
+}
+
 /// `imt_trace_cell`: one cell of the advice column of a hash (imt_hash_trace_layout).
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -125,6 +135,8 @@ pub const IMT_PROF_HOST: usize = 5;
 pub const IMT_PROF_CLASSES: usize = 6;
 
 pub const IMT_OPT_COOP_MAX_EVENTS: c_int = 1;
+pub const IMT_SEG_GLUE: u32 = 0;
+pub const IMT_SEG_HASH: u32 = 1;
 pub const IMT_SLICED_ROUNDS: usize = 4;
 pub const IMT_RCCL_UNIQUE_ID_BYTES: usize = 128;
 
@@ -163,6 +175,14 @@ extern "C" {
     pub fn imt_hash_trace_layout(ctx: *mut imt_ctx, arity: c_int, cells: *mut imt_trace_cell, cells_cap: usize, n_cells: *mut usize, constants: *mut c_void, const_cap: usize, n_constants: *mut usize, out_row: *mut u32, flags: c_uint) -> c_int;
 
     // ---- a2 / a3 / a4: dense native tree
+    // ---- f3: the rest of insert_leaf's advice column
+    pub fn imt_less_than_trace_rows(lookup_bits: c_uint) -> usize;
+    pub fn imt_less_than_trace_batch(ctx: *mut imt_ctx, a: *const c_void, b: *const c_void, n: usize, lookup_bits: c_uint, trace: *mut c_void, lt_out: *mut u8, flags: c_uint) -> c_int;
+    pub fn imt_less_than_trace_layout(ctx: *mut imt_ctx, lookup_bits: c_uint, cells: *mut imt_trace_cell, cells_cap: usize, n_cells: *mut usize, constants: *mut c_void, const_cap: usize, n_constants: *mut usize, out_row: *mut u32, flags: c_uint) -> c_int;
+    pub fn imt_insert_gadget_rows(depth: c_uint, lookup_bits: c_uint) -> usize;
+    pub fn imt_insert_gadget_trace_batch(ctx: *mut imt_ctx, low_leaf: *const c_void, low_index: *const u64, low_sib: *const c_void, new_leaf: *const c_void, new_index: *const u64, new_path_index: *const u64, new_sib: *const c_void, is_largest: *const u8, depth: c_uint, lookup_bits: c_uint, n: usize, trace: *mut c_void, flags: c_uint) -> c_int;
+    pub fn imt_insert_column_segments(depth: c_uint, lookup_bits: c_uint, segs: *mut imt_column_segment, cap: usize, n_segs: *mut usize) -> c_int;
+
     pub fn imt_tree_new(ctx: *mut imt_ctx, leaves: *const c_void, n_leaves: usize, flags: c_uint, out: *mut *mut imt_tree) -> c_int;
     pub fn imt_tree_free(t: *mut imt_tree);
     pub fn imt_tree_num_levels(t: *const imt_tree) -> usize;

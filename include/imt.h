@@ -213,6 +213,52 @@ typedef struct imt_trace_cell {
 int imt_hash_trace_layout(imt_ctx *ctx, int arity, imt_trace_cell *cells, size_t cells_cap, size_t *n_cells,
                           void *constants, size_t const_cap, size_t *n_constants, uint32_t *out_row, unsigned flags);
 
+/* ---- f3: the rest of insert_leaf's advice column --------------------------------------------------
+ * After f1 the only advice values of insert_leaf (src/indexed_merkle_tree.rs:231-314) a chip would still compute on the
+ * CPU are those outside hash_fix_len_array: the two is_less_than calls of verify_non_inclusion (:180, :226 -> :98-125:
+ * range.is_less_than(.,.,128) + gate.is_equal for the high and the low 128-bit limbs, then not x4, and x3, and, or),
+ * is_equal(next_val, 0) with its inverse (:143), the limb loads and their mul_add checks (:169-178, :219-224), select
+ * (:182-189 -> :33-45) and, per path, load_witness(leaf) + dual_mux's four values per level (:78-96 -> :47-63).  These
+ * calls produce every such NEW advice value on the GPU, in assignment order.  Cell structure: the published halo2-lib
+ * v0.4.x GateChip / RangeChip (sub [W a-b, b, 1, a]; mul [0, a, b, W]; mul_add [c, a, b, W]; or [W 1-b, 1, b, 1, b, a,
+ * W 1-b, W out]; is_zero [W z, a, W 1/a, 1, 0, a, W z, 0]; range.is_less_than [W 2^p+a-b, b, 1, W 2^p+a, -2^p, 1, a] +
+ * the limbs of the first cell as an inner product with 2^(lookup_bits i) + is_zero(top limb)).  UNPINNED BY THE
+ * REFERENCE, exactly like f1 (halo2-base is not vendored): pinned by every gate of the column holding, by the results
+ * equalling the reference's boolean formula, by the CPU oracle (oracle/gadget.c) and an independent big-integer model.
+ * lookup_bits: the RangeChip's (the reference's tests: 18, :436); 1 .. 28.  Formats and layouts as for the f1 calls. */
+size_t imt_less_than_trace_rows(unsigned lookup_bits);      /* 4 * (ceil(128 / lookup_bits) + 1) + 27; 63 for 18 */
+/* rows of is_less_than(a_q, a_r, b_q, b_r) for the 256-bit values a[i], b[i] (a_q = a >> 128, ...: what
+ * imt_split128_batch returns); trace [rows][n][32] or, with IMT_TRACE_ITEM_MAJOR, [n][rows][32]; lt_out[i] (optional)
+ * = a[i] < b[i] */
+int imt_less_than_trace_batch(imt_ctx *ctx, const void *a /*[n][32]*/, const void *b /*[n][32]*/, size_t n,
+                              unsigned lookup_bits, void *trace, uint8_t *lt_out /*[n] or NULL*/, unsigned flags);
+/* the column of one is_less_than, cell by cell, like imt_hash_trace_layout: IMT_CELL_INPUT index 0..3 = a_q, a_r, b_q,
+ * b_r; *out_row = the row holding the result */
+int imt_less_than_trace_layout(imt_ctx *ctx, unsigned lookup_bits, imt_trace_cell *cells, size_t cells_cap, size_t *n_cells,
+                               void *constants, size_t const_cap, size_t *n_constants, uint32_t *out_row, unsigned flags);
+/* ALL rows of insert_leaf outside its hashes ("glue rows"), in assignment order: is_equal(next_val, 0) [4 rows], the
+ * limbs nl_q nl_r ll_q ll_r [4], their two mul_add [2], is_less_than(new, low.next_val) [K], select [3], then for the low
+ * leaf's path load_witness [1] + dual_mux a-b, b-a, left, right per level [4 depth], the limbs of low.val + mul_add
+ * [3], is_less_than(low.val, new) [K], and the same 1 + 4 depth rows for the rewritten low leaf's, the zero leaf's and
+ * the new leaf's path: 20 + 2 K + 16 depth rows (658 at depth 32, lookup_bits 18).  Inputs as imt_insert_trace_batch
+ * (what imt_itree_insert_batch returned) plus is_largest; depth >= 1.  Together with imt_insert_trace_batch this is
+ * every new advice value of the call; imt_insert_column_segments tells how the two traces interleave. */
+size_t imt_insert_gadget_rows(unsigned depth, unsigned lookup_bits);
+int imt_insert_gadget_trace_batch(imt_ctx *ctx, const void *low_leaf /*[n][3][32]*/, const uint64_t *low_index,
+                                  const void *low_sib, const void *new_leaf /*[n][3][32]*/, const uint64_t *new_index,
+                                  const uint64_t *new_path_index /*[n] or NULL = new_index*/, const void *new_sib,
+                                  const uint8_t *is_largest /*[n]*/, unsigned depth, unsigned lookup_bits, size_t n,
+                                  void *trace, unsigned flags);
+#define IMT_SEG_GLUE 0      /* n_rows rows of imt_insert_gadget_trace_batch starting at first_row */
+#define IMT_SEG_HASH 1      /* one hash_fix_len_array call of `arity` inputs: rows [first_row, + n_rows) of imt_insert_trace_batch */
+typedef struct imt_column_segment {
+    uint32_t kind, arity;
+    uint64_t first_row, n_rows;
+} imt_column_segment;
+/* the advice column of insert_leaf as alternating stretches of the two traces (3 + 4 depth hash segments); segs may be
+ * NULL (count only) */
+int imt_insert_column_segments(unsigned depth, unsigned lookup_bits, imt_column_segment *segs, size_t cap, size_t *n_segs);
+
 /* ---- a2 / a3 / a4: dense native tree ------------------------------------------- */
 /* IndexedMerkleTree::new (src/utils.rs:20-57): level-by-level build on the device.
  * n_leaves == 0 -> IMT_ERR_NO_LEAVES; 1 -> root = leaf; odd -> IMT_ERR_ODD_LEAVES;

@@ -67,6 +67,10 @@ class SlicedInfo(ctypes.Structure):
                [(n, ctypes.c_double) for n in ("host_issue_ms", "host_wait_ms")]
 
 
+class ColumnSegment(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint32), ("arity", ctypes.c_uint32), ("first_row", ctypes.c_uint64), ("n_rows", ctypes.c_uint64)]
+
+
 class InsertOut(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("low_index", "low_leaf", "is_largest", "old_root", "interim_root",
                                         "new_root", "new_leaf", "low_sib", "new_sib")]
@@ -98,6 +102,14 @@ SIGNATURES = {
                                        c_size_t, c_void_p, c_uint]),
     "imt_hash_trace_layout": (c_int, [c_void_p, c_int, P(TraceCell), c_size_t, P(c_size_t), c_void_p, c_size_t,
                                       P(c_size_t), P(ctypes.c_uint32), c_uint]),
+    "imt_less_than_trace_rows": (c_size_t, [c_uint]),
+    "imt_less_than_trace_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint, c_void_p, c_void_p, c_uint]),
+    "imt_less_than_trace_layout": (c_int, [c_void_p, c_uint, P(TraceCell), c_size_t, P(c_size_t), c_void_p, c_size_t,
+                                           P(c_size_t), P(ctypes.c_uint32), c_uint]),
+    "imt_insert_gadget_rows": (c_size_t, [c_uint, c_uint]),
+    "imt_insert_gadget_trace_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_uint, c_uint, c_size_t, c_void_p, c_uint]),
+    "imt_insert_column_segments": (c_int, [c_uint, c_uint, P(ColumnSegment), c_size_t, P(c_size_t)]),
     "imt_tree_new": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, P(c_void_p)]),
     "imt_tree_free": (None, [c_void_p]),
     "imt_tree_num_levels": (c_size_t, [c_void_p]),
@@ -188,5 +200,6 @@ F_RANGE_PRED, F_LOW_IN_ROOT, F_LOW_LT_NEW, F_ZERO_SLOT, F_NEXT_VAL, F_NEXT_IDX, 
 CELL_CONST, CELL_INPUT, CELL_INIT, CELL_WITNESS, CELL_COPY = 0, 1, 2, 3, 4
 TRACE_ITEM_MAJOR = SIB_ITEM_MAJOR
 OPT_COOP_MAX_EVENTS = 1
+SEG_GLUE, SEG_HASH = 0, 1
 SLICED_ROUNDS = 4
 RCCL_UNIQUE_ID_BYTES = 128

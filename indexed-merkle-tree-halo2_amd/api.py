@@ -186,6 +186,41 @@ class Context:
                                                fmt | (_ffi.TRACE_ITEM_MAJOR if item_major else 0)))
         return out
 
+    # ---- f3: the advice values of insert_leaf outside its hashes ----
+    def less_than_trace(self, a, b, lookup_bits=18, fmt=0, item_major=False):
+        """rows of is_less_than(a_q, a_r, b_q, b_r) (src/indexed_merkle_tree.rs:98-125) for n pairs of 256-bit values:
+        (uint8 [rows, n, 32] or item-major [n, rows, 32], lt uint8 [n])"""
+        a, b = _arr(a, (32,)), _arr(b, (32,))
+        n = a.shape[0]
+        rows = lib.imt_less_than_trace_rows(lookup_bits)
+        out = np.empty((n, rows, 32) if item_major else (rows, n, 32), dtype=np.uint8)
+        lt = np.empty(n, dtype=np.uint8)
+        self._check(lib.imt_less_than_trace_batch(self.h, _p(a), _p(b), n, lookup_bits, _p(out), _p(lt),
+                                                  fmt | (_ffi.TRACE_ITEM_MAJOR if item_major else 0)))
+        return out, lt
+
+    def less_than_layout(self, lookup_bits=18, fmt=0):
+        """(cells, constants, out_row) of one is_less_than call (imt_less_than_trace_layout); inputs 0..3 = a_q, a_r, b_q, b_r"""
+        return trace_layout(lambda *a: lib.imt_less_than_trace_layout(self.h, *a), lookup_bits, fmt, self._check)
+
+    def insert_gadget_trace(self, low_leaf, low_index, low_sib, new_leaf, new_index, new_sib, is_largest, depth,
+                            lookup_bits=18, new_path_index=None, fmt=0, item_major=False):
+        """every new advice value of insert_leaf OUTSIDE its hashes for n insertions (imt_insert_gadget_trace_batch):
+        uint8 [rows, n, 32] or item-major [n, rows, 32] (siblings then item-major too)"""
+        ll = _arr(low_leaf, (3, 32))
+        n = ll.shape[0]
+        args = [ll, np.ascontiguousarray(low_index, dtype=np.uint64), _arr(low_sib, (32,)), _arr(new_leaf, (3, 32)),
+                np.ascontiguousarray(new_index, dtype=np.uint64),
+                None if new_path_index is None else np.ascontiguousarray(new_path_index, dtype=np.uint64),
+                _arr(new_sib, (32,)), np.ascontiguousarray(is_largest, dtype=np.uint8)]
+        rows = lib.imt_insert_gadget_rows(depth, lookup_bits)
+        if not rows:
+            raise ValueError("depth >= 1 and 1 <= lookup_bits <= 28")
+        out = np.empty((n, rows, 32) if item_major else (rows, n, 32), dtype=np.uint8)
+        self._check(lib.imt_insert_gadget_trace_batch(self.h, *[_p(a) for a in args], depth, lookup_bits, n, _p(out),
+                                                      fmt | (_ffi.TRACE_ITEM_MAJOR if item_major else 0)))
+        return out
+
     def hash_trace_layout(self, arity, fmt=0):
         """(cells, constants, out_row): the advice column of one hash, cell by cell (imt_hash_trace_layout).
         cells: structured array with fields kind (_ffi.CELL_*), gate, index; constants: uint8 [k, 32]."""
@@ -292,6 +327,20 @@ def trace_layout(call, arity, fmt, check):
     check(call(arity, cells.ctypes.data_as(ctypes.POINTER(_ffi.TraceCell)), nc.value, ctypes.byref(nc),
                consts.ctypes.data_as(ctypes.c_void_p), nk.value, ctypes.byref(nk), ctypes.byref(row), fmt))
     return cells, consts, row.value
+
+
+def insert_column_segments(depth, lookup_bits=18):
+    """[(kind, arity, first_row, n_rows)]: how the glue rows (kind 0, imt_insert_gadget_trace_batch) and the hash blocks
+    (kind 1, imt_insert_trace_batch) interleave in insert_leaf's advice column"""
+    n = ctypes.c_size_t()
+    rc = lib.imt_insert_column_segments(depth, lookup_bits, None, 0, ctypes.byref(n))
+    if rc:
+        raise ImtError(rc, "imt_insert_column_segments")
+    segs = (_ffi.ColumnSegment * n.value)()
+    rc = lib.imt_insert_column_segments(depth, lookup_bits, segs, n.value, ctypes.byref(n))
+    if rc:
+        raise ImtError(rc, "imt_insert_column_segments")
+    return [(s.kind, s.arity, s.first_row, s.n_rows) for s in segs]
 
 
 def rebuild_advice_column(cells, consts, inputs, trace_rows):

@@ -2,6 +2,7 @@
 // hashes, dense tree, path recompute, non-membership, insert witness, multi-GPU helpers).
 // Host code only; the kernels are in imt_kernels.hip and imt_prep.hip.
 #include "imt_ctx.hpp"
+#include "imt_gadget.hpp"
 #include <cstring>
 #include <new>
 
@@ -459,6 +460,141 @@ extern "C" int imt_insert_trace_batch(imt_ctx* c, const void* low_leaf, const ui
     for (int k = 0; k < 4; k++) path_trace_jobs(tj, pc.c[k].leaf3, pc.c[k].pairs, depth, n, row0, fmt);
     launch::hash_trace_jobs(c->stream, tj, fmt);
     return io.finish();
+}
+
+// ------------------------------------------------------------------------------------
+// f3: the advice values of insert_leaf outside hash_fix_len_array (imt_gadget.hip)
+// ------------------------------------------------------------------------------------
+static unsigned lt_limbs(unsigned lookup_bits) { return (128 + lookup_bits - 1) / lookup_bits + 1; }
+
+extern "C" size_t imt_less_than_trace_rows(unsigned lookup_bits) {
+    return (lookup_bits < 1 || lookup_bits > 28) ? 0 : 4 * (size_t)lt_limbs(lookup_bits) + 27;
+}
+extern "C" size_t imt_insert_gadget_rows(unsigned depth, unsigned lookup_bits) {
+    const size_t k = imt_less_than_trace_rows(lookup_bits);
+    return (k && depth >= 1 && depth <= IMT_MAX_DEPTH) ? 20 + 2 * k + 16 * (size_t)depth : 0;
+}
+
+extern "C" int imt_less_than_trace_batch(imt_ctx* c, const void* a, const void* b, size_t n, unsigned lookup_bits, void* trace,
+                                         uint8_t* lt_out, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    const size_t rows = imt_less_than_trace_rows(lookup_bits);
+    if (!rows) return c->fail(IMT_ERR_RANGE, "lookup_bits %u out of [1, 28]", lookup_bits);
+    if (n == 0) return IMT_OK;
+    if (!a || !b || !trace) return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    const uint8_t* d_a = io.in_fe(a, n * 32);
+    const uint8_t* d_b = io.in_fe(b, n * 32);
+    uint8_t* d_tr = io.out_fe(trace, n * rows * 32);
+    uint8_t* d_lt = io.out(lt_out, n);
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    if (fmt != IMT_FMT_CANONICAL && !io.rc) {          // the kernel works on canonical integers
+        uint8_t* ca = io.temp(n * 32);
+        uint8_t* cb = io.temp(n * 32);
+        if (io.rc) return io.rc;
+        launch::convert(c->stream, d_a, ca, n, fmt, IMT_FMT_CANONICAL, c->d_err);
+        launch::convert(c->stream, d_b, cb, n, fmt, IMT_FMT_CANONICAL, c->d_err);
+        d_a = ca;
+        d_b = cb;
+    } else if (!io.rc) {
+        // canonical inputs are still range-checked (>= p sets the context's error word: IMT_ERR_NONCANONICAL at the sync)
+        uint8_t* chk = io.temp(n * 32);
+        if (io.rc) return io.rc;
+        launch::convert(c->stream, d_a, chk, n, IMT_FMT_CANONICAL, IMT_FMT_DEVICE, c->d_err);
+        launch::convert(c->stream, d_b, chk, n, IMT_FMT_CANONICAL, IMT_FMT_DEVICE, c->d_err);
+    }
+    if (io.rc) return io.rc;
+    const bool item_major = flags & IMT_TRACE_ITEM_MAJOR;
+    launch::less_than_trace(c->stream, d_a, d_b, n, lookup_bits, d_tr, item_major ? 32 : n * 32, item_major ? rows * 32 : 32, d_lt);
+    if (fmt != IMT_FMT_CANONICAL) launch::convert(c->stream, d_tr, d_tr, n * rows, IMT_FMT_CANONICAL, fmt, c->d_err);
+    return io.finish();
+}
+
+extern "C" int imt_insert_gadget_trace_batch(imt_ctx* c, const void* low_leaf, const uint64_t* low_index, const void* low_sib,
+                                             const void* new_leaf, const uint64_t* new_index, const uint64_t* new_path_index,
+                                             const void* new_sib, const uint8_t* is_largest, unsigned depth,
+                                             unsigned lookup_bits, size_t n, void* trace, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    const size_t rows = imt_insert_gadget_rows(depth, lookup_bits);
+    if (!rows) return c->fail(IMT_ERR_RANGE, "depth %u out of [1, %d] or lookup_bits %u out of [1, 28]", depth, IMT_MAX_DEPTH, lookup_bits);
+    if (n == 0) return IMT_OK;
+    if (!low_leaf || !low_index || !new_leaf || !new_index || !trace || !low_sib || !new_sib || !is_largest)
+        return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    const uint8_t* d_ll = io.in_fe(low_leaf, n * 96);
+    const uint64_t* d_li = (const uint64_t*)io.in(low_index, n * 8);
+    const uint8_t* d_ls = io.in_fe(low_sib, (size_t)depth * n * 32);
+    const uint8_t* d_nl = io.in_fe(new_leaf, n * 96);
+    const uint64_t* d_ni = (const uint64_t*)io.in(new_index, n * 8);
+    const uint64_t* d_np = new_path_index ? (const uint64_t*)io.in(new_path_index, n * 8) : d_ni;
+    const uint8_t* d_ns = io.in_fe(new_sib, (size_t)depth * n * 32);
+    const uint8_t* d_lg = io.in(is_largest, n);
+    uint8_t* d_tr = io.out_fe(trace, n * rows * 32);
+    const size_t ps = (size_t)depth * n * 64;
+    uint8_t* pairs = io.temp(4 * ps);
+    uint8_t* tmp3 = io.temp(n * 96);      // the rewritten low leaf {low.val, new.val, new_index}   :265-269
+    uint8_t* tmpz = io.temp(n * 32);      // the zero-leaf hash per item                            :247-251
+    uint8_t* cll = io.temp(n * 96);
+    uint8_t* cnl = io.temp(n * 96);
+    if (io.rc) return io.rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    // the same path walk as imt_insert_trace_batch: the (left, right) inputs of every path hash of the four chains
+    launch::insert_trace_inputs(c->stream, d_ll, d_nl, d_ni, n, tmp3, tmpz, fmt, c->d_err);
+    launch::PathChains pc{};
+    pc.c[0] = {nullptr, d_ll, d_li, d_ls, pairs, nullptr};
+    pc.c[1] = {nullptr, tmp3, d_li, d_ls, pairs + ps, nullptr};
+    pc.c[2] = {tmpz, nullptr, d_np, d_ns, pairs + 2 * ps, nullptr};
+    pc.c[3] = {nullptr, d_nl, d_np, d_ns, pairs + 3 * ps, nullptr};
+    pc.n_chains = 4;
+    pc.lay = sib_layout(flags, depth, n);
+    pc.depth = depth; pc.n = n; pc.fmt_in = fmt; pc.fmt_out = fmt; pc.err = c->d_err;
+    launch::path_pairs(c->stream, pc, c->coop_max_events);
+    // the glue kernel works on canonical integers
+    launch::convert(c->stream, pairs, pairs, 4 * (size_t)depth * n * 2, IMT_FMT_DEVICE, IMT_FMT_CANONICAL, c->d_err);
+    launch::convert(c->stream, d_ll, cll, n * 3, fmt, IMT_FMT_CANONICAL, c->d_err);
+    launch::convert(c->stream, d_nl, cnl, n * 3, fmt, IMT_FMT_CANONICAL, c->d_err);
+    const bool item_major = flags & IMT_TRACE_ITEM_MAJOR;
+    launch::insert_gadget(c->stream, cll, d_li, cnl, d_np, d_lg, pairs, depth, lookup_bits, n, d_tr, item_major ? 32 : n * 32,
+                          item_major ? rows * 32 : 32);
+    if (fmt != IMT_FMT_CANONICAL) launch::convert(c->stream, d_tr, d_tr, n * rows, IMT_FMT_CANONICAL, fmt, c->d_err);
+    return io.finish();
+}
+
+// how the glue rows and the hash blocks (imt_insert_trace_batch's order) interleave in insert_leaf's advice column
+extern "C" int imt_insert_column_segments(unsigned depth, unsigned lookup_bits, imt_column_segment* segs, size_t cap, size_t* n_segs) {
+    const size_t k = imt_less_than_trace_rows(lookup_bits);
+    if (!k || depth < 1 || depth > IMT_MAX_DEPTH) return IMT_ERR_RANGE;
+    std::vector<imt_column_segment> v;
+    uint64_t glue = 0, hash = 0;
+    auto G = [&](uint64_t rows) {
+        if (!v.empty() && v.back().kind == IMT_SEG_GLUE) v.back().n_rows += rows;
+        else v.push_back(imt_column_segment{IMT_SEG_GLUE, 0, glue, rows});
+        glue += rows;
+    };
+    auto H = [&](unsigned arity) {
+        const uint64_t rows = imt_hash_trace_rows((int)arity);
+        v.push_back(imt_column_segment{IMT_SEG_HASH, arity, hash, rows});
+        hash += rows;
+    };
+    auto chain = [&]() {
+        G(1);                                  // load_witness(leaf) :88
+        for (unsigned l = 0; l < depth; l++) { G(4); H(2); }      // dual_mux, hash :90-93
+    };
+    G(4 + 4 + 2 + k + 3);                      // verify_non_inclusion up to the select :143-191
+    H(3); chain();                             // low leaf hash + verify_merkle_proof :193-204
+    G(3 + k);                                  // :206-228
+    H(3); chain();                             // rewritten low leaf + interim root :271-284
+    chain();                                   // zero leaf in the interim root :286-294
+    H(3); chain();                             // new leaf + new root :299-312
+    if (n_segs) *n_segs = v.size();
+    if (glue != imt_insert_gadget_rows(depth, lookup_bits) || hash != imt_insert_trace_rows(depth)) return IMT_ERR_INTERNAL;
+    if (segs) {
+        if (cap < v.size()) return IMT_ERR_RANGE;
+        std::memcpy(segs, v.data(), v.size() * sizeof(imt_column_segment));
+    }
+    return IMT_OK;
 }
 
 // ------------------------------------------------------------------------------------

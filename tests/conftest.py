@@ -33,7 +33,7 @@ def emul():
     so = os.path.join(ROOT, "tests", "native", "libemul.so")
     csrc = os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc")
     srcs = [os.path.join(ROOT, "tests", "native", "emul_device.cpp"), os.path.join(csrc, "imt_params.cpp"),
-            os.path.join(csrc, "imt_trace_layout.cpp")]
+            os.path.join(csrc, "imt_trace_layout.cpp"), os.path.join(csrc, "imt_gadget_layout.cpp")]
     deps = srcs + [os.path.join(csrc, f) for f in ("imt_device.hpp", "imt_consts.hpp", "imt_sweep.hpp",
                                                     "imt_params.hpp", "imt_fr_host.hpp", "imt_prep_logic.hpp",
                                                     "imt_trace_device.hpp", "imt_ctx.hpp")] + [

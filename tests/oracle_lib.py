@@ -89,6 +89,45 @@ class Oracle:
                     region=d["region"].copy(),
                     witness=wit[:nw.value].copy(), out_row=row.value)
 
+    # ---- f3: the cells of insert_leaf outside its hashes (oracle/gadget.c) ----
+    def less_than_trace(self, a, b, lookup_bits=18):
+        """the column of ONE is_less_than(a_q, a_r, b_q, b_r) (src/indexed_merkle_tree.rs:98-125): same dict as hash_trace"""
+        cap, wcap = 1200, 400
+        cells = np.empty((cap, 32), np.uint8)
+        desc = (TraceCell * cap)()
+        wit = np.empty((wcap, 32), np.uint8)
+        nc, nw, row = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_uint32()
+        rc = self.lib.orc_less_than_trace(b32(a), b32(b), ctypes.c_uint(lookup_bits), cells.ctypes.data_as(ctypes.c_void_p), desc,
+                                          ctypes.c_size_t(cap), ctypes.byref(nc), wit.ctypes.data_as(ctypes.c_void_p),
+                                          ctypes.c_size_t(wcap), ctypes.byref(nw), ctypes.byref(row))
+        assert rc == 0, rc
+        d = np.frombuffer(bytes(desc), dtype=np.dtype([("kind", "u1"), ("gate", "u1"), ("region", "<u2"), ("index", "<u4")]))
+        d = d[:nc.value]
+        assert nw.value == self.lib.orc_less_than_trace_rows(ctypes.c_uint(lookup_bits))
+        return dict(cells=cells[:nc.value].copy(), kind=d["kind"].copy(), gate=d["gate"].copy(), index=d["index"].copy(),
+                    region=d["region"].copy(), witness=wit[:nw.value].copy(), out_row=row.value)
+
+    def insert_gadget_trace(self, low_leaf3, low_index, low_proof, new_leaf3, new_index, new_proof, largest, depth,
+                            lookup_bits=18, new_path_index=None):
+        """(glue rows uint8 [g, 32], segments [(kind, arity, first_row, n_rows)]) of one insert_leaf (:231-314)"""
+        self.lib.orc_insert_gadget_rows.restype = ctypes.c_size_t
+        g = self.lib.orc_insert_gadget_rows(ctypes.c_size_t(depth), ctypes.c_uint(lookup_bits))
+        wit = np.empty((g, 32), np.uint8)
+        segs = np.zeros(8 * depth + 16, dtype=np.dtype([("kind", "<u4"), ("arity", "<u4"), ("first_row", "<u8"), ("n_rows", "<u8")]))
+        nw, ns = ctypes.c_size_t(), ctypes.c_size_t()
+        lp = np.ascontiguousarray(low_proof, dtype=np.uint8)
+        npf = np.ascontiguousarray(new_proof, dtype=np.uint8)
+        rc = self.lib.orc_insert_gadget_trace(b"".join(b32(x) for x in low_leaf3), ctypes.c_uint64(low_index),
+                                              lp.ctypes.data_as(ctypes.c_void_p), b"".join(b32(x) for x in new_leaf3),
+                                              ctypes.c_uint64(new_index),
+                                              ctypes.c_uint64(new_index if new_path_index is None else new_path_index),
+                                              npf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(1 if largest else 0),
+                                              ctypes.c_size_t(depth), ctypes.c_uint(lookup_bits),
+                                              wit.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(g), ctypes.byref(nw),
+                                              segs.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(segs)), ctypes.byref(ns))
+        assert rc == 0 and nw.value == g, (rc, nw.value, g)
+        return wit, [tuple(int(x) for x in s_) for s_ in segs[:ns.value]]
+
     # ---- dense tree (src/utils.rs) ----
     def tree_new(self, leaves_arr):
         leaves_arr = np.ascontiguousarray(leaves_arr, dtype=np.uint8)
@@ -225,6 +264,88 @@ def arr_ints(a):
     return [int.from_bytes(x.tobytes(), "little") for x in np.asarray(a, dtype=np.uint8).reshape(-1, 32)]
 
 
+def less_than_rows_model(a, b, lookup_bits=18):
+    """Test-side restatement of the NEW witnesses of is_less_than(a_q, a_r, b_q, b_r) (src/indexed_merkle_tree.rs:98-125)
+    with Python integers, written from the gadget descriptions in oracle/gadget.c's header and independent of its code:
+    per limb pair range.is_less_than (shifted difference, shifted a, the limbs of the range check with their running
+    sums, is_zero of the top limb), gate.is_equal (difference, is_zero), then not x4, and x3, and, or."""
+    k = -(-128 // lookup_bits)
+    padded, L = k * lookup_bits, k + 1
+    inv = lambda x: pow(x, P - 2, P) if x % P else 1
+
+    def is_zero(x):
+        z = 1 if x % P == 0 else 0
+        return [z, inv(x), z], z
+
+    def range_lt(x, y):
+        sab, sa = (1 << padded) + x - y, (1 << padded) + x
+        rows, acc, limbs = [sab, sa], 0, []
+        for i in range(L):
+            limb = (sab >> (lookup_bits * i)) & ((1 << lookup_bits) - 1)
+            limbs.append(limb)
+            acc += limb << (lookup_bits * i)
+            rows += [limb] if i == 0 else [limb, acc]
+        assert acc == sab
+        zr, z = is_zero(limbs[-1])
+        return rows + zr, z
+
+    def is_equal(x, y):
+        d = (x - y) % P
+        zr, z = is_zero(d)
+        return [d] + zr, z
+
+    a_q, a_r, b_q, b_r = a >> 128, a & ((1 << 128) - 1), b >> 128, b & ((1 << 128) - 1)
+    rows = []
+    r, msb_lt = range_lt(a_q, b_q); rows += r
+    r, msb_eq = is_equal(a_q, b_q); rows += r
+    r, lsb_lt = range_lt(a_r, b_r); rows += r
+    r, lsb_eq = is_equal(a_r, b_r); rows += r
+    c_not, a_not = 1 - msb_eq, 1 - msb_lt
+    c, d_not = 1 - c_not, 1 - lsb_eq
+    rows += [c_not, a_not, c, d_not]
+    t1 = a_not * lsb_lt; t2 = t1 * c; rhs = t2 * d_not
+    lhs = msb_lt * c_not
+    rows += [t1, t2, rhs, lhs]
+    out = lhs + rhs - lhs * rhs
+    rows += [1 - rhs, 1 - rhs, out]
+    assert out == (1 if a < b else 0)
+    return [x % P for x in rows], out
+
+
+def insert_gadget_rows_model(orc, low_leaf3, low_index, low_proof, new_leaf3, new_index, new_proof, largest, depth,
+                             lookup_bits=18, new_path_index=None):
+    """Test-side restatement of the glue rows of insert_leaf (:231-314), Python integers + the oracle's HASH only."""
+    new_path_index = new_index if new_path_index is None else new_path_index
+    inv = lambda x: pow(x, P - 2, P) if x % P else 1
+    M = (1 << 128) - 1
+    low_val, low_next, _ = low_leaf3
+    nv = new_leaf3[0]
+    iz = 1 if low_next == 0 else 0
+    rows = [low_next % P, iz, inv(low_next), iz, nv >> 128, nv & M, low_next >> 128, low_next & M, nv, low_next]
+    r, lt = less_than_rows_model(nv, low_next, lookup_bits)
+    rows += r
+    s = 1 if largest else 0
+    rows += [iz * s, 1 - s, (1 - s) * lt + iz * s]
+
+    def chain(leaf, index, proof):
+        out = [leaf]
+        cur = leaf
+        for l, sib in enumerate(arr_ints(proof)[:depth]):
+            sw = ((index >> l) & 1) ^ 1
+            left, right = (cur, sib) if sw else (sib, cur)
+            out += [(cur - sib) % P, (sib - cur) % P, left, right]
+            cur = orc.hash([left, right])
+        return out
+    rows += chain(orc.hash(low_leaf3), low_index, low_proof)
+    rows += [low_val >> 128, low_val & M, low_val]
+    r, _ = less_than_rows_model(low_val, nv, lookup_bits)
+    rows += r
+    rows += chain(orc.hash([low_val, nv, new_index]), low_index, low_proof)
+    rows += chain(orc.hash([0, 0, 0]), new_path_index, new_proof)
+    rows += chain(orc.hash(new_leaf3), new_path_index, new_proof)
+    return rows
+
+
 def path_trace(orc, start, leaf3, index, proof, depth):
     """The witness rows of every hash_fix_len_array call of one compute_merkle_root
     (/root/reference/src/indexed_merkle_tree.rs:78-96), in call order: the 3-input leaf hash first when `leaf3` is given
@@ -268,8 +389,8 @@ def load():
     if _cached is not None:
         return _cached
     so = os.path.join(ODIR, "liboracle.so")
-    srcs = [os.path.join(ODIR, f) for f in ("fr.c", "poseidon.c", "tree.c", "indexed.c", "sparse.c", "trace.c",
-                                            "imt_oracle.h")]
+    srcs = [os.path.join(ODIR, f) for f in ("fr.c", "poseidon.c", "tree.c", "indexed.c", "sparse.c", "trace.c", "gadget.c",
+                                            "column.h", "imt_oracle.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         r = subprocess.run(["make", "-C", ODIR, "liboracle.so"], capture_output=True, text=True)
         if r.returncode != 0:

@@ -1,0 +1,144 @@
+"""GPU (MI355X): f3 -- imt_less_than_trace_batch / imt_insert_gadget_trace_batch / imt_insert_column_segments against the
+CPU oracle (oracle/gadget.c) and the committed digests: every new advice value the reference's insert_leaf
+(/root/reference/src/indexed_merkle_tree.rs:231-314) assigns OUTSIDE hash_fix_len_array, in assignment order.  Together
+with the f1 traces (imt_insert_trace_batch) that is the whole advice column: the last test walks the segment table and
+checks that the two traces cover it.  ORDER UNPINNED BY THE REFERENCE (halo2-base is un-vendored), like f1."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib  # noqa: E402
+from oracle_lib import P  # noqa: E402
+from test_gadget_cpu import EDGE  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+R256 = (1 << 256) % P
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "gadget_digest.json")))
+
+
+@pytest.mark.parametrize("lookup_bits", [18, 8])
+def test_less_than_trace_vs_oracle_formats_and_layouts(imt, ctx, oracle, lookup_bits):
+    import random
+    rng = random.Random(31 + lookup_bits)
+    pairs = EDGE + [(rng.randrange(P), rng.randrange(P)) for _ in range(200)]
+    pairs += [((q << 128) + rng.randrange(1 << 128), (q << 128) + rng.randrange(1 << 128)) for q in [rng.randrange(1 << 125) for _ in range(60)]]
+    pairs += [(x, x) for x in (rng.randrange(P) for _ in range(20))]
+    a, b = imt.to_bytes([p[0] for p in pairs]), imt.to_bytes([p[1] for p in pairs])
+    want = np.stack([oracle.less_than_trace(x, y, lookup_bits)["witness"] for x, y in pairs], axis=1)     # [rows, n, 32]
+    got, lt = ctx.less_than_trace(a, b, lookup_bits)
+    assert got.shape == want.shape and (got == want).all()
+    assert list(lt) == [1 if x < y else 0 for x, y in pairs]
+    got_im, _ = ctx.less_than_trace(a, b, lookup_bits, item_major=True)
+    assert (got_im == want.transpose(1, 0, 2)).all()
+    F = imt._ffi
+    am, bm = imt.to_bytes([x * R256 % P for x, _ in pairs]), imt.to_bytes([y * R256 % P for _, y in pairs])
+    got_m, lt_m = ctx.less_than_trace(am, bm, lookup_bits, fmt=F.FMT_MONT256)
+    assert oracle_lib.arr_ints(got_m) == [v * R256 % P for v in oracle_lib.arr_ints(want)] and (lt_m == lt).all()
+    # the layout the library reports rebuilds a column whose every gate holds (the chip's view of one comparison)
+    cells, consts, out_row = ctx.less_than_layout(lookup_bits)
+    for j in (0, 3, len(EDGE) + 5, len(pairs) - 1):
+        x, y = pairs[j]
+        col = imt.rebuild_advice_column(cells, consts, [x >> 128, x & ((1 << 128) - 1), y >> 128, y & ((1 << 128) - 1)], got[:, j])
+        assert imt.check_vertical_gates(cells, col) == int(cells["gate"].sum())
+        assert oracle_lib.arr_ints(got[out_row, j])[0] == (1 if x < y else 0)
+    if lookup_bits == GOLD["lookup_bits"]:
+        for g in GOLD["less_than"]:
+            r, _ = ctx.less_than_trace(imt.to_bytes([int(g["a"])]), imt.to_bytes([int(g["b"])]), lookup_bits)
+            assert hashlib.sha256(np.ascontiguousarray(r[:, 0]).tobytes()).hexdigest() == g["sha256_rows"]
+
+
+def test_less_than_trace_refuses_bad_arguments(imt, ctx):
+    F, lib = imt._ffi, imt.lib
+    big = np.frombuffer(P.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32).copy()
+    one = imt.to_bytes([1])
+    with pytest.raises(imt.ImtError) as e:
+        ctx.less_than_trace(big, one)
+    assert e.value.code == F.ERR["NONCANONICAL"]
+    with pytest.raises(imt.ImtError) as e:
+        ctx.less_than_trace(one, one, lookup_bits=29)
+    assert e.value.code == F.ERR["RANGE"]
+    assert lib.imt_less_than_trace_rows(0) == 0 and lib.imt_less_than_trace_rows(18) == 63
+    assert lib.imt_insert_gadget_rows(0, 18) == 0 and lib.imt_insert_gadget_rows(32, 18) == 658
+
+
+def _real_insertions(imt, ctx, depth, vals):
+    t = imt.IndexedTree(ctx, depth, 1 << min(depth, 10))
+    res = t.insert_batch(vals)
+    t.close()
+    return res
+
+
+@pytest.mark.parametrize("depth,vals", [(3, [30, 10, 20, 5, 50, 35]), (32, None)])
+def test_insert_gadget_trace_vs_oracle(imt, ctx, oracle, depth, vals):
+    vals = vals or oracle_lib.synth_values(40, 0x494D54B2)
+    res = _real_insertions(imt, ctx, depth, vals)
+    n = len(vals)
+    got = ctx.insert_gadget_trace(res["low_leaf"], res["low_index"], res["low_sib"], res["new_leaf"], res["new_index"],
+                                  res["new_sib"], res["is_largest"], depth)
+    K = 63
+    assert got.shape == (20 + 2 * K + 16 * depth, n, 32)
+    want_segs = None
+    for i in range(n):
+        low3, new3 = oracle_lib.arr_ints(res["low_leaf"][i]), oracle_lib.arr_ints(res["new_leaf"][i])
+        want, segs = oracle.insert_gadget_trace(low3, int(res["low_index"][i]), res["low_sib"][:, i], new3, int(res["new_index"][i]),
+                                                res["new_sib"][:, i], int(res["is_largest"][i]), depth)
+        assert (got[:, i] == want).all(), i
+        want_segs = segs
+    assert imt.insert_column_segments(depth) == want_segs
+    key = "depth3_reference_sequence" if depth == 3 else "depth32_seed_0x494D54B2"
+    for i, d in enumerate(GOLD["insert"][key]):
+        assert hashlib.sha256(np.ascontiguousarray(got[:, i]).tobytes()).hexdigest() == d
+    # halo2curves' in-memory form, item-major (siblings item-major too): what a Rust chip reads per insertion
+    F = imt._ffi
+    mont = lambda x: imt.to_bytes([v * R256 % P for v in oracle_lib.arr_ints(x)]).reshape(np.asarray(x).shape)
+    ls_im = np.ascontiguousarray(np.asarray(res["low_sib"]).transpose(1, 0, 2))
+    ns_im = np.ascontiguousarray(np.asarray(res["new_sib"]).transpose(1, 0, 2))
+    got_m = ctx.insert_gadget_trace(mont(res["low_leaf"]), res["low_index"], mont(ls_im), mont(res["new_leaf"]), res["new_index"],
+                                    mont(ns_im), res["is_largest"], depth, fmt=F.FMT_MONT256, item_major=True)
+    assert got_m.shape == (n, got.shape[0], 32)
+    assert oracle_lib.arr_ints(got_m[3]) == [v * R256 % P for v in oracle_lib.arr_ints(got[:, 3])]
+    assert oracle_lib.arr_ints(got_m[n - 1]) == [v * R256 % P for v in oracle_lib.arr_ints(got[:, n - 1])]
+
+
+def test_the_two_traces_cover_the_whole_advice_column_of_insert_leaf(imt, ctx, oracle):
+    """insert_leaf at depth 32: walking imt_insert_column_segments, the glue rows (f3) and the hash blocks (f1) alternate,
+    each hash block's inputs are what the glue rows before it say (the leaf preimage, or dual_mux's left / right), its
+    output is the next path's current node, and the last block's output is the new root -- i.e. the two GPU traces
+    together are every new advice value of the call, in order, with no host arithmetic in between."""
+    depth = 32
+    vals = oracle_lib.synth_values(3, 0x494D54B3)
+    res = _real_insertions(imt, ctx, depth, vals)
+    glue = ctx.insert_gadget_trace(res["low_leaf"], res["low_index"], res["low_sib"], res["new_leaf"], res["new_index"],
+                                   res["new_sib"], res["is_largest"], depth)
+    hashes = ctx.insert_trace(res["low_leaf"], res["low_index"], res["low_sib"], res["new_leaf"], res["new_index"], res["new_sib"], depth)
+    segs = imt.insert_column_segments(depth)
+    assert sum(s[3] for s in segs if s[0] == 0) == glue.shape[0] and sum(s[3] for s in segs if s[0] == 1) == hashes.shape[0]
+    i = 2
+    g = oracle_lib.arr_ints(glue[:, i])
+    out_row = {2: 1208 - 4, 3: 1209 - 4}
+    roots, prev_out, last_glue = [], None, None
+    for kind, arity, first, rows in segs:
+        if kind == 0:
+            last_glue = g[first:first + rows]
+            left, right = last_glue[-2], last_glue[-1]
+            if rows == 4:                                         # a path continues: dual_mux of (previous hash, sibling)
+                assert prev_out in (left, right)
+            elif rows == 5:                                       # a path starts: load_witness(leaf), then dual_mux
+                assert last_glue[0] in (left, right)
+                assert last_glue[0] in (prev_out, oracle.hash([0, 0, 0]))      # the leaf hash just computed, or the zero leaf
+        else:
+            block = oracle_lib.arr_ints(hashes[first:first + rows, i])
+            out = block[out_row[arity]]
+            if arity == 2:
+                assert oracle.hash(last_glue[-2:]) == out          # hashed exactly dual_mux's (left, right)
+            prev_out = out
+            roots.append(out)
+    assert roots[-1] == imt.to_int(res["new_root"][i])             # :313
+    assert roots[1 + depth - 1] == imt.to_int(res["old_root"][i])  # the low leaf's path ends in the old root :196-204
