@@ -544,7 +544,7 @@ def bench_single_list(env):
                          "rounds_in_flight": i1["rounds_in_flight"], "payload_bytes": i1["payload_bytes"],
                          "driver": "libimt_hip.so (imt_sliced_step: schedule, streams, events and the collective behind the C ABI)",
                          "transport": kind, "rccl": rccl_lib},
-            "ctx": ctx, "be": tree}
+            "ctx": ctx, "be": tree, "boot": boot}       # boot: the context the transport was made on, alive until it is destroyed
 
 
 def mode_summary(r, world):
@@ -715,6 +715,7 @@ def main():
         dist.barrier()              # nobody closes the buffers it exports while a peer may still read them
     if "single-list" in legs:
         legs["single-list"]["be"].close()
+        legs["single-list"]["boot"].close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -512,7 +512,7 @@ size_t imt_transport_ipc_blob_bytes(void);
 int imt_transport_ipc_create(imt_ctx *ctx, int world, int rank, unsigned depth, size_t max_slice, int lag,
                              imt_transport **out, void *blob_out);
 int imt_transport_ipc_connect(imt_transport *tp, const void *all_blobs /*[world][blob_bytes]*/);
-void imt_transport_destroy(imt_transport *tp);   /* after every imt_sliced that uses it */
+void imt_transport_destroy(imt_transport *tp);   /* after every imt_sliced that uses it, and before the imt_ctx it was created on */
 const char *imt_transport_last_error(const imt_transport *tp);
 
 /* trees[k] = the replica of rank first_rank + k (each on its own context; empty or with the same contents on every rank;

@@ -20,7 +20,8 @@ def local_transport(imt):
 
 
 def rccl_transport(imt, ctx, dist, world, rank, n_comms=4, device=None):
-    """ncclAllGather inside the library on its own communicators; torch.distributed only carries the unique ids"""
+    """ncclAllGather inside the library on its own communicators; torch.distributed only carries the unique ids.
+    `ctx` must stay alive until the transport has been destroyed (imt.h)."""
     ids = torch.zeros(n_comms * imt._ffi.RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8)
     if rank == 0:
         for i in range(n_comms):
@@ -35,7 +36,8 @@ def rccl_transport(imt, ctx, dist, world, rank, n_comms=4, device=None):
 
 
 def ipc_transport(imt, ctx, dist, world, rank, depth, batch, lag=None, device=None):
-    """direct peer copies between the processes of one node (HIP IPC handles); torch.distributed carries the handle blobs"""
+    """direct peer copies between the processes of one node (HIP IPC handles); torch.distributed carries the handle blobs.
+    `ctx` must stay alive until the transport has been destroyed (imt.h)."""
     nb = int(imt.lib.imt_transport_ipc_blob_bytes())
     mine = torch.zeros(nb, dtype=torch.uint8)
     h = ctypes.c_void_p()

@@ -18,6 +18,7 @@ SKIP = {"imt_ctx_create"}                 # takes no handle; covered by test_no_
 # generic loop would hand them a context as scratch memory; they get their own hostile calls below
 SLICED = {n for n in _ffi.SIGNATURES if n.startswith(("imt_transport_", "imt_sliced_", "imt_rccl_"))}
 SKIP |= SLICED
+SKIP.add("imt_insert_column_segments")    # no handle at all: (depth, lookup_bits, ...)
 
 
 def handle_for(name):
@@ -95,6 +96,8 @@ calls = [
     ("imt_sliced_create", (None, 1, 1, 0, None, 8, 0, None)), ("imt_sliced_create", ((vp * 1)(itree.h), 1, 1, 0, None, 8, 0, ctypes.byref(vp()))),
     ("imt_sliced_step", (None, None, 1, None, 0, None)), ("imt_sliced_wait", (None, 0, 0)), ("imt_sliced_flush", (None,)),
     ("imt_sliced_get_info", (None, None)),
+    ("imt_insert_column_segments", (0, 18, None, 0, None)), ("imt_insert_column_segments", (32, 0, None, 0, None)),
+    ("imt_insert_column_segments", (32, 18, (_ffi.ColumnSegment * 2)(), 2, None)),       # too small a table
 ]
 for k, (name, args) in enumerate(calls):
     print(f"CALL {name} hostile-{k}", flush=True)
