@@ -52,50 +52,15 @@ using namespace dev;
 constexpr int BLOCK = IMT_BLOCK;   // 256 = 4 waves = one per SIMD of a CU
 
 __device__ __forceinline__ size_t gtid() { return (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
+// the same, recomputed where it is called: behind a loop of inlined hashes the item number costs three instructions to
+// rebuild but two registers (and every address the compiler would hoist from it) to keep across the loop
+__device__ __forceinline__ size_t gtid_again() {
+    uint32_t lo = blockIdx.x * blockDim.x + threadIdx.x, hi = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return ((size_t)hi << 32) | lo;
+}
 __device__ __forceinline__ void flag_err(int* err, bool ok) {
     if (!ok && err) atomicOr(err, 1);
-}
-
-// ONE copy of the hash in the code object, shared by every kernel.  Inlined per kernel, the 47 KB
-// permutation body exists once per kernel; when two different hash kernels of consecutive batches
-// share a CU (IMT_PIPELINE) they then evict each other from the 64 KB instruction cache.  A called
-// function is the same instructions for all of them.  g_pc is referenced directly so that the
-// constant loads stay scalar (function arguments would be treated as divergent).
-//
-// Arguments: the first input travels in registers; the second (and third) go through a per-thread slot
-// in LDS, [limb][thread] so that a wave's accesses hit 64 different banks.  Passed as further struct
-// arguments they went through 36 B of the caller's scratch each -- HBM-backed stack traffic that the
-// PMC pass of round 1 showed as 4.6 MB of the 13.3 MB a k_sweep_level launch writes; passed as
-// vectors they stay in registers but the function then saves 19-35 callee-saved VGPRs per call.
-// LDS is otherwise unused by these kernels; 2 x 9 x 256 x 4 B = 18 KB per block.
-__shared__ uint32_t s_hash_arg[2][NL][IMT_BLOCK];
-
-template <bool THREE>
-__device__ __noinline__ Fe hash_shared(Fe a) {
-    Fe b, c, o;
-    const unsigned t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < NL; i++) b.v[i] = s_hash_arg[0][i][t];
-    if (THREE) {
-#pragma unroll
-        for (int i = 0; i < NL; i++) c.v[i] = s_hash_arg[1][i][t];
-    } else {
-        c = a;
-    }
-    hash23(g_pc, o, a, b, c, THREE);
-    return o;
-}
-__device__ __forceinline__ void hash_call(Fe& o, const Fe& a, const Fe& b, const Fe& c, bool three) {
-    const unsigned t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < NL; i++) s_hash_arg[0][i][t] = b.v[i];
-    if (three) {
-#pragma unroll
-        for (int i = 0; i < NL; i++) s_hash_arg[1][i][t] = c.v[i];
-        o = hash_shared<true>(a);
-    } else {
-        o = hash_shared<false>(a);
-    }
 }
 
 // integer value (not Montgomery) of a device-form element, canonical limbs
@@ -123,33 +88,67 @@ __device__ __forceinline__ void fe_from_u64(Fe& r, uint64_t x) {
 }
 
 // ---------------------------------------------------------------------------------
-// One hash chain: `depth` 2-input hashes up the tree from `cur` (callers hash a 3-input leaf first, so
-// that nothing but `cur` and the index is live across the calls of the loop).
-//   right child at level l  <=>  bit l of idx is 1  (src/utils.rs:93-101)
+// One hash chain with the hash INLINED, exactly once per kernel (round 4; what k_sweep got in round 2): one loop whose
+// iteration -1 is the 3-input leaf hash (when `with_leaf`, wave-uniform) and whose iterations 0 .. depth-1 climb the
+// path -- right child at level l <=> bit l of idx is 1 (src/utils.rs:93-101).  No call, hence no call ABI: rounds 1-3
+// had ONE shared, non-inlined hash function for these kernels (so that different hash kernels of consecutive batches
+// would not evict each other's 47 KB from the 64 KB instruction cache -- k_sweep is one kernel for that reason); its
+// callers kept 1-3 VGPRs spilled and 80-156 B of scratch per thread (the callee owns the registers;
+// profiles/r03_kernel_resources.txt), 0 / 0 now.  The third input of
+// the leaf hash waits in LDS for the second permutation (hash23_stashed); `on_level` sees the (left, right) pair of
+// every level before it is hashed (k_path_pairs stores it).  These kernels run alone on the chip (a batch of paths, a
+// tree level), so a private copy of the 47 KB hash body per kernel costs no instruction-cache sharing.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void hash_chain(Fe& cur, uint64_t idx, const uint8_t* sib, launch::SibLayout lay, size_t item,
-                                           unsigned depth, unsigned fmt_in, bool& ok) {
+struct NoLevelHook {
+    __device__ __forceinline__ void operator()(unsigned, const Fe&, const Fe&) const {}
+};
+struct NoLeafHook {
+    __device__ __forceinline__ void operator()(const Fe&) const {}
+};
+// `index` / `flip`: bit l of index[item] ^ flip = the node is a right child at level l.  The index word is re-read and
+// the item number rebuilt (gtid_again) inside every iteration on purpose: a cached 8-byte load and three scalar-ish
+// instructions per hash instead of four registers live across it.
+template <class LoadLeaf, class OnLeaf = NoLeafHook, class OnLevel = NoLevelHook>
+__device__ __forceinline__ void chain_inline(Fe& cur, bool with_leaf, LoadLeaf load_leaf, OnLeaf on_leaf,
+                                             const uint64_t* __restrict__ index, uint64_t flip, const uint8_t* sib,
+                                             launch::SibLayout lay, unsigned depth, unsigned fmt_in, bool& ok, uint32_t* stash,
+                                             OnLevel on_level = OnLevel()) {
 #pragma unroll 1
-    for (unsigned it = 0; it < depth; it++) {
-        Fe a, b, sv;
-        ok &= load_fe(g_pc, sv, sib + ((uint64_t)it * lay.level_stride + item * lay.item_stride) * 32, fmt_in);
-        const bool right = (idx >> it) & 1;
+    for (int it = with_leaf ? -1 : 0; it < (int)depth; it++) {
+        Fe A, B;
+        const bool three = it < 0;
+        if (three) {
+            Fe C;
+            load_leaf(A, B, C, ok);
 #pragma unroll
-        for (int i = 0; i < NL; i++) {
-            a.v[i] = right ? sv.v[i] : cur.v[i];
-            b.v[i] = right ? cur.v[i] : sv.v[i];
+            for (int i = 0; i < NL; i++) stash[(size_t)i * BLOCK] = C.v[i];
+        } else {
+            const size_t item = gtid_again();
+            Fe sv;
+            ok &= load_fe(g_pc, sv, sib + ((uint64_t)it * lay.level_stride + item * lay.item_stride) * 32, fmt_in);
+            const bool right = ((index[item] ^ flip) >> it) & 1;
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                A.v[i] = right ? sv.v[i] : cur.v[i];
+                B.v[i] = right ? cur.v[i] : sv.v[i];
+            }
+            on_level((unsigned)it, A, B);
         }
-        hash_call(cur, a, b, a, false);
+        hash23_stashed(g_pc, cur, A, B, three, stash, BLOCK);
+        if (three) on_leaf(cur);
     }
 }
-// H(val, next_val, next_idx) of a leaf preimage at `p` ([3][32], fmt_in)
-__device__ __forceinline__ void leaf_hash(Fe& out, const uint8_t* p, unsigned fmt_in, bool& ok) {
-    Fe a, b, c;
-    ok &= load_fe(g_pc, a, p, fmt_in);
-    ok &= load_fe(g_pc, b, p + 32, fmt_in);
-    ok &= load_fe(g_pc, c, p + 64, fmt_in);
-    hash_call(out, a, b, c, true);
-}
+// the leaf preimage at p ([3][32], fmt_in) as the three inputs
+struct LeafAt {
+    const uint8_t* base;     // [n][3][32]
+    unsigned fmt_in;
+    __device__ __forceinline__ void operator()(Fe& a, Fe& b, Fe& c, bool& ok) const {
+        const uint8_t* p = base + gtid_again() * 96;
+        ok &= load_fe(g_pc, a, p, fmt_in);
+        ok &= load_fe(g_pc, b, p + 32, fmt_in);
+        ok &= load_fe(g_pc, c, p + 64, fmt_in);
+    }
+};
 
 // ---- a1 / a10 --------------------------------------------------------------------
 __global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_hash_batch(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
@@ -158,12 +157,17 @@ __global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_hash_batch(const uint8
     const size_t i = gtid();
     if (i >= n) return;
     const uint8_t* p = in + i * 32 * (size_t)arity;
-    Fe a, b, c, o;
+    __shared__ uint32_t stash[NL][BLOCK];
+    Fe a, b, o;
     bool ok = load_fe(g_pc, a, p, fmt_in);
     ok &= load_fe(g_pc, b, p + 32, fmt_in);
-    c = a;
-    if (arity == 3) ok &= load_fe(g_pc, c, p + 64, fmt_in);
-    hash_call(o, a, b, c, arity == 3);
+    if (arity == 3) {
+        Fe c;
+        ok &= load_fe(g_pc, c, p + 64, fmt_in);
+#pragma unroll
+        for (int q = 0; q < NL; q++) stash[q][threadIdx.x] = c.v[q];
+    }
+    hash23_stashed(g_pc, o, a, b, arity == 3, &stash[0][threadIdx.x], BLOCK);
     store_fe(g_pc, out + i * 32, o, fmt_out);
     flag_err(err, ok);
 }
@@ -251,32 +255,25 @@ __global__ IMT_TRACE_WAVES void __launch_bounds__(BLOCK) k_hash_trace(launch::Tr
 // (left, right) inputs of every hash2 along n paths, for the trace of a whole path: pairs[l][i][2] in device
 // format (the leaf hash's output is the level-0 start).  Same walk as k_path_root.  blockIdx.y selects one of up to
 // four chains (the four compute_merkle_root calls of insert_leaf run as one launch).
-__global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_path_pairs(launch::PathChains a) {
+// (4 or 5 waves per SIMD: with the pair stores inside the loop, 96 registers left the work-item id in scratch)
+__global__ __attribute__((amdgpu_waves_per_eu(4, 5))) void __launch_bounds__(BLOCK) k_path_pairs(launch::PathChains a) {
     const size_t i = gtid();
     if (i >= a.n) return;
     const launch::PathChains::Chain ch = a.c[blockIdx.y];
+    __shared__ uint32_t stash[NL][BLOCK];
     bool ok = true;
     Fe cur;
-    if (ch.leaf3) leaf_hash(cur, ch.leaf3 + i * 96, a.fmt_in, ok);
-    else ok &= load_fe(g_pc, cur, ch.leaf + i * 32, a.fmt_in);
-    const uint64_t idx = ch.index[i];
-#pragma unroll 1
-    for (unsigned l = 0; l < a.depth; l++) {
-        Fe sv, x, y, o;
-        ok &= load_fe(g_pc, sv, ch.sib + ((uint64_t)l * a.lay.level_stride + i * a.lay.item_stride) * 32, a.fmt_in);
-        const bool right = (idx >> l) & 1;
-#pragma unroll
-        for (int q = 0; q < NL; q++) {
-            x.v[q] = right ? sv.v[q] : cur.v[q];
-            y.v[q] = right ? cur.v[q] : sv.v[q];
-        }
-        uint8_t* dst = ch.pairs + ((size_t)l * a.n + i) * 64;
+    if (!ch.leaf3) ok &= load_fe(g_pc, cur, ch.leaf + i * 32, a.fmt_in);
+    uint8_t* const pairs = ch.pairs;
+    const size_t n = a.n;
+    auto store_pair = [pairs, n](unsigned l, const Fe& x, const Fe& y) {
+        uint8_t* dst = pairs + ((size_t)l * n + gtid_again()) * 64;
         store_packed(dst, x);
         store_packed(dst + 32, y);
-        hash_call(o, x, y, x, false);
-        cur = o;
-    }
-    if (ch.root_out) store_fe(g_pc, ch.root_out + i * 32, cur, a.fmt_out);
+    };
+    chain_inline(cur, ch.leaf3 != nullptr, LeafAt{ch.leaf3, a.fmt_in}, NoLeafHook(), ch.index, 0, ch.sib, a.lay, a.depth,
+                 a.fmt_in, ok, &stash[0][threadIdx.x], store_pair);
+    if (ch.root_out) store_fe(g_pc, ch.root_out + gtid_again() * 32, cur, a.fmt_out);
     flag_err(a.err, ok);
 }
 
@@ -344,15 +341,16 @@ k_path_root(const uint8_t* __restrict__ leaf, const uint8_t* __restrict__ leaf3,
             int is_helper, const uint8_t* __restrict__ sib, launch::SibLayout lay, unsigned depth, size_t n,
             uint8_t* __restrict__ root_out, const uint8_t* __restrict__ expect, unsigned expect_stride,
             uint8_t* __restrict__ ok_out, unsigned fmt_in, unsigned fmt_out, int* err) {
-    const size_t i = gtid();
-    if (i >= n) return;
+    const size_t i0 = gtid();
+    if (i0 >= n) return;
+    __shared__ uint32_t stash[NL][BLOCK];
     bool ok = true;
     Fe cur;
-    if (leaf3) leaf_hash(cur, leaf3 + i * 96, fmt_in, ok);
-    else ok &= load_fe(g_pc, cur, leaf + i * 32, fmt_in);
-    uint64_t idx = index[i];
-    if (is_helper) idx = ~idx;   // helper 1 = left child (src/utils.rs:79)
-    hash_chain(cur, idx, sib, lay, i, depth, fmt_in, ok);
+    if (!leaf3) ok &= load_fe(g_pc, cur, leaf + i0 * 32, fmt_in);
+    // helper 1 = left child (src/utils.rs:79): the helper mask is the complement of the index
+    chain_inline(cur, leaf3 != nullptr, LeafAt{leaf3, fmt_in}, NoLeafHook(), index, is_helper ? ~(uint64_t)0 : 0, sib, lay, depth,
+                 fmt_in, ok, &stash[0][threadIdx.x]);
+    const size_t i = gtid_again();
     if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
     if (ok_out) {
         Fe e;
@@ -422,36 +420,47 @@ k_non_membership(const uint8_t* __restrict__ root, unsigned root_stride, const u
                  unsigned depth, const uint8_t* __restrict__ new_val, const uint8_t* __restrict__ is_largest,
                  size_t n, uint8_t* __restrict__ fail_out, uint8_t* __restrict__ root_out, unsigned fmt_in,
                  unsigned fmt_out, int* err) {
-    const size_t i = gtid();
-    if (i >= n) return;
+    const size_t i0 = gtid();
+    if (i0 >= n) return;
     bool ok = true;
     unsigned fail = 0;
-    // The hash chain first, the range predicates after it: every value that is live across a call of the shared hash
-    // function is saved to scratch by the caller (the callee owns the registers), so nothing but `ok` is kept over
-    // the 33 calls (the other order carried the failure bits and spilled 23 VGPRs).
+    // The hash chain first, the range predicates after it: nothing but `ok` is live across the 33 hashes.
+    __shared__ uint32_t stash[NL][BLOCK];
     Fe cur;
-    leaf_hash(cur, low_leaf + i * 96, fmt_in, ok);                  // :193-194
-    hash_chain(cur, low_index[i], sib, lay, i, depth, fmt_in, ok);  // :196-204
+    chain_inline(cur, true, LeafAt{low_leaf, fmt_in}, NoLeafHook(), low_index, 0, sib, lay, depth, fmt_in, ok,
+                 &stash[0][threadIdx.x]);                           // :193-204
+    const size_t i = gtid_again();
     {
         Fe rt;
         ok &= load_fe(g_pc, rt, root + i * (size_t)root_stride, fmt_in);
         if (!fe_eq(cur, rt)) fail |= 0x02;
     }
     if (root_out) store_fe(g_pc, root_out + i * 32, cur, fmt_out);
-    {
-        Fe v, nx, nv, nvi, lvi, lni;
-        ok &= load_fe(g_pc, v, low_leaf + (i * 3 + 0) * 32, fmt_in);
-        ok &= load_fe(g_pc, nx, low_leaf + (i * 3 + 1) * 32, fmt_in);
-        ok &= load_fe(g_pc, nv, new_val + i * 32, fmt_in);
-        to_int(nvi, nv); to_int(lvi, v); to_int(lni, nx);
-        const unsigned s = is_largest[i];
-        if (s > 1) fail |= 0x80;                                    // assert_bit :41
-        const bool is_zero = fe_is_zero(nx);                        // :143
-        const bool next_gr = int_lt(nvi, lni);                      // :180
-        if (!(s ? is_zero : next_gr)) fail |= 0x01;                 // :182-191
-        if (!int_lt(lvi, nvi)) fail |= 0x04;                        // :206-228
-    }
     fail_out[i] = (uint8_t)fail;
+    flag_err(err, ok);
+}
+// ... and the range predicates of the same call (:143, :180-191, :206-228) as a kernel of their own, after the chain
+// kernel: three integer comparisons per item, no hash.  Inside the chain kernel they needed 54 registers of operands on
+// top of the inlined hash's budget and spilled; here they have the whole register file.  ORs its bits into fail_out.
+__global__ void __launch_bounds__(BLOCK)
+k_non_membership_pred(const uint8_t* __restrict__ low_leaf, const uint8_t* __restrict__ new_val, const uint8_t* __restrict__ is_largest,
+                      size_t n, uint8_t* __restrict__ fail_out, unsigned fmt_in, int* err) {
+    const size_t i = gtid();
+    if (i >= n) return;
+    bool ok = true;
+    unsigned fail = 0;
+    Fe v, nx, nv, nvi, lvi, lni;
+    ok &= load_fe(g_pc, v, low_leaf + (i * 3 + 0) * 32, fmt_in);
+    ok &= load_fe(g_pc, nx, low_leaf + (i * 3 + 1) * 32, fmt_in);
+    ok &= load_fe(g_pc, nv, new_val + i * 32, fmt_in);
+    to_int(nvi, nv); to_int(lvi, v); to_int(lni, nx);
+    const unsigned s = is_largest[i];
+    if (s > 1) fail |= 0x80;                                    // assert_bit :41
+    const bool is_zero = fe_is_zero(nx);                        // :143
+    const bool next_gr = int_lt(nvi, lni);                      // :180
+    if (!(s ? is_zero : next_gr)) fail |= 0x01;                 // :182-191
+    if (!int_lt(lvi, nvi)) fail |= 0x04;                        // :206-228
+    fail_out[i] |= (uint8_t)fail;
     flag_err(err, ok);
 }
 
@@ -547,36 +556,31 @@ k_insert_chains(const uint8_t* __restrict__ low_leaf, const uint64_t* __restrict
                 uint8_t* __restrict__ trace, unsigned fmt_in, int* err) {
     const size_t i = gtid();
     if (i >= n) return;
-    const int chain = blockIdx.y;
+    const int chain = blockIdx.y;         // wave-uniform: which of the four compute_merkle_root calls
+    __shared__ uint32_t stash[NL][BLOCK];
     bool ok = true;
     Fe cur;
     const uint8_t* sib = chain < 2 ? low_sib : new_sib;
-    const uint64_t idx = chain < 2 ? low_index[i] : new_path_index[i];
-    uint8_t* leaf_out = nullptr;
-    uint8_t* root_out;
-    if (chain == 0) {            // low leaf as given                       :193-204
-        leaf_hash(cur, low_leaf + i * 96, fmt_in, ok);
-        leaf_out = trace + (0 * n + i) * 32;
-        root_out = trace + (1 * n + i) * 32;
-    } else if (chain == 1) {     // {low.val, new.val, new_leaf_index}      :265-284
-        Fe a, b, c;
-        ok &= load_fe(g_pc, a, low_leaf + (i * 3 + 0) * 32, fmt_in);
-        ok &= load_fe(g_pc, b, new_leaf + (i * 3 + 0) * 32, fmt_in);
-        fe_from_u64(c, new_index[i]);
-        hash_call(cur, a, b, c, true);
-        leaf_out = trace + (2 * n + i) * 32;
-        root_out = trace + (3 * n + i) * 32;
-    } else if (chain == 2) {     // the zero leaf at the new slot           :286-294
-        cur = g_pc.zero_leaf;
-        root_out = trace + (4 * n + i) * 32;
-    } else {                     // the new leaf                            :299-312
-        leaf_hash(cur, new_leaf + i * 96, fmt_in, ok);
-        leaf_out = trace + (5 * n + i) * 32;
-        root_out = trace + (6 * n + i) * 32;
-    }
-    if (leaf_out) store_packed(leaf_out, cur);
-    hash_chain(cur, idx, sib, lay, i, depth, fmt_in, ok);
-    store_packed(root_out, cur);
+    const uint64_t* index = chain < 2 ? low_index : new_path_index;
+    // chain 0: low leaf as given :193-204; 1: {low.val, new.val, new_leaf_index} :265-284; 2: the zero leaf at the new
+    // slot :286-294 (no leaf hash); 3: the new leaf :299-312.  Trace rows: leaf hash at 0 / 2 / - / 5, root at 1 / 3 / 4 / 6.
+    const int leaf_row = chain == 0 ? 0 : chain == 1 ? 2 : 5, root_row = chain == 0 ? 1 : chain == 1 ? 3 : chain == 2 ? 4 : 6;
+    if (chain == 2) cur = g_pc.zero_leaf;
+    auto load_leaf = [=](Fe& a, Fe& b, Fe& c, bool& okk) {
+        const size_t it = gtid_again();
+        const uint8_t* const p0 = (chain == 3 ? new_leaf : low_leaf) + it * 96;
+        okk &= load_fe(g_pc, a, p0, fmt_in);
+        if (chain == 1) {
+            okk &= load_fe(g_pc, b, new_leaf + it * 96, fmt_in);
+            fe_from_u64(c, new_index[it]);
+        } else {
+            okk &= load_fe(g_pc, b, p0 + 32, fmt_in);
+            okk &= load_fe(g_pc, c, p0 + 64, fmt_in);
+        }
+    };
+    auto store_leaf = [=](const Fe& h) { store_packed(trace + ((size_t)leaf_row * n + gtid_again()) * 32, h); };
+    chain_inline(cur, chain != 2, load_leaf, store_leaf, index, 0, sib, lay, depth, fmt_in, ok, &stash[0][threadIdx.x]);
+    store_packed(trace + ((size_t)root_row * n + gtid_again()) * 32, cur);
     flag_err(err, ok);
 }
 
@@ -685,7 +689,7 @@ __global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_tree_level(const uint8
     Fe a, b, o;
     load_packed(a, prev + (2 * i) * 32);
     load_packed(b, prev + (2 * i + 1) * 32);
-    hash_call(o, a, b, a, false);
+    hash23_stashed(g_pc, o, a, b, false, nullptr, 0);      // inlined: a 2-input hash never reads the stash
     store_packed(next + i * 32, o);
 }
 
@@ -726,7 +730,7 @@ __global__ IMT_HASH_WAVES void k_extend_root(uint8_t* cur_io, const uint8_t* zer
     for (unsigned l = from; l < to; l++) {
         Fe z, o;
         load_packed(z, zero + (size_t)l * 32);
-        hash_call(o, cur, z, cur, false);
+        hash23_stashed(g_pc, o, cur, z, false, nullptr, 0);
         cur = o;
     }
     store_packed(cur_io, cur);
@@ -962,7 +966,7 @@ k_lift_roots(uint8_t* __restrict__ old_root, uint8_t* __restrict__ interim_root,
             a.v[i] = right ? sv.v[i] : cur.v[i];
             b.v[i] = right ? cur.v[i] : sv.v[i];
         }
-        hash_call(o, a, b, a, false);
+        hash23_stashed(g_pc, o, a, b, false, nullptr, 0);
         cur = o;
     }
     store_fe(g_pc, row, cur, fmt);
@@ -1267,9 +1271,12 @@ void non_membership(hipStream_t s, const uint8_t* root, unsigned root_stride, co
     if (n * 4 <= coop_max)
         hipLaunchKernelGGL(k_non_membership_coop, dim3(nblk(n * 4)), dim3(BLOCK), 0, s, root, root_stride, low_leaf,
                            low_index, sib, lay, depth, new_val, is_largest, n, fail_out, root_out, fmt_in, fmt_out, err);
-    else
+    else {
         hipLaunchKernelGGL(k_non_membership, dim3(nblk(n)), dim3(BLOCK), 0, s, root, root_stride, low_leaf, low_index,
                            sib, lay, depth, new_val, is_largest, n, fail_out, root_out, fmt_in, fmt_out, err);
+        hipLaunchKernelGGL(k_non_membership_pred, dim3(nblk(n)), dim3(BLOCK), 0, s, low_leaf, new_val, is_largest, n, fail_out,
+                           fmt_in, err);
+    }
 }
 void insert_witness(hipStream_t s, const uint8_t* old_root, const uint8_t* low_leaf, const uint64_t* low_index,
                     const uint8_t* low_sib, const uint8_t* new_root, const uint8_t* new_leaf,
