@@ -144,9 +144,15 @@ impl<F: BigPrimeField> FixLenHasher<F> for TracedPoseidonHasher<F> {
 /// constrain_owner_subtree(ctx, range, &new_leaf.val,   &new_leaf_proof_helper, k);   // insert_leaf: v lands in its own list
 /// ```
 ///
-/// It constrains `v mod 2^k` (a `div_mod` by `2^k`: one 254-bit range decomposition) to equal the subtree number the
-/// path's top `k` helper bits spell (`helper = 1` means "left child", `src/utils.rs:79`, so bit `j` of the subtree number
-/// is `1 - helper[d - k + j]`).  The single-list layout (`sliced.py`, `bench.py`'s `value`) needs none of this.
+/// It constrains `v mod 2^k` to equal the subtree number the path's top `k` helper bits spell (`helper = 1` means "left
+/// child", `src/utils.rs:79`, so bit `j` of the subtree number is `1 - helper[d - k + j]`).  `v mod 2^k` is taken from the
+/// CANONICAL integer of `v`: the value is split into two range-checked 128-bit limbs `(q, r)` with `q 2^128 + r = v`
+/// in the field AND `(q, r) <= ((p - 1) >> 128, (p - 1) mod 2^128)` lexicographically.  Without the second condition
+/// the decomposition is not unique -- for every `v < 2^254 - p` (a quarter of the field, all small values) the limbs of
+/// `v + p` satisfy the same field equation, and since `p` is odd they name ANOTHER subtree: the forgery this constraint
+/// exists to stop would go through (a single `range.div_mod(v, 2^k, 254)` has exactly that hole: halo2-base's div_mod
+/// is only sound below the field's capacity of 253 bits).  The residue itself is then a `div_mod` of the 128-bit low
+/// limb.  The single-list layout (`sliced.py`, `bench.py`'s `value`) needs none of this.
 pub fn constrain_owner_subtree<F: BigPrimeField>(
     ctx: &mut Context<F>,
     range: &halo2_base::gates::RangeChip<F>,
@@ -154,14 +160,50 @@ pub fn constrain_owner_subtree<F: BigPrimeField>(
     proof_helper: &[AssignedValue<F>],
     k: usize,
 ) {
+    constrain_owner_subtree_with(ctx, range, value, proof_helper, k, None)
+}
+
+/// The same with the prover's choice of limbs made explicit (`limbs = Some((q, r))`): what a negative test needs to
+/// show that the limbs of `v + p` are refused (`tests/mockprover.rs::owner_constraint_refuses_the_limbs_of_v_plus_p`).
+pub fn constrain_owner_subtree_with<F: BigPrimeField>(
+    ctx: &mut Context<F>,
+    range: &halo2_base::gates::RangeChip<F>,
+    value: &AssignedValue<F>,
+    proof_helper: &[AssignedValue<F>],
+    k: usize,
+    limbs: Option<(num_bigint::BigUint, num_bigint::BigUint)>,
+) {
     use halo2_base::gates::RangeInstructions;
+    use halo2_base::utils::{biguint_to_fe, fe_to_biguint, modulus};
+    use num_bigint::BigUint;
     if k == 0 {
         return;
     }
     let gate = range.gate();
     let d = proof_helper.len();
-    assert!(k <= d, "more subtree bits than tree levels");
-    let (_, residue) = range.div_mod(ctx, *value, num_bigint::BigUint::from(1u64) << k, F::NUM_BITS as usize);
+    assert!(k <= d && k <= 128, "more subtree bits than tree levels (or than a limb)");
+    let one = BigUint::from(1u64);
+    let mask = (&one << 128) - &one;
+    // canonical 128-bit limbs of the value
+    let v = fe_to_biguint(value.value());
+    let (q_bu, r_bu) = limbs.unwrap_or((&v >> 128, &v & &mask));
+    let q = ctx.load_witness(biguint_to_fe::<F>(&q_bu));
+    let r = ctx.load_witness(biguint_to_fe::<F>(&r_bu));
+    range.range_check(ctx, q, 128);
+    range.range_check(ctx, r, 128);
+    let recomposed = gate.mul_add(ctx, q, Constant(biguint_to_fe::<F>(&(&one << 128))), r);
+    ctx.constrain_equal(&recomposed, value);
+    // (q, r) <= limbs of p - 1:  q < pq  or  (q == pq and r < pr + 1)
+    let p_minus_1 = modulus::<F>() - &one;
+    let (pq, pr) = (&p_minus_1 >> 128, &p_minus_1 & &mask);
+    let q_lt = range.is_less_than(ctx, q, Constant(biguint_to_fe::<F>(&pq)), 128);
+    let q_eq = gate.is_equal(ctx, q, Constant(biguint_to_fe::<F>(&pq)));
+    let r_le = range.is_less_than(ctx, r, Constant(biguint_to_fe::<F>(&(&pr + &one))), 128);
+    let tail = gate.and(ctx, q_eq, r_le);
+    let canonical = gate.or(ctx, q_lt, tail);
+    gate.assert_is_const(ctx, &canonical, &F::ONE);
+    // the residue of the canonical integer (k <= 128: it lives in the low limb)
+    let (_, residue) = range.div_mod(ctx, r, &one << k, 128);
     let bits: Vec<AssignedValue<F>> = proof_helper[d - k..].iter().map(|h| gate.not(ctx, *h)).collect();
     let weights = (0..k).map(|j| Constant(F::from(1u64 << j)));
     let subtree = gate.inner_product(ctx, bits, weights);

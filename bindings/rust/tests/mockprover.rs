@@ -15,6 +15,9 @@
 //!    (`:69`, `:82`, `:131`, `:235`); make that parameter `&impl imt_hip::chip::FixLenHasher<F>` (README.md here has
 //!    the sed line).  They are behind the cargo feature `reference-gadget`.
 //!
+//!  * the soundness of the subtree layout's extra constraint: `owner_constraint_refuses_the_limbs_of_v_plus_p` (no GPU,
+//!    no reference crate).
+//!
 //! Run:  IMT_HIP_LIB_DIR=<repo>/indexed-merkle-tree-halo2_amd/csrc cargo test --release --features reference-gadget
 //!
 //! tests/test_rust_binding.py checks that every `imt_hip::` item and every chip / gpu method named here exists in
@@ -161,4 +164,34 @@ mod with_reference_gadget {
             assert_eq!(hasher.pending(), 0);
         });
     }
+}
+
+/// The owner constraint of the SUBTREE layout (`chip::constrain_owner_subtree`) decomposes the value canonically: the
+/// honest limbs of a small `v` are accepted, the limbs of `v + p` -- the same field element, another residue mod 2^k
+/// since p is odd -- are refused.  (A bare `range.div_mod(v, 2^k, 254)` accepts both: halo2-base's div_mod is sound
+/// only below the field's 253-bit capacity.)  Needs neither the GPU nor the reference crate.
+#[test]
+fn owner_constraint_refuses_the_limbs_of_v_plus_p() {
+    use halo2_base::utils::{fe_to_biguint, modulus};
+    use imt_hip::chip::constrain_owner_subtree_with;
+    use num_bigint::BigUint;
+    let k = 3usize;
+    let v = Fr::from(10u64);                              // list 10 mod 8 = 2 owns it
+    let helpers_for = |subtree: u64| -> Vec<Fr> { (0..8).map(|l| if l >= 5 { Fr::from(1 - ((subtree >> (l - 5)) & 1)) } else { Fr::from(1u64) }).collect() };
+    let one = BigUint::from(1u64);
+    let mask = (&one << 128) - &one;
+    // honest: limbs of 10, subtree 2
+    base_test().k(12).lookup_bits(8).expect_satisfied(true).run(|ctx, range| {
+        let value = ctx.load_witness(v);
+        let helper: Vec<_> = helpers_for(2).into_iter().map(|h| ctx.load_witness(h)).collect();
+        constrain_owner_subtree_with(ctx, range, &value, &helper, k, None);
+    });
+    // forged: limbs of 10 + p (fits 254 bits), whose residue mod 8 is (10 + 1) mod 8 = 3: claims subtree 3
+    let forged = fe_to_biguint(&v) + modulus::<Fr>();
+    assert_eq!((&forged & BigUint::from(7u64)), BigUint::from(3u64));
+    base_test().k(12).lookup_bits(8).expect_satisfied(false).run(|ctx, range| {
+        let value = ctx.load_witness(v);
+        let helper: Vec<_> = helpers_for(3).into_iter().map(|h| ctx.load_witness(h)).collect();
+        constrain_owner_subtree_with(ctx, range, &value, &helper, k, Some((&forged >> 128, &forged & &mask)));
+    });
 }

@@ -371,3 +371,33 @@ def test_bench_synthetic_values_are_field_elements_of_the_right_residue():
         assert len(set(vals)) == len(vals)
         assert max(vals) > bench.P // 2 and min(vals) < bench.P // 8          # spread over the field, not clustered
     assert (bench.synth_values(100, 0, 1, 3) == bench.synth_values(100, 0, 1, 3)).all()       # seeded: every rank draws the same step
+
+
+def test_owner_subtree_constraint_needs_the_canonical_decomposition():
+    """bindings/rust/src/chip.rs::constrain_owner_subtree (the one extra constraint of the subtree layout), as integers:
+    the field equation q 2^128 + r = v alone is satisfied by the limbs of v AND of v + p for every v < 2^254 - p, and p
+    being odd the two disagree about v mod 2^k; the lexicographic bound (q, r) <= limbs(p - 1) keeps exactly the honest one.
+    The Rust source carries both conditions and the negative MockProver test."""
+    import random
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    M = (1 << 128) - 1
+    pq, pr = (P - 1) >> 128, (P - 1) & M
+
+    def accepted(v, q, r, canonical):
+        ok = q < (1 << 128) and r < (1 << 128) and (q * (1 << 128) + r) % P == v % P
+        if canonical:
+            ok = ok and (q < pq or (q == pq and r < pr + 1))
+        return ok
+    rng = random.Random(9)
+    for v in [10, 1, 0, (1 << 254) - P - 1] + [rng.randrange((1 << 254) - P) for _ in range(200)]:
+        honest, forged = (v >> 128, v & M), ((v + P) >> 128, (v + P) & M)
+        assert accepted(v, *honest, False) and accepted(v, *forged, False)          # the hole
+        assert (v & 7) != ((v + P) & 7)                                              # ... names another subtree
+        assert accepted(v, *honest, True) and not accepted(v, *forged, True)         # closed
+    for v in [P - 1, P - 2, rng.randrange(P)]:
+        assert accepted(v, v >> 128, v & M, True)
+    src = open(os.path.join(ROOT, "bindings", "rust", "src", "chip.rs")).read()
+    assert "range.range_check(ctx, q, 128)" in src and "gate.assert_is_const(ctx, &canonical, &F::ONE)" in src
+    assert "range.div_mod(ctx, r, &one << k, 128)" in src and "div_mod(ctx, *value" not in src
+    t = open(os.path.join(ROOT, "bindings", "rust", "tests", "mockprover.rs")).read()
+    assert "owner_constraint_refuses_the_limbs_of_v_plus_p" in t and "expect_satisfied(false)" in t
