@@ -64,9 +64,9 @@ VALU_PEAK_GMADS = 36443.0           # measured v_mad_u64_u32 lane-ops/ns (profil
 # reports half of 16-B/lane reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, counter unit KB, mean over the k_sweep
 # dispatches of the run.  bench.py cannot read PMC counters itself, so this is a STATIC figure, reported as
 # roofline.traffic_static with its source.
-PMC_TRAFFIC_SWEEP_LEVEL = {"bytes": int((2 * 3572.3 + 8067.9) * 1024), "fetch_size_kb": 3572.3, "write_size_kb": 8067.9,
-                           "source": "profiles/r03_pmc_hbm_traffic_raw.txt (round 2: 3580.1 / 8067.9, "
-                                     "profiles/r02_pmc_hbm_traffic.txt)", "measured_at_commit": "round-3 build"}
+PMC_TRAFFIC_SWEEP_LEVEL = {"bytes": int((2 * 3580.0 + 8067.9) * 1024), "fetch_size_kb": 3580.0, "write_size_kb": 8067.9,
+                           "source": "profiles/r04_pmc_hbm_traffic_raw.txt (round 3: 3572.3 / 8067.9, "
+                                     "profiles/r03_pmc_hbm_traffic_raw.txt)", "measured_at_commit": "round-4 build"}
 TRACE_ROWS = 1208                   # witnesses per 2-input hash (imt_hash_trace_batch)
 DTYPE = "u32 limbs (9 x 29-bit, Montgomery mod p), 64-bit accumulate"
 METRIC = "indexed-tree insertions/sec at depth=32 (bn256::Fr)"

@@ -23,7 +23,9 @@ bench)
   ( export IMT_NO_PIPELINE=1 IMT_BENCH_NO_ATTRIBUTION=1 IMT_BENCH_NO_TRACE=1; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err ) && echo "pmc fetch ok" &&
   ( export IMT_NO_PIPELINE=1 IMT_BENCH_NO_ATTRIBUTION=1 IMT_BENCH_NO_TRACE=1; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err ) && echo "pmc write ok" &&
   ( export IMT_NO_PIPELINE=1 IMT_BENCH_NO_ATTRIBUTION=1 IMT_BENCH_NO_TRACE=1; timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_valu_alone -o v -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_valu_alone.err ) && echo "pmc valu (alone) ok" &&
-  python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/pmc_bench_summary.txt && python tools/pmc_summary.py $O/pmc_valu_alone > $O/pmc_valu_alone_summary.txt
+  ( export IMT_NO_PIPELINE=1 IMT_BENCH_NO_ATTRIBUTION=1 IMT_BENCH_NO_TRACE=1; timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU --output-format csv -d $O/pmc_classes -o c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_classes.err ) && echo "pmc classes ok" &&
+  ( export IMT_NO_PIPELINE=1 IMT_BENCH_NO_ATTRIBUTION=1 IMT_BENCH_NO_TRACE=1; timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $O/pmc_other -o o -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_other.err ) && echo "pmc other ok" &&
+  python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/pmc_bench_summary.txt && python tools/pmc_summary.py $O/pmc_valu_alone > $O/pmc_valu_alone_summary.txt && python tools/pmc_summary.py $O/pmc_classes $O/pmc_other > $O/pmc_classes_summary.txt
   echo "bench part exit $?" ;;
 multi)
   ( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo; timeout -k 10 400 python3 bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2rank_rehearsal_ipc.json 2> $O/bench_2rank.err ) && echo "2-rank ok" &&
