@@ -31,9 +31,7 @@ using namespace dev;
 #ifndef IMT_BLOCK
 #define IMT_BLOCK 256
 #endif
-// Every kernel that calls the shared hash function asks for 5 waves per SIMD (96 VGPRs).  The
-// attribute cannot be put on a device function, but LLVM propagates it from the callers when ALL of
-// them carry it; without it the three-input instance is allocated 228 VGPRs (2 waves/SIMD).  With
+// Every hash kernel asks for 5 waves per SIMD (96 VGPRs).  With
 // the assembly multipliers the hash needs < 90 registers; measured on MI355X (bench.py, 16 steps,
 // same box): 4 waves 2.93 M insertions/s, 5 waves 3.05 M, 6 waves 3.02-3.07 M but the kernel alone
 // 2 % slower, 8 waves 2.93 M.  The fifth wave is what the small kernels of the other batch and the
@@ -809,7 +807,8 @@ k_writeback(const uint8_t* __restrict__ val_l, const uint32_t* __restrict__ from
 // on top of the hash's ~90 registers spilled, so those levels are ordinary launches now (same hashes, and
 // consecutive batches overlap there level by level too).  The mode is a kernel argument: wave-uniform branches.
 // The third input of a leaf hash waits in LDS for the second permutation (hash23_stashed).
-// The other, much rarer hash kernels (paths, dense levels, lift) keep calling the shared function.
+// The other, much rarer hash kernels (paths, dense levels, lift) run alone on the chip and inline the hash once each
+// too (chain_inline, round 4; rounds 1-3 called a shared function there).
 // -----------------------------------------------------------------------------------------------
 __global__ IMT_HASH_WAVES void __launch_bounds__(BLOCK) k_sweep(launch::SweepArgs a) {
     __shared__ uint32_t stash[NL][BLOCK];
