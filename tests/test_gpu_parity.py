@@ -740,6 +740,18 @@ def test_c_example_runs(imt):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "replicas equal the one-GPU tree (49 leaves; lag 6, " in r.stdout, r.stdout + r.stderr
+    # examples/sliced_procs_demo.c: a multi-PROCESS host in plain C (fork, pipes for the bootstrap bytes, no Python, no
+    # torch): two and three ranks sharing this GPU over the IPC transport, one rank over RCCL (ncclCommInitRank and
+    # ncclAllGather called by the library); every replica's root = the one-tree batch's
+    exe = os.path.join(root, "examples", "sliced_procs_demo")
+    r = subprocess.run(["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "examples", "sliced_procs_demo.c"), "-L", csrc, "-limt_hip", "-Wl,-rpath," + csrc, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, IMT_DEMO_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for args in (["2", "ipc", "6", "256"], ["3", "ipc", "5", "100"], ["1", "rccl", "4", "128"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "replicas equal" in r.stdout and "root " in r.stdout, (args, r.stdout + r.stderr)
 
 
 def test_c_abi_survives_null_and_nonsense_arguments(imt):

@@ -298,14 +298,19 @@ def test_header_is_plain_c_and_example_links():
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
                         os.path.join(ROOT, "include", "imt.h")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    for name in ("insert_demo", "slice_demo"):
+    for name in ("insert_demo", "slice_demo", "sliced_procs_demo"):
         exe = os.path.join(ROOT, "examples", name)
-        r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(ROOT, "include"),
+        r = subprocess.run(["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(ROOT, "include"),
                             os.path.join(ROOT, "examples", name + ".c"), "-L",
                             os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc"), "-limt_hip",
                             "-Wl,-rpath," + os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc"), "-o", exe],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+    # the multi-process host fails loudly without a GPU (every rank stops at context creation: no CPU path)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([os.path.join(ROOT, "examples", "sliced_procs_demo"), "2", "ipc", "2", "8"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 3 and "imt_ctx_create: -7" in r.stderr and "FAILED" in r.stdout
 
 
 def test_cpp_host_side_builds_and_fails_loudly_without_a_gpu(tmp_path):
