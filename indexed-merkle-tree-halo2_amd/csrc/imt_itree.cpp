@@ -165,6 +165,7 @@ struct imt_itree {
     size_t canon_all_cap = 0;
     uint32_t* d_sorted_extra = nullptr;      // third index buffer: a step's up to three merges never write the committed one
     double slice_wait_ms = 0;                // host time spent waiting for the GPU inside imt_itree_slice_prepare
+    bool sliced_busy = false;                // an imt_sliced world has steps in flight on this replica (until its flush)
 };
 
 static void plan_free(PlanSet& p) {
@@ -378,6 +379,14 @@ static bool slice_open(const imt_itree* t) {
     return false;
 }
 
+// Between imt_sliced_step and imt_sliced_flush the replica is mid-step: other ranks' write-backs are still arriving on
+// the world's own streams, which nothing here is ordered behind.  The ordinary entry points refuse instead of reading
+// or writing a half-applied tree (include/imt.h: "only imt_sliced_* calls may touch the trees").
+#define IMT_NOT_SLICED(t)                                                                                              \
+    do {                                                                                                               \
+        if ((t)->sliced_busy) return (t)->ctx->fail(IMT_ERR_ARG, "the tree has sliced steps in flight: imt_sliced_flush first"); \
+    } while (0)
+
 // order the context's stream behind every pipelined batch still in flight
 static int join_top(imt_itree* t) {
     if (!t->pipe_pending) return IMT_OK;
@@ -432,6 +441,9 @@ extern "C" uint64_t imt_itree_size(const imt_itree* t) { return t ? t->size : 0;
 // internal (imt_itree_internal.hpp): what imt_sliced.cpp needs to know about a tree
 imt_ctx* imt_itree_ctx(const imt_itree* t) { return t ? t->ctx : nullptr; }
 unsigned imt_itree_depth(const imt_itree* t) { return t ? t->depth : 0; }
+void imt_itree_mark_sliced(imt_itree* t, bool busy) {
+    if (t) t->sliced_busy = busy;
+}
 double imt_itree_take_wait_ms(imt_itree* t) {
     const double w = t ? t->slice_wait_ms : 0;
     if (t) t->slice_wait_ms = 0;
@@ -442,6 +454,7 @@ bool imt_itree_is_plain(const imt_itree* t) { return t && !t->index_base && t->p
 extern "C" int imt_itree_root(imt_itree* t, void* root, unsigned flags) {
     if (!t || !root) return IMT_ERR_ARG;
     imt_ctx* c = t->ctx;
+    IMT_NOT_SLICED(t);
     int rc = c->set_device();
     if (rc) return rc;
     if ((rc = check_fe_ptrs(c, flags & IMT_DEVICE_PTRS, {root}))) return rc;
@@ -463,6 +476,7 @@ extern "C" int imt_itree_root(imt_itree* t, void* root, unsigned flags) {
 extern "C" int imt_itree_root_lagged(imt_itree* t, unsigned lag, void* root, unsigned flags) {
     if (!t || !root) return IMT_ERR_ARG;
     imt_ctx* c = t->ctx;
+    IMT_NOT_SLICED(t);
     if (lag > 1) return c->fail(IMT_ERR_RANGE, "lag must be 0 or 1");
     int rc = c->set_device();
     if (rc) return rc;
@@ -540,6 +554,7 @@ static int find_pred(const imt_itree* t, const U256& v, size_t& pos) {
 extern "C" int imt_itree_find_low_batch(imt_itree* t, const void* vals, size_t n, uint64_t* low_index, unsigned flags) {
     if (!t) return IMT_ERR_ARG;
     imt_ctx* c = t->ctx;
+    IMT_NOT_SLICED(t);
     if (n == 0) return IMT_OK;
     if (!vals || !low_index) return c->fail(IMT_ERR_ARG, "null buffer");
     int rc = c->set_device();
@@ -568,6 +583,7 @@ extern "C" int imt_itree_find_low_batch(imt_itree* t, const void* vals, size_t n
 extern "C" int imt_itree_get_leaves(imt_itree* t, const uint64_t* index, size_t n, void* preimage, unsigned flags) {
     if (!t) return IMT_ERR_ARG;
     imt_ctx* c = t->ctx;
+    IMT_NOT_SLICED(t);
     if (n == 0) return IMT_OK;
     if (!index || !preimage) return c->fail(IMT_ERR_ARG, "null buffer");
     if (flags & IMT_DEVICE_PTRS) return c->fail(IMT_ERR_ARG, "imt_itree_get_leaves takes host pointers");
@@ -603,6 +619,7 @@ extern "C" int imt_itree_get_leaves(imt_itree* t, const uint64_t* index, size_t 
 extern "C" int imt_itree_get_proof_batch(imt_itree* t, const uint64_t* index, size_t n, void* sib, unsigned flags) {
     if (!t) return IMT_ERR_ARG;
     imt_ctx* c = t->ctx;
+    IMT_NOT_SLICED(t);
     if (n == 0) return IMT_OK;
     if (!index || !sib) return c->fail(IMT_ERR_ARG, "null buffer");
     int rc = c->set_device();
@@ -639,6 +656,7 @@ extern "C" int imt_itree_non_membership_witness(imt_itree* t, const void* vals, 
                                                 void* low_leaf, uint8_t* is_largest, void* low_sib, unsigned flags) {
     if (!t) return IMT_ERR_ARG;
     imt_ctx* c = t->ctx;
+    IMT_NOT_SLICED(t);
     if (n == 0) return IMT_OK;
     if (!vals) return c->fail(IMT_ERR_ARG, "null vals");
     if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
@@ -713,6 +731,7 @@ extern "C" int imt_itree_non_membership_witness(imt_itree* t, const void* vals, 
 extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, unsigned flags) {
     if (!t) return IMT_ERR_ARG;
     imt_ctx* c = t->ctx;
+    IMT_NOT_SLICED(t);
     if (!preimages || n == 0) return c->fail(IMT_ERR_ARG, "null / empty snapshot");
     if (n > t->cap) return c->fail(IMT_ERR_FULL, "snapshot has %llu leaves, capacity is %llu", (unsigned long long)n,
                                    (unsigned long long)t->cap);
@@ -1049,6 +1068,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
                                       unsigned flags) {
     if (!t) return IMT_ERR_ARG;
     imt_ctx* c = t->ctx;
+    IMT_NOT_SLICED(t);
     if (n == 0) return IMT_OK;
     if (!vals) return c->fail(IMT_ERR_ARG, "null vals");
     if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
@@ -1286,6 +1306,7 @@ extern "C" int imt_itree_batch_begin(imt_itree* t, const void* vals, size_t n, u
                                      uint32_t* l0_out) {
     if (!t) return IMT_ERR_ARG;
     imt_ctx* c = t->ctx;
+    IMT_NOT_SLICED(t);
     if (!vals || n == 0) return c->fail(IMT_ERR_ARG, "null / empty batch");
     if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
     if (t->pending.active) return c->fail(IMT_ERR_ARG, "a sharded batch is already open");

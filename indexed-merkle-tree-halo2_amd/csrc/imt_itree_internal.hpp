@@ -8,3 +8,5 @@ bool imt_itree_is_plain(const imt_itree* t);     // not placed, not partitioned,
 // milliseconds the host has spent waiting for the GPU inside imt_itree_slice_prepare (the values check, plan-set
 // back-pressure) since the last call; reset by the call
 double imt_itree_take_wait_ms(imt_itree* t);
+// an imt_sliced world marks its replicas while steps are in flight; the ordinary imt_itree_* entry points then refuse
+void imt_itree_mark_sliced(imt_itree* t, bool busy);

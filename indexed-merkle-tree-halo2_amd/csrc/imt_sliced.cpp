@@ -425,7 +425,10 @@ void imt_sliced_destroy(imt_sliced* s) {
                 s->ranks.empty() ? -1 : s->ranks[0]->rank, (unsigned long long)s->w.n_rounds, s->w.phase_ms[0], s->w.phase_ms[1], s->w.phase_ms[2],
                 s->host_issue_ms, s->host_wait_ms);
     if (!s->ranks.empty() && s->w.n_rounds) s->w.flush();
-    for (auto& be : s->bes) be->sync();
+    for (auto& be : s->bes) {
+        be->sync();
+        imt_itree_mark_sliced(be->tree, false);
+    }
     for (auto& r : s->ranks) r->destroy();
     if (s->tp) s->tp->users--;
     delete s;
@@ -488,6 +491,8 @@ int imt_sliced_step(imt_sliced* s, const void* vals, size_t n, const imt_insert_
         return c0->fail(IMT_ERR_ARG, "imt_sliced_step takes IMT_FMT_*, IMT_SIB_ITEM_MAJOR, IMT_INPUTS_READY");
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = s->w.step(vals, n, outs, flags, round_out);
+    if (rc == IMT_OK)
+        for (auto& be : s->bes) imt_itree_mark_sliced(be->tree, true);
     const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     double waited = 0;
     for (auto& be : s->bes) waited += imt_itree_take_wait_ms(be->tree);
@@ -501,7 +506,13 @@ int imt_sliced_wait(imt_sliced* s, int local_rank, uint64_t round) {
     return s->w.wait_round((size_t)local_rank, round);
 }
 
-int imt_sliced_flush(imt_sliced* s) { return s ? s->w.flush() : IMT_ERR_ARG; }
+int imt_sliced_flush(imt_sliced* s) {
+    if (!s) return IMT_ERR_ARG;
+    const int rc = s->w.flush();
+    if (rc == IMT_OK)
+        for (auto& be : s->bes) imt_itree_mark_sliced(be->tree, false);     // every replica holds the whole step now
+    return rc;
+}
 
 int imt_sliced_get_info(const imt_sliced* s, imt_sliced_info* o) {
     if (!s || !o) return IMT_ERR_ARG;

@@ -483,6 +483,11 @@ def test_batches_before_and_after_slices_on_one_tree(imt, ctx):
     for k in (4, 5):        # and back: batches behind the slices
         c._check(imt.lib.imt_itree_insert_batch(tr.h, P_(k), batch, None, F.DEVICE_PTRS | F.PIPELINE))
     t.step(arr[6 * batch:7 * batch])        # a slice right behind two pipelined batches
+    # mid-step the replica is not a tree anyone should read or write through the ordinary calls: they refuse
+    with pytest.raises(imt.ImtError) as e:
+        tr.root()
+    assert e.value.code == F.ERR["ARG"] and "imt_sliced_flush" in str(e.value)
+    assert imt.lib.imt_itree_insert_batch(tr.h, P_(7), batch, None, F.DEVICE_PTRS | F.PIPELINE) == F.ERR["ARG"]
     t.flush()
     c._check(imt.lib.imt_itree_insert_batch(tr.h, P_(7), batch, None, F.DEVICE_PTRS | F.PIPELINE))
     c.sync()
