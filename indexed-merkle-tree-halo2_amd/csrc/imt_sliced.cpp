@@ -12,6 +12,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -162,6 +165,7 @@ constexpr int IPC_NEV = ROUNDS * IPC_RING_MAX;
 struct IpcBlob {
     hipIpcMemHandle_t mem;
     char shm_name[64];
+    char bus_id[32];                 // PCI bus id of the rank's GPU: ranks that SHARE a device wait on the host (below)
     uint64_t arena_bytes;
     int32_t rank, world, ring, pid;
 };
@@ -204,8 +208,39 @@ struct IpcTransport : Transport {
     std::vector<Peer> peers;
     bool connected = false;
     uint64_t timeout_ticks = 0;
+    double timeout_s = 60.0;
+    // ---- host-polled form (ranks that share ONE GPU: the one-GPU rehearsal) ----
+    // A kernel that waits for a peer holds one of its process's few hardware queues until the peer has got there; with
+    // several processes time-sharing one device that is most of the time, and whatever sits behind it -- other rounds'
+    // hash kernels, the side stream of the next step's value check -- waits too (profiles/r04_ipc_rehearsal_notes.txt).
+    // So when a peer shares this rank's device the waiting moves to the host: a worker thread watches the peers'
+    // `packed` counters in the shared pages and enqueues each payload's copy when it is there; the fence waits (on the
+    // host) until the worker has enqueued everything of that gather and the peers' `copied` counters have arrived.
+    // Nothing on the GPU ever waits for another process.  Ranks on different GPUs keep the GPU-polled form: no host in
+    // the data path.  IMT_IPC_HOST_POLL=0 / 1 overrides.
+    bool host_poll = false;
+    struct Job {
+        int slot, i;
+        size_t bytes, off;
+        uint64_t k;
+        uint8_t* recv;
+        uint32_t copied_mask;
+        bool ordered;            // the worker's stream has been put behind ready_ev
+    };
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    bool stop = false;
+    std::atomic<uint64_t> issued[IPC_NEV];
+    std::atomic<int> worker_error{0};
+    hipStream_t ws[ROUNDS] = {};
+    hipEvent_t done_ev[IPC_NEV] = {}, ready_ev[IPC_NEV] = {};
+    char my_bus[32] = {0};
 
-    IpcTransport(imt_ctx* c, int w, int r) : ctx(c), world(w), rank(r) {}
+    IpcTransport(imt_ctx* c, int w, int r) : ctx(c), world(w), rank(r) {
+        for (auto& x : issued) x.store(0);
+    }
     static int ei(int slot, int r) { return slot * IPC_RING_MAX + r; }
 
     int map_page(const char* name, bool create, IpcShm** host, IpcShm** dev) {
@@ -239,9 +274,9 @@ struct IpcTransport : Transport {
         if (rc) return rc;
         int khz = 100000;                        // wall_clock64 ticks per millisecond (100 MHz on gfx9)
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
-        double limit_s = 60.0;
-        if (const char* e = getenv("IMT_IPC_TIMEOUT_S")) limit_s = atof(e);
-        timeout_ticks = (uint64_t)(limit_s * 1e3 * khz);
+        if (const char* e = getenv("IMT_IPC_TIMEOUT_S")) timeout_s = atof(e);
+        timeout_ticks = (uint64_t)(timeout_s * 1e3 * khz);
+        if (hipDeviceGetPCIBusId(my_bus, (int)sizeof my_bus, ctx->device) != hipSuccess) my_bus[0] = 0;
         payload_cap = imt_itree_slice_payload_bytes(max_slice);
         const size_t bytes = (size_t)ROUNDS * ring * payload_cap;
         IMT_HIP(ctx, hipMalloc((void**)&arena, bytes));
@@ -254,6 +289,7 @@ struct IpcTransport : Transport {
         if ((rc = map_page(name, true, &my_shm, &my_shm_dev))) return rc;
         shm_name = name;
         snprintf(blob->shm_name, sizeof blob->shm_name, "%s", name);
+        snprintf(blob->bus_id, sizeof blob->bus_id, "%s", my_bus);
         blob->arena_bytes = bytes;
         blob->rank = rank;
         blob->world = world;
@@ -274,16 +310,95 @@ struct IpcTransport : Transport {
             Peer& p = peers[h];
             IMT_HIP(ctx, hipIpcOpenMemHandle((void**)&p.arena, b.mem, hipIpcMemLazyEnablePeerAccess));
             if ((rc = map_page(b.shm_name, false, &p.shm, &p.shm_dev))) return rc;
+            if (my_bus[0] && !strncmp(my_bus, b.bus_id, sizeof my_bus)) host_poll = true;      // a peer on MY device
+        }
+        if (const char* e = getenv("IMT_IPC_HOST_POLL")) host_poll = atoi(e) != 0;
+        if (host_poll) {
+            for (int slot = 0; slot < ROUNDS; slot++) IMT_HIP(ctx, hipStreamCreateWithFlags(&ws[slot], hipStreamNonBlocking));
+            for (int slot = 0; slot < ROUNDS; slot++)
+                for (int r = 0; r < ring; r++) {
+                    IMT_HIP(ctx, hipEventCreateWithFlags(&done_ev[ei(slot, r)], hipEventDisableTiming));
+                    IMT_HIP(ctx, hipEventCreateWithFlags(&ready_ev[ei(slot, r)], hipEventDisableTiming));
+                }
+            worker = std::thread([this] { this->work(); });
         }
         connected = true;
         return IMT_OK;
+    }
+    // the worker of the host-polled form: enqueue each peer's payload copy as soon as that peer says it is packed
+    void work() {
+        if (hipSetDevice(ctx->device) != hipSuccess) { worker_error.store(1); return; }
+        std::vector<Job> pend;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (pend.empty()) cv.wait(lk, [this] { return stop || !jobs.empty(); });
+                while (!jobs.empty()) { pend.push_back(jobs.front()); jobs.pop_front(); }
+                if (stop && pend.empty()) return;
+                if (stop) return;
+            }
+            bool progress = false;
+            for (size_t q = 0; q < pend.size();) {
+                Job& j = pend[q];
+                const uint32_t all = ((1u << world) - 1u) & ~(1u << rank);
+                for (int d = 1; d < world; d++) {
+                    const int h = (rank + d) % world;
+                    if (j.copied_mask & (1u << h)) continue;
+                    if (__atomic_load_n(&peers[h].shm->packed[j.i], __ATOMIC_ACQUIRE) < j.k) continue;
+                    if (!j.ordered) {
+                        if (hipStreamWaitEvent(ws[j.slot], ready_ev[j.i], 0) != hipSuccess) worker_error.store(3);
+                        j.ordered = true;
+                    }
+                    imt::launch::copy16(ws[j.slot], j.recv + (size_t)h * j.bytes, peers[h].arena + j.off, j.bytes);
+                    j.copied_mask |= 1u << h;
+                    progress = true;
+                }
+                if (j.copied_mask == all) {
+                    imt::launch::flag_set(ws[j.slot], &my_shm_dev->copied[j.i], j.k);
+                    if (hipEventRecord(done_ev[j.i], ws[j.slot]) != hipSuccess || hipGetLastError() != hipSuccess) worker_error.store(2);
+                    issued[j.i].store(j.k, std::memory_order_release);
+                    pend.erase(pend.begin() + (long)q);
+                    progress = true;
+                } else {
+                    q++;
+                }
+            }
+            if (!progress) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    // host: wait until `cond` holds or the time limit passes
+    template <class F>
+    bool host_wait(F cond) {
+        if (cond()) return true;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++) {
+            if (cond()) return true;
+            if ((spins & 255) == 255) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+                std::this_thread::yield();
+            }
+        }
     }
     ~IpcTransport() override {
         if (ht.on)
             fprintf(stderr, "[imt ipc rank %d] host ms (calls): flag_set %.1f (%llu)  wait packed %.1f (%llu)  memcpy %.1f (%llu)  wait copied %.1f (%llu)\n",
                     rank, ht.ms[0], (unsigned long long)ht.n[0], ht.ms[1], (unsigned long long)ht.n[1], ht.ms[2], (unsigned long long)ht.n[2], ht.ms[3],
                     (unsigned long long)ht.n[3]);
+        if (worker.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stop = true;
+            }
+            cv.notify_all();
+            worker.join();
+        }
         if (ctx->set_device()) return;
+        for (auto& w_ : ws)
+            if (w_) { hipStreamSynchronize(w_); hipStreamDestroy(w_); }
+        for (auto& e : done_ev)
+            if (e) hipEventDestroy(e);
+        for (auto& e : ready_ev)
+            if (e) hipEventDestroy(e);
         for (auto& p : peers) {
             if (p.arena) hipIpcCloseMemHandle(p.arena);
             unmap_page(p.shm);
@@ -322,10 +437,22 @@ struct IpcTransport : Transport {
             HostTimer::Scope sc(ht, 0);
             imt::launch::flag_set(st, &my_shm_dev->packed[i], k);
         }
-        int rc = wait_peers(st, i, k, false);
-        if (rc) return rc;
         uint8_t* recv = (uint8_t*)rk.recv[rk.at(slot, r)];
         const size_t off = ((size_t)slot * ring + r) * payload_cap;
+        if (host_poll) {                               // the worker copies each payload when its owner says it is there
+            IMT_HIP(ctx, hipGetLastError());
+            // the receive buffer is free again once st gets here (st is behind this tick's unit, hence behind the apply
+            // that read the buffer's previous contents): the worker's copies wait for that
+            IMT_HIP(ctx, hipEventRecord(ready_ev[i], st));
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                jobs.push_back(Job{slot, i, bytes, off, k, recv, 0u, false});
+            }
+            cv.notify_one();
+            return IMT_OK;
+        }
+        int rc = wait_peers(st, i, k, false);
+        if (rc) return rc;
         for (int d = 1; d < world; d++) {              // start with the next rank: spread the reads over the peers
             const int h = (rank + d) % world;
             HostTimer::Scope sc(ht, 2);
@@ -338,7 +465,20 @@ struct IpcTransport : Transport {
     }
     int fence(Rank&, int slot, int r, Stream st_) override {
         const int i = ei(slot, r);
-        return wait_peers((hipStream_t)st_, i, seq[i], true);
+        if (!host_poll) return wait_peers((hipStream_t)st_, i, seq[i], true);
+        const uint64_t k = seq[i];
+        HostTimer::Scope sc(ht, 3);
+        // my gather: every payload's copy is enqueued (the stream then waits for them, not for a peer) ...
+        if (!host_wait([&] { return issued[i].load(std::memory_order_acquire) >= k || worker_error.load(); }) || worker_error.load())
+            return ctx->fail(IMT_ERR_INTERNAL, "IPC transport: a peer's payload did not arrive within %.0f s (a rank died or hangs)", timeout_s);
+        IMT_HIP(ctx, hipStreamWaitEvent((hipStream_t)st_, done_ev[i], 0));
+        // ... and my send buffer: every peer has copied it (their GPUs say so in their pages)
+        for (int h = 0; h < world; h++) {
+            if (h == rank) continue;
+            if (!host_wait([&] { return __atomic_load_n(&peers[h].shm->copied[i], __ATOMIC_ACQUIRE) >= k; }))
+                return ctx->fail(IMT_ERR_INTERNAL, "IPC transport: rank %d did not copy gather %llu within %.0f s", h, (unsigned long long)k, timeout_s);
+        }
+        return IMT_OK;
     }
     int poll_error() override {
         const uint32_t e = my_shm ? *(volatile uint32_t*)&my_shm->err : 0;

@@ -345,8 +345,10 @@ def test_local_world_montgomery_format_and_refused_values(imt, ctx):
 P_DEPTH, P_BATCH, P_ROUNDS = 32, 384, 5
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, host_poll):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if host_poll is not None:
+        os.environ["IMT_IPC_HOST_POLL"] = str(host_poll)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)       # carries the IPC handle blobs, nothing else
     import imt_amd
@@ -375,18 +377,19 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_processes_over_ipc_equal_one_gpu_tree(imt, ctx, world):
-    """one PROCESS per rank on the one GPU (2 and 4: the box admits six GPU processes), payloads copied peer to peer
-    through HIP IPC memory handles, ordered by interprocess events: every rank's witnesses and every replica's root equal
-    the one-GPU tree"""
+@pytest.mark.parametrize("world,host_poll", [(2, None), (4, None), (2, 0), (3, 0)])
+def test_processes_over_ipc_equal_one_gpu_tree(imt, ctx, world, host_poll):
+    """one PROCESS per rank on the one GPU (2 to 4: the box admits six GPU processes), payloads copied peer to peer out
+    of IPC-mapped device memory, ordered by counters in shared host pages: every rank's witnesses and every replica's
+    root equal the one-GPU tree.  host_poll None = the library's choice (ranks share the device: a worker thread on the
+    host watches the counters); 0 = the form for ranks on different GPUs (the GPUs poll the counters themselves)"""
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [mpctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [mpctx.Process(target=_worker, args=(r, world, port, q, host_poll)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda x: x[0])
