@@ -542,8 +542,9 @@ typedef struct imt_sliced_info {
     size_t payload_bytes;            /* size of one send buffer */
     uint64_t rounds, collectives, bytes_gathered;    /* since creation; collectives / bytes per local rank summed */
     double host_issue_ms, host_wait_ms;              /* wall time inside imt_sliced_step since creation: issuing work (every
-                                                        launch, event and collective of the step) / waiting for the GPU (the
-                                                        values check of the step, back-pressure when the host runs ahead) */
+                                                        launch, event and collective of the step) / waiting (for the GPU: the
+                                                        values check of the step, back-pressure when the host runs ahead; for
+                                                        peers: the host-polled IPC transport) */
 } imt_sliced_info;
 int imt_sliced_get_info(const imt_sliced *w, imt_sliced_info *out);
 const char *imt_sliced_last_error(const imt_sliced *w);

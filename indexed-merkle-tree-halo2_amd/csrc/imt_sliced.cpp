@@ -367,17 +367,26 @@ struct IpcTransport : Transport {
         }
     }
     // host: wait until `cond` holds or the time limit passes
+    double waited_ms = 0;
+    double take_wait_ms() override {
+        const double w = waited_ms;
+        waited_ms = 0;
+        return w;
+    }
     template <class F>
     bool host_wait(F cond) {
         if (cond()) return true;
         const auto t0 = std::chrono::steady_clock::now();
+        bool ok = false;
         for (unsigned spins = 0;; spins++) {
-            if (cond()) return true;
+            if (cond()) { ok = true; break; }
             if ((spins & 255) == 255) {
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) break;
                 std::this_thread::yield();
             }
         }
+        waited_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return ok;
     }
     ~IpcTransport() override {
         if (ht.on)
@@ -629,12 +638,14 @@ int imt_sliced_step(imt_sliced* s, const void* vals, size_t n, const imt_insert_
     if (n == 0 || n > s->max_slice) return c0->fail(IMT_ERR_RANGE, "a step is world x n values with 0 < n <= max_slice = %zu", s->max_slice);
     if (flags & ~(IMT_FMT_MASK | IMT_SIB_ITEM_MAJOR | IMT_INPUTS_READY | IMT_DEVICE_PTRS))
         return c0->fail(IMT_ERR_ARG, "imt_sliced_step takes IMT_FMT_*, IMT_SIB_ITEM_MAJOR, IMT_INPUTS_READY");
+    (void)s->tp->impl->take_wait_ms();                     // waits of imt_sliced_wait / _flush are not this call's
+    for (auto& be : s->bes) (void)imt_itree_take_wait_ms(be->tree);
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = s->w.step(vals, n, outs, flags, round_out);
     if (rc == IMT_OK)
         for (auto& be : s->bes) imt_itree_mark_sliced(be->tree, true);
     const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    double waited = 0;
+    double waited = s->tp->impl->take_wait_ms();           // the host-polled transport: waiting for peers' payloads
     for (auto& be : s->bes) waited += imt_itree_take_wait_ms(be->tree);
     s->host_wait_ms += waited;
     s->host_issue_ms += total - waited;

@@ -128,6 +128,7 @@ struct Transport {
     virtual int all_gather(Rank& rk, int slot, int ring, size_t bytes, Stream st) = 0;
     virtual int fence(Rank& rk, int slot, int ring, Stream st) { (void)rk; (void)slot; (void)ring; (void)st; return IMT_OK; }
     virtual int poll_error() { return IMT_OK; }    // after a host-side wait: did the transport give up on a peer?
+    virtual double take_wait_ms() { return 0; }    // host time spent WAITING for peers since the last call (not issuing)
     uint64_t collectives = 0, bytes_moved = 0;
 };
 
