@@ -120,6 +120,26 @@ int imt_transport_rccl_create(imt_ctx* ctx, const void* unique_ids, int n_comms,
         }
         t->n_comms = i + 1;
     }
+    // One small all-gather per communicator, waited for: RCCL sets a communicator's connections up at its FIRST
+    // collective (hundreds of milliseconds), and with one communicator per step in flight the last of them would
+    // otherwise meet that inside somebody's timed region; it also fails here, loudly, if the ranks cannot reach
+    // each other.
+    {
+        uint8_t* warm = nullptr;
+        const size_t wb = 256;
+        hipError_t e = hipMalloc((void**)&warm, wb * ((size_t)world + 1));
+        if (e == hipSuccess) e = hipMemsetAsync(warm, 0, wb * ((size_t)world + 1), ctx->stream);
+        ncclResult_t res = ncclSuccess;
+        for (int i = 0; e == hipSuccess && res == ncclSuccess && i < n_comms; i++)
+            res = rccl().AllGather(warm, warm + wb, wb, ncclUint8, t->comms[i], ctx->stream);
+        if (e == hipSuccess && res == ncclSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (warm) hipFree(warm);
+        if (e != hipSuccess || res != ncclSuccess) {
+            rc = res != ncclSuccess ? t->fail(res, "ncclAllGather (warm-up)") : ctx->hip_fail(e, "RCCL warm-up");
+            delete t;
+            return rc;
+        }
+    }
     *out = imt_transport_wrap(t, ctx);
     if (*out) t->handle = *out;
     return *out ? IMT_OK : IMT_ERR_ALLOC;
