@@ -166,6 +166,7 @@ struct imt_itree {
     uint32_t* d_sorted_extra = nullptr;      // third index buffer: a step's up to three merges never write the committed one
     double slice_wait_ms = 0;                // host time spent waiting for the GPU inside imt_itree_slice_prepare
     bool sliced_busy = false;                // an imt_sliced world has steps in flight on this replica (until its flush)
+    size_t reserved_events = 0;              // every plan set holds at least this many events (reserve_all_plans)
 };
 
 static void plan_free(PlanSet& p) {
@@ -247,6 +248,19 @@ static int plan_reserve(imt_ctx* c, PlanSet& p, size_t events, unsigned levels, 
     }
     p.cap_events = E;
     p.cap_levels = L;
+    return IMT_OK;
+}
+
+// All plan sets at once: a pipelined caller (IMT_PIPELINE, imt_sliced_*) rotates through every set within its first
+// NSETS batches, and each first use is a dozen hipMalloc calls in the middle of somebody's pipeline.
+static int reserve_all_plans(imt_itree* t, size_t events) {
+    if (t->reserved_events >= events) return IMT_OK;
+    for (auto& p : t->plan) {
+        if (p.in_flight || p.open) continue;              // its buffers are in use: it grows when its turn comes
+        int rc = plan_reserve(t->ctx, p, events, t->depth, t->cap);
+        if (rc) return rc;
+    }
+    t->reserved_events = events;
     return IMT_OK;
 }
 
@@ -1098,6 +1112,7 @@ extern "C" int imt_itree_insert_batch(imt_itree* t, const void* vals, size_t n, 
     }
     rc = plan_reserve(c, P, E, t->depth, t->cap);   // all levels up front: growing later would stall the pipeline
     if (rc) return rc;
+    if (dev && (flags & IMT_PIPELINE) && (rc = reserve_all_plans(t, E))) return rc;
 
     // ---- hash-free part: low leaves, event preimages, event order (side stream) ----
     // The side stream reads the caller's `vals` and writes the caller's hash-free outputs (low_index,
@@ -1617,6 +1632,7 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
         P.in_flight = false;
     }
     if ((rc = plan_reserve(c, P, 2 * n_own, t->depth, t->cap))) return rc;
+    if ((rc = reserve_all_plans(t, 2 * n_own))) return rc;
     if (n_before || n_after)
         if ((rc = fws_reserve(t, std::max(n_before, n_after)))) return rc;
     hipStream_t ps = t->up_stream;
