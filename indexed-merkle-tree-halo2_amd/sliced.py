@@ -55,9 +55,12 @@ class SlicedTree:
     rank k's witnesses of ITS slice of round R, valid after wait(R, k) or flush()."""
 
     def __init__(self, imt, device_index, depth, capacity, batch, world, first_rank=0, n_local=1, transport=None, lag=None,
-                 nbuf=5, fmt=0):
+                 nbuf=5, fmt=0, item_major=False):
         self.imt, self.F, self.lib = imt, imt._ffi, imt.lib
         self.depth, self.batch, self.world, self.first_rank, self.n_local, self.fmt = depth, batch, world, first_rank, n_local, fmt
+        self.item_major = item_major         # sibling rows [n][depth] (the reference's per-proof Vec<F>) instead of [depth][n]
+        if item_major:
+            self.fmt |= imt._ffi.SIB_ITEM_MAJOR
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(device_index)
         self.ctxs = [imt.Context(device_index) for _ in range(n_local)]
@@ -68,7 +71,8 @@ class SlicedTree:
                           low_leaf=torch.empty((batch, 3, 32), **u8), is_largest=torch.empty(batch, **u8),
                           old_root=torch.empty((batch, 32), **u8), interim_root=torch.empty((batch, 32), **u8),
                           new_root=torch.empty((batch, 32), **u8), new_leaf=torch.empty((batch, 3, 32), **u8),
-                          low_sib=torch.empty((depth, batch, 32), **u8), new_sib=torch.empty((depth, batch, 32), **u8))
+                          low_sib=torch.empty((batch, depth, 32) if item_major else (depth, batch, 32), **u8),
+                          new_sib=torch.empty((batch, depth, 32) if item_major else (depth, batch, 32), **u8))
         self.sets = [[mk() for _ in range(n_local)] for _ in range(nbuf)]       # [slot][local rank]
         self.rounds = []                     # per round: (n, size_before)
         arr = (ctypes.c_void_p * n_local)(*[t.h for t in self.trees])
@@ -105,12 +109,16 @@ class SlicedTree:
         return int(self.lib.imt_itree_size(self.trees[0].h))
 
     def outputs(self, R, k=0):
-        """rows [0, n) of every field (n = the round's slice length); sibling arrays are [depth, n, 32]"""
+        """rows [0, n) of every field (n = the round's slice length); sibling arrays are [depth, n, 32] (item_major:
+        [n, depth, 32])"""
         n, size_before = self.rounds[R]
         d = dict(self.sets[R % len(self.sets)][k])
         if n != self.batch:
             for f, t in d.items():
-                d[f] = t.view(-1)[:self.depth * n * 32].view(self.depth, n, 32) if f.endswith("_sib") else t[:n]
+                if f.endswith("_sib") and not self.item_major:
+                    d[f] = t.view(-1)[:self.depth * n * 32].view(self.depth, n, 32)
+                else:
+                    d[f] = t[:n]
         d["first_insertion"] = size_before + (self.first_rank + k) * n      # = first new leaf index
         return d
 

@@ -307,6 +307,34 @@ def test_local_world_ragged_steps(imt, ctx):
     t.close()
 
 
+def test_local_world_item_major_siblings(imt, ctx):
+    """IMT_SIB_ITEM_MAJOR through imt_sliced_step: each insertion's proof as one contiguous [depth][32] row (the reference's
+    per-proof Vec<F>, src/utils.rs:63-85), ragged last step included"""
+    sl = load_sliced()
+    depth, cap, world, batch = 32, 1 << 11, 2, 96
+    sizes = [96, 96, 17]
+    vals = oracle_lib.synth_values(world * sum(sizes), 0x494D5485)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world, item_major=True)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    ref = imt.IndexedTree(ctx, depth, cap)
+    off = 0
+    for r, n in enumerate(sizes):
+        t.step(arr[off:off + world * n])
+        t.flush()
+        want = ref.insert_batch(vals[off:off + world * n])
+        for k in range(world):
+            got = t.outputs(r, k)
+            lo, hi = k * n, (k + 1) * n
+            for f in ("low_sib", "new_sib"):
+                assert got[f].shape == (n, depth, 32)
+                assert (got[f].cpu().numpy() == np.asarray(want[f])[:, lo:hi].transpose(1, 0, 2)).all(), (r, k, f)
+            assert (got["new_root"].cpu().numpy() == np.asarray(want["new_root"])[lo:hi]).all()
+        off += world * n
+    assert all(tr.root() == ref.root() for tr in t.trees)
+    ref.close()
+    t.close()
+
+
 def test_local_world_montgomery_format_and_refused_values(imt, ctx):
     sl = load_sliced()
     depth, cap, world, batch = 32, 1 << 12, 2, 128
