@@ -368,15 +368,21 @@ int imt_itree_insert_batch(imt_itree *t, const void *vals /*[n][32]*/, size_t n,
 /* current siblings of leaf `index` for n indices (get_proof on the stored tree) */
 int imt_itree_get_proof_batch(imt_itree *t, const uint64_t *index, size_t n, void *sib,
                               unsigned flags);
-/* preimages of n leaves */
-int imt_itree_get_leaves(imt_itree *t, const uint64_t *index, size_t n, void *preimage /*[n][3][32]*/,
+/* preimages {val, next_val, next_idx} of n leaves, all-zero for an empty slot.  index == NULL: the n leaves from the
+ * tree's first one on (the whole tree: n = imt_itree_size).  Read from the device-resident index by one kernel (a leaf's
+ * successor is the next value in value order); with IMT_DEVICE_PTRS `index` and `preimage` are device pointers and
+ * nothing crosses PCIe.  An index outside the tree's capacity -> IMT_ERR_RANGE. */
+int imt_itree_get_leaves(imt_itree *t, const uint64_t *index /*[n] or NULL*/, size_t n, void *preimage /*[n][3][32]*/,
                          unsigned flags);
 /* Checkpoint / resume and bulk build.  The snapshot of a tree is its leaf preimages in index order
- * (imt_itree_get_leaves over [0, size)): the reference's serde leaf {val, next_val, next_idx}
- * (src/utils.rs:12-17).  imt_itree_load replaces the tree's contents with n such leaves: it checks
- * on the host that they form one sorted linked list starting at the {0,..} sentinel (IMT_ERR_VALUE
- * otherwise), then rebuilds every stored level on the GPU (n leaf hashes + one pass of k_tree_level
- * per level: about 2 hashes per leaf, the "final root only" build of SURVEY.md 8d). */
+ * (imt_itree_get_leaves(t, NULL, size, ..)): the reference's serde leaf {val, next_val, next_idx}
+ * (src/utils.rs:12-17).  imt_itree_load replaces the tree's contents with n such leaves (host memory, or device memory
+ * with IMT_DEVICE_PTRS; any IMT_FMT_*).  ON THE GPU it checks that they form one sorted linked list starting at the
+ * {0,..} sentinel -- leaves ordered by val (radix sort, 256-bit merge sort if top limbs tie), every leaf's next_val /
+ * next_idx = its successor, the largest one's = {0, 0}, no duplicates, every element < p: IMT_ERR_VALUE /
+ * IMT_ERR_NONCANONICAL otherwise, naming the first leaf with a broken link, and the tree is left as it was -- then
+ * rebuilds every stored level (n leaf hashes + one pass of k_tree_level per level: about 2 hashes per leaf, the "final
+ * root only" build of SURVEY.md 8d).  Host memory needed: none beyond the caller's own buffer. */
 int imt_itree_load(imt_itree *t, const void *preimages /*[n][3][32]*/, uint64_t n, unsigned flags);
 /* low leaf (greatest val < v) for n candidate values; IMT_ERR_VALUE if some v is 0, present, or (with a value
  * partition set) of another subtree's residue */

@@ -359,6 +359,16 @@ public:
         if (!index.empty()) c_->check(imt_itree_get_leaves(t_, index.data(), index.size(), out.data(), IMT_FMT_CANONICAL));
         return out;
     }
+    // checkpoint / resume (the reference's serde leaf, src/utils.rs:12-17): every leaf in index order; load() checks the
+    // list on the GPU and throws, leaving the tree as it was, if it is not one sorted chain from the sentinel
+    std::vector<IndexedMerkleTreeLeaf> snapshot() {
+        std::vector<IndexedMerkleTreeLeaf> out(size());
+        if (!out.empty()) c_->check(imt_itree_get_leaves(t_, nullptr, out.size(), out.data(), IMT_FMT_CANONICAL));
+        return out;
+    }
+    void load(const std::vector<IndexedMerkleTreeLeaf>& leaves) {
+        c_->check(imt_itree_load(t_, leaves.data(), leaves.size(), IMT_FMT_CANONICAL));
+    }
     std::vector<Fr> get_proof(uint64_t index) {
         std::vector<Fr> sib(depth_);
         if (depth_) c_->check(imt_itree_get_proof_batch(t_, &index, 1, sib.data(), IMT_FMT_CANONICAL | IMT_SIB_ITEM_MAJOR));

@@ -569,14 +569,28 @@ class IndexedTree:
         self.ctx._check(lib.imt_itree_get_leaves(self.h, _p(idx), idx.size, _p(out), 0))
         return out
 
-    def snapshot(self):
-        """Leaf preimages [size, 3, 32] in index order: the checkpoint of the tree."""
-        return self.get_leaves(np.arange(self.size, dtype=np.uint64) + np.uint64(self.index_base))
+    def snapshot(self, fmt=0):
+        """Leaf preimages [size, 3, 32] in index order: the checkpoint of the tree (read from the device index)."""
+        out = np.empty((self.size, 3, 32), dtype=np.uint8)
+        self.ctx._check(lib.imt_itree_get_leaves(self.h, None, self.size, _p(out), fmt))
+        return out
 
-    def load(self, preimages):
-        """Replace the contents with a snapshot (bulk rebuild on the GPU)."""
+    def snapshot_into(self, device_ptr, fmt=0):
+        """The same into device memory the caller owns ([size][3][32] bytes, 16-byte aligned): nothing crosses PCIe."""
+        self.ctx._check(lib.imt_itree_get_leaves(self.h, None, self.size, ctypes.c_void_p(device_ptr), fmt | _ffi.DEVICE_PTRS))
+
+    def load(self, preimages, fmt=0):
+        """Replace the contents with a snapshot: checked (one sorted linked list from the sentinel) and rebuilt on the
+        GPU; a refused snapshot leaves the tree as it was."""
         a = _arr(preimages, (3, 32))
-        rc = lib.imt_itree_load(self.h, _p(a), a.shape[0], 0)
+        self._load(_p(a), a.shape[0], fmt)
+
+    def load_device(self, device_ptr, n, fmt=0):
+        """load() of n leaf preimages already in device memory (16-byte aligned)."""
+        self._load(ctypes.c_void_p(device_ptr), n, fmt | _ffi.DEVICE_PTRS)
+
+    def _load(self, ptr, n, flags):
+        rc = lib.imt_itree_load(self.h, ptr, n, flags)
         if rc == _ffi.ERR["VALUE"]:
             raise ValueError(lib.imt_last_error(self.ctx.h).decode())
         self.ctx._check(rc)

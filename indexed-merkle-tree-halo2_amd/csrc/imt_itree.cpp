@@ -599,34 +599,65 @@ extern "C" int imt_itree_get_leaves(imt_itree* t, const uint64_t* index, size_t 
     imt_ctx* c = t->ctx;
     IMT_NOT_SLICED(t);
     if (n == 0) return IMT_OK;
-    if (!index || !preimage) return c->fail(IMT_ERR_ARG, "null buffer");
-    if (flags & IMT_DEVICE_PTRS) return c->fail(IMT_ERR_ARG, "imt_itree_get_leaves takes host pointers");
+    if (!preimage) return c->fail(IMT_ERR_ARG, "null buffer");
+    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
+    if (n > ((size_t)1 << 32) - 1) return c->fail(IMT_ERR_RANGE, "too many leaves in one call");
     int rc = c->set_device();
     if (rc) return rc;
-    if ((rc = ensure_mirror(t))) return rc;
-    std::vector<uint8_t> buf(n * 96);
-    for (size_t i = 0; i < n; i++) {
-        const uint64_t li = index[i] - t->index_base;      // wraps for an index below the base: caught below
-        if (li >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
-        if (li < t->size) {
-            const Pre& p = t->pre[li];                      // the mirror holds local indices; 0 = "no successor"
-            put_pre(&buf[i * 96], p.val, p.next_val, is_zero256(p.next_val) ? 0 : t->index_base + p.next_idx);
-        } else {
-            std::memset(&buf[i * 96], 0, 96);
-        }
-    }
+    const bool dev = flags & IMT_DEVICE_PTRS;
     const unsigned fmt = flags & IMT_FMT_MASK;
-    if (fmt == IMT_FMT_CANONICAL) {
-        std::memcpy(preimage, buf.data(), n * 96);
+    if ((rc = check_fe_ptrs(c, dev, {preimage}))) return rc;
+    if (dev && index && ((uintptr_t)index & 7u)) return c->fail(IMT_ERR_ARG, "device index array is not 8-byte aligned");
+    if (!dev && t->mirror_valid) {
+        // the host mirror is current (host-prepared batches): answer from it
+        std::vector<uint8_t> buf(n * 96);
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t li = (index ? index[i] : t->index_base + i) - t->index_base;   // wraps below the base: caught below
+            if (li >= t->cap) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
+            if (li < t->size) {
+                const Pre& p = t->pre[li];                      // the mirror holds local indices; 0 = "no successor"
+                put_pre(&buf[i * 96], p.val, p.next_val, is_zero256(p.next_val) ? 0 : t->index_base + p.next_idx);
+            } else {
+                std::memset(&buf[i * 96], 0, 96);
+            }
+        }
+        if (fmt == IMT_FMT_CANONICAL) {
+            std::memcpy(preimage, buf.data(), n * 96);
+            return IMT_OK;
+        }
+        uint8_t* d_in = (uint8_t*)c->dev_scratch(0, n * 96);
+        uint8_t* d_out = (uint8_t*)c->dev_scratch(1, n * 96);
+        if (!d_in || !d_out) return IMT_ERR_HIP;
+        IMT_HIP(c, hipMemcpyAsync(d_in, buf.data(), n * 96, hipMemcpyHostToDevice, c->stream));
+        launch::convert(c->stream, d_in, d_out, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+        IMT_HIP(c, hipMemcpyAsync(preimage, d_out, n * 96, hipMemcpyDeviceToHost, c->stream));
+        IMT_HIP(c, hipStreamSynchronize(c->stream));
         return IMT_OK;
     }
-    uint8_t* d_in = (uint8_t*)c->dev_scratch(0, n * 96);
-    uint8_t* d_out = (uint8_t*)c->dev_scratch(1, n * 96);
-    if (!d_in || !d_out) return IMT_ERR_HIP;
-    IMT_HIP(c, hipMemcpyAsync(d_in, buf.data(), n * 96, hipMemcpyHostToDevice, c->stream));
-    launch::convert(c->stream, d_in, d_out, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
-    IMT_HIP(c, hipMemcpyAsync(preimage, d_out, n * 96, hipMemcpyDeviceToHost, c->stream));
-    IMT_HIP(c, hipStreamSynchronize(c->stream));
+    // from the device index: a leaf's successor is the next value in value order (k_leaves)
+    if ((rc = ensure_device_index(t))) return rc;
+    if ((rc = join_top(t))) return rc;
+    hipStream_t s = c->stream;
+    IMT_HIP(c, hipStreamSynchronize(t->up_stream));     // the index may have been written on the side stream
+    const uint64_t* d_idx = index;
+    if (index && !dev) {
+        uint64_t* up = (uint64_t*)c->dev_scratch(0, n * 8);
+        if (!up) return IMT_ERR_HIP;
+        IMT_HIP(c, hipMemcpyAsync(up, index, n * 8, hipMemcpyHostToDevice, s));
+        d_idx = up;
+    }
+    uint8_t* d_out = dev ? (uint8_t*)preimage : (uint8_t*)c->dev_scratch(1, n * 96);
+    int* d_perr = (int*)c->dev_scratch(2, sizeof(int));
+    if (!d_out || !d_perr) return IMT_ERR_HIP;
+    IMT_HIP(c, hipMemsetAsync(d_perr, 0, sizeof(int), s));
+    prep::leaves(s, d_idx, t->index_base, (uint32_t)n, t->d_val, t->d_sorted[t->sorted_cur], (uint32_t)t->size, t->cap,
+                 t->index_base, d_out, d_perr);
+    if (fmt != IMT_FMT_CANONICAL) launch::convert(s, d_out, d_out, n * 3, IMT_FMT_CANONICAL, fmt, c->d_err);
+    int perr = 0;
+    IMT_HIP(c, hipMemcpyAsync(&perr, d_perr, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (!dev) IMT_HIP(c, hipMemcpyAsync(preimage, d_out, n * 96, hipMemcpyDeviceToHost, s));
+    IMT_HIP(c, hipStreamSynchronize(s));
+    if (perr & prep::ERR_RANGE) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
     return IMT_OK;
 }
 
@@ -747,55 +778,66 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
     imt_ctx* c = t->ctx;
     IMT_NOT_SLICED(t);
     if (!preimages || n == 0) return c->fail(IMT_ERR_ARG, "null / empty snapshot");
+    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
     if (n > t->cap) return c->fail(IMT_ERR_FULL, "snapshot has %llu leaves, capacity is %llu", (unsigned long long)n,
                                    (unsigned long long)t->cap);
     if (slice_open(t)) return c->fail(IMT_ERR_ARG, "a slice is open (issue its remaining units first)");
     int rc = c->set_device();
     if (rc) return rc;
+    const bool dev = flags & IMT_DEVICE_PTRS;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    if ((rc = check_fe_ptrs(c, dev, {preimages}))) return rc;
     if ((rc = join_top(t))) return rc;
     for (auto& pl : t->plan)
         if (pl.in_flight) { IMT_HIP(c, hipEventSynchronize(pl.done)); pl.in_flight = false; pl.pipelined = false; }
-    // canonical host copy (3 elements per leaf)
-    std::vector<U256> flat;
-    rc = fetch_canonical(c, c->stream, preimages, (size_t)n * 3, flags, flat);
-    if (rc) return rc;
-    // ---- list check: sorted by val, next pointers = successor in that order, last points to 0 ----
-    // next_idx fields are global indices (index_base + local) except the "no successor" 0; make them local
-    for (uint64_t i = 0; i < n; i++) {
-        U256& nx = flat[3 * i + 2];
-        if (!is_zero256(flat[3 * i + 1])) {
-            if (nx[1] | nx[2] | nx[3] || nx[0] < t->index_base)
-                return c->fail(IMT_ERR_VALUE, "leaf %llu: next_idx out of range", (unsigned long long)i);
-            nx[0] -= t->index_base;
-        }
-        if (nx[1] | nx[2] | nx[3] || nx[0] >= n)
-            return c->fail(IMT_ERR_VALUE, "leaf %llu: next_idx out of range", (unsigned long long)i);
-    }
-    if (!is_zero256(flat[0])) return c->fail(IMT_ERR_VALUE, "leaf 0 must be the {0,..} sentinel");
-    std::vector<uint64_t> order(n);
-    std::iota(order.begin(), order.end(), (uint64_t)0);
-    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return lt256(flat[3 * a], flat[3 * b]); });
-    static const U256 ZERO = {0, 0, 0, 0};
-    for (uint64_t r = 0; r < n; r++) {
-        const uint64_t i = order[r];
-        if (r + 1 < n) {
-            const uint64_t j = order[r + 1];
-            if (flat[3 * i] == flat[3 * j]) return c->fail(IMT_ERR_VALUE, "duplicate value in snapshot");
-            if (!(flat[3 * i + 1] == flat[3 * j]) || flat[3 * i + 2][0] != j)
-                return c->fail(IMT_ERR_VALUE, "leaf %llu does not point to its successor", (unsigned long long)i);
-        } else if (!(flat[3 * i + 1] == ZERO) || flat[3 * i + 2][0] != 0) {
-            return c->fail(IMT_ERR_VALUE, "the largest leaf must have next_val = next_idx = 0");
-        }
-    }
-    // ---- device rebuild ----
+    IMT_HIP(c, hipStreamSynchronize(t->up_stream));
     hipStream_t s = c->stream;
+    // ---- the canonical preimages on the device (what is hashed; next_idx fields are global indices) ----
+    const uint8_t* d_pre = (const uint8_t*)preimages;
+    if (!dev || fmt != IMT_FMT_CANONICAL) {
+        uint8_t* buf = (uint8_t*)c->dev_scratch(2, (size_t)n * 96);
+        if (!buf) return IMT_ERR_HIP;
+        if (!dev) IMT_HIP(c, hipMemcpyAsync(buf, preimages, (size_t)n * 96, hipMemcpyHostToDevice, s));
+        if (fmt != IMT_FMT_CANONICAL) {
+            if ((rc = c->clear_err())) return rc;
+            launch::convert(s, dev ? d_pre : buf, buf, (size_t)n * 3, fmt, IMT_FMT_CANONICAL, c->d_err);
+            if ((rc = c->sync_and_check())) return rc;
+        }
+        d_pre = buf;
+    }
+    // ---- list check on the device: ordered by val, every leaf points to its successor, the last one to {0, 0} ----
+    const size_t ws_bytes = prep::load_ws_bytes((size_t)n);
+    uint8_t* ws = (uint8_t*)c->dev_scratch(3, ws_bytes + 64);
+    if (!ws) return IMT_ERR_HIP;
+    int* d_perr = (int*)ws;
+    const uint32_t* d_order = nullptr;
+    int perr = 0;
+    uint32_t bad = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        uint32_t* d_bad = nullptr;
+        IMT_HIP(c, hipMemsetAsync(d_perr, 0, sizeof(int), s));
+        IMT_HIP(c, prep::load_check(s, d_pre, (uint32_t)n, t->index_base, t->part_mod, t->part_res, ws + 64, ws_bytes,
+                                    attempt == 1, d_perr, &d_bad, &d_order));
+        IMT_HIP(c, hipMemcpyAsync(&perr, d_perr, sizeof(int), hipMemcpyDeviceToHost, s));
+        IMT_HIP(c, hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));
+        IMT_HIP(c, hipStreamSynchronize(s));
+        // values that agree in their top 64 bits and came out of the radix sort in the wrong order: sort with the
+        // 256-bit comparator and check again (the other bits of a first attempt that tied mean nothing)
+        if (!(perr & prep::LOAD_TIE)) break;
+    }
+    if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a field element in the snapshot is not reduced (>= p)");
+    if (perr & prep::LOAD_SENTINEL) return c->fail(IMT_ERR_VALUE, "leaf 0 must be the {0,..} sentinel");
+    if (perr & prep::LOAD_DUP) return c->fail(IMT_ERR_VALUE, "duplicate value in snapshot");
+    if (perr & prep::LOAD_LINK)
+        return c->fail(IMT_ERR_VALUE, "leaf %llu does not point to its successor", (unsigned long long)(t->index_base + bad));
+    if (perr & prep::LOAD_LAST) return c->fail(IMT_ERR_VALUE, "the largest leaf must have next_val = next_idx = 0");
+    if (perr & prep::ERR_FOREIGN)
+        return c->fail(IMT_ERR_VALUE, "a value belongs to another subtree (v %% %u != %u)", t->part_mod, t->part_res);
+    if (perr) return c->fail(IMT_ERR_INTERNAL, "snapshot check: unexpected error bits %d", perr);
+    // ---- device rebuild: nothing of the tree has been written up to here ----
     if ((rc = c->clear_err())) return rc;
-    uint8_t* d_pre = (uint8_t*)c->dev_scratch(2, (size_t)n * 96);
-    if (!d_pre) return IMT_ERR_HIP;
-    if (t->index_base)      // what is hashed is the global index
-        for (uint64_t i = 0; i < n; i++)
-            if (!is_zero256(flat[3 * i + 1])) flat[3 * i + 2][0] += t->index_base;
-    IMT_HIP(c, hipMemcpyAsync(d_pre, flat.data(), (size_t)n * 96, hipMemcpyHostToDevice, s));
+    prep::load_commit(s, d_pre, (uint32_t)n, t->d_val);
+    IMT_HIP(c, hipMemcpyAsync(t->d_sorted[t->sorted_cur], d_order, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     for (unsigned l = 0; l <= t->depth; l++)
         launch::fill_level(s, t->d_nodes + t->h_off[l] * 32, t->h_len[l], c->d_zero + (size_t)l * 32);
     launch::hash_batch(s, d_pre, t->d_nodes, (size_t)n, 3, IMT_FMT_CANONICAL, IMT_FMT_DEVICE, c->d_err);
@@ -813,16 +855,14 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
     }
     rc = c->sync_and_check();
     if (rc) return rc;
-    // ---- host mirror ----
-    t->pre.resize(n);
-    t->sorted.resize(n);
-    for (uint64_t i = 0; i < n; i++)
-        t->pre[i] = Pre{flat[3 * i], flat[3 * i + 1],
-                        is_zero256(flat[3 * i + 1]) ? 0 : flat[3 * i + 2][0] - t->index_base};
-    for (uint64_t r = 0; r < n; r++) t->sorted[r] = SortedEnt{flat[3 * order[r]][3], order[r]};
+    // the device index is the tree's list now; the host mirror is rebuilt from it if a host-side call asks (ensure_mirror)
+    t->pre.clear();
+    t->pre.shrink_to_fit();
+    t->sorted.clear();
+    t->sorted.shrink_to_fit();
     t->size = n;
-    t->mirror_valid = true;
-    t->dev_index_valid = false;
+    t->mirror_valid = false;
+    t->dev_index_valid = true;
     t->pending.active = false;
     for (auto& pl : t->plan) pl.has_root = false;
     return IMT_OK;

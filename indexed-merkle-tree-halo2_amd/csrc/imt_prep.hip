@@ -194,6 +194,62 @@ k_nm_witness(const uint8_t* __restrict__ vals, const uint8_t* __restrict__ d_val
     }
 }
 
+// ---- snapshot: imt_itree_load's list check and imt_itree_get_leaves, on the device ----
+struct PreLess {                       // order leaf indices by the val field of their [3][32] preimage
+    const uint8_t* pre;
+    __device__ bool operator()(uint32_t a, uint32_t b) const {
+        return lt256(pre + (uint64_t)a * 96, pre + (uint64_t)b * 96);
+    }
+};
+
+__global__ void __launch_bounds__(BLOCK) k_load_keys(const uint8_t* __restrict__ pre, uint32_t n, uint32_t part_mod,
+                                                     uint32_t part_res, uint64_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ idx, int* err) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = pre + (uint64_t)i * 96;
+    if (geq_p(p) || geq_p(p + 32) || geq_p(p + 64)) atomicOr(err, ERR_NONCANONICAL);
+    if (part_mod > 1 && i > 0 && mod_small(p, part_mod) != part_res) atomicOr(err, ERR_FOREIGN);
+    keys[i] = reinterpret_cast<const uint64_t*>(p)[3];
+    idx[i] = i;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_load_check(const uint8_t* __restrict__ pre, uint32_t n, uint64_t base,
+                                                      const uint32_t* __restrict__ idx, int* err, uint32_t* bad) {
+    const uint32_t r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int e = load_check_rank(pre, n, base, idx, r);
+    if (e) {
+        atomicOr(err, e);
+        if (e & LOAD_LINK) atomicMin(bad, idx[r]);
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_load_commit(const uint8_t* __restrict__ pre, uint32_t n,
+                                                       uint8_t* __restrict__ d_val) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    copy32(d_val + (uint64_t)i * 32, pre + (uint64_t)i * 96);
+}
+
+// preimage {val, next_val, next_idx} of leaves: the successor of a stored value is the next one in value order
+__global__ void __launch_bounds__(BLOCK) k_leaves(const uint64_t* __restrict__ index, uint64_t first, uint32_t n,
+                                                  const uint8_t* __restrict__ d_val, const uint32_t* __restrict__ sorted,
+                                                  uint32_t M, uint64_t cap, uint64_t base, uint8_t* __restrict__ out,
+                                                  int* err) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t li = (index ? index[i] : first + i) - base;     // wraps below the base: out of range
+    uint8_t* o = out + (uint64_t)i * 96;
+    if (li >= cap) atomicOr(err, ERR_RANGE);
+    if (li >= M) { zero32(o); zero32(o + 32); zero32(o + 64); return; }
+    const uint8_t* x = d_val + li * 32;
+    const uint32_t r = count_below(d_val, sorted, M, x);            // its rank: sorted[r] == li
+    copy32(o, x);
+    if (r + 1 < M) { const uint32_t su = sorted[r + 1]; copy32(o + 32, d_val + (uint64_t)su * 32); put_u64(o + 64, base + su); }
+    else { zero32(o + 32); zero32(o + 64); }
+}
+
 int levels_for(uint32_t n) {
     int k = 1;
     while ((1u << k) <= n) k++;
@@ -273,6 +329,50 @@ void find_low(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const ui
               uint64_t base, uint64_t* low_index, int* err) {
     if (!n) return;
     hipLaunchKernelGGL(k_find_low, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, sorted, M, n, base, low_index, err);
+}
+
+size_t load_ws_bytes(size_t n) {
+    size_t a = 0, b = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                    (uint32_t*)nullptr, n, 0, 64, nullptr);
+    (void)rocprim::merge_sort(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, n, PreLess{nullptr}, nullptr);
+    const size_t r = (n + 63) / 64 * 64;
+    return 2 * r * 8 + 2 * r * 4 + 256 + (a > b ? a : b) + 256;
+}
+
+hipError_t load_check(hipStream_t s, const uint8_t* pre, uint32_t n, uint64_t base, uint32_t part_mod, uint32_t part_res,
+                      void* ws, size_t ws_bytes, bool full_sort, int* err, uint32_t** bad, const uint32_t** sorted) {
+    if (load_ws_bytes(n) > ws_bytes) return hipErrorInvalidValue;
+    const size_t r = ((size_t)n + 63) / 64 * 64;
+    uint8_t* w = (uint8_t*)ws;
+    uint64_t* keys = (uint64_t*)w;
+    uint64_t* keys2 = keys + r;
+    uint32_t* idx = (uint32_t*)(keys2 + r);
+    uint32_t* idx2 = idx + r;
+    *bad = idx2 + r;
+    void* tmp = (uint8_t*)(*bad) + 256;
+    size_t tb = ws_bytes - (size_t)((uint8_t*)tmp - w);
+    hipError_t e;
+    (void)hipGetLastError();
+    if ((e = hipMemsetAsync(*bad, 0xff, 4, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_load_keys, dim3(nblk(n)), dim3(BLOCK), 0, s, pre, n, part_mod, part_res, keys, idx, err);
+    if (full_sort) e = rocprim::merge_sort(tmp, tb, idx, idx2, (size_t)n, PreLess{pre}, s);
+    else e = rocprim::radix_sort_pairs(tmp, tb, keys, keys2, idx, idx2, (size_t)n, 0, 64, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_load_check, dim3(nblk(n)), dim3(BLOCK), 0, s, pre, n, base, idx2, err, *bad);
+    *sorted = idx2;
+    return hipGetLastError();
+}
+
+void load_commit(hipStream_t s, const uint8_t* pre, uint32_t n, uint8_t* d_val) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_load_commit, dim3(nblk(n)), dim3(BLOCK), 0, s, pre, n, d_val);
+}
+
+void leaves(hipStream_t s, const uint64_t* index, uint64_t first, uint32_t n, const uint8_t* d_val, const uint32_t* sorted,
+            uint32_t M, uint64_t cap, uint64_t base, uint8_t* out, int* err) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_leaves, dim3(nblk(n)), dim3(BLOCK), 0, s, index, first, n, d_val, sorted, M, cap, base, out, err);
 }
 
 }  // namespace prep

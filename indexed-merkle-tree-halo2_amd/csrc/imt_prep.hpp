@@ -21,6 +21,8 @@ namespace prep {
 constexpr uint32_t NONE = 0xffffffffu;
 // error bits written by the kernels
 constexpr int ERR_NONCANONICAL = 1, ERR_ZERO = 2, ERR_DUPLICATE = 4, ERR_FOREIGN = 8;
+// 16 / 32 / 64 / 128: LOAD_SENTINEL / LOAD_LINK / LOAD_LAST / LOAD_TIE of the snapshot check (imt_prep_logic.hpp)
+constexpr int ERR_RANGE = 256;
 
 struct Workspace {            // per plan set, sized for `cap_n` insertions
     size_t cap_n = 0;
@@ -80,6 +82,22 @@ void nm_witness(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const 
 // predecessor search only (imt_itree_find_low_batch): low[i] = leaf index of the greatest value < vals[i]
 void find_low(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
               uint64_t base, uint64_t* low_index, int* err);
+
+// ---- snapshot (imt_itree_load, imt_itree_get_leaves): the tree's list checked and read on the device ----
+// load_check: pre = [n][3][32] canonical leaf preimages in index order.  Orders the leaves by val (radix sort on the top
+// 64 bits; full_sort: merge sort with the 256-bit comparator -- the caller's second attempt after LOAD_TIE) and checks
+// every rank (load_check_rank, imt_prep_logic.hpp); error bits are OR-ed into *err, the smallest leaf index with a broken
+// link into **bad (0xffffffff if none).  *sorted = the leaf indices in value order, inside `ws` (load_ws_bytes(n) bytes of
+// device memory).  Writes nothing but ws / err.
+size_t load_ws_bytes(size_t n);
+hipError_t load_check(hipStream_t s, const uint8_t* pre, uint32_t n, uint64_t base, uint32_t part_mod, uint32_t part_res,
+                      void* ws, size_t ws_bytes, bool full_sort, int* err, uint32_t** bad, const uint32_t** sorted);
+// d_val[i] = pre[i].val
+void load_commit(hipStream_t s, const uint8_t* pre, uint32_t n, uint8_t* d_val);
+// out[i] = canonical preimage of leaf index[i] (index == NULL: first + i), all-zero for an empty slot below `cap`;
+// ERR_RANGE for an index outside [base, base + cap)
+void leaves(hipStream_t s, const uint64_t* index, uint64_t first, uint32_t n, const uint8_t* d_val, const uint32_t* sorted,
+            uint32_t M, uint64_t cap, uint64_t base, uint8_t* out, int* err);
 
 }  // namespace prep
 }  // namespace imt

@@ -65,5 +65,33 @@ IMT_PL_HD uint32_t nearest_smaller_right(const uint32_t* st, uint32_t n, int lev
     return p < n ? p : n;
 }
 
+// ---- snapshot check (imt_itree_load): the leaves, visited in value order, must be ONE linked list ----------------
+// pre = [n][3][32] canonical {val, next_val, next_idx}; idx[r] = leaf index of the r-th smallest val (candidate order:
+// sorted by the top 64 bits at least).  Rank r checks leaf idx[r] against its successor idx[r + 1]: strictly larger
+// val (equal: duplicate; smaller under an equal top limb: the candidate order was too coarse, LOAD_TIE -> the caller
+// re-sorts with the full comparator), next_val = the successor's val, next_idx = base + its index; the last leaf points
+// to {0, 0}; rank 0 is leaf 0 = the {0,..} sentinel (the reference's first leaf, src/indexed_merkle_tree.rs:710-713).
+constexpr int LOAD_SENTINEL = 16, LOAD_LINK = 32, LOAD_LAST = 64, LOAD_TIE = 128, LOAD_DUP = 4;
+IMT_PL_HD bool is_u64_256(const uint8_t* a, uint64_t v) {
+    const uint64_t* x = reinterpret_cast<const uint64_t*>(a);
+    return x[0] == v && (x[1] | x[2] | x[3]) == 0;
+}
+IMT_PL_HD int load_check_rank(const uint8_t* pre, uint32_t n, uint64_t base, const uint32_t* idx, uint32_t r) {
+    const uint32_t i = idx[r];
+    const uint8_t* p = pre + (uint64_t)i * 96;
+    int e = 0;
+    if (r == 0 && (i != 0 || !is_u64_256(p, 0))) e |= LOAD_SENTINEL;
+    if (r + 1 < n) {
+        const uint32_t j = idx[r + 1];
+        const uint8_t* q = pre + (uint64_t)j * 96;
+        if (eq256(p, q)) return e | LOAD_DUP;
+        if (!lt256(p, q)) return e | LOAD_TIE;
+        if (!eq256(p + 32, q) || !is_u64_256(p + 64, base + j)) e |= LOAD_LINK;
+    } else if (!is_u64_256(p + 32, 0) || !is_u64_256(p + 64, 0)) {
+        e |= LOAD_LAST;
+    }
+    return e;
+}
+
 }  // namespace prep
 }  // namespace imt

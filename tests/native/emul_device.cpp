@@ -100,6 +100,12 @@ extern "C" uint32_t emul_nsl(const uint32_t* st, uint32_t n, int levels, uint32_
 extern "C" uint32_t emul_nsr(const uint32_t* st, uint32_t n, int levels, uint32_t j) {
     return imt::prep::nearest_smaller_right(st, n, levels, j);
 }
+// snapshot check of imt_itree_load: OR of load_check_rank over every rank
+extern "C" int emul_load_check(const uint8_t* pre, uint32_t n, uint64_t base, const uint32_t* idx) {
+    int e = 0;
+    for (uint32_t r = 0; r < n; r++) e |= prep::load_check_rank(pre, n, base, idx, r);
+    return e;
+}
 extern "C" uint32_t emul_count_below(const uint8_t* val, const uint32_t* sorted, uint32_t M, const uint8_t* x) {
     return imt::prep::count_below(val, sorted, M, x);
 }

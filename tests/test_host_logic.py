@@ -291,6 +291,41 @@ def test_prepare_logic_nearest_smaller_and_count_below(emul):
         assert got == sum(1 for y in vals if y < x)
 
 
+def test_snapshot_check_logic(emul, oracle):
+    """imt_itree_load's per-rank list check (imt_prep_logic.hpp, run by k_load_check) against the oracle's own leaves
+    (update_idx_leaf, /root/reference/src/indexed_merkle_tree.rs:632-660) and against planted corruptions."""
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    n, base = 200, 5 << 32
+    vals = oracle_lib.synth_values(n - 1, 0x4C4F41)
+    # two values that agree in their top 64 bits: the radix order leaves them in leaf order
+    top = (vals[10] >> 192) << 192
+    vals[20] = top | 5
+    vals[30] = top | 3
+    leaves = [[0, 0, 0]]
+    for v in vals:                                   # the reference's sequential insertion
+        lo = max((l for l in leaves if l[0] < v), key=lambda l: l[0])
+        leaves.append([v, lo[1], lo[2]])
+        lo[1], lo[2] = v, base + len(leaves) - 1
+    pre = np.frombuffer(b"".join(b32(x) for l in leaves for x in l), dtype=np.uint8).reshape(n, 3, 32).copy()
+    order = np.array(sorted(range(n), key=lambda i: leaves[i][0]), dtype=np.uint32)
+    coarse = np.array(sorted(range(n), key=lambda i: (leaves[i][0] >> 192, i)), dtype=np.uint32)
+    run = lambda p, idx: emul.emul_load_check(p.ctypes.data_as(ctypes.c_void_p), n, ctypes.c_uint64(base), idx.ctypes.data_as(u32p))
+    SENT, LINK, LAST, TIE, DUP = 16, 32, 64, 128, 4
+    assert run(pre, order) == 0
+    assert (coarse != order).any() and run(pre, coarse) & TIE          # leaf 21 (..|5) before leaf 31 (..|3)
+    bad = pre.copy(); bad[3, 1, 0] ^= 1;   assert run(bad, order) == LINK      # next_val
+    bad = pre.copy(); bad[3, 2, 0] ^= 1;   assert run(bad, order) == LINK      # next_idx
+    bad = pre.copy(); bad[7, 2, 20] = 1;   assert run(bad, order) == LINK      # next_idx beyond 64 bits
+    bad = pre.copy(); bad[0, 0, 0] = 1;    assert run(bad, order) & SENT
+    last = int(order[-1])
+    bad = pre.copy(); bad[last, 2, 0] = 1; assert run(bad, order) == LAST
+    bad = pre.copy(); bad[last, 1, 0] = 1; assert run(bad, order) == LAST
+    a, b = int(order[50]), int(order[51])
+    bad = pre.copy(); bad[b, 0] = bad[a, 0]; assert run(bad, order) & DUP
+    # without the index base the pointers of a placed subtree do not check
+    assert emul.emul_load_check(pre.ctypes.data_as(ctypes.c_void_p), n, ctypes.c_uint64(0), order.ctypes.data_as(u32p)) & LINK
+
+
 def test_header_is_plain_c_and_example_links():
     """include/imt.h must compile as C11 (it is the FFI contract) and the C example must link against
     the library (no compute: there is no GPU here)."""

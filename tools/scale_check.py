@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The timed path on BIG trees: prefill a depth-32 tree with imt_itree_load to 2^k leaves (k from SCALE_SIZES, default
-20 24 26 27), then 50 pipelined batches of 2^16 insertions exactly as bench.py issues them (device pointers,
+20 24 26 27 28; the snapshot is generated, checked and loaded in HBM -- no host copy of the tree exists), then 50 pipelined batches of 2^16 insertions exactly as bench.py issues them (device pointers,
 IMT_PIPELINE | IMT_INPUTS_READY, every witness written), and report the rate, the per-class kernel times
 (imt_profile_read) and a correctness check at that size: the last batch's witnesses through imt_insert_witness_batch
 (every insert_leaf constraint at depth 32), the root chain, the tree's root.
@@ -27,28 +27,23 @@ from imt_amd import _ffi  # noqa: E402
 lib = imt_amd.lib
 DEPTH, BATCH = 32, 1 << 16
 STEPS, WARM = int(os.environ.get("SCALE_STEPS", "50")), 4
-sizes = [int(x) for x in os.environ.get("SCALE_SIZES", "20 24 26 27").split()]
+sizes = [int(x) for x in os.environ.get("SCALE_SIZES", "20 24 26 27 28").split()]
 dev = torch.device("cuda", 0)
 P_ = lambda x: ctypes.c_void_p(x.data_ptr())
 
 
-def avail_gb():
-    for line in open("/proc/meminfo"):
-        if line.startswith("MemAvailable"):
-            return int(line.split()[1]) / 1e6
-    return 0.0
-
-
-def snapshot(M, rng):
-    """[M][3][32] uint8: the sorted linked list of M leaves described above"""
-    pre = np.zeros((M, 3, 4), dtype=np.uint64)           # 4 x u64 little-endian limbs per element
-    r = rng.integers(1, 1 << 63, size=M, dtype=np.uint64)
+def snapshot(M, seed):
+    """[M][3][32] uint8 on the device: the sorted linked list of M leaves described above"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    pre = torch.zeros((M, 3, 4), dtype=torch.int64, device=dev)          # 4 x u64 little-endian limbs per element
+    r = torch.randint(1, 1 << 62, (M,), dtype=torch.int64, device=dev, generator=g)
     r[0] = 0
-    idx = np.arange(M, dtype=np.uint64)
+    idx = torch.arange(M, dtype=torch.int64, device=dev)
     pre[:, 0, 0], pre[:, 0, 1] = r, idx                   # val = (i << 64) + r_i
     pre[:-1, 1, 0], pre[:-1, 1, 1] = r[1:], idx[1:]       # next_val
     pre[:-1, 2, 0] = idx[1:]                              # next_idx
-    return pre.view(np.uint8).reshape(M, 3, 32)
+    return pre.view(torch.uint8).reshape(M, 3, 32)
 
 
 def new_values(n, M, rng):
@@ -59,24 +54,36 @@ def new_values(n, M, rng):
     return v.view(np.uint8).reshape(n, 32)
 
 
-print(f"host memory available: {avail_gb():.0f} GB; steps {STEPS} x 2^16 after {WARM} warm-up batches", flush=True)
+print(f"steps {STEPS} x 2^16 after {WARM} warm-up batches", flush=True)
 for k in sizes:
     M = 1 << k
-    need = M * 96 * 3.3 / 1e9         # snapshot + the library's canonical copy + host mirror
-    if need > 0.6 * avail_gb():
-        print(f"2^{k} leaves: skipped ({need:.0f} GB of host memory needed for imt_itree_load, {avail_gb():.0f} GB available)", flush=True)
-        continue
     rng = np.random.default_rng(1000 + k)
     total = (STEPS + WARM) * BATCH
     cap = 1 << (M + total).bit_length()
     ctx = imt_amd.Context(0)
     tree = imt_amd.IndexedTree(ctx, DEPTH, cap)
-    t0 = time.perf_counter()
-    snap = snapshot(M, rng)
+    snap = snapshot(M, 1000 + k)
+    torch.cuda.synchronize()
     t1 = time.perf_counter()
-    ctx._check(lib.imt_itree_load(tree.h, snap.ctypes.data_as(ctypes.c_void_p), M, 0))
+    tree.load_device(snap.data_ptr(), M)                  # returns after the rebuild has been checked (synchronous)
     t2 = time.perf_counter()
+    # the checkpoint read back from the device index equals what was loaded; a corrupted one is refused
+    back = torch.empty_like(snap)
+    tree.snapshot_into(back.data_ptr())
+    torch.cuda.synchronize()
+    t2b = time.perf_counter()
+    same = torch.equal(back, snap)
+    del back
+    snap[M // 3, 1, 0] ^= 1
+    try:
+        tree.load_device(snap.data_ptr(), M)
+        refused = False
+    except ValueError as e:
+        refused = f"leaf {M // 3} " in str(e)
+    print(f"2^{k} leaves: imt_itree_load {t2 - t1:.2f} s from HBM ({M / (t2 - t1) / 1e6:.0f} M leaves/s), "
+          f"imt_itree_get_leaves of all of them {t2b - t2:.2f} s, equal {same}; corrupted snapshot refused {refused}", flush=True)
     del snap
+    torch.cuda.empty_cache()
     vals = torch.from_numpy(new_values(total, M, rng)).to(dev)
     u8 = dict(dtype=torch.uint8, device=dev)
     sets = [dict(low_index=torch.empty(BATCH, dtype=torch.int64, device=dev), low_leaf=torch.empty((BATCH, 3, 32), **u8),
@@ -97,7 +104,7 @@ for k in sizes:
         batch(i, i & 1)
     ctx.sync()
     torch.cuda.synchronize()
-    first_ms = (time.perf_counter() - tw) * 1e3          # includes the device index built from the loaded host mirror
+    first_ms = (time.perf_counter() - tw) * 1e3
     lib.imt_profile_enable(ctx.h, 1)
     t3 = time.perf_counter()
     for i in range(WARM, WARM + STEPS):
@@ -123,7 +130,7 @@ for k in sizes:
     ok = ok and imt_amd.to_int(o["new_root"][-1].cpu().numpy()) == tree.root()
     spread = int(o["low_index"].max()) - int(o["low_index"].min())
     l0 = (M + total - 1).bit_length()
-    print(f"2^{k} leaves prefilled (snapshot {t1 - t0:.1f} s, imt_itree_load {t2 - t1:.1f} s, first {WARM} batches {first_ms:.0f} ms): "
+    print(f"2^{k} leaves prefilled (first {WARM} batches {first_ms:.0f} ms): "
           f"{STEPS * BATCH / dt / 1e6:.3f} M insertions/s, {dt / STEPS * 1e3:.2f} ms per 2^16 batch, L0 = {l0}; "
           f"verified {ok} (last batch: witness kernels + root chain + tree root; low leaves span {spread} positions)", flush=True)
     print("    per batch: " + "; ".join(f"{n_} {ms:.2f} ms / {cnt} launches" for n_, (ms, cnt) in per.items()), flush=True)
