@@ -384,8 +384,9 @@ int imt_itree_get_leaves(imt_itree *t, const uint64_t *index /*[n] or NULL*/, si
  * rebuilds every stored level (n leaf hashes + one pass of k_tree_level per level: about 2 hashes per leaf, the "final
  * root only" build of SURVEY.md 8d).  Host memory needed: none beyond the caller's own buffer. */
 int imt_itree_load(imt_itree *t, const void *preimages /*[n][3][32]*/, uint64_t n, unsigned flags);
-/* low leaf (greatest val < v) for n candidate values; IMT_ERR_VALUE if some v is 0, present, or (with a value
- * partition set) of another subtree's residue */
+/* low leaf (greatest val < v) for n candidate values: a binary search per value in the device-resident index
+ * (k_find_low; with IMT_DEVICE_PTRS `vals` and `low_index` are device pointers); IMT_ERR_VALUE if some v is 0, present,
+ * or (with a value partition set) of another subtree's residue */
 int imt_itree_find_low_batch(imt_itree *t, const void *vals /*[n][32]*/, size_t n,
                              uint64_t *low_index /*[n]*/, unsigned flags);
 

@@ -574,7 +574,42 @@ extern "C" int imt_itree_find_low_batch(imt_itree* t, const void* vals, size_t n
     int rc = c->set_device();
     if (rc) return rc;
     if ((rc = check_fe_ptrs(c, flags & IMT_DEVICE_PTRS, {vals}))) return rc;
-    if ((rc = ensure_mirror(t))) return rc;
+    if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
+    if ((flags & IMT_DEVICE_PTRS) || !t->mirror_valid) {
+        // predecessor search in the device-resident index (k_find_low); the host mirror is not built for it
+        const bool dev = flags & IMT_DEVICE_PTRS;
+        const unsigned fmt = flags & IMT_FMT_MASK;
+        if (n > ((size_t)1 << 31)) return c->fail(IMT_ERR_RANGE, "batch too large");
+        if (dev && ((uintptr_t)low_index & 7u)) return c->fail(IMT_ERR_ARG, "device low_index array is not 8-byte aligned");
+        if ((rc = ensure_device_index(t))) return rc;
+        if ((rc = join_top(t))) return rc;
+        hipStream_t s = c->stream;
+        IMT_HIP(c, hipStreamSynchronize(t->up_stream));
+        const uint8_t* d_vals = (const uint8_t*)vals;
+        int* d_perr = (int*)c->dev_scratch(2, sizeof(int));
+        if (!d_perr) return IMT_ERR_HIP;
+        IMT_HIP(c, hipMemsetAsync(d_perr, 0, sizeof(int), s));
+        if (!dev || fmt != IMT_FMT_CANONICAL) {
+            uint8_t* buf = (uint8_t*)c->dev_scratch(0, n * 32);
+            if (!buf) return IMT_ERR_HIP;
+            if (!dev) IMT_HIP(c, hipMemcpyAsync(buf, vals, n * 32, hipMemcpyHostToDevice, s));
+            if (fmt != IMT_FMT_CANONICAL) launch::convert(s, dev ? d_vals : buf, buf, n, fmt, IMT_FMT_CANONICAL, d_perr);
+            d_vals = buf;
+        }
+        uint64_t* d_low = dev ? low_index : (uint64_t*)c->dev_scratch(1, n * 8);
+        if (!d_low) return IMT_ERR_HIP;
+        prep::find_low(s, d_vals, t->d_val, t->d_sorted[t->sorted_cur], (uint32_t)t->size, (uint32_t)n, t->index_base,
+                       t->part_mod, t->part_res, d_low, d_perr);
+        int perr = 0;
+        IMT_HIP(c, hipMemcpyAsync(&perr, d_perr, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (!dev) IMT_HIP(c, hipMemcpyAsync(low_index, d_low, n * 8, hipMemcpyDeviceToHost, s));
+        IMT_HIP(c, hipStreamSynchronize(s));
+        if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
+        if (perr & prep::ERR_FOREIGN)
+            return c->fail(IMT_ERR_VALUE, "a value belongs to another subtree (v %% %u != %u)", t->part_mod, t->part_res);
+        if (perr & (prep::ERR_ZERO | prep::ERR_DUPLICATE)) return c->fail(IMT_ERR_VALUE, "a value is zero or already in the tree");
+        return IMT_OK;
+    }
     std::vector<U256> v;
     rc = fetch_canonical(c, c->stream, vals, n, flags, v);
     if (rc) return rc;

@@ -159,11 +159,13 @@ __global__ void __launch_bounds__(BLOCK) k_runs(const uint64_t* __restrict__ key
 
 __global__ void __launch_bounds__(BLOCK) k_find_low(const uint8_t* __restrict__ vals, const uint8_t* __restrict__ d_val,
                                                     const uint32_t* __restrict__ sorted, uint32_t M, uint32_t n,
-                                                    uint64_t base, uint64_t* __restrict__ low_index, int* err) {
+                                                    uint64_t base, uint32_t part_mod, uint32_t part_res,
+                                                    uint64_t* __restrict__ low_index, int* err) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint8_t* x = vals + (uint64_t)i * 32;
     if (geq_p(x)) atomicOr(err, ERR_NONCANONICAL);
+    if (part_mod > 1 && mod_small(x, part_mod) != part_res) atomicOr(err, ERR_FOREIGN);
     const uint32_t g = count_below(d_val, sorted, M, x);
     if (g == 0) { atomicOr(err, ERR_ZERO); low_index[i] = base; return; }
     if (g < M && eq256(d_val + (uint64_t)sorted[g] * 32, x)) atomicOr(err, ERR_DUPLICATE);
@@ -326,9 +328,10 @@ void nm_witness(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const 
 }
 
 void find_low(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
-              uint64_t base, uint64_t* low_index, int* err) {
+              uint64_t base, uint32_t part_mod, uint32_t part_res, uint64_t* low_index, int* err) {
     if (!n) return;
-    hipLaunchKernelGGL(k_find_low, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, sorted, M, n, base, low_index, err);
+    hipLaunchKernelGGL(k_find_low, dim3(nblk(n)), dim3(BLOCK), 0, s, vals, d_val, sorted, M, n, base, part_mod, part_res,
+                       low_index, err);
 }
 
 size_t load_ws_bytes(size_t n) {

@@ -81,7 +81,7 @@ void nm_witness(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const 
 
 // predecessor search only (imt_itree_find_low_batch): low[i] = leaf index of the greatest value < vals[i]
 void find_low(hipStream_t s, const uint8_t* vals, const uint8_t* d_val, const uint32_t* sorted, uint32_t M, uint32_t n,
-              uint64_t base, uint64_t* low_index, int* err);
+              uint64_t base, uint32_t part_mod, uint32_t part_res, uint64_t* low_index, int* err);
 
 // ---- snapshot (imt_itree_load, imt_itree_get_leaves): the tree's list checked and read on the device ----
 // load_check: pre = [n][3][32] canonical leaf preimages in index order.  Orders the leaves by val (radix sort on the top

@@ -621,6 +621,7 @@ def test_snapshot_and_load_on_the_device(imt, ctx, oracle):
     """The checkpoint without the host: imt_itree_get_leaves / imt_itree_load with device pointers and with index = NULL,
     in every boundary format; the list check (k_load_check) refuses each kind of broken snapshot with its own message and
     writes nothing; values that agree in their top 64 bits take the second, fully compared sort."""
+    import ctypes
     import torch
     depth, n = 32, 600
     vals = oracle_lib.synth_values(n, 0x494D5421)
@@ -663,6 +664,19 @@ def test_snapshot_and_load_on_the_device(imt, ctx, oracle):
     b = imt.IndexedTree(ctx, depth, 1024)
     b.load(snap)
     root = b.root()
+    # the low-leaf search of a loaded tree runs in the device index (k_find_low): host and device pointers
+    stored = [0] + vals
+    probe = [v + 1 for v in vals[:40] if v + 1 not in set(vals)] + [top | 5, top | 8, P - 1, 1]
+    want = [max((i for i in range(n + 1) if stored[i] < x), key=lambda i: stored[i]) for x in probe]
+    assert [int(x) for x in b.find_low(probe)] == want
+    d_probe = torch.from_numpy(imt.to_bytes(probe)).cuda()
+    d_low = torch.empty(len(probe), dtype=torch.int64, device="cuda")
+    ctx._check(imt.lib.imt_itree_find_low_batch(b.h, ctypes.c_void_p(d_probe.data_ptr()), len(probe),
+                                                ctypes.c_void_p(d_low.data_ptr()), imt._ffi.DEVICE_PTRS))
+    assert d_low.cpu().tolist() == want
+    for member in (vals[3], 0):
+        with pytest.raises(ValueError):
+            b.find_low([member])
     order = sorted(range(n + 1), key=lambda i: int.from_bytes(snap[i, 0].tobytes(), "little"))
     def refused(bad, text, exc=ValueError):
         with pytest.raises(exc, match=text):
