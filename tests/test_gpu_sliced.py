@@ -529,6 +529,35 @@ def test_batches_before_and_after_slices_on_one_tree(imt, ctx):
     t.close()
 
 
+def test_sliced_world_resumes_from_a_checkpoint(imt, ctx):
+    """checkpoint / resume of the multi-GPU mode: the snapshot of ANY replica (imt_itree_get_leaves from its device index,
+    right after a flush) loaded into every replica of a new world (imt_itree_load: checked and rebuilt on the GPU)
+    continues bit-exactly -- witnesses and roots equal the one-GPU tree that never stopped."""
+    sl = load_sliced()
+    depth, cap, world, batch = 32, 1 << 13, 2, 300
+    vals = oracle_lib.synth_values(6 * world * batch, 0x494D5484)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    step = world * batch
+    want, root = reference_run(imt, ctx, depth, cap, vals, step)
+    a = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world)
+    for r in range(3):
+        a.step(arr[r * step:(r + 1) * step])
+    a.flush()
+    snap = a.trees[1].snapshot()
+    assert (snap == a.trees[0].snapshot()).all() and snap.shape[0] == 3 * step + 1
+    a.close()
+    b = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world)
+    for t in b.trees:
+        t.load(snap)
+    for r in range(3, 6):
+        R = b.step(arr[r * step:(r + 1) * step])
+        b.flush()
+        for k in range(world):
+            check_round(want[r], b.outputs(R, k), k * batch, (k + 1) * batch)
+    assert b.trees[0].root() == b.trees[1].root() == root
+    b.close()
+
+
 def test_slice_calls_refuse_bad_arguments(imt, ctx):
     """the C entry points directly: misaligned payloads / values, units out of order, a second preparation of too many
     slices, a placed tree, a short payload stride, worlds that are no schedule -- documented codes, nothing reaches a kernel"""
