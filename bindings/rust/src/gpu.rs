@@ -237,6 +237,34 @@ impl IndexedTree {
     }
 }
 
+impl IndexedTree {
+    /// Checkpoint: every leaf `{val, next_val, next_idx}` in index order (the reference's serde leaf, `src/utils.rs:12-17`),
+    /// read from the device-resident index (`imt_itree_get_leaves` with `index = NULL`).
+    pub fn snapshot<F: ScalarField>(&self) -> Result<Vec<[F; 3]>, ImtError> {
+        let g = context().lock().unwrap();
+        let n = self.size() as usize;
+        let mut pre = vec![0u8; n * 96];
+        check(&g, unsafe {
+            imt_itree_get_leaves(self.handle, std::ptr::null(), n, pre.as_mut_ptr() as *mut c_void, IMT_FMT_CANONICAL)
+        })?;
+        Ok((0..n)
+            .map(|i| [F::from_bytes_le(&pre[i * 96..][..32]), F::from_bytes_le(&pre[i * 96 + 32..][..32]),
+                      F::from_bytes_le(&pre[i * 96 + 64..][..32])])
+            .collect())
+    }
+    /// Resume: replace the contents with a snapshot.  The GPU checks that the leaves are one sorted linked list from the
+    /// `{0,..}` sentinel and rebuilds every level; `Err(code -10)` names the first leaf with a broken link and leaves the
+    /// tree as it was (`imt_itree_load`).
+    pub fn load<F: ScalarField>(&mut self, leaves: &[[F; 3]]) -> Result<(), ImtError> {
+        let g = context().lock().unwrap();
+        let mut pre = Vec::with_capacity(leaves.len() * 96);
+        for l in leaves {
+            pre.extend_from_slice(&to_bytes(&l[..]));
+        }
+        check(&g, unsafe { imt_itree_load(self.handle, pre.as_ptr() as *const c_void, leaves.len() as u64, IMT_FMT_CANONICAL) })
+    }
+}
+
 impl Drop for IndexedTree {
     fn drop(&mut self) {
         let _g = context().lock().unwrap();

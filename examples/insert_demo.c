@@ -1,7 +1,8 @@
 /* insert_demo.c -- plain C against include/imt.h: 6 insertions into a depth-3 tree (the values of the
  * reference's test_insert_leaf_multiple_round, src/indexed_merkle_tree.rs:683-690), then every
  * insert_leaf constraint re-checked on the GPU, then the witness trace of all 3 + 4*3 Poseidon gadget calls
- * of every insert_leaf (what a chip assigns instead of recomputing) and its cell map.  Build:
+ * of every insert_leaf (what a chip assigns instead of recomputing) and its cell map, then a checkpoint of the tree
+ * reloaded into a second one.  Build:
  *   gcc -std=c11 -I include examples/insert_demo.c -L indexed-merkle-tree-halo2_amd/csrc -limt_hip -o insert_demo
  */
 #include <stdio.h>
@@ -77,6 +78,25 @@ int main(void) {
            n_cells, n_consts, out_row, trace_ok ? "trace rows ok" : "MISMATCH");
     bad |= !trace_ok;
     free(trace);
+    /* f4: checkpoint / resume -- the leaves {val, next_val, next_idx} in index order (the reference's serde leaf,
+     * src/utils.rs:12-17) read from the device index, loaded into a second tree (list check + rebuild on the GPU) */
+    const uint64_t size = imt_itree_size(tree);
+    unsigned char(*snap)[3][32] = malloc(size * 96);
+    unsigned char root_a[32], root_b[32];
+    imt_itree *resumed = NULL;
+    rc = imt_itree_get_leaves(tree, NULL, size, snap, IMT_FMT_CANONICAL);
+    if (!rc) rc = imt_itree_new(ctx, DEPTH, 8, &resumed);
+    if (!rc) rc = imt_itree_load(resumed, snap, size, IMT_FMT_CANONICAL);
+    if (!rc) rc = imt_itree_root(tree, root_a, IMT_FMT_CANONICAL);
+    if (!rc) rc = imt_itree_root(resumed, root_b, IMT_FMT_CANONICAL);
+    if (rc) { fprintf(stderr, "checkpoint: %s\n", imt_last_error(ctx)); return 1; }
+    snap[2][1][0] ^= 1;                                  /* leaf 2 no longer points to its successor */
+    const int refused = imt_itree_load(resumed, snap, size, IMT_FMT_CANONICAL) == IMT_ERR_VALUE;
+    printf("checkpoint: %llu leaves reloaded, root %s; corrupted snapshot %s (%s)\n", (unsigned long long)size,
+           memcmp(root_a, root_b, 32) ? "DIFFERS" : "equal", refused ? "refused" : "ACCEPTED", imt_last_error(ctx));
+    bad |= memcmp(root_a, root_b, 32) != 0 || !refused;
+    free(snap);
+    imt_itree_free(resumed);
     imt_itree_free(tree);
     imt_ctx_destroy(ctx);
     return bad != 0;

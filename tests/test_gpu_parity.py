@@ -814,6 +814,7 @@ def test_c_example_runs(imt):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all satisfied" in r.stdout and "trace rows ok" in r.stdout and "4506 cells" in r.stdout
+    assert "7 leaves reloaded, root equal; corrupted snapshot refused (leaf 2 does not point to its successor)" in r.stdout
     want = int(GOLD["multi_round_depth3"][-1]["new_root"])
     assert f"{want:064x}" in r.stdout          # the last root of test_insert_leaf_multiple_round
     # examples/slice_demo.c: two replicas of ONE list driven through imt_sliced_step from plain C (schedule and exchange
