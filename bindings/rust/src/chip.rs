@@ -99,34 +99,86 @@ impl<F: BigPrimeField> FixLenHasher<F> for TracedPoseidonHasher<F> {
         };
         let rows = self.queue.borrow_mut().pop_front().expect("no precomputed trace queued for this hash");
         assert_eq!(rows.len(), layout.rows);
-        let mut assigned: Vec<Option<AssignedValue<F>>> = vec![None; layout.rows];
-        let cells = &layout.cells;
-        let mut a = 0usize;
-        while a < cells.len() {
-            let mut b = a + 1;
-            while b < cells.len() && cells[b].region == 0 {
-                b += 1;
-            }
-            let region = &cells[a..b];
-            let quantum = region.iter().map(|c| match c.kind {
-                IMT_CELL_CONST => Constant(layout.constants[c.index as usize]),
-                IMT_CELL_INPUT => Existing(inputs[c.index as usize]),
-                IMT_CELL_INIT => Existing(self.init_state[c.index as usize]),
-                IMT_CELL_WITNESS => Witness(rows[c.index as usize]),
-                IMT_CELL_COPY => Existing(assigned[c.index as usize].expect("copy of a row that is not assigned yet")),
-                k => panic!("unknown cell kind {k}"),
-            });
-            let gates = region.iter().enumerate().filter(|(_, c)| c.gate == 1).map(|(i, _)| i as isize);
-            let start = ctx.advice.len();
-            ctx.assign_region(quantum.collect::<Vec<_>>(), gates.collect::<Vec<_>>());
-            for (i, c) in region.iter().enumerate() {
-                if c.kind == IMT_CELL_WITNESS {
-                    assigned[c.index as usize] = Some(ctx.get((start + i) as isize));
-                }
-            }
-            a = b;
-        }
+        let assigned = assign_layout(ctx, &layout.cells, &layout.constants, inputs, &self.init_state, &rows);
         assigned[layout.out_row].unwrap()
+    }
+}
+
+/// Lay one gadget's column down from its cell map: region by region (a region = one `ctx.assign_region` call of the
+/// original gadget), every NEW value taken from `rows`, every copy an `Existing(..)` of a cell assigned earlier.
+/// Returns the assigned cell of every trace row.  Shared by the hash layouts (f1) and the comparison layout (f3).
+pub fn assign_layout<F: BigPrimeField>(
+    ctx: &mut Context<F>,
+    cells: &[imt_trace_cell],
+    constants: &[F],
+    inputs: &[AssignedValue<F>],
+    init_state: &[AssignedValue<F>],
+    rows: &[F],
+) -> Vec<Option<AssignedValue<F>>> {
+    let mut assigned: Vec<Option<AssignedValue<F>>> = vec![None; rows.len()];
+    let mut a = 0usize;
+    while a < cells.len() {
+        let mut b = a + 1;
+        while b < cells.len() && cells[b].region == 0 {
+            b += 1;
+        }
+        let region = &cells[a..b];
+        let quantum = region.iter().map(|c| match c.kind {
+            IMT_CELL_CONST => Constant(constants[c.index as usize]),
+            IMT_CELL_INPUT => Existing(inputs[c.index as usize]),
+            IMT_CELL_INIT => Existing(init_state[c.index as usize]),
+            IMT_CELL_WITNESS => Witness(rows[c.index as usize]),
+            IMT_CELL_COPY => Existing(assigned[c.index as usize].expect("copy of a row that is not assigned yet")),
+            k => panic!("unknown cell kind {k}"),
+        });
+        let gates = region.iter().enumerate().filter(|(_, c)| c.gate == 1).map(|(i, _)| i as isize);
+        let start = ctx.advice.len();
+        ctx.assign_region(quantum.collect::<Vec<_>>(), gates.collect::<Vec<_>>());
+        for (i, c) in region.iter().enumerate() {
+            if c.kind == IMT_CELL_WITNESS {
+                assigned[c.index as usize] = Some(ctx.get((start + i) as isize));
+            }
+        }
+        a = b;
+    }
+    assigned
+}
+
+/// f3: the reference's `is_less_than` (`src/indexed_merkle_tree.rs:98-125`: `range.is_less_than(.., 128)` and
+/// `gate.is_equal` for the high and the low 128-bit limbs, `not` x4, `and` x4, `or`) with every new value -- the shifted
+/// differences, their `lookup_bits`-wide limbs, the running sums, both inverses, the booleans -- taken from rows the GPU
+/// produced (`gpu::less_than_traces`, or the two K-row stretches of `imt_insert_gadget_trace_batch`) instead of being
+/// computed while assigning.  Same cells, same gates, same copies; the limb cells are registered with the RangeChip's
+/// lookup exactly where `range_check` would (`imt_less_than_lookup_rows`).  In the reference the function is private, so
+/// using this means replacing its body by `traced.is_less_than(ctx, range, [a_q, a_r, b_q, b_r], rows)`.
+pub struct TracedLessThan<F: BigPrimeField> {
+    cells: Vec<imt_trace_cell>,
+    constants: Vec<F>,
+    out_row: usize,
+    lookup_rows: Vec<u32>,
+    pub rows: usize,
+}
+
+impl<F: BigPrimeField> TracedLessThan<F> {
+    pub fn new(lookup_bits: usize) -> Self {
+        let (cells, constants, out_row, lookup_rows) = gpu::less_than_layout::<F>(lookup_bits).expect("imt_less_than_trace_layout");
+        let rows = cells.iter().filter(|c| c.kind == IMT_CELL_WITNESS).count();
+        TracedLessThan { cells, constants, out_row, lookup_rows, rows }
+    }
+
+    pub fn is_less_than(
+        &self,
+        ctx: &mut Context<F>,
+        range: &halo2_base::gates::RangeChip<F>,
+        limbs: [AssignedValue<F>; 4],
+        rows: &[F],
+    ) -> AssignedValue<F> {
+        assert_eq!(rows.len(), self.rows, "one comparison is {} rows", self.rows);
+        let assigned = assign_layout(ctx, &self.cells, &self.constants, &limbs, &[], rows);
+        for &r in &self.lookup_rows {
+            range.add_cell_to_lookup(ctx, assigned[r as usize].expect("a lookup row is a trace row"));
+        }
+        assigned[self.out_row].unwrap()
     }
 }
 

@@ -179,7 +179,9 @@ extern "C" {
     pub fn imt_less_than_trace_rows(lookup_bits: c_uint) -> usize;
     pub fn imt_less_than_trace_batch(ctx: *mut imt_ctx, a: *const c_void, b: *const c_void, n: usize, lookup_bits: c_uint, trace: *mut c_void, lt_out: *mut u8, flags: c_uint) -> c_int;
     pub fn imt_less_than_trace_layout(ctx: *mut imt_ctx, lookup_bits: c_uint, cells: *mut imt_trace_cell, cells_cap: usize, n_cells: *mut usize, constants: *mut c_void, const_cap: usize, n_constants: *mut usize, out_row: *mut u32, flags: c_uint) -> c_int;
+    pub fn imt_less_than_lookup_rows(lookup_bits: c_uint, rows: *mut u32, cap: usize, n_rows: *mut usize) -> c_int;
     pub fn imt_insert_gadget_rows(depth: c_uint, lookup_bits: c_uint) -> usize;
+    pub fn imt_insert_gadget_lookup_rows(depth: c_uint, lookup_bits: c_uint, rows: *mut u32, cap: usize, n_rows: *mut usize) -> c_int;
     pub fn imt_insert_gadget_trace_batch(ctx: *mut imt_ctx, low_leaf: *const c_void, low_index: *const u64, low_sib: *const c_void, new_leaf: *const c_void, new_index: *const u64, new_path_index: *const u64, new_sib: *const c_void, is_largest: *const u8, depth: c_uint, lookup_bits: c_uint, n: usize, trace: *mut c_void, flags: c_uint) -> c_int;
     pub fn imt_insert_column_segments(depth: c_uint, lookup_bits: c_uint, segs: *mut imt_column_segment, cap: usize, n_segs: *mut usize) -> c_int;
 

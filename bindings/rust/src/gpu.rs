@@ -356,3 +356,40 @@ pub fn trace_layout<F: ScalarField>(arity: usize) -> Result<(Vec<imt_trace_cell>
     })?;
     Ok((cells, from_bytes(&consts), row as usize))
 }
+
+/// f3: the static cell map of one `is_less_than` (`src/indexed_merkle_tree.rs:98-125`) at the RangeChip's `lookup_bits`
+/// (`imt_less_than_trace_layout`): cells, constants, output row, and the rows whose cells also go to the lookup table
+/// (`imt_less_than_lookup_rows`: the limbs of both range checks).  Inputs 0..3 = a_q, a_r, b_q, b_r.
+pub fn less_than_layout<F: ScalarField>(lookup_bits: usize) -> Result<(Vec<imt_trace_cell>, Vec<F>, usize, Vec<u32>), ImtError> {
+    let g = context().lock().unwrap();
+    let (mut nc, mut nk, mut row) = (0usize, 0usize, 0u32);
+    check(&g, unsafe {
+        imt_less_than_trace_layout(g.ctx, lookup_bits as u32, std::ptr::null_mut(), 0, &mut nc, std::ptr::null_mut(), 0, &mut nk, &mut row, IMT_FMT_CANONICAL)
+    })?;
+    let mut cells = vec![imt_trace_cell::default(); nc];
+    let mut consts = vec![0u8; nk * 32];
+    check(&g, unsafe {
+        imt_less_than_trace_layout(g.ctx, lookup_bits as u32, cells.as_mut_ptr(), nc, &mut nc, consts.as_mut_ptr() as *mut c_void, nk, &mut nk, &mut row, IMT_FMT_CANONICAL)
+    })?;
+    let mut nl = 0usize;
+    check(&g, unsafe { imt_less_than_lookup_rows(lookup_bits as u32, std::ptr::null_mut(), 0, &mut nl) })?;
+    let mut lookup = vec![0u32; nl];
+    check(&g, unsafe { imt_less_than_lookup_rows(lookup_bits as u32, lookup.as_mut_ptr(), nl, &mut nl) })?;
+    Ok((cells, from_bytes(&consts), row as usize, lookup))
+}
+
+/// f3: every new advice value of `is_less_than(a, b)` for n pairs of field elements, item-major: `rows[i]` =
+/// `imt_less_than_trace_rows(lookup_bits)` elements in assignment order (`imt_less_than_trace_batch`).
+pub fn less_than_traces<F: ScalarField>(a: &[F], b: &[F], lookup_bits: usize) -> Result<Vec<Vec<F>>, ImtError> {
+    assert_eq!(a.len(), b.len());
+    let g = context().lock().unwrap();
+    let n = a.len();
+    let rows = unsafe { imt_less_than_trace_rows(lookup_bits as u32) };
+    let mut trace = vec![0u8; n * rows * 32];
+    check(&g, unsafe {
+        imt_less_than_trace_batch(g.ctx, to_bytes(a).as_ptr() as *const c_void, to_bytes(b).as_ptr() as *const c_void, n,
+                                  lookup_bits as u32, trace.as_mut_ptr() as *mut c_void, std::ptr::null_mut(),
+                                  IMT_FMT_CANONICAL | IMT_TRACE_ITEM_MAJOR)
+    })?;
+    Ok((0..n).map(|i| from_bytes(&trace[i * rows * 32..][..rows * 32])).collect())
+}

@@ -15,6 +15,11 @@
 //!    (`:69`, `:82`, `:131`, `:235`); make that parameter `&impl imt_hip::chip::FixLenHasher<F>` (README.md here has
 //!    the sed line).  They are behind the cargo feature `reference-gadget`.
 //!
+//!  * f3, the ORDER of the comparison's rows: `traced_less_than_lays_down_the_same_column` runs the gadget sequence of
+//!    the reference's private `is_less_than` (`:98-125`: halo2-base's `range.is_less_than(.., 128)` + `gate.is_equal` per
+//!    128-bit limb, `not` x4, `and` x4, `or`) and [`TracedLessThan`] (GPU rows, `imt_less_than_trace_batch`) in two
+//!    contexts and compares the advice columns value by value, the copy constraints and the cells sent to the lookup.
+//!    Needs nothing of the reference crate.
 //!  * the soundness of the subtree layout's extra constraint: `owner_constraint_refuses_the_limbs_of_v_plus_p` (no GPU,
 //!    no reference crate).
 //!
@@ -28,7 +33,7 @@ use halo2_base::poseidon::hasher::spec::OptimizedPoseidonSpec;
 use halo2_base::poseidon::hasher::PoseidonHasher;
 use halo2_base::utils::testing::base_test;
 use halo2_base::Context;
-use imt_hip::chip::{FixLenHasher, IndexedMerkleTreeChip, TracedPoseidonHasher};
+use imt_hip::chip::{FixLenHasher, IndexedMerkleTreeChip, TracedLessThan, TracedPoseidonHasher};
 use imt_hip::gpu;
 
 const T: usize = 3;
@@ -88,6 +93,70 @@ fn traced_hasher_lays_down_the_same_column() {
             assert_eq!(a, b, "advice cell {i} of a {arity}-input hash: the trace order differs from halo2-base's");
         }
         assert_eq!(copies[0], copies[1], "number of copy constraints");
+    }
+}
+
+/// f3: same cells, same order, same equality constraints, same lookup cells as the gadgets the reference's
+/// `is_less_than` calls (`src/indexed_merkle_tree.rs:98-125`).
+#[test]
+fn traced_less_than_lays_down_the_same_column() {
+    use halo2_base::gates::GateInstructions;
+    use halo2_base::utils::{biguint_to_fe, fe_to_biguint};
+    use num_bigint::BigUint;
+    let lookup_bits = 18usize;                            // the reference's tests, `:436`
+    let big = |x: u128, y: u128| -> Fr { biguint_to_fe(&((BigUint::from(x) << 128) + BigUint::from(y))) };
+    let cases: Vec<(Fr, Fr)> = vec![
+        (Fr::from(5), Fr::from(9)), (Fr::from(9), Fr::from(5)), (Fr::from(7), Fr::from(7)), (Fr::from(0), -Fr::from(1)),
+        (big(3, u128::MAX), big(4, 0)), (big(4, 0), big(3, u128::MAX)), (big(6, 11), big(6, 12)), (big(6, 12), big(6, 11)),
+    ];
+    let traced = TracedLessThan::<Fr>::new(lookup_bits);
+    let one = BigUint::from(1u64);
+    let mask = (&one << 128) - &one;
+    for (a, b) in cases {
+        let rows = gpu::less_than_traces(&[a], &[b], lookup_bits).expect("imt_less_than_trace_batch").remove(0);
+        let limbs: Vec<Fr> = [a, b].iter().flat_map(|v| { let x = fe_to_biguint(v); [biguint_to_fe(&(&x >> 128)), biguint_to_fe(&(&x & &mask))] }).collect();
+        let mut columns: Vec<Vec<Fr>> = Vec::new();
+        let mut copies: Vec<usize> = Vec::new();
+        let mut lookups: Vec<usize> = Vec::new();
+        let mut outputs: Vec<Fr> = Vec::new();
+        for use_trace in [false, true] {
+            base_test().k(12).lookup_bits(lookup_bits).expect_satisfied(true).run(|ctx, range| {
+                let gate = range.gate();
+                let l: Vec<_> = limbs.iter().map(|v| ctx.load_witness(*v)).collect();
+                let (a_q, a_r, b_q, b_r) = (l[0], l[1], l[2], l[3]);
+                let out = if use_trace {
+                    traced.is_less_than(ctx, range, [a_q, a_r, b_q, b_r], &rows)
+                } else {
+                    // the call sequence of the reference's is_less_than, on halo2-base's own chips
+                    let msb_lt = range.is_less_than(ctx, a_q, b_q, 128);
+                    let msb_eq = gate.is_equal(ctx, a_q, b_q);
+                    let lsb_lt = range.is_less_than(ctx, a_r, b_r, 128);
+                    let lsb_eq = gate.is_equal(ctx, a_r, b_r);
+                    let msb_ne = gate.not(ctx, msb_eq);
+                    let msb_ge = gate.not(ctx, msb_lt);
+                    let msb_eq2 = gate.not(ctx, msb_ne);
+                    let lsb_ne = gate.not(ctx, lsb_eq);
+                    let mut rhs = msb_ge;
+                    for x in [lsb_lt, msb_eq2, lsb_ne] {
+                        rhs = gate.and(ctx, rhs, x);
+                    }
+                    let lhs = gate.and(ctx, msb_lt, msb_ne);
+                    gate.or(ctx, lhs, rhs)
+                };
+                outputs.push(*out.value());
+                columns.push(advice_values(ctx));
+                copies.push(ctx.copy_manager.lock().unwrap().advice_equalities.len());
+                lookups.push(ctx.copy_manager.lock().unwrap().assigned_advices.len());
+            });
+        }
+        assert_eq!(outputs[0], outputs[1], "comparison result");
+        assert_eq!(outputs[0], if fe_to_biguint(&a) < fe_to_biguint(&b) { Fr::from(1) } else { Fr::from(0) });
+        assert_eq!(columns[0].len(), columns[1].len(), "number of advice cells of one is_less_than");
+        for (i, (x, y)) in columns[0].iter().zip(columns[1].iter()).enumerate() {
+            assert_eq!(x, y, "advice cell {i} of is_less_than: the trace order differs from halo2-base's");
+        }
+        assert_eq!(copies[0], copies[1], "number of copy constraints");
+        assert_eq!(lookups[0], lookups[1], "cells known to the copy manager (lookup registrations included)");
     }
 }
 

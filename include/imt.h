@@ -236,6 +236,11 @@ int imt_less_than_trace_batch(imt_ctx *ctx, const void *a /*[n][32]*/, const voi
  * b_r; *out_row = the row holding the result */
 int imt_less_than_trace_layout(imt_ctx *ctx, unsigned lookup_bits, imt_trace_cell *cells, size_t cells_cap, size_t *n_cells,
                                void *constants, size_t const_cap, size_t *n_constants, uint32_t *out_row, unsigned flags);
+/* Which of those rows the RangeChip ALSO constrains through its lookup table: range.is_less_than range-checks each
+ * shifted difference by decomposing it into lookup_bits-wide limbs and adding every limb cell to the lookup
+ * (add_cell_to_lookup); these are the 2 (ceil(128 / lookup_bits) + 1) limb rows, in column order.  A chip that assigns
+ * the rows itself registers exactly these cells.  rows may be NULL (count only).  Arithmetic on sizes: no context. */
+int imt_less_than_lookup_rows(unsigned lookup_bits, uint32_t *rows, size_t cap, size_t *n_rows);
 /* ALL rows of insert_leaf outside its hashes ("glue rows"), in assignment order: is_equal(next_val, 0) [4 rows], the
  * limbs nl_q nl_r ll_q ll_r [4], their two mul_add [2], is_less_than(new, low.next_val) [K], select [3], then for the low
  * leaf's path load_witness [1] + dual_mux a-b, b-a, left, right per level [4 depth], the limbs of low.val + mul_add
@@ -244,6 +249,9 @@ int imt_less_than_trace_layout(imt_ctx *ctx, unsigned lookup_bits, imt_trace_cel
  * (what imt_itree_insert_batch returned) plus is_largest; depth >= 1.  Together with imt_insert_trace_batch this is
  * every new advice value of the call; imt_insert_column_segments tells how the two traces interleave. */
 size_t imt_insert_gadget_rows(unsigned depth, unsigned lookup_bits);
+/* the glue rows that are also lookup cells (imt_less_than_lookup_rows for both comparisons of the call, as glue-row
+ * numbers): 4 (ceil(128 / lookup_bits) + 1) rows */
+int imt_insert_gadget_lookup_rows(unsigned depth, unsigned lookup_bits, uint32_t *rows, size_t cap, size_t *n_rows);
 int imt_insert_gadget_trace_batch(imt_ctx *ctx, const void *low_leaf /*[n][3][32]*/, const uint64_t *low_index,
                                   const void *low_sib, const void *new_leaf /*[n][3][32]*/, const uint64_t *new_index,
                                   const uint64_t *new_path_index /*[n] or NULL = new_index*/, const void *new_sib,

@@ -106,7 +106,9 @@ SIGNATURES = {
     "imt_less_than_trace_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint, c_void_p, c_void_p, c_uint]),
     "imt_less_than_trace_layout": (c_int, [c_void_p, c_uint, P(TraceCell), c_size_t, P(c_size_t), c_void_p, c_size_t,
                                            P(c_size_t), P(ctypes.c_uint32), c_uint]),
+    "imt_less_than_lookup_rows": (c_int, [c_uint, P(ctypes.c_uint32), c_size_t, P(c_size_t)]),
     "imt_insert_gadget_rows": (c_size_t, [c_uint, c_uint]),
+    "imt_insert_gadget_lookup_rows": (c_int, [c_uint, c_uint, P(ctypes.c_uint32), c_size_t, P(c_size_t)]),
     "imt_insert_gadget_trace_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_uint, c_uint, c_size_t, c_void_p, c_uint]),
     "imt_insert_column_segments": (c_int, [c_uint, c_uint, P(ColumnSegment), c_size_t, P(c_size_t)]),

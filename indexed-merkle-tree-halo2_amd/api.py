@@ -203,6 +203,27 @@ class Context:
         """(cells, constants, out_row) of one is_less_than call (imt_less_than_trace_layout); inputs 0..3 = a_q, a_r, b_q, b_r"""
         return trace_layout(lambda *a: lib.imt_less_than_trace_layout(self.h, *a), lookup_bits, fmt, self._check)
 
+    @staticmethod
+    def less_than_lookup_rows(lookup_bits=18):
+        """trace rows of one is_less_than that the RangeChip also adds to its lookup table (the limbs of both range
+        checks), in column order (imt_less_than_lookup_rows)"""
+        n = ctypes.c_size_t()
+        if lib.imt_less_than_lookup_rows(lookup_bits, None, 0, ctypes.byref(n)):
+            raise ValueError("1 <= lookup_bits <= 28")
+        rows = np.empty(n.value, dtype=np.uint32)
+        assert lib.imt_less_than_lookup_rows(lookup_bits, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n.value, None) == 0
+        return rows
+
+    @staticmethod
+    def insert_gadget_lookup_rows(depth, lookup_bits=18):
+        """glue rows of one insert_leaf (insert_gadget_trace) that are also lookup cells: both comparisons' limbs"""
+        n = ctypes.c_size_t()
+        if lib.imt_insert_gadget_lookup_rows(depth, lookup_bits, None, 0, ctypes.byref(n)):
+            raise ValueError("depth >= 1 and 1 <= lookup_bits <= 28")
+        rows = np.empty(n.value, dtype=np.uint32)
+        assert lib.imt_insert_gadget_lookup_rows(depth, lookup_bits, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n.value, None) == 0
+        return rows
+
     def insert_gadget_trace(self, low_leaf, low_index, low_sib, new_leaf, new_index, new_sib, is_largest, depth,
                             lookup_bits=18, new_path_index=None, fmt=0, item_major=False):
         """every new advice value of insert_leaf OUTSIDE its hashes for n insertions (imt_insert_gadget_trace_batch):

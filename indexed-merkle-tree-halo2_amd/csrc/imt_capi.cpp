@@ -465,15 +465,9 @@ extern "C" int imt_insert_trace_batch(imt_ctx* c, const void* low_leaf, const ui
 // ------------------------------------------------------------------------------------
 // f3: the advice values of insert_leaf outside hash_fix_len_array (imt_gadget.hip)
 // ------------------------------------------------------------------------------------
-static unsigned lt_limbs(unsigned lookup_bits) { return (128 + lookup_bits - 1) / lookup_bits + 1; }
-
-extern "C" size_t imt_less_than_trace_rows(unsigned lookup_bits) {
-    return (lookup_bits < 1 || lookup_bits > 28) ? 0 : 4 * (size_t)lt_limbs(lookup_bits) + 27;
-}
-extern "C" size_t imt_insert_gadget_rows(unsigned depth, unsigned lookup_bits) {
-    const size_t k = imt_less_than_trace_rows(lookup_bits);
-    return (k && depth >= 1 && depth <= IMT_MAX_DEPTH) ? 20 + 2 * k + 16 * (size_t)depth : 0;
-}
+// row counts: imt_gadget_layout.cpp (host-only arithmetic, shared with the CPU test build)
+extern "C" size_t imt_less_than_trace_rows(unsigned lookup_bits);
+extern "C" size_t imt_insert_gadget_rows(unsigned depth, unsigned lookup_bits);
 
 extern "C" int imt_less_than_trace_batch(imt_ctx* c, const void* a, const void* b, size_t n, unsigned lookup_bits, void* trace,
                                          uint8_t* lt_out, unsigned flags) {

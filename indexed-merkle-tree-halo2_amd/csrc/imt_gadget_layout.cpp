@@ -21,6 +21,7 @@ struct GWalker {
     std::vector<imt_trace_cell> cells;
     std::vector<HFr> consts;
     uint32_t n_witness = 0;
+    std::vector<uint32_t> lookup;          // witness rows RangeChip::range_check adds to the lookup table (the limbs)
     bool region_open = false;
     explicit GWalker(const HostPoseidon& h) : hp(h) {}
 
@@ -74,8 +75,10 @@ struct GWalker {
         witness(true); constant(hp.F.sub(hp.F.zero(), pow2(padded))); constant(hp.F.one()); existing(a);
         begin_region();
         Ref last = witness(L > 1);                      // limb 0 (limb_bases[0] = 1) opens the running sum
+        lookup.push_back(last.index);
         for (unsigned i = 1; i < L; i++) {
             last = witness();
+            lookup.push_back(last.index);
             constant(pow2(i * lb));
             witness(i + 1 < L);
         }
@@ -96,7 +99,17 @@ struct GWalker {
 
 }  // namespace
 
-extern "C" size_t imt_less_than_trace_rows(unsigned lookup_bits);
+// new advice values of one is_less_than: two range.is_less_than (2 L + 4 rows each with L = ceil(128 / lookup_bits) + 1
+// limbs), two is_equal (4 each), not x4, mul x4, or (3): 4 L + 27; of a whole insert_leaf outside its hashes: 20 + 2 K +
+// 16 depth (imt.h)
+extern "C" size_t imt_less_than_trace_rows(unsigned lookup_bits) {
+    return (lookup_bits < 1 || lookup_bits > 28) ? 0 : 4 * (size_t)((128 + lookup_bits - 1) / lookup_bits + 1) + 27;
+}
+extern "C" size_t imt_insert_gadget_rows(unsigned depth, unsigned lookup_bits) {
+    const size_t k = imt_less_than_trace_rows(lookup_bits);
+    return (k && depth >= 1 && depth <= IMT_MAX_DEPTH) ? 20 + 2 * k + 16 * (size_t)depth : 0;
+}
+extern "C" int imt_less_than_lookup_rows(unsigned lookup_bits, uint32_t* rows, size_t cap, size_t* n_rows);
 
 extern "C" int imt_less_than_trace_layout(imt_ctx* c, unsigned lookup_bits, imt_trace_cell* cells, size_t cells_cap,
                                           size_t* n_cells, void* constants, size_t const_cap, size_t* n_constants,
@@ -109,6 +122,13 @@ extern "C" int imt_less_than_trace_layout(imt_ctx* c, unsigned lookup_bits, imt_
     GWalker w(c->hp);
     const uint32_t row = w.less_than(lookup_bits);
     if (w.n_witness != imt_less_than_trace_rows(lookup_bits)) return c->fail(IMT_ERR_INTERNAL, "layout and kernel disagree");
+    {   // the closed form of imt_less_than_lookup_rows against the limb cells this walk has just laid down
+        std::vector<uint32_t> lk(w.lookup.size() + 1);
+        size_t nl = 0;
+        if (imt_less_than_lookup_rows(lookup_bits, lk.data(), lk.size(), &nl) || nl != w.lookup.size() ||
+            std::memcmp(lk.data(), w.lookup.data(), nl * sizeof(uint32_t)))
+            return c->fail(IMT_ERR_INTERNAL, "lookup rows: closed form and layout disagree");
+    }
     if (n_cells) *n_cells = w.cells.size();
     if (n_constants) *n_constants = w.consts.size();
     if (out_row) *out_row = row;
@@ -130,6 +150,50 @@ extern "C" int imt_less_than_trace_layout(imt_ctx* c, unsigned lookup_bits, imt_
                 std::memcpy(o, words, 32);
             }
         }
+    }
+    return IMT_OK;
+}
+
+// Which rows of that column the RangeChip also constrains through its LOOKUP table: range_check(shifted, padded +
+// lookup_bits) decomposes each shifted difference into lookup_bits-wide limbs and calls add_cell_to_lookup on every limb
+// cell (padded + lookup_bits is a multiple of lookup_bits: no scaled last limb).  Row numbers (trace rows of
+// imt_less_than_trace_batch) in column order: the L limbs of the high-limb comparison, then the L of the low-limb one.
+// Arithmetic on sizes only: no context, no GPU.
+extern "C" int imt_less_than_lookup_rows(unsigned lookup_bits, uint32_t* rows, size_t cap, size_t* n_rows) {
+    if (lookup_bits < 1 || lookup_bits > 28) return IMT_ERR_RANGE;
+    const unsigned L = (128 + lookup_bits - 1) / lookup_bits + 1;
+    // rows of one range.is_less_than: shifted, shift_a, limb 0, then (limb i, running sum i) for i = 1 .. L-1, then the 3
+    // of is_zero = 2 L + 4; gate.is_equal adds 4 (difference + is_zero); the low-limb comparison follows both
+    const uint32_t per_range = 2 * L + 4, per_half = per_range + 4;
+    if (n_rows) *n_rows = 2 * (size_t)L;
+    if (!rows) return IMT_OK;
+    if (cap < 2 * (size_t)L) return IMT_ERR_RANGE;
+    for (unsigned h = 0; h < 2; h++) {
+        uint32_t* o = rows + h * L;
+        const uint32_t base = h * per_half;
+        o[0] = base + 2;
+        for (unsigned i = 1; i < L; i++) o[i] = base + 3 + 2 * (i - 1);
+    }
+    return IMT_OK;
+}
+
+// The same for the glue rows of a whole insert_leaf (imt_insert_gadget_trace_batch): its two is_less_than calls start
+// at glue row 10 (behind is_equal [4], the four limbs [4], two mul_add [2]) and at 17 + K + 4 depth (behind the first
+// comparison [K], select [3], the low leaf's path [1 + 4 depth] and the limbs of low.val with their mul_add [3]).
+extern "C" int imt_insert_gadget_lookup_rows(unsigned depth, unsigned lookup_bits, uint32_t* rows, size_t cap, size_t* n_rows) {
+    if (!imt_insert_gadget_rows(depth, lookup_bits)) return IMT_ERR_RANGE;
+    size_t per = 0;
+    int rc = imt_less_than_lookup_rows(lookup_bits, nullptr, 0, &per);
+    if (rc) return rc;
+    if (n_rows) *n_rows = 2 * per;
+    if (!rows) return IMT_OK;
+    if (cap < 2 * per) return IMT_ERR_RANGE;
+    if ((rc = imt_less_than_lookup_rows(lookup_bits, rows, per, nullptr))) return rc;
+    const uint32_t K = (uint32_t)imt_less_than_trace_rows(lookup_bits);
+    const uint32_t first = 10, second = 17 + K + 4 * depth;
+    for (size_t i = 0; i < per; i++) {
+        rows[per + i] = rows[i] + second;
+        rows[i] += first;
     }
     return IMT_OK;
 }

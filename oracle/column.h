@@ -18,6 +18,8 @@ typedef struct {
     size_t wcap, nw;
     int overflow;
     int region_open;           /* the next cell starts a new ctx.assign_region call */
+    uint32_t *lookup;          /* [lookup_cap] witness rows the RangeChip adds to its lookup (range_check limbs), may be NULL */
+    size_t lookup_cap, n_lookup;
 } col_t;
 
 static void put(col_t *c, const ofr_t *v, uint8_t kind, uint32_t index, int gate) {

@@ -133,6 +133,12 @@ static aval g_load_constant(col_t *c, const ofr_t *v) {
     return r;
 }
 
+/* RangeChip::add_cell_to_lookup on the witness just put */
+static void mark_lookup(col_t *c, const aval *a) {
+    if (c->lookup && c->n_lookup < c->lookup_cap) c->lookup[c->n_lookup] = a->index;
+    c->n_lookup++;
+}
+
 /* ---- RangeChip::is_less_than(a, b, 128) with the given lookup_bits; a, b < 2^128 as integers ---- */
 static aval r_is_less_than(col_t *c, const aval *a, const aval *b, unsigned lb) {
     const unsigned k = (128 + lb - 1) / lb, padded = k * lb, L = k + 1;
@@ -166,11 +172,13 @@ static aval r_is_less_than(col_t *c, const aval *a, const aval *b, unsigned lb) 
             sum = lf;
             last = put_witness(c, &lf);              /* limb_bases[0] = 1: the first limb opens the running sum */
             if (L > 1) mark_gate_last(c);
+            mark_lookup(c, &last);
         } else {
             pow2(&base, i * lb);
             ofr_mul(&t, &lf, &base);
             ofr_add(&sum, &sum, &t);
             last = put_witness(c, &lf);
+            mark_lookup(c, &last);
             put_const(c, &base, 0);
             put_witness(c, &sum);
             if (i + 1 < L) mark_gate_last(c);
@@ -231,6 +239,21 @@ int orc_less_than_trace(const uint8_t a[32], const uint8_t b[32], unsigned looku
     if (n_witness) *n_witness = c.nw;
     if (out_row) *out_row = out.index;
     return c.overflow ? ORC_ERR_RANGE : ORC_OK;
+}
+
+/* The witness rows of that column the RangeChip adds to its lookup table (range_check: the lookup_bits-wide limbs of
+ * both shifted differences; padded + lookup_bits is a multiple of lookup_bits, so no scaled last limb): 2 L of them. */
+int orc_less_than_lookup_rows(unsigned lookup_bits, uint32_t *rows, size_t cap, size_t *n_rows) {
+    ginit();
+    if (lookup_bits < 1 || lookup_bits > 28) return ORC_ERR_RANGE;
+    col_t c;
+    memset(&c, 0, sizeof c);
+    c.lookup = rows; c.lookup_cap = rows ? cap : 0;
+    aval in[4];
+    for (int i = 0; i < 4; i++) { in[i].v = G_ZERO; in[i].kind = ORC_CELL_INPUT; in[i].index = (uint32_t)i; }
+    (void)ref_is_less_than(&c, &in[0], &in[1], &in[2], &in[3], lookup_bits);
+    if (n_rows) *n_rows = c.n_lookup;
+    return rows && c.n_lookup > cap ? ORC_ERR_RANGE : ORC_OK;
 }
 
 /* ---- the non-hash part of insert_leaf :231-314 ---- */

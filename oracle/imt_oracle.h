@@ -154,6 +154,8 @@ void orc_trace_spec(uint8_t *start /*[5][3][32]*/, uint8_t *partial /*[57][32]*/
 size_t orc_less_than_trace_rows(unsigned lookup_bits);
 int orc_less_than_trace(const uint8_t a[32], const uint8_t b[32], unsigned lookup_bits, uint8_t *cells, orc_trace_cell *desc,
                         size_t cap, size_t *n_cells, uint8_t *witness, size_t wcap, size_t *n_witness, uint32_t *out_row);
+/* the witness rows of that column which are range-checked through the lookup table (the limbs), in column order */
+int orc_less_than_lookup_rows(unsigned lookup_bits, uint32_t *rows, size_t cap, size_t *n_rows);
 /* every new witness of insert_leaf (:231-314) that is not inside a hash ("glue rows": is_equal, the limb loads, both
  * is_less_than, select, load_witness + dual_mux of the four paths), in assignment order, and the segments -- glue rows
  * (kind 0) / one hash_fix_len_array call (kind 1, rows of orc_hash_trace in imt_insert_trace_batch's order) -- that make

@@ -144,9 +144,6 @@ extern "C" int emul_trace_layout(int arity, imt_trace_cell* cells, size_t cells_
     return imt_hash_trace_layout(fake, arity, cells, cells_cap, n_cells, constants, const_cap, n_constants, out_row, flags);
 }
 // f3: the cell layout of one is_less_than (imt_gadget_layout.cpp), the same way
-extern "C" size_t imt_less_than_trace_rows(unsigned lookup_bits) {
-    return (lookup_bits < 1 || lookup_bits > 28) ? 0 : 4 * (size_t)((128 + lookup_bits - 1) / lookup_bits + 1) + 27;
-}
 extern "C" int emul_less_than_layout(int lookup_bits, imt_trace_cell* cells, size_t cells_cap, size_t* n_cells, void* constants,
                                      size_t const_cap, size_t* n_constants, uint32_t* out_row, unsigned flags) {
     static imt_ctx* fake = nullptr;

@@ -90,6 +90,14 @@ class Oracle:
                     witness=wit[:nw.value].copy(), out_row=row.value)
 
     # ---- f3: the cells of insert_leaf outside its hashes (oracle/gadget.c) ----
+    def less_than_lookup_rows(self, lookup_bits=18):
+        n = ctypes.c_size_t()
+        assert self.lib.orc_less_than_lookup_rows(ctypes.c_uint(lookup_bits), None, ctypes.c_size_t(0), ctypes.byref(n)) == 0
+        rows = np.empty(n.value, dtype=np.uint32)
+        assert self.lib.orc_less_than_lookup_rows(ctypes.c_uint(lookup_bits), rows.ctypes.data_as(ctypes.c_void_p),
+                                                  ctypes.c_size_t(n.value), None) == 0
+        return rows
+
     def less_than_trace(self, a, b, lookup_bits=18):
         """the column of ONE is_less_than(a_q, a_r, b_q, b_r) (src/indexed_merkle_tree.rs:98-125): same dict as hash_trace"""
         cap, wcap = 1200, 400

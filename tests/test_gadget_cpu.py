@@ -80,9 +80,11 @@ def _insertions(depth, n, seed):
 
 
 @pytest.mark.parametrize("depth,n", [(3, 6), (32, 5)])
-def test_insert_gadget_rows_against_the_model(depth, n):
+def test_insert_gadget_rows_against_the_model(imt, depth, n):
     orc, ins = _insertions(depth, n, 0x494D54A0 + depth)
     K = 4 * 9 + 27
+    lk = imt.Context.insert_gadget_lookup_rows(depth, 18)
+    assert len(lk) == 4 * 9 and len(set(lk.tolist())) == len(lk)
     for v, new_index, o in ins:
         low3 = oracle_lib.arr_ints(o["low_leaf"])
         new3 = [v, low3[1], low3[2]]
@@ -93,6 +95,13 @@ def test_insert_gadget_rows_against_the_model(depth, n):
         assert len(want) == 20 + 2 * K + 16 * depth
         # the select row: is_largest ? next_val == 0 : new < next_val -- 1 for a real insertion (:182-191)
         assert want[10 + K + 2] == 1
+        # the lookup rows are the 18-bit limbs of the four shifted differences of the two comparisons (:180, :226)
+        M128 = (1 << 128) - 1
+        pairs = [(v >> 128, low3[1] >> 128), (v & M128, low3[1] & M128), (low3[0] >> 128, v >> 128), (low3[0] & M128, v & M128)]
+        for g, (x, y) in enumerate(pairs):
+            limbs = [want[r] for r in lk[9 * g:9 * g + 9]]
+            assert all(t < (1 << 18) for t in limbs)
+            assert sum(t << (18 * i) for i, t in enumerate(limbs)) == (1 << 144) + x - y
         # segments: glue rows and hash blocks alternate, cover both traces exactly, hash blocks in imt_insert_trace_batch's order
         glue = [s for s in segs if s[0] == 0]
         hsh = [s for s in segs if s[0] == 1]
@@ -112,6 +121,29 @@ def test_less_than_rejects_bad_arguments():
                                        ctypes.byref(nc), None, ctypes.c_size_t(0), None, None) != 0
     assert orc.lib.orc_less_than_trace((P).to_bytes(32, "little"), oracle_lib.b32(2), ctypes.c_uint(18), None, None,
                                        ctypes.c_size_t(0), ctypes.byref(nc), None, ctypes.c_size_t(0), None, None) != 0
+
+
+@pytest.mark.parametrize("lookup_bits", [18, 17, 8, 4, 28])
+def test_lookup_rows_are_the_limbs_of_both_range_checks(imt, lookup_bits):
+    """imt_less_than_lookup_rows (closed form, no GPU) = the cells oracle/gadget.c's RangeChip restatement adds to the
+    lookup; on real columns those rows hold values below 2^lookup_bits that recompose both shifted differences --
+    exactly what range_check(shifted, padded + lookup_bits) constrains (halo2-lib v0.4.x gates/range.rs)."""
+    orc = oracle_lib.load()
+    L = -(-128 // lookup_bits) + 1
+    rows = imt.Context.less_than_lookup_rows(lookup_bits)
+    assert rows.tolist() == orc.less_than_lookup_rows(lookup_bits).tolist() and len(rows) == 2 * L
+    assert len(set(rows.tolist())) == 2 * L and list(rows) == sorted(rows)
+    with pytest.raises(ValueError):
+        imt.Context.less_than_lookup_rows(0)
+    for a, b in EDGE[:6] + list(zip(oracle_lib.synth_values(4, 93), oracle_lib.synth_values(4, 94))):
+        w = oracle_lib.arr_ints(orc.less_than_trace(a, b, lookup_bits)["witness"])
+        for h, (x, y) in enumerate(((a >> 128, b >> 128), (a & ((1 << 128) - 1), b & ((1 << 128) - 1)))):
+            limbs = [w[r] for r in rows[h * L:(h + 1) * L]]
+            assert all(v < (1 << lookup_bits) for v in limbs)
+            shifted = (1 << ((L - 1) * lookup_bits)) + x - y
+            assert sum(v << (lookup_bits * i) for i, v in enumerate(limbs)) == shifted == w[rows[h * L] - 2]
+    # no other row of the column needs the table: every remaining witness is tied down by a vertical gate alone
+    assert imt.lib.imt_less_than_trace_rows(lookup_bits) == 4 * L + 27
 
 
 @pytest.mark.parametrize("lookup_bits", [18, 8, 28])
