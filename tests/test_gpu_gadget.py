@@ -48,6 +48,11 @@ def test_less_than_trace_vs_oracle_formats_and_layouts(imt, ctx, oracle, lookup_
         col = imt.rebuild_advice_column(cells, consts, [x >> 128, x & ((1 << 128) - 1), y >> 128, y & ((1 << 128) - 1)], got[:, j])
         assert imt.check_vertical_gates(cells, col) == int(cells["gate"].sum())
         assert oracle_lib.arr_ints(got[out_row, j])[0] == (1 if x < y else 0)
+    # the rows the RangeChip would send to its lookup table are the lookup_bits-wide limbs, for all 2^8+ pairs at once
+    lk = ctx.less_than_lookup_rows(lookup_bits)
+    limbs = got[lk]                                          # [2 L, n, 32]
+    assert (limbs[:, :, 4:] == 0).all()
+    assert (limbs[:, :, :4].copy().view("<u4")[..., 0] < (1 << lookup_bits)).all()
     if lookup_bits == GOLD["lookup_bits"]:
         for g in GOLD["less_than"]:
             r, _ = ctx.less_than_trace(imt.to_bytes([int(g["a"])]), imt.to_bytes([int(g["b"])]), lookup_bits)

@@ -16,6 +16,7 @@ t0 = time.time()
 total = 0
 last_progress = t0
 case = 0
+snaps = refused = 0
 forms = {}
 while time.time() - t0 < budget:
     depth = rng.choice([4, 9, 14, 32, 32])
@@ -56,7 +57,29 @@ while time.time() - t0 < budget:
                 assert (r["low_sib"][:, j] == o["low_proof"]).all() and (r["new_sib"][:, j] == o["new_proof"]).all()
                 assert (r["low_leaf"][j] == o["low_leaf"]).all()
         i += b
+        if rng.random() < 0.15:
+            # checkpoint here and continue on the reloaded tree (imt_itree_get_leaves from the device index ->
+            # imt_itree_load: list check + rebuild on the GPU); the snapshot itself against the oracle's leaves
+            snap = t.snapshot(); snaps += 1
+            t2 = imt_amd.IndexedTree(ctx, depth, cap)
+            t2.load(snap)
+            assert t2.root() == t.root() == rows[i - 1]["new_root"], (case, depth, style, i, "resume")
+            if i < n_total:
+                probe = vals[i]                      # not stored yet: its low leaf must be the oracle's for the next insertion
+                assert int(t2.find_low([probe])[0]) == rows[i]["low"], (case, depth, style, i, "find_low")
+            if rng.random() < 0.5:                   # one flipped bit anywhere in a next pointer is refused
+                bad = snap.copy()
+                bad[rng.randrange(i + 1), rng.choice([1, 2]), rng.randrange(4)] ^= 1 << rng.randrange(8)
+                try:
+                    t2.load(bad); raise AssertionError("corrupted snapshot accepted")
+                except ValueError:
+                    refused += 1
+                assert t2.root() == t.root()
+            t.close(); t = t2
     assert t.root() == oroot
+    final = t.snapshot()
+    for q in rng.sample(range(n_total + 1), min(n_total + 1, 16)):
+        assert (final[q] == orc.sparse_preimage(oh, q)).all(), (case, depth, style, q, "leaf")
     orc.sparse_free(oh)
     t.close()
     total += n_total
@@ -65,4 +88,5 @@ while time.time() - t0 < budget:
         last_progress = time.time()
         print(f"... {case} trees, {total} insertions, {time.time() - t0:.0f} s", flush=True)
 print("differential soak: %d trees, %d insertions, every root and low index equal to the oracle (%.0f s); "
-      "trees per IMT_OPT_COOP_MAX_EVENTS setting: %s" % (case, total, time.time() - t0, dict(sorted(forms.items()))))
+      "%d checkpoints reloaded mid-stream (root, next low leaf and final leaves equal), %d corrupted snapshots refused; "
+      "trees per IMT_OPT_COOP_MAX_EVENTS setting: %s" % (case, total, time.time() - t0, snaps, refused, dict(sorted(forms.items()))))
