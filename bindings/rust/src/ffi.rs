@@ -184,6 +184,9 @@ extern "C" {
     pub fn imt_insert_gadget_lookup_rows(depth: c_uint, lookup_bits: c_uint, rows: *mut u32, cap: usize, n_rows: *mut usize) -> c_int;
     pub fn imt_insert_gadget_trace_batch(ctx: *mut imt_ctx, low_leaf: *const c_void, low_index: *const u64, low_sib: *const c_void, new_leaf: *const c_void, new_index: *const u64, new_path_index: *const u64, new_sib: *const c_void, is_largest: *const u8, depth: c_uint, lookup_bits: c_uint, n: usize, trace: *mut c_void, flags: c_uint) -> c_int;
     pub fn imt_insert_column_segments(depth: c_uint, lookup_bits: c_uint, segs: *mut imt_column_segment, cap: usize, n_segs: *mut usize) -> c_int;
+    pub fn imt_non_inclusion_gadget_rows(depth: c_uint, lookup_bits: c_uint) -> usize;
+    pub fn imt_non_inclusion_gadget_trace_batch(ctx: *mut imt_ctx, low_leaf: *const c_void, low_index: *const u64, low_sib: *const c_void, new_val: *const c_void, is_largest: *const u8, depth: c_uint, lookup_bits: c_uint, n: usize, trace: *mut c_void, flags: c_uint) -> c_int;
+    pub fn imt_non_inclusion_column_segments(depth: c_uint, lookup_bits: c_uint, segs: *mut imt_column_segment, cap: usize, n_segs: *mut usize) -> c_int;
 
     pub fn imt_tree_new(ctx: *mut imt_ctx, leaves: *const c_void, n_leaves: usize, flags: c_uint, out: *mut *mut imt_tree) -> c_int;
     pub fn imt_tree_free(t: *mut imt_tree);

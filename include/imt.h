@@ -257,6 +257,17 @@ int imt_insert_gadget_trace_batch(imt_ctx *ctx, const void *low_leaf /*[n][3][32
                                   const uint64_t *new_path_index /*[n] or NULL = new_index*/, const void *new_sib,
                                   const uint8_t *is_largest /*[n]*/, unsigned depth, unsigned lookup_bits, size_t n,
                                   void *trace, unsigned flags);
+/* The same for ONE verify_non_inclusion call on its own (src/indexed_merkle_tree.rs:127-229 -- BASELINE config 3's
+ * gadget): is_equal [4], limbs [4], mul_add [2], is_less_than(new, low.next_val) [K], select [3], the low leaf's path
+ * [1 + 4 depth], the limbs of low.val + mul_add [3], is_less_than(low.val, new) [K] = 17 + 2 K + 4 depth rows per item
+ * (the first rows of the insert_leaf call above, which begins with this gadget).  Inputs: what
+ * imt_itree_non_membership_witness returned + the candidate values.  Its lookup cells: imt_insert_gadget_lookup_rows
+ * (same row numbers).  Its hash blocks: imt_path_trace_batch(leaf3 = low_leaf, low_index, low_sib). */
+size_t imt_non_inclusion_gadget_rows(unsigned depth, unsigned lookup_bits);
+int imt_non_inclusion_gadget_trace_batch(imt_ctx *ctx, const void *low_leaf /*[n][3][32]*/, const uint64_t *low_index,
+                                         const void *low_sib, const void *new_val /*[n][32]*/,
+                                         const uint8_t *is_largest /*[n]*/, unsigned depth, unsigned lookup_bits, size_t n,
+                                         void *trace, unsigned flags);
 #define IMT_SEG_GLUE 0      /* n_rows rows of imt_insert_gadget_trace_batch starting at first_row */
 #define IMT_SEG_HASH 1      /* one hash_fix_len_array call of `arity` inputs: rows [first_row, + n_rows) of imt_insert_trace_batch */
 typedef struct imt_column_segment {
@@ -266,6 +277,9 @@ typedef struct imt_column_segment {
 /* the advice column of insert_leaf as alternating stretches of the two traces (3 + 4 depth hash segments); segs may be
  * NULL (count only) */
 int imt_insert_column_segments(unsigned depth, unsigned lookup_bits, imt_column_segment *segs, size_t cap, size_t *n_segs);
+/* ... and of verify_non_inclusion alone: 3 + 2 depth segments, 1 + depth of them hashes (rows of imt_path_trace_batch) */
+int imt_non_inclusion_column_segments(unsigned depth, unsigned lookup_bits, imt_column_segment *segs, size_t cap,
+                                      size_t *n_segs);
 
 /* ---- a2 / a3 / a4: dense native tree ------------------------------------------- */
 /* IndexedMerkleTree::new (src/utils.rs:20-57): level-by-level build on the device.

@@ -9,7 +9,7 @@ from . import _ffi
 from ._ffi import lib, LIB_PATH
 from .api import (Context, IndexedMerkleTree, IndexedTree, ImtError, ConstraintError, verify_non_inclusion,
                   insert_leaf, to_bytes, to_int, P_MODULUS, trace_layout, rebuild_advice_column, check_vertical_gates,
-                  insert_column_segments)
+                  insert_column_segments, non_inclusion_column_segments)
 
 __all__ = ["Context", "IndexedMerkleTree", "IndexedTree", "ImtError", "ConstraintError", "verify_non_inclusion",
            "insert_leaf", "to_bytes", "to_int", "P_MODULUS", "lib", "LIB_PATH"]

@@ -112,6 +112,10 @@ SIGNATURES = {
     "imt_insert_gadget_trace_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_uint, c_uint, c_size_t, c_void_p, c_uint]),
     "imt_insert_column_segments": (c_int, [c_uint, c_uint, P(ColumnSegment), c_size_t, P(c_size_t)]),
+    "imt_non_inclusion_gadget_rows": (c_size_t, [c_uint, c_uint]),
+    "imt_non_inclusion_gadget_trace_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint,
+                                                     c_size_t, c_void_p, c_uint]),
+    "imt_non_inclusion_column_segments": (c_int, [c_uint, c_uint, P(ColumnSegment), c_size_t, P(c_size_t)]),
     "imt_tree_new": (c_int, [c_void_p, c_void_p, c_size_t, c_uint, P(c_void_p)]),
     "imt_tree_free": (None, [c_void_p]),
     "imt_tree_num_levels": (c_size_t, [c_void_p]),

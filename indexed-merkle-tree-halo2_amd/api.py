@@ -242,6 +242,22 @@ class Context:
                                                       fmt | (_ffi.TRACE_ITEM_MAJOR if item_major else 0)))
         return out
 
+    def non_inclusion_gadget_trace(self, low_leaf, low_index, low_sib, new_val, is_largest, depth, lookup_bits=18, fmt=0,
+                                   item_major=False):
+        """every new advice value of ONE verify_non_inclusion outside its hashes, for n candidates
+        (imt_non_inclusion_gadget_trace_batch): uint8 [rows, n, 32] or item-major [n, rows, 32]"""
+        ll = _arr(low_leaf, (3, 32))
+        n = ll.shape[0]
+        rows = lib.imt_non_inclusion_gadget_rows(depth, lookup_bits)
+        if not rows:
+            raise ValueError("depth >= 1 and 1 <= lookup_bits <= 28")
+        out = np.empty((n, rows, 32) if item_major else (rows, n, 32), dtype=np.uint8)
+        self._check(lib.imt_non_inclusion_gadget_trace_batch(
+            self.h, _p(ll), _p(np.ascontiguousarray(low_index, dtype=np.uint64)), _p(_arr(low_sib, (32,))), _p(_arr(new_val, (32,))),
+            _p(np.ascontiguousarray(is_largest, dtype=np.uint8)), depth, lookup_bits, n, _p(out),
+            fmt | (_ffi.TRACE_ITEM_MAJOR if item_major else 0)))
+        return out
+
     def hash_trace_layout(self, arity, fmt=0):
         """(cells, constants, out_row): the advice column of one hash, cell by cell (imt_hash_trace_layout).
         cells: structured array with fields kind (_ffi.CELL_*), gate, index; constants: uint8 [k, 32]."""
@@ -350,18 +366,28 @@ def trace_layout(call, arity, fmt, check):
     return cells, consts, row.value
 
 
+def _column_segments(fn, name, depth, lookup_bits):
+    n = ctypes.c_size_t()
+    rc = fn(depth, lookup_bits, None, 0, ctypes.byref(n))
+    if rc:
+        raise ImtError(rc, name)
+    segs = (_ffi.ColumnSegment * n.value)()
+    rc = fn(depth, lookup_bits, segs, n.value, ctypes.byref(n))
+    if rc:
+        raise ImtError(rc, name)
+    return [(s.kind, s.arity, s.first_row, s.n_rows) for s in segs]
+
+
 def insert_column_segments(depth, lookup_bits=18):
     """[(kind, arity, first_row, n_rows)]: how the glue rows (kind 0, imt_insert_gadget_trace_batch) and the hash blocks
     (kind 1, imt_insert_trace_batch) interleave in insert_leaf's advice column"""
-    n = ctypes.c_size_t()
-    rc = lib.imt_insert_column_segments(depth, lookup_bits, None, 0, ctypes.byref(n))
-    if rc:
-        raise ImtError(rc, "imt_insert_column_segments")
-    segs = (_ffi.ColumnSegment * n.value)()
-    rc = lib.imt_insert_column_segments(depth, lookup_bits, segs, n.value, ctypes.byref(n))
-    if rc:
-        raise ImtError(rc, "imt_insert_column_segments")
-    return [(s.kind, s.arity, s.first_row, s.n_rows) for s in segs]
+    return _column_segments(lib.imt_insert_column_segments, "imt_insert_column_segments", depth, lookup_bits)
+
+
+def non_inclusion_column_segments(depth, lookup_bits=18):
+    """the same for one verify_non_inclusion alone: glue rows of imt_non_inclusion_gadget_trace_batch, hash blocks of
+    imt_path_trace_batch (leaf3 form)"""
+    return _column_segments(lib.imt_non_inclusion_column_segments, "imt_non_inclusion_column_segments", depth, lookup_bits)
 
 
 def rebuild_advice_column(cells, consts, inputs, trace_rows):

@@ -468,6 +468,7 @@ extern "C" int imt_insert_trace_batch(imt_ctx* c, const void* low_leaf, const ui
 // row counts: imt_gadget_layout.cpp (host-only arithmetic, shared with the CPU test build)
 extern "C" size_t imt_less_than_trace_rows(unsigned lookup_bits);
 extern "C" size_t imt_insert_gadget_rows(unsigned depth, unsigned lookup_bits);
+extern "C" size_t imt_non_inclusion_gadget_rows(unsigned depth, unsigned lookup_bits);
 
 extern "C" int imt_less_than_trace_batch(imt_ctx* c, const void* a, const void* b, size_t n, unsigned lookup_bits, void* trace,
                                          uint8_t* lt_out, unsigned flags) {
@@ -556,8 +557,48 @@ extern "C" int imt_insert_gadget_trace_batch(imt_ctx* c, const void* low_leaf, c
     return io.finish();
 }
 
-// how the glue rows and the hash blocks (imt_insert_trace_batch's order) interleave in insert_leaf's advice column
-extern "C" int imt_insert_column_segments(unsigned depth, unsigned lookup_bits, imt_column_segment* segs, size_t cap, size_t* n_segs) {
+// verify_non_inclusion alone (:127-229; BASELINE config 3's gadget): the same kernel stopped behind the second comparison
+extern "C" int imt_non_inclusion_gadget_trace_batch(imt_ctx* c, const void* low_leaf, const uint64_t* low_index, const void* low_sib,
+                                                    const void* new_val, const uint8_t* is_largest, unsigned depth,
+                                                    unsigned lookup_bits, size_t n, void* trace, unsigned flags) {
+    int rc = begin(c, flags);
+    if (rc) return rc;
+    const size_t rows = imt_non_inclusion_gadget_rows(depth, lookup_bits);
+    if (!rows) return c->fail(IMT_ERR_RANGE, "depth %u out of [1, %d] or lookup_bits %u out of [1, 28]", depth, IMT_MAX_DEPTH, lookup_bits);
+    if (n == 0) return IMT_OK;
+    if (!low_leaf || !low_index || !low_sib || !new_val || !is_largest || !trace) return c->fail(IMT_ERR_ARG, "null buffer");
+    Io io(c, flags);
+    const uint8_t* d_ll = io.in_fe(low_leaf, n * 96);
+    const uint64_t* d_li = (const uint64_t*)io.in(low_index, n * 8);
+    const uint8_t* d_ls = io.in_fe(low_sib, (size_t)depth * n * 32);
+    const uint8_t* d_nv = io.in_fe(new_val, n * 32);
+    const uint8_t* d_lg = io.in(is_largest, n);
+    uint8_t* d_tr = io.out_fe(trace, n * rows * 32);
+    const size_t ps = (size_t)depth * n * 64;
+    uint8_t* pairs = io.temp(ps);
+    uint8_t* cll = io.temp(n * 96);
+    uint8_t* cnv = io.temp(n * 32);
+    if (io.rc) return io.rc;
+    const unsigned fmt = flags & IMT_FMT_MASK;
+    launch::PathChains pc{};
+    pc.c[0] = {nullptr, d_ll, d_li, d_ls, pairs, nullptr};
+    pc.n_chains = 1;
+    pc.lay = sib_layout(flags, depth, n);
+    pc.depth = depth; pc.n = n; pc.fmt_in = fmt; pc.fmt_out = fmt; pc.err = c->d_err;
+    launch::path_pairs(c->stream, pc, c->coop_max_events);
+    launch::convert(c->stream, pairs, pairs, (size_t)depth * n * 2, IMT_FMT_DEVICE, IMT_FMT_CANONICAL, c->d_err);
+    launch::convert(c->stream, d_ll, cll, n * 3, fmt, IMT_FMT_CANONICAL, c->d_err);
+    launch::convert(c->stream, d_nv, cnv, n, fmt, IMT_FMT_CANONICAL, c->d_err);
+    const bool item_major = flags & IMT_TRACE_ITEM_MAJOR;
+    launch::non_inclusion_gadget(c->stream, cll, d_li, cnv, d_lg, pairs, depth, lookup_bits, n, d_tr, item_major ? 32 : n * 32,
+                                 item_major ? rows * 32 : 32);
+    if (fmt != IMT_FMT_CANONICAL) launch::convert(c->stream, d_tr, d_tr, n * rows, IMT_FMT_CANONICAL, fmt, c->d_err);
+    return io.finish();
+}
+
+// how the glue rows and the hash blocks (imt_insert_trace_batch's order) interleave in insert_leaf's advice column;
+// whole = false: verify_non_inclusion's part alone, whose hash blocks are imt_path_trace_batch's (leaf3 form)
+static int column_segments(unsigned depth, unsigned lookup_bits, bool whole, imt_column_segment* segs, size_t cap, size_t* n_segs) {
     const size_t k = imt_less_than_trace_rows(lookup_bits);
     if (!k || depth < 1 || depth > IMT_MAX_DEPTH) return IMT_ERR_RANGE;
     std::vector<imt_column_segment> v;
@@ -579,16 +620,28 @@ extern "C" int imt_insert_column_segments(unsigned depth, unsigned lookup_bits, 
     G(4 + 4 + 2 + k + 3);                      // verify_non_inclusion up to the select :143-191
     H(3); chain();                             // low leaf hash + verify_merkle_proof :193-204
     G(3 + k);                                  // :206-228
-    H(3); chain();                             // rewritten low leaf + interim root :271-284
-    chain();                                   // zero leaf in the interim root :286-294
-    H(3); chain();                             // new leaf + new root :299-312
+    if (whole) {
+        H(3); chain();                         // rewritten low leaf + interim root :271-284
+        chain();                               // zero leaf in the interim root :286-294
+        H(3); chain();                         // new leaf + new root :299-312
+    }
     if (n_segs) *n_segs = v.size();
-    if (glue != imt_insert_gadget_rows(depth, lookup_bits) || hash != imt_insert_trace_rows(depth)) return IMT_ERR_INTERNAL;
+    if (whole ? (glue != imt_insert_gadget_rows(depth, lookup_bits) || hash != imt_insert_trace_rows(depth))
+              : (glue != imt_non_inclusion_gadget_rows(depth, lookup_bits) ||
+                 hash != imt_hash_trace_rows(3) + (uint64_t)depth * imt_hash_trace_rows(2)))
+        return IMT_ERR_INTERNAL;
     if (segs) {
         if (cap < v.size()) return IMT_ERR_RANGE;
         std::memcpy(segs, v.data(), v.size() * sizeof(imt_column_segment));
     }
     return IMT_OK;
+}
+extern "C" int imt_insert_column_segments(unsigned depth, unsigned lookup_bits, imt_column_segment* segs, size_t cap, size_t* n_segs) {
+    return column_segments(depth, lookup_bits, true, segs, cap, n_segs);
+}
+extern "C" int imt_non_inclusion_column_segments(unsigned depth, unsigned lookup_bits, imt_column_segment* segs, size_t cap,
+                                                 size_t* n_segs) {
+    return column_segments(depth, lookup_bits, false, segs, cap, n_segs);
 }
 
 // ------------------------------------------------------------------------------------

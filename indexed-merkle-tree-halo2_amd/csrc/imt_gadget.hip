@@ -245,14 +245,15 @@ __device__ void emit_chain(Out& o, const uint8_t* __restrict__ pairs, uint64_t i
 
 __global__ void __launch_bounds__(BLOCK)
 k_insert_gadget(const uint8_t* __restrict__ low_leaf, const uint64_t* __restrict__ low_index, const uint8_t* __restrict__ new_leaf,
-                const uint64_t* __restrict__ new_path_index, const uint8_t* __restrict__ is_largest,
-                const uint8_t* __restrict__ pairs /*[4][depth][n][2][32] canonical*/, unsigned depth, unsigned lb, size_t n,
+                unsigned new_stride /*96: leaves; 32: bare values*/, const uint64_t* __restrict__ new_path_index,
+                const uint8_t* __restrict__ is_largest, const uint8_t* __restrict__ pairs /*[chains][depth][n][2][32] canonical*/,
+                unsigned depth, unsigned lb, size_t n, int whole_insert /*0: verify_non_inclusion alone (one chain)*/,
                 uint8_t* __restrict__ trace, uint64_t row_stride, uint64_t item_stride) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     Out o{trace, row_stride, item_stride, i, 0};
     const U256 low_val = load256(low_leaf + i * 96), low_next = load256(low_leaf + i * 96 + 32);
-    const U256 nv = load256(new_leaf + i * 96);
+    const U256 nv = load256(new_leaf + i * (size_t)new_stride);
     // verify_non_inclusion :127-229
     const uint32_t iz = emit_is_equal(o, low_next, u256_zero());                       // :143
     o.put(high128(nv)); o.put(low128(nv)); o.put(high128(low_next)); o.put(low128(low_next));   // :169-172
@@ -264,6 +265,7 @@ k_insert_gadget(const uint8_t* __restrict__ low_leaf, const uint64_t* __restrict
     emit_chain(o, pairs, low_index[i], depth, n, i);                                    // :196-204
     o.put(high128(low_val)); o.put(low128(low_val)); o.put(low_val);                    // :219-224
     emit_less_than(o, low_val, nv, lb);                                                 // :226
+    if (!whole_insert) return;
     // insert_leaf :277-312
     emit_chain(o, pairs + ps, low_index[i], depth, n, i);
     emit_chain(o, pairs + 2 * ps, new_path_index[i], depth, n, i);
@@ -286,7 +288,15 @@ void insert_gadget(hipStream_t s, const uint8_t* low_leaf, const uint64_t* low_i
                    unsigned lookup_bits, size_t n, uint8_t* trace, uint64_t row_stride, uint64_t item_stride) {
     if (!n) return;
     hipLaunchKernelGGL(k_insert_gadget, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, low_leaf, low_index, new_leaf,
-                       new_path_index, is_largest, pairs, depth, lookup_bits, n, trace, row_stride, item_stride);
+                       96u, new_path_index, is_largest, pairs, depth, lookup_bits, n, 1, trace, row_stride, item_stride);
+}
+
+void non_inclusion_gadget(hipStream_t s, const uint8_t* low_leaf, const uint64_t* low_index, const uint8_t* new_val,
+                          const uint8_t* is_largest, const uint8_t* pairs, unsigned depth, unsigned lookup_bits, size_t n,
+                          uint8_t* trace, uint64_t row_stride, uint64_t item_stride) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_insert_gadget, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, low_leaf, low_index, new_val,
+                       32u, low_index, is_largest, pairs, depth, lookup_bits, n, 0, trace, row_stride, item_stride);
 }
 
 }  // namespace launch

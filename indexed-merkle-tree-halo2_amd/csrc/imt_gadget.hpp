@@ -16,6 +16,11 @@ void less_than_trace(hipStream_t s, const uint8_t* a, const uint8_t* b, size_t n
 void insert_gadget(hipStream_t s, const uint8_t* low_leaf, const uint64_t* low_index, const uint8_t* new_leaf,
                    const uint64_t* new_path_index, const uint8_t* is_largest, const uint8_t* pairs, unsigned depth,
                    unsigned lookup_bits, size_t n, uint8_t* trace, uint64_t row_stride, uint64_t item_stride);
+// the glue rows of ONE verify_non_inclusion (the first 17 + 2 K + 4 depth of the above); new_val [n][32]; pairs =
+// [depth][n][2][32] of the low leaf's chain alone
+void non_inclusion_gadget(hipStream_t s, const uint8_t* low_leaf, const uint64_t* low_index, const uint8_t* new_val,
+                          const uint8_t* is_largest, const uint8_t* pairs, unsigned depth, unsigned lookup_bits, size_t n,
+                          uint8_t* trace, uint64_t row_stride, uint64_t item_stride);
 
 }  // namespace launch
 }  // namespace imt

@@ -109,6 +109,11 @@ extern "C" size_t imt_insert_gadget_rows(unsigned depth, unsigned lookup_bits) {
     const size_t k = imt_less_than_trace_rows(lookup_bits);
     return (k && depth >= 1 && depth <= IMT_MAX_DEPTH) ? 20 + 2 * k + 16 * (size_t)depth : 0;
 }
+// ... of one verify_non_inclusion alone (:127-229): insert_leaf's rows up to and including the second comparison
+extern "C" size_t imt_non_inclusion_gadget_rows(unsigned depth, unsigned lookup_bits) {
+    const size_t k = imt_less_than_trace_rows(lookup_bits);
+    return (k && depth >= 1 && depth <= IMT_MAX_DEPTH) ? 17 + 2 * k + 4 * (size_t)depth : 0;
+}
 extern "C" int imt_less_than_lookup_rows(unsigned lookup_bits, uint32_t* rows, size_t cap, size_t* n_rows);
 
 extern "C" int imt_less_than_trace_layout(imt_ctx* c, unsigned lookup_bits, imt_trace_cell* cells, size_t cells_cap,

@@ -842,7 +842,7 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
     }
     // ---- list check on the device: ordered by val, every leaf points to its successor, the last one to {0, 0} ----
     const size_t ws_bytes = prep::load_ws_bytes((size_t)n);
-    uint8_t* ws = (uint8_t*)c->dev_scratch(3, ws_bytes + 64);
+    uint8_t* ws = (uint8_t*)c->dev_scratch(3, ws_bytes + 256);      // [error word | 256-byte aligned workspace]
     if (!ws) return IMT_ERR_HIP;
     int* d_perr = (int*)ws;
     const uint32_t* d_order = nullptr;
@@ -851,7 +851,7 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
     for (int attempt = 0; attempt < 2; attempt++) {
         uint32_t* d_bad = nullptr;
         IMT_HIP(c, hipMemsetAsync(d_perr, 0, sizeof(int), s));
-        IMT_HIP(c, prep::load_check(s, d_pre, (uint32_t)n, t->index_base, t->part_mod, t->part_res, ws + 64, ws_bytes,
+        IMT_HIP(c, prep::load_check(s, d_pre, (uint32_t)n, t->index_base, t->part_mod, t->part_res, ws + 256, ws_bytes,
                                     attempt == 1, d_perr, &d_bad, &d_order));
         IMT_HIP(c, hipMemcpyAsync(&perr, d_perr, sizeof(int), hipMemcpyDeviceToHost, s));
         IMT_HIP(c, hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s));

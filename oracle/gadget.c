@@ -320,6 +320,86 @@ static aval ext(const ofr_t *v, uint32_t index) {
     return r;
 }
 
+/* verify_non_inclusion :127-229 -- the cells outside its hashes: is_equal(next_val, 0), the limb loads and their
+ * mul_add checks, is_less_than(new, low.next_val), select, the low leaf's path (load_witness + dual_mux per level), the
+ * limbs of low.val, is_less_than(low.val, new) */
+static void walk_non_inclusion(walk_t *w, const aval low[3], const aval *new_val, const aval *largest, const aval *lp,
+                               const aval *lh, size_t depth, unsigned lookup_bits) {
+    col_t *c = &w->c;
+    aval one = g_load_constant(c, &G_ONE);
+    aval zero = g_load_constant(c, &G_ZERO);
+    aval is_zero = g_is_equal(c, &low[1], &zero);
+    uint8_t nlb[32], llb[32], llvb[32];
+    ofr_to_bytes(nlb, &new_val->v);
+    ofr_to_bytes(llb, &low[1].v);
+    ofr_to_bytes(llvb, &low[0].v);
+    ofr_t q, r, p128;
+    split128(nlb, &q, &r);
+    aval nl_q = g_load_witness(c, &q), nl_r = g_load_witness(c, &r);
+    split128(llb, &q, &r);
+    aval ll_q = g_load_witness(c, &q), ll_r = g_load_witness(c, &r);
+    pow2(&p128, 128);
+    aval pow_128 = g_load_constant(c, &p128);
+    g_mul_add(c, &nl_q, &pow_128, &nl_r);
+    g_mul_add(c, &ll_q, &pow_128, &ll_r);
+    aval is_next_val_greater = ref_is_less_than(c, &nl_q, &nl_r, &ll_q, &ll_r, lookup_bits);
+    ref_select(c, &one, largest, &is_zero, &is_next_val_greater);
+    aval low_leaf_hash = hash_block(w, low, 3);
+    ref_compute_merkle_root(w, &low_leaf_hash, lp, lh, depth);
+    split128(llvb, &q, &r);
+    aval llv_q = g_load_witness(c, &q), llv_r = g_load_witness(c, &r);
+    g_mul_add(c, &llv_q, &pow_128, &llv_r);
+    ref_is_less_than(c, &llv_q, &llv_r, &nl_q, &nl_r, lookup_bits);
+    g_load_constant(c, &G_ONE);
+}
+
+size_t orc_non_inclusion_gadget_rows(size_t depth, unsigned lookup_bits) {
+    return 17 + 2 * orc_less_than_trace_rows(lookup_bits) + 4 * depth;
+}
+
+/* The same for ONE verify_non_inclusion call on its own (BASELINE config 3's gadget): witness rows outside its 1 + depth
+ * hashes and how they interleave with the hash blocks (the rows of orc_hash_trace for H(low_leaf) and the path, in the
+ * order imt_path_trace_batch lays them out). */
+int orc_non_inclusion_gadget_trace(const uint8_t low_leaf[3][32], uint64_t low_index, const uint8_t *low_proof,
+                                   const uint8_t new_val[32], int is_new_leaf_largest, size_t depth, unsigned lookup_bits,
+                                   uint8_t *witness, size_t wcap, size_t *n_witness, orc_column_segment *segs,
+                                   size_t seg_cap, size_t *n_segs) {
+    ginit();
+    orc_poseidon_init();
+    if (lookup_bits < 1 || lookup_bits > 28 || depth == 0 || depth > 64) return ORC_ERR_RANGE;
+    walk_t w;
+    memset(&w, 0, sizeof w);
+    w.c.wit = witness; w.c.wcap = wcap;
+    w.segs = segs; w.seg_cap = seg_cap;
+    ofr_t v;
+    aval low[3], *lp = malloc(depth * sizeof(aval)), *lh = malloc(depth * sizeof(aval));
+    int rc = ORC_OK;
+    for (int i = 0; i < 3; i++) {
+        if (ofr_from_bytes(&v, low_leaf[i])) rc = ORC_ERR_NONCANONICAL;
+        low[i] = ext(&v, (uint32_t)i);
+    }
+    if (ofr_from_bytes(&v, new_val)) rc = ORC_ERR_NONCANONICAL;
+    aval nv = ext(&v, 8);
+    for (size_t l = 0; l < depth && !rc; l++) {
+        if (ofr_from_bytes(&v, low_proof + 32 * l)) rc = ORC_ERR_NONCANONICAL;
+        lp[l] = ext(&v, 100);
+        ofr_from_u64(&v, ((low_index >> l) & 1) ^ 1);
+        lh[l] = ext(&v, 102);
+    }
+    if (!rc) {
+        ofr_from_u64(&v, is_new_leaf_largest ? 1 : 0);
+        aval largest = ext(&v, 12);
+        walk_non_inclusion(&w, low, &nv, &largest, lp, lh, depth, lookup_bits);
+        close_glue(&w);
+    }
+    free(lp); free(lh);
+    if (rc) return rc;
+    if (n_witness) *n_witness = w.c.nw;
+    if (n_segs) *n_segs = w.n_segs;
+    if (w.c.overflow || (segs && w.n_segs > seg_cap)) return ORC_ERR_RANGE;
+    return w.c.nw == orc_non_inclusion_gadget_rows(depth, lookup_bits) ? ORC_OK : ORC_ERR_RANGE;
+}
+
 size_t orc_insert_gadget_rows(size_t depth, unsigned lookup_bits) {
     return 20 + 2 * orc_less_than_trace_rows(lookup_bits) + 16 * depth;
 }
@@ -371,32 +451,8 @@ int orc_insert_gadget_trace(const uint8_t low_leaf[3][32], uint64_t low_index, c
     orc_hash3(zh, ZERO3[0], ZERO3[1], ZERO3[2]);
     ofr_from_bytes(&v, zh);
     aval zero_leaf_hash = g_load_constant(c, &v);
-    /* verify_non_inclusion(old_root, low_leaf, low proof, new_leaf.val, is_largest) :127-229 */
-    aval one = g_load_constant(c, &G_ONE);
-    aval zero = g_load_constant(c, &G_ZERO);
-    aval is_zero = g_is_equal(c, &low[1], &zero);
-    uint8_t nlb[32], llb[32], llvb[32];
-    ofr_to_bytes(nlb, &nw[0].v);
-    ofr_to_bytes(llb, &low[1].v);
-    ofr_to_bytes(llvb, &low[0].v);
-    ofr_t q, r, p128;
-    split128(nlb, &q, &r);
-    aval nl_q = g_load_witness(c, &q), nl_r = g_load_witness(c, &r);
-    split128(llb, &q, &r);
-    aval ll_q = g_load_witness(c, &q), ll_r = g_load_witness(c, &r);
-    pow2(&p128, 128);
-    aval pow_128 = g_load_constant(c, &p128);
-    g_mul_add(c, &nl_q, &pow_128, &nl_r);
-    g_mul_add(c, &ll_q, &pow_128, &ll_r);
-    aval is_next_val_greater = ref_is_less_than(c, &nl_q, &nl_r, &ll_q, &ll_r, lookup_bits);
-    ref_select(c, &one, &largest, &is_zero, &is_next_val_greater);
-    aval low_leaf_hash = hash_block(&w, low, 3);
-    ref_compute_merkle_root(&w, &low_leaf_hash, lp, lh, depth);
-    split128(llvb, &q, &r);
-    aval llv_q = g_load_witness(c, &q), llv_r = g_load_witness(c, &r);
-    g_mul_add(c, &llv_q, &pow_128, &llv_r);
-    ref_is_less_than(c, &llv_q, &llv_r, &nl_q, &nl_r, lookup_bits);
-    g_load_constant(c, &G_ONE);
+    /* verify_non_inclusion(old_root, low_leaf, low proof, new_leaf.val, is_largest) :253-257 -> :127-229 */
+    walk_non_inclusion(&w, low, &nw[0], &largest, lp, lh, depth, lookup_bits);
     /* :259-312 */
     aval newlow[3] = {low[0], nw[0], new_idx_fe};
     aval new_low_leaf_hash = hash_block(&w, newlow, 3);

@@ -167,6 +167,14 @@ int orc_insert_gadget_trace(const uint8_t low_leaf[3][32], uint64_t low_index, c
                             const uint8_t *new_proof, int is_new_leaf_largest, size_t depth, unsigned lookup_bits,
                             uint8_t *witness, size_t wcap, size_t *n_witness, orc_column_segment *segs, size_t seg_cap,
                             size_t *n_segs);
+/* the same for one verify_non_inclusion call alone (:127-229): 17 + 2 K + 4 depth glue rows, 3 + 2 depth segments (the
+ * hash blocks are H(low_leaf) and the path's hashes, imt_path_trace_batch's order) */
+size_t orc_non_inclusion_gadget_rows(size_t depth, unsigned lookup_bits);
+int orc_non_inclusion_gadget_trace(const uint8_t low_leaf[3][32], uint64_t low_index, const uint8_t *low_proof,
+                                   const uint8_t new_val[32], int is_new_leaf_largest, size_t depth, unsigned lookup_bits,
+                                   uint8_t *witness, size_t wcap, size_t *n_witness, orc_column_segment *segs,
+                                   size_t seg_cap, size_t *n_segs);
+
 
 /* ---- indexed-list insertion of the test module (:632-671) */
 /* update_idx_leaf: linear scan, in place on preimages[n][3][32]; returns low idx in *low */

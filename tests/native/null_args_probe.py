@@ -21,6 +21,7 @@ SKIP |= SLICED
 SKIP.add("imt_insert_column_segments")    # no handle at all: (depth, lookup_bits, ...)
 SKIP.add("imt_less_than_lookup_rows")     # likewise: (lookup_bits, rows, cap, n_rows)
 SKIP.add("imt_insert_gadget_lookup_rows")
+SKIP.add("imt_non_inclusion_column_segments")
 
 
 def handle_for(name):
@@ -100,6 +101,7 @@ calls = [
     ("imt_sliced_get_info", (None, None)),
     ("imt_insert_column_segments", (0, 18, None, 0, None)), ("imt_insert_column_segments", (32, 0, None, 0, None)),
     ("imt_insert_column_segments", (32, 18, (_ffi.ColumnSegment * 2)(), 2, None)),       # too small a table
+    ("imt_non_inclusion_column_segments", (0, 18, None, 0, None)), ("imt_non_inclusion_column_segments", (32, 18, (_ffi.ColumnSegment * 2)(), 2, None)),
     ("imt_less_than_lookup_rows", (0, None, 0, None)), ("imt_less_than_lookup_rows", (29, None, 0, None)),
     ("imt_less_than_lookup_rows", (18, (ctypes.c_uint32 * 3)(), 3, None)),                # too small an array
     ("imt_insert_gadget_lookup_rows", (0, 18, None, 0, None)), ("imt_insert_gadget_lookup_rows", (32, 18, (ctypes.c_uint32 * 3)(), 3, None)),

@@ -136,6 +136,23 @@ class Oracle:
         assert rc == 0 and nw.value == g, (rc, nw.value, g)
         return wit, [tuple(int(x) for x in s_) for s_ in segs[:ns.value]]
 
+    def non_inclusion_gadget_trace(self, low_leaf3, low_index, low_proof, new_val, largest, depth, lookup_bits=18):
+        """(glue rows uint8 [g, 32], segments) of one verify_non_inclusion alone (:127-229)"""
+        self.lib.orc_non_inclusion_gadget_rows.restype = ctypes.c_size_t
+        g = self.lib.orc_non_inclusion_gadget_rows(ctypes.c_size_t(depth), ctypes.c_uint(lookup_bits))
+        wit = np.empty((g, 32), np.uint8)
+        segs = np.zeros(2 * depth + 8, dtype=np.dtype([("kind", "<u4"), ("arity", "<u4"), ("first_row", "<u8"), ("n_rows", "<u8")]))
+        nw, ns = ctypes.c_size_t(), ctypes.c_size_t()
+        lp = np.ascontiguousarray(low_proof, dtype=np.uint8)
+        rc = self.lib.orc_non_inclusion_gadget_trace(b"".join(b32(x) for x in low_leaf3), ctypes.c_uint64(low_index),
+                                                     lp.ctypes.data_as(ctypes.c_void_p), b32(new_val),
+                                                     ctypes.c_int(1 if largest else 0), ctypes.c_size_t(depth),
+                                                     ctypes.c_uint(lookup_bits), wit.ctypes.data_as(ctypes.c_void_p),
+                                                     ctypes.c_size_t(g), ctypes.byref(nw), segs.ctypes.data_as(ctypes.c_void_p),
+                                                     ctypes.c_size_t(len(segs)), ctypes.byref(ns))
+        assert rc == 0 and nw.value == g, (rc, nw.value, g)
+        return wit, [tuple(int(x) for x in s_) for s_ in segs[:ns.value]]
+
     # ---- dense tree (src/utils.rs) ----
     def tree_new(self, leaves_arr):
         leaves_arr = np.ascontiguousarray(leaves_arr, dtype=np.uint8)

@@ -113,6 +113,26 @@ def test_insert_gadget_rows_against_the_model(imt, depth, n):
         assert all(x[0] != y[0] for x, y in zip(segs, segs[1:]) if x[0] == 0)           # never two glue segments in a row
 
 
+@pytest.mark.parametrize("depth,n", [(3, 6), (32, 3)])
+def test_non_inclusion_gadget_is_the_head_of_the_insert_gadget(imt, depth, n):
+    """verify_non_inclusion (:127-229) on its own = the first 17 + 2 K + 4 depth glue rows and the first 3 + 2 depth
+    segments of the insert_leaf that inserts the same value (insert_leaf begins with it, :253-257) -- oracle against
+    oracle, and the product's segment table and row count (host arithmetic, no GPU) against both"""
+    orc, ins = _insertions(depth, n, 0x494D54A8 + depth)
+    K = 4 * 9 + 27
+    for v, new_index, o in ins:
+        low3 = oracle_lib.arr_ints(o["low_leaf"])
+        full, fsegs = orc.insert_gadget_trace(low3, o["low"], o["low_proof"], [v, low3[1], low3[2]], new_index, o["new_proof"],
+                                              o["largest"], depth)
+        head, hsegs = orc.non_inclusion_gadget_trace(low3, o["low"], o["low_proof"], v, o["largest"], depth)
+        assert len(head) == 17 + 2 * K + 4 * depth == imt.lib.imt_non_inclusion_gadget_rows(depth, 18)
+        assert (head == full[:len(head)]).all()
+        assert hsegs == fsegs[:len(hsegs)] and len(hsegs) == 3 + 2 * depth
+        assert imt.non_inclusion_column_segments(depth) == hsegs
+        assert sum(s[3] for s in hsegs if s[0] == 1) == 1209 + depth * 1208
+    assert imt.lib.imt_non_inclusion_gadget_rows(0, 18) == 0 and imt.lib.imt_non_inclusion_gadget_rows(32, 29) == 0
+
+
 def test_less_than_rejects_bad_arguments():
     orc = oracle_lib.load()
     import ctypes

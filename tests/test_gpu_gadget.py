@@ -112,6 +112,67 @@ def test_insert_gadget_trace_vs_oracle(imt, ctx, oracle, depth, vals):
     assert oracle_lib.arr_ints(got_m[n - 1]) == [v * R256 % P for v in oracle_lib.arr_ints(got[:, n - 1])]
 
 
+@pytest.mark.parametrize("depth", [5, 32])
+def test_non_inclusion_gadget_trace_vs_oracle(imt, ctx, oracle, depth):
+    """BASELINE config 3's gadget: every new advice value of verify_non_inclusion (:127-229) outside its hashes for real
+    non-members of a real tree -- the witness imt_itree_non_membership_witness returns, through
+    imt_non_inclusion_gadget_trace_batch -- against oracle/gadget.c, row by row; the rows are the first rows of the
+    insert_leaf call that would insert the same value; the segment table alternates with imt_path_trace_batch's blocks
+    and every hash block hashes exactly the (left, right) the glue rows before it hold."""
+    stored = oracle_lib.synth_values(24 if depth == 5 else 300, 0x494D54C0 + depth)
+    t = imt.IndexedTree(ctx, depth, 1 << min(depth, 10))
+    t.insert_batch(stored, proofs=False)
+    S = set(stored)
+    cand = [v + 1 for v in stored[:20] if v + 1 not in S] + [1, P - 1, max(stored) + 5, min(stored) - 1]
+    n = len(cand)
+    low, leaves, sib, largest = t.non_membership_witness(cand)
+    K, rows = 63, 17 + 2 * 63 + 4 * depth
+    got = ctx.non_inclusion_gadget_trace(leaves, low, sib, imt.to_bytes(cand), largest, depth)
+    assert got.shape == (rows, n, 32) and imt.lib.imt_non_inclusion_gadget_rows(depth, 18) == rows
+    want_segs = None
+    for i in range(n):
+        want, want_segs = oracle.non_inclusion_gadget_trace(oracle_lib.arr_ints(leaves[i]), int(low[i]), sib[:, i], cand[i],
+                                                            int(largest[i]), depth)
+        assert (got[:, i] == want).all(), i
+    segs = imt.non_inclusion_column_segments(depth)
+    assert segs == want_segs and len(segs) == 3 + 2 * depth
+    assert segs == imt.insert_column_segments(depth)[:len(segs)]                 # insert_leaf begins with this gadget
+    assert int(max(oracle_lib.arr_ints(got[10 + K + 2]))) == 1 == int(min(oracle_lib.arr_ints(got[10 + K + 2])))   # select: satisfied
+    assert set(oracle_lib.arr_ints(got[-1])) == {1}                               # low.val < new: the last row of the gadget
+    # the lookup cells: same row numbers as in the insert_leaf column, all below 2^18
+    lk = ctx.insert_gadget_lookup_rows(depth)
+    assert lk.max() < rows and (got[lk][:, :, 3:] == 0).all() and (got[lk][:, :, 2] < 4).all()
+    # walk the column of one candidate: glue rows and the hash blocks of imt_path_trace_batch
+    tr, root = ctx.path_trace(low, sib, depth, leaf3=leaves)
+    assert oracle_lib.arr_ints(root) == [t.root()] * n
+    out2, out3 = ctx.hash_trace_layout(2)[2], ctx.hash_trace_layout(3)[2]
+    for i in (0, n - 1):
+        g, h = oracle_lib.arr_ints(got[:, i]), oracle_lib.arr_ints(tr[:, i])
+        cur, gi = None, 0
+        for kind, arity, first, cnt in segs:
+            if kind == 0:
+                gi = first + cnt
+            elif arity == 3:
+                cur = h[first + out3]
+            else:
+                left, right = g[gi - 2], g[gi - 1]                                # dual_mux's outputs, the rows right before
+                assert oracle.hash([left, right]) == h[first + out2]
+                assert cur in (left, right)
+                cur = h[first + out2]
+        assert cur == t.root()
+    # halo2curves' form, item-major
+    F = imt._ffi
+    mont = lambda x: imt.to_bytes([v * R256 % P for v in oracle_lib.arr_ints(x)]).reshape(np.asarray(x).shape)
+    sib_im = np.ascontiguousarray(np.asarray(sib).transpose(1, 0, 2))
+    got_m = ctx.non_inclusion_gadget_trace(mont(leaves), low, mont(sib_im), mont(imt.to_bytes(cand)), largest, depth,
+                                           fmt=F.FMT_MONT256, item_major=True)
+    assert got_m.shape == (n, rows, 32)
+    assert oracle_lib.arr_ints(got_m[2]) == [v * R256 % P for v in oracle_lib.arr_ints(got[:, 2])]
+    with pytest.raises(ValueError):
+        ctx.non_inclusion_gadget_trace(leaves, low, sib, imt.to_bytes(cand), largest, 0)
+    t.close()
+
+
 def test_the_two_traces_cover_the_whole_advice_column_of_insert_leaf(imt, ctx, oracle):
     """insert_leaf at depth 32: walking imt_insert_column_segments, the glue rows (f3) and the hash blocks (f1) alternate,
     each hash block's inputs are what the glue rows before it say (the leaf preimage, or dual_mux's left / right), its

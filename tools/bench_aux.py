@@ -54,6 +54,19 @@ assert int(fail.max()) == 0
 print(f"non-membership 2^20 items depth 32: {ms:.2f} ms  {n / ms / 1e3:.2f} M items/s  {n * 33 / ms / 1e3:.1f} Mhash/s  "
       f"{n * 1192 / ms / 1e6:.2f} GB/s algorithmic   (host witness prep {t_wit:.2f} s)")
 
+# f3 for the same gadget: the glue rows of verify_non_inclusion for 2^18 of those items, written to HBM
+m = 1 << 18
+rows = lib.imt_non_inclusion_gadget_rows(depth, 18)
+gtr = torch.empty((rows, m, 32), dtype=torch.uint8, device=dev)
+sib_m = d["sib"][:, :m].contiguous()
+ms = timed(lambda: lib.imt_non_inclusion_gadget_trace_batch(ctx.h, P(d["leaves"].data_ptr()), P(d["low"].data_ptr()), P(sib_m.data_ptr()),
+                                                            P(d["cand"].data_ptr()), P(d["largest"].data_ptr()), depth, 18, m,
+                                                            P(gtr.data_ptr()), D))
+assert int(gtr[-1, :, 0].min()) == 1 and int(gtr[-1, :, 1:].max()) == 0          # last row: low.val < candidate holds
+print(f"verify_non_inclusion glue rows (f3) 2^18 items depth 32: {ms:.2f} ms  {m / ms / 1e3:.2f} M items/s  {rows} rows/item  "
+      f"{m * rows * 32 / ms / 1e6:.1f} GB/s written  (32 path hashes per item recomputed for dual_mux's inputs)")
+del gtr, sib_m
+
 leaf = rnd((n,)); idx = torch.randint(0, 1 << 32, (n,), dtype=torch.int64, device=dev)
 out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
 ms = timed(lambda: lib.imt_path_root_batch(ctx.h, P(leaf.data_ptr()), P(idx.data_ptr()), P(d["sib"].data_ptr()), depth, n,
@@ -69,9 +82,14 @@ t0 = time.perf_counter()
 dt = imt_amd.IndexedMerkleTree.new(ctx, lv)
 print(f"IndexedMerkleTree.new 2^20 leaves (host pointers, incl. H2D): {(time.perf_counter() - t0) * 1e3:.1f} ms")
 
-snap = t.snapshot()
-t2 = imt_amd.IndexedTree(ctx, depth, 1 << 17)
 t0 = time.perf_counter()
+snap = t.snapshot()
+t1 = time.perf_counter()
+t2 = imt_amd.IndexedTree(ctx, depth, 1 << 17)
+t2.load(snap); t2.close()
+t2 = imt_amd.IndexedTree(ctx, depth, 1 << 17)
+t1b = time.perf_counter()
 t2.load(snap)
-print(f"imt_itree_load {snap.shape[0]} leaves: {(time.perf_counter() - t0) * 1e3:.1f} ms")
+print(f"imt_itree_get_leaves {snap.shape[0]} leaves to the host: {(t1 - t0) * 1e3:.1f} ms; imt_itree_load of them from the host "
+      f"(list check + rebuild on the GPU): {(time.perf_counter() - t1b) * 1e3:.1f} ms")
 assert t2.root() == t.root()
