@@ -206,7 +206,16 @@ class Env:
             if self.backend == "nccl":
                 self.dist.init_process_group("nccl", device_id=self.dev, timeout=to)
             else:
-                self.dist.init_process_group(self.backend, timeout=to)
+                # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."), which belongs to the ONE
+                # JSON line: send this process's fd 1 to stderr while the group forms
+                sys.stdout.flush()
+                keep = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    self.dist.init_process_group(self.backend, timeout=to)
+                finally:
+                    os.dup2(keep, 1)
+                    os.close(keep)
             self.ranks_seen = self.dist.get_world_size()
         import imt_amd
         self.imt = imt_amd

@@ -8,8 +8,8 @@ cp $O/bench_alone_under_rocprof.json $P/r04_alone_under_rocprof.json
 cp $O/prof_alone/alone_kernel_stats.csv $P/r04_alone_kernel_stats.csv
 cp $O/bench_pipe_under_rocprof.json $P/r04_pipelined_under_rocprof.json
 cp $O/prof_pipe/pipe_kernel_stats.csv $P/r04_pipelined_kernel_stats.csv
-cp $O/bench_2rank_rehearsal_ipc.json $P/r04_bench_2rank_rehearsal_ipc.json
-cp $O/bench_4rank_rehearsal_ipc.json $P/r04_bench_4rank_rehearsal_ipc.json
+grep "^{" $O/bench_2rank_rehearsal_ipc.json > $P/r04_bench_2rank_rehearsal_ipc.json
+grep "^{" $O/bench_4rank_rehearsal_ipc.json > $P/r04_bench_4rank_rehearsal_ipc.json
 grep -v amdgpu.ids $O/sliced_costs.txt > $P/r04_sliced_costs.txt
 grep -v amdgpu.ids $O/latency_vs_cpu.txt > $P/r04_latency_vs_cpu.txt
 grep -v amdgpu.ids $O/bench_aux.txt > $P/r04_bench_aux.txt
