@@ -32,6 +32,16 @@ void* imt_ctx::dev_scratch(size_t slot, size_t bytes) {
     return s.p;
 }
 
+void imt_ctx::trim_scratch(size_t slot, size_t keep_below) {
+    if (slot >= scratch.size()) return;
+    Scratch& s = scratch[slot];
+    if (!s.p || s.cap <= keep_below) return;
+    hipStreamSynchronize(stream);
+    hipFree(s.p);
+    s.p = nullptr;
+    s.cap = 0;
+}
+
 int imt_ctx::set_device() {
     IMT_HIP(this, hipSetDevice(device));
     return IMT_OK;

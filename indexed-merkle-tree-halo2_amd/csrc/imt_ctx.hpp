@@ -49,6 +49,9 @@ struct imt_ctx {
     }
     // device scratch of at least `bytes` in slot `slot`; nullptr on failure (last_error set)
     void* dev_scratch(size_t slot, size_t bytes);
+    // give a slot's buffer back if it has grown beyond `keep_below` bytes (a one-off bulk call: imt_itree_load); the
+    // stream must have drained (the callers sync before they return)
+    void trim_scratch(size_t slot, size_t keep_below);
     int set_device();
     // zero the error word / read it back (synchronises the stream)
     int clear_err();

@@ -692,6 +692,8 @@ extern "C" int imt_itree_get_leaves(imt_itree* t, const uint64_t* index, size_t 
     IMT_HIP(c, hipMemcpyAsync(&perr, d_perr, sizeof(int), hipMemcpyDeviceToHost, s));
     if (!dev) IMT_HIP(c, hipMemcpyAsync(preimage, d_out, n * 96, hipMemcpyDeviceToHost, s));
     IMT_HIP(c, hipStreamSynchronize(s));
+    c->trim_scratch(0, (size_t)64 << 20);               // a whole-tree snapshot to the host staged 104 bytes per leaf here
+    c->trim_scratch(1, (size_t)64 << 20);
     if (perr & prep::ERR_RANGE) return c->fail(IMT_ERR_RANGE, "leaf index out of range");
     return IMT_OK;
 }
@@ -827,6 +829,11 @@ extern "C" int imt_itree_load(imt_itree* t, const void* preimages, uint64_t n, u
         if (pl.in_flight) { IMT_HIP(c, hipEventSynchronize(pl.done)); pl.in_flight = false; pl.pipelined = false; }
     IMT_HIP(c, hipStreamSynchronize(t->up_stream));
     hipStream_t s = c->stream;
+    // the snapshot copy and the sort workspace are as large as the tree: not something a context keeps after the call
+    struct Trim {
+        imt_ctx* c;
+        ~Trim() { c->trim_scratch(2, (size_t)64 << 20); c->trim_scratch(3, (size_t)64 << 20); }
+    } trim{c};
     // ---- the canonical preimages on the device (what is hashed; next_idx fields are global indices) ----
     const uint8_t* d_pre = (const uint8_t*)preimages;
     if (!dev || fmt != IMT_FMT_CANONICAL) {
