@@ -245,9 +245,16 @@ class SymWorld:
         w = rp.buffers[payload]
 
         def run():
+            if q >= 2:
+                # the level it READS (children and siblings of the nodes it computes): every earlier slice's write-backs
+                # and its own (its previous unit), nothing of a later slice yet
+                # (arrivals are appended in strictly increasing order -- asserted where they are appended -- so length and
+                # last element pin the whole list)
+                rd = rp.levels[q - 2]
+                assert len(rd) == k + 1 and rd[-1] == k, f"rank {rank}: slice {k} unit {q} reads level {q - 2} holding {rd[-6:]} (wants 0..{k})"
             if q >= 1:
                 lvl = rp.levels[q - 1]
-                assert lvl == list(range(k)), f"rank {rank}: slice {k} level {q - 1} sees {lvl[-6:]} (wants 0..{k - 1})"
+                assert len(lvl) == k and (k == 0 or lvl[-1] == k - 1), f"rank {rank}: slice {k} level {q - 1} sees {lvl[-6:]} (wants 0..{k - 1})"
                 lvl.append(k)
             w[0], w[1], w[2] = k, q, k * 1000003 + q
             rp.computed.append((k, q))

@@ -144,7 +144,7 @@ def test_gloo_ranks_line_up(world, depth, lag):
     procs = [ctx.Process(target=_worker, args=(r, world, port, depth, lag, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=400) for _ in range(world)]      # 8 spawned interpreters import torch on as many cores
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
