@@ -34,7 +34,7 @@ namespace {
 struct HipBackend : Backend {
     imt_itree* tree;
     imt_ctx* ctx;
-    hipStream_t rs[ROUNDS] = {}, cs[ROUNDS] = {};
+    hipStream_t rs[ROUNDS] = {}, cs[ROUNDS] = {}, aps[ROUNDS] = {};     // round, collective and apply streams
     int n_comm = ROUNDS;
 
     explicit HipBackend(imt_itree* t) : tree(t), ctx(imt_itree_ctx(t)) {}
@@ -67,12 +67,25 @@ struct HipBackend : Backend {
             IMT_HIP(ctx, hipStreamCreateWithPriority(&cs[i], hipStreamNonBlocking, comm_prio));
             ctx->side_streams.push_back(cs[i]);
         }
+        // The schedule (imt_sliced_sched.hpp) lets the other ranks' write-backs be applied on a stream of their own per round
+        // slot; here they stay on the round's stream unless IMT_SLICED_APPLY_STREAMS=1.  Measured with one rank of an
+        // 8-rank run alone on the GPU (tools/rank_emulation.py, profiles/r04_rank_emulation.txt): what moved the rate was
+        // the PRECISE cross-round waits (round R + 1's unit q behind round R's apply of tick q + world * lag and its own
+        // unit q + 1, instead of behind round R's whole tick q + world * lag, which made two rounds march in lockstep):
+        // 2.66 -> 2.85 M insertions/s per rank.  Four more streams on the runtime's four hardware queues cost some of it
+        // back (2.77 / 2.67 first / last rank), helper streams placed on other rounds' queues or at high priority more.
+        const char* ae = getenv("IMT_SLICED_APPLY_STREAMS");
+        if (ae && atoi(ae) != 0)
+            for (int i = 0; i < ROUNDS; i++) {
+                IMT_HIP(ctx, hipStreamCreateWithPriority(&aps[i], hipStreamNonBlocking, 0));
+                ctx->side_streams.push_back(aps[i]);
+            }
         return IMT_OK;
     }
     ~HipBackend() override {
         if (ctx->set_device()) return;
         auto& ss = ctx->side_streams;
-        for (hipStream_t* arr : {rs, cs})
+        for (hipStream_t* arr : {rs, cs, aps})
             for (int i = 0; i < ROUNDS; i++)
                 if (arr[i]) {
                     hipStreamSynchronize(arr[i]);
@@ -82,6 +95,7 @@ struct HipBackend : Backend {
     }
     Stream round_stream(int slot) override { return rs[slot]; }
     Stream comm_stream(int slot) override { return n_comm ? cs[slot % n_comm] : rs[slot]; }
+    Stream apply_stream(int slot) override { return aps[slot] ? aps[slot] : rs[slot]; }
     int new_event(Event* out) override {
         hipEvent_t e;
         IMT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -127,7 +141,7 @@ struct HipBackend : Backend {
     int sync() override {
         int rc = ctx->set_device();
         if (rc) return rc;
-        for (hipStream_t* arr : {rs, cs})
+        for (hipStream_t* arr : {rs, cs, aps})
             for (int i = 0; i < ROUNDS; i++)
                 if (arr[i]) IMT_HIP(ctx, hipStreamSynchronize(arr[i]));
         return imt_ctx_sync(ctx);

@@ -42,6 +42,12 @@ constexpr int ROUNDS = 4;            // rounds in flight = slices a tree keeps o
 #ifndef IMT_SCHED_MUTATION
 #define IMT_SCHED_MUTATION 0
 #endif
+// (mutation 6: round R writes a level once round R - 1 has WRITTEN it, without waiting for that round to have read it)
+#if IMT_SCHED_MUTATION == 6
+#define IMT_SCHED_OWN_READ_SLACK (-1)
+#else
+#define IMT_SCHED_OWN_READ_SLACK 0
+#endif
 
 struct Schedule {
     int world = 0, units = 0, lag = 0;
@@ -94,6 +100,7 @@ struct Backend {
     virtual ~Backend() {}
     virtual Stream round_stream(int slot) = 0;      // the stream round R runs on, slot = R % ROUNDS
     virtual Stream comm_stream(int slot) = 0;       // the stream its collectives are enqueued on
+    virtual Stream apply_stream(int slot) = 0;      // the stream the other ranks' gathered write-backs are applied on
     virtual int new_event(Event* out) = 0;
     virtual void free_event(Event e) = 0;
     virtual int record(Event e, Stream s) = 0;
@@ -150,8 +157,11 @@ struct Rank {
     std::vector<char> send_owned;
     std::vector<size_t> gather_bytes;           // [ROUNDS][ring] bytes per rank of the collective in flight
     std::vector<char> pending;                  // [ROUNDS][ring] a collective has been issued and not yet consumed
-    std::vector<Event> tick_ev;                 // [ROUNDS][round_ticks]
+    std::vector<char> send_busy;                // [ROUNDS][ring] ... and the send buffer not yet known to be free again
+    std::vector<Event> tick_ev;                 // [ROUNDS][round_ticks] round stream: the tick's unit is computed and packed
+    std::vector<Event> applied_ev;              // [ROUNDS][round_ticks] apply stream: the tick's (and every earlier) apply is done
     std::vector<Event> packed_ev, gathered_ev;  // [ROUNDS][ring]
+    std::vector<Event> consumed_ev;             // [ROUNDS][ring] apply stream: the receive buffer's payloads have been applied
     Event done_ev[ROUNDS] = {};
     Round rounds[ROUNDS + 1];                   // round R at R % (ROUNDS + 1)
     uint64_t n_rounds = 0;
@@ -180,9 +190,12 @@ struct Rank {
         send_owned.assign(nb, 0);
         gather_bytes.assign(nb, payload_cap);
         pending.assign(nb, 0);
+        send_busy.assign(nb, 0);
         packed_ev.assign(nb, nullptr);
         gathered_ev.assign(nb, nullptr);
+        consumed_ev.assign(nb, nullptr);
         tick_ev.assign((size_t)ROUNDS * sc.round_ticks, nullptr);
+        applied_ev.assign((size_t)ROUNDS * sc.round_ticks, nullptr);
         w_units.resize(world);
         w_sb.resize(world);
         w_n.resize(world);
@@ -197,9 +210,13 @@ struct Rank {
                     send_owned[i] = 1;
                 }
                 if ((rc = be->alloc(payload_cap * world, &recv[i]))) return rc;
-                if ((rc = be->new_event(&packed_ev[i])) || (rc = be->new_event(&gathered_ev[i]))) return rc;
+                if ((rc = be->new_event(&packed_ev[i])) || (rc = be->new_event(&gathered_ev[i])) ||
+                    (rc = be->new_event(&consumed_ev[i])))
+                    return rc;
             }
         for (auto& e : tick_ev)
+            if ((rc = be->new_event(&e))) return rc;
+        for (auto& e : applied_ev)
             if ((rc = be->new_event(&e))) return rc;
         for (auto& e : done_ev)
             if ((rc = be->new_event(&e))) return rc;
@@ -213,43 +230,71 @@ struct Rank {
             if (recv[i]) be->free_buffer(recv[i]);
             if (packed_ev[i]) be->free_event(packed_ev[i]);
             if (gathered_ev[i]) be->free_event(gathered_ev[i]);
+            if (consumed_ev[i]) be->free_event(consumed_ev[i]);
         }
         for (auto e : tick_ev)
+            if (e) be->free_event(e);
+        for (auto e : applied_ev)
             if (e) be->free_event(e);
         for (auto e : done_ev)
             if (e) be->free_event(e);
         send.clear();
         recv.clear();
         tick_ev.clear();
+        applied_ev.clear();
         be = nullptr;
     }
 
-    // gathered payloads of tick rt - lag -> this replica
+    // What round R needs of round R - 1 before it touches level u - 1 of this replica (its own unit u, or other ranks'
+    // payloads of unit u): every write-back round R - 1 made to that level is here -- the other ranks' by that round's
+    // apply of tick u + world * lag (the last slice's unit u is gathered at tick u + (world - 1) lag and applied `lag`
+    // later), this rank's own by its unit u -- and this rank's round R - 1 has READ the level (its unit u + 1, which
+    // computes level u from it).  Both streams of round R - 1 are in order, so one event of each covers everything before.
+    int wait_previous_round(Stream st, uint64_t R, int u) {
+        const size_t base = (size_t)((R - 1) % ROUNDS) * sc.round_ticks;
+        int rc;
+        if ((rc = be->wait(st, applied_ev[base + u + sc.period]))) return rc;
+        const int own = std::min(u + 1 + IMT_SCHED_OWN_READ_SLACK, sc.units - 1) + rank * sc.lag;
+        return be->wait(st, tick_ev[base + own]);
+    }
+
+    // gathered payloads of tick rt - lag -> this replica, on the round's APPLY stream: an apply waits for a collective and
+    // for the previous round's applies, not for this rank's own hashing, so the round's units are never queued behind it
     int phase_apply(uint64_t R, int rt) {
         const int src = rt - sc.lag;
-        if (src < 0 || !sc.has_gather(src)) return IMT_OK;
-        const int slot = (int)(R % ROUNDS), i = at(slot, src % ring);
-        Stream st = be->round_stream(slot);
+        const int slot = (int)(R % ROUNDS);
+        Stream ast = be->apply_stream(slot);
+        Event done = applied_ev[(size_t)slot * sc.round_ticks + rt];
+        if (src < 0 || !sc.has_gather(src)) return be->record(done, ast);
+        const int i = at(slot, src % ring);
         const Round& rd = round(R);
         int rc;
-        if (pending[i]) {           // the round's stream waits for the collective; the host does not
-            if ((rc = be->wait(st, gathered_ev[i])) || (IMT_SCHED_MUTATION != 3 && (rc = tp->fence(*this, slot, src % ring, st)))) return rc;
+        if (pending[i]) {           // the apply stream waits for the collective; the host does not
+            if ((rc = be->wait(ast, gathered_ev[i])) || (IMT_SCHED_MUTATION != 3 && (rc = tp->fence(*this, slot, src % ring, ast)))) return rc;
             pending[i] = 0;
+            if (ast == be->round_stream(slot)) send_busy[i] = 0;    // the stream that will pack into it has just waited
         }
         sc.payload_units(src, w_units.data());
         w_units[rank] = -1;         // own write-backs are already in this replica
         int top = -1;
         for (int g = 0; g < world; g++) top = std::max(top, (int)w_units[g]);
-        if (top < 0) return IMT_OK;
+        if (top < 0) return be->record(done, ast);
         if (R >= 1 && IMT_SCHED_MUTATION != 2)
-            // a write-back of round R lands on a node after every write-back round R - 1 made to that level (they run
-            // on different streams): behind that round's tick max(unit) + world * lag
-            if ((rc = be->wait(st, tick_ev[(size_t)((R - 1) % ROUNDS) * sc.round_ticks + top + sc.period]))) return rc;
+            // a write-back of round R lands on a node after every write-back round R - 1 made to that level and after
+            // that round's last look at it
+            if ((rc = wait_previous_round(ast, R, top))) return rc;
         for (int g = 0; g < world; g++) {
             w_sb[g] = rd.size_before + (uint64_t)g * rd.n;
             w_n[g] = rd.n;
         }
-        return be->apply_gathered(recv[i], gather_bytes[i], world, w_sb.data(), w_n.data(), w_units.data(), st);
+        // Within the round no further wait is needed: a LATER slice's payload of unit u reaches this replica through a
+        // collective that also carries this rank's own unit of that tick, u + (g - rank) lag >= u + 1 -- the unit that read
+        // level u - 1 -- so the collective cannot complete before that read; an EARLIER slice's payload writes levels this
+        // rank's units have not reached, and those wait for this apply (phase_compute).
+        if ((rc = be->apply_gathered(recv[i], gather_bytes[i], world, w_sb.data(), w_n.data(), w_units.data(), ast)) ||
+            (rc = be->record(consumed_ev[i], ast)))
+            return rc;
+        return be->record(done, ast);
     }
 
     // this rank's unit of the tick, packed into the tick's send buffer
@@ -257,16 +302,22 @@ struct Rank {
         const int q = sc.unit_of(rank, rt);
         const int slot = (int)(R % ROUNDS);
         Stream st = be->round_stream(slot);
+        const int i = at(slot, rt % ring);
         int rc;
         if (q >= 0) {
+            // the earlier slices' write-backs of this tick (the previous slice's level q - 1 arrives exactly now)
+            if (IMT_SCHED_MUTATION != 4 && (rc = be->wait(st, applied_ev[(size_t)slot * sc.round_ticks + rt]))) return rc;
             if (q >= 1 && R >= 1 && IMT_SCHED_MUTATION != 1)
-                // level q - 1 of every slice of round R - 1 must be in this replica: applied (others) or written back
-                // (own) by the end of that round's tick q + world * lag
-                if ((rc = be->wait(st, tick_ev[(size_t)((R - 1) % ROUNDS) * sc.round_ticks + q + sc.period]))) return rc;
-            if ((rc = be->unit(round(R).slice, (unsigned)q, send[at(slot, rt % ring)], st))) return rc;
+                // level q - 1 of every slice of round R - 1 must be in this replica, and that round done reading it
+                if ((rc = wait_previous_round(st, R, q))) return rc;
+            if (send_busy[i]) {     // the unit packs into a send buffer an earlier collective may still be reading
+                if ((rc = be->wait(st, gathered_ev[i])) || (IMT_SCHED_MUTATION != 3 && (rc = tp->fence(*this, slot, rt % ring, st)))) return rc;
+                send_busy[i] = 0;
+            }
+            if ((rc = be->unit(round(R).slice, (unsigned)q, send[i], st))) return rc;
             if (q == sc.units - 1 && (rc = be->record(done_ev[slot], st))) return rc;
         }
-        if (sc.has_gather(rt) && (rc = be->record(packed_ev[at(slot, rt % ring)], st))) return rc;
+        if (sc.has_gather(rt) && (rc = be->record(packed_ev[i], st))) return rc;
         return IMT_OK;
     }
 
@@ -286,10 +337,12 @@ struct Rank {
                 if (w_units[g] >= 0) mx = std::max(mx, be->unit_bytes(rd.size_before + (uint64_t)g * rd.n, rd.n, (unsigned)w_units[g]));
             gather_bytes[i] = mx;
             Stream cs = be->comm_stream(slot);
-            if ((rc = be->wait(cs, packed_ev[i])) || (rc = tp->all_gather(*this, slot, r, mx, cs)) ||
-                (rc = be->record(gathered_ev[i], cs)))
+            // the receive buffer is free once its previous payloads have been applied (another stream's business now)
+            if ((IMT_SCHED_MUTATION != 5 && (rc = be->wait(cs, consumed_ev[i]))) || (rc = be->wait(cs, packed_ev[i])) ||
+                (rc = tp->all_gather(*this, slot, r, mx, cs)) || (rc = be->record(gathered_ev[i], cs)))
                 return rc;
             pending[i] = 1;
+            send_busy[i] = 1;
             tp->collectives++;
             tp->bytes_moved += mx * (uint64_t)world;
         }

@@ -44,6 +44,7 @@ struct SymBackend : Backend {
     SymBackend(const sym_callbacks& c, int r, size_t p) : cb(c), rank(r), payload(p) {}
     Stream round_stream(int slot) override { return handle(rank, slot); }
     Stream comm_stream(int slot) override { return handle(rank, ROUNDS + slot); }
+    Stream apply_stream(int slot) override { return handle(rank, 2 * ROUNDS + slot); }
     int new_event(Event* out) override { *out = handle(rank, next_event++); return IMT_OK; }
     void free_event(Event) override {}
     int record(Event e, Stream s) override { return cb.record(rank, h_id(e), h_id(s)); }

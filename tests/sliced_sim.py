@@ -148,7 +148,7 @@ class Replica:
     def __init__(self, sim, depth, batch, world, rank):
         self.sim, self.depth, self.batch, self.world, self.rank = sim, depth, batch, world, rank
         self.units = depth + 1
-        self.streams = [sim.stream() for _ in range(2 * ROUNDS)]       # round streams, then comm streams
+        self.streams = [sim.stream() for _ in range(3 * ROUNDS)]       # round streams, comm streams, apply streams
         self.events = {}                                   # id -> token of the latest record issued (or None)
         self.buffers = {}                                  # id -> int64 words
         self.levels = [[] for _ in range(depth)]           # slices written back per level, in arrival order

@@ -84,9 +84,12 @@ def test_every_level_sees_exactly_the_earlier_slices(lib, world, depth, lag):
 
 
 def test_the_simulator_catches_planted_mutations(tmp_path):
-    """the schedule code rebuilt with one ordering rule dropped each time -- round R's units behind round R - 1's tick
-    (1), round R's applies behind it (2), the fence that keeps a send buffer until every peer has copied it (3) -- must
-    fail under the adversarial scheduler for some seed; the unmodified code passes the same runs"""
+    """the schedule code rebuilt with one ordering rule dropped each time -- round R's units behind round R - 1's applies
+    and own units (1), round R's applies behind them (2), the fence that keeps a send buffer until every peer has copied
+    it (3), a unit behind its own tick's apply now that applies have a stream of their own (4), a collective behind the
+    apply that last read its receive buffer (5), round R writing a level as soon as round R - 1 has written it, without
+    waiting for that round to have read it (6) -- must fail under the adversarial scheduler for some seed; the unmodified
+    code passes the same runs"""
     src = os.path.join(ROOT, "tests", "native", "sliced_sym.cpp")
 
     def outcome(mutation):
@@ -108,7 +111,7 @@ def test_the_simulator_catches_planted_mutations(tmp_path):
         return "passed"
 
     assert outcome(0) == "passed"
-    for m in (1, 2, 3):
+    for m in (1, 2, 3, 4, 5, 6):
         assert outcome(m) == "caught", f"mutation {m} went unnoticed"
 
 
