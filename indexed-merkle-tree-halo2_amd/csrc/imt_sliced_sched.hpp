@@ -16,8 +16,15 @@
 // gathered at q + g' lag and applied by q + g' lag + lag <= q + g lag; round R - 1's last payload for unit q (rank world - 1)
 // is applied at its round tick q + world * lag = the global tick at which (R, 0, q) runs, older rounds first.  A later
 // slice's level l does not exist yet when an earlier one reads it.  Two ordering rules between rounds (different streams):
-// round R's unit q runs behind round R - 1's tick q + world * lag, and round R's APPLIES of unit q run behind that tick
-// too (two rounds' write-backs to one node must land in slice order).  Within a round everything is on one stream.
+// before round R touches level q - 1 -- its own unit q, or its APPLY of other ranks' unit-q payloads (two rounds'
+// write-backs to one node must land in slice order) -- round R - 1 has finished with that level: the other ranks' unit-q
+// write-backs are in (round R - 1's apply of tick q + world * lag, an event on that round's apply stream), this rank's own
+// is in and its next unit, which reads the level, has run (round R - 1's own unit q + 1, an event on its round stream).
+// (Until late in round 4 both rules waited for round R - 1's whole TICK q + world * lag, i.e. also for this rank's own
+// unit of that tick, 15 levels further up: nothing needs that, and it made the two rounds a rank has in flight march in
+// lockstep -- tools/rank_emulation.py.)  Within a round a unit waits for its tick's apply; an apply needs no wait for the
+// round's own units: a later slice's payload arrives through a collective that carries this rank's own, later, unit.
+// Applies may run on a stream of their own per round slot (Backend::apply_stream) or on the round's.
 //
 // The classes here drive an abstract Backend (streams, events, buffers, the slice calls of one replica) and an abstract
 // Transport (the all-gather).  The product instantiates them over HIP (imt_sliced.cpp: imt_itree_slice_*, RCCL / IPC /
