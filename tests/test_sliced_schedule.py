@@ -79,7 +79,7 @@ def run_world(lib, world, depth, lag, seed, rounds=7, batch=4):
 @pytest.mark.parametrize("world,depth,lag", [(1, 8, None), (2, 8, None), (2, 8, 5), (4, 8, None), (4, 32, None), (8, 32, None),
                                              (8, 32, 4), (3, 8, None), (16, 32, None), (8, 8, 1), (2, 3, 2)])
 def test_every_level_sees_exactly_the_earlier_slices(lib, world, depth, lag):
-    for seed in range(int(os.environ.get("IMT_SIM_SEEDS", "4"))):
+    for seed in range(int(os.environ.get("IMT_SIM_SEEDS", "4" if world < 16 else "2"))):
         run_world(lib, world, depth, lag, seed)
 
 
@@ -135,7 +135,9 @@ def _worker(rank, world, port, depth, lag, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,depth,lag", [(2, 8, None), (4, 6, 2), (8, 32, None)])
+# (a gloo all-gather between 8 processes on 8 cores takes ~0.3 s: the 8-rank case keeps the depth small; depth 32 at
+# world 8 and 16 runs in-process above, under the adversarial scheduler)
+@pytest.mark.parametrize("world,depth,lag", [(2, 8, None), (4, 6, 2), (8, 10, None)])
 def test_gloo_ranks_line_up(world, depth, lag):
     import socket
     sliced_sim.build_lib()               # once, before the ranks race to build it
