@@ -558,6 +558,19 @@ def test_sliced_world_resumes_from_a_checkpoint(imt, ctx):
     b.close()
 
 
+def test_rank_emulation_tool_runs(imt):
+    """tools/rank_emulation.py (one rank of an N-rank run over a modelled transport, a timing tool): rank 1 of 4 goes
+    through imt_sliced_step with a custom vtable whose receive slots hold its own payload -- the library must take that
+    without a fault (the apply kernel clamps counts and node indices) and report a rate"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rank_emulation.py"), "4"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, EMU_ROUNDS="3", EMU_RANKS="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("N = 4 rank 1 lag 3")]
+    assert len(lines) == 2 and "free collectives" in lines[0] and "GB/s links" in lines[1], r.stdout
+    assert all(float(l.split(": ")[1].split(" M insertions/s")[0]) > 0.5 for l in lines)
+
+
 def test_slice_calls_refuse_bad_arguments(imt, ctx):
     """the C entry points directly: misaligned payloads / values, units out of order, a second preparation of too many
     slices, a placed tree, a short payload stride, worlds that are no schedule -- documented codes, nothing reaches a kernel"""
