@@ -7,6 +7,7 @@
 #   scale     the timed path on trees of 2^20 .. 2^27 leaves (+ rocprofv3 at 2^26)
 #   soak      differential soaks against the sequential oracle
 #   aux       secondary rates and latency tables, kernel resources
+#   emu       one rank of an N = 2 / 4 / 8 single-list run alone on the GPU over a modelled transport (timing emulation)
 set -o pipefail
 O=gpurun_out/r04
 mkdir -p $O
@@ -40,6 +41,9 @@ soak)
   SOAK_SECONDS=60 timeout -k 10 400 python tools/differential_soak.py > $O/differential_soak.txt 2>&1 && echo "soak ok" &&
   SOAK_SECONDS=120 timeout -k 10 400 python tools/sliced_soak.py > $O/sliced_soak.txt 2>&1 && echo "sliced soak ok"
   echo "soak part exit $?" ;;
+emu)
+  timeout -k 10 900 python tools/rank_emulation.py > $O/rank_emulation.txt 2>&1 && echo "emulation ok"
+  echo "emu part exit $?"; grep "^N =" $O/rank_emulation.txt | cut -c1-110 ;;
 aux)
   timeout -k 10 300 python tools/latency_vs_cpu.py > $O/latency_vs_cpu.txt 2>&1 && echo "latency vs cpu ok" &&
   timeout -k 10 300 python tools/bench_aux.py > $O/bench_aux.txt 2>&1 && echo "aux ok" &&
