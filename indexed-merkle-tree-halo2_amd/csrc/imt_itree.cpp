@@ -164,6 +164,7 @@ struct imt_itree {
     uint8_t* d_canon_all = nullptr;
     size_t canon_all_cap = 0;
     uint32_t* d_sorted_extra = nullptr;      // third index buffer: a step's up to three merges never write the committed one
+    hipStream_t slice_prep_stream = nullptr; // where the next imt_itree_slice_prepare runs (nullptr: the side stream)
     double slice_wait_ms = 0;                // host time spent waiting for the GPU inside imt_itree_slice_prepare
     bool sliced_busy = false;                // an imt_sliced world has steps in flight on this replica (until its flush)
     size_t reserved_events = 0;              // every plan set holds at least this many events (reserve_all_plans)
@@ -457,6 +458,9 @@ imt_ctx* imt_itree_ctx(const imt_itree* t) { return t ? t->ctx : nullptr; }
 unsigned imt_itree_depth(const imt_itree* t) { return t ? t->depth : 0; }
 void imt_itree_mark_sliced(imt_itree* t, bool busy) {
     if (t) t->sliced_busy = busy;
+}
+void imt_itree_set_slice_prep_stream(imt_itree* t, void* hip_stream) {
+    if (t) t->slice_prep_stream = (hipStream_t)hip_stream;
 }
 double imt_itree_take_wait_ms(imt_itree* t) {
     const double w = t ? t->slice_wait_ms : 0;
@@ -1717,7 +1721,13 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
     if ((rc = reserve_all_plans(t, 2 * n_own))) return rc;
     if (n_before || n_after)
         if ((rc = fws_reserve(t, std::max(n_before, n_after)))) return rc;
-    hipStream_t ps = t->up_stream;
+    // The side stream, or a stream the sliced schedule names (imt_itree_set_slice_prep_stream: the NEW round's own stream,
+    // whose hardware queue is idle -- the side stream shares one with some round's stream, and a hardware queue runs what
+    // it holds in submission order: the preparation then stood behind a whole period of that round's hash kernels and the
+    // host's wait for the verdict lasted until the GPU had run dry).  Preparations of consecutive steps are ordered by the
+    // host: each is waited for (the verdict) before the call returns.
+    hipStream_t ps = t->slice_prep_stream ? t->slice_prep_stream : t->up_stream;
+    if (t->slice_prep_stream) IMT_HIP(c, hipStreamSynchronize(t->up_stream));      // whatever an earlier call left there
     if (!(flags & IMT_INPUTS_READY)) {
         IMT_HIP(c, hipEventRecord(t->in_mark, c->stream));
         IMT_HIP(c, hipStreamWaitEvent(ps, t->in_mark, 0));

@@ -10,3 +10,5 @@ bool imt_itree_is_plain(const imt_itree* t);     // not placed, not partitioned,
 double imt_itree_take_wait_ms(imt_itree* t);
 // an imt_sliced world marks its replicas while steps are in flight; the ordinary imt_itree_* entry points then refuse
 void imt_itree_mark_sliced(imt_itree* t, bool busy);
+// the stream the NEXT imt_itree_slice_prepare calls enqueue their work on (NULL: the tree's side stream, the default)
+void imt_itree_set_slice_prep_stream(imt_itree* t, void* hip_stream);

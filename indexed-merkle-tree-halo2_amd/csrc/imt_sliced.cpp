@@ -130,8 +130,24 @@ struct HipBackend : Backend {
     uint64_t tree_size() override { return imt_itree_size(tree); }
     size_t payload_bytes(size_t n) override { return imt_itree_slice_payload_bytes(n); }
     size_t unit_bytes(uint64_t sb, size_t n, unsigned q) override { return imt_itree_slice_unit_bytes(tree, sb, n, q); }
-    int prepare(const void* vals, size_t nb, size_t no, size_t na, const imt_insert_out* out, unsigned flags, int* slice) override {
-        return imt_itree_slice_prepare(tree, vals, nb, no, na, out, flags | IMT_DEVICE_PTRS, slice, nullptr);
+    int prepare(const void* vals, size_t nb, size_t no, size_t na, const imt_insert_out* out, unsigned flags, int slot,
+                int* slice) override {
+        // Where the step's preparation (some sixty small dependent kernels: sort, merges, low-leaf search, level tables)
+        // is enqueued.  The tree's side stream shares a hardware queue with some round's stream, and a queue runs what it
+        // holds in submission order: there the preparation stood behind that round's hash kernels.  The NEW round's slot has
+        // been idle since its previous round ended, so its streams' queue is free; on the slot's collective stream the
+        // preparation is also not in front of the round's own first units in stream order.  One rank of N = 2 / 4 / 8
+        // alone on the GPU (tools/rank_emulation.py, first rank, modelled links): side stream 2.93 / 2.89 / 2.81, the round's
+        // stream 3.02 / 2.99 / 2.77, the slot's collective stream 3.03 / 2.97 / 2.80 M insertions/s.
+        // IMT_SLICED_PREP_STREAM = comm (default) / round / side.
+        static const char* where = getenv("IMT_SLICED_PREP_STREAM");
+        void* st = n_comm ? (void*)cs[slot % n_comm] : (void*)rs[slot];
+        if (where && !strcmp(where, "side")) st = nullptr;
+        if (where && !strcmp(where, "round")) st = rs[slot];
+        imt_itree_set_slice_prep_stream(tree, st);
+        const int rc = imt_itree_slice_prepare(tree, vals, nb, no, na, out, flags | IMT_DEVICE_PTRS, slice, nullptr);
+        imt_itree_set_slice_prep_stream(tree, nullptr);
+        return rc;
     }
     int unit(int slice, unsigned q, Buffer payload, Stream s) override { return imt_itree_slice_unit(tree, slice, q, payload, s); }
     int apply_gathered(Buffer g, size_t stride, int count, const uint64_t* sb, const uint64_t* n, const int32_t* units,

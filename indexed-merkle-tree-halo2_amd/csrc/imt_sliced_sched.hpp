@@ -120,8 +120,9 @@ struct Backend {
     virtual uint64_t tree_size() = 0;
     virtual size_t payload_bytes(size_t n) = 0;     // imt_itree_slice_payload_bytes
     virtual size_t unit_bytes(uint64_t size_before, size_t n, unsigned unit) = 0;
+    // slot = the round slot the step will run in (R % ROUNDS): a backend may prepare on that round's stream
     virtual int prepare(const void* vals, size_t n_before, size_t n_own, size_t n_after, const imt_insert_out* out,
-                        unsigned flags, int* slice) = 0;
+                        unsigned flags, int slot, int* slice) = 0;
     virtual int unit(int slice, unsigned q, Buffer payload, Stream s) = 0;
     virtual int apply_gathered(Buffer gathered, size_t stride, int count, const uint64_t* size_before, const uint64_t* n,
                                const int32_t* units, Stream s) = 0;
@@ -408,7 +409,7 @@ struct World {
             Rank* rk = ranks[k];
             if (rk->be->tree_size() != size_before) return IMT_ERR_INTERNAL;
             int rc = rk->be->prepare(vals, (size_t)rk->rank * n, n, (size_t)(rk->world - 1 - rk->rank) * n,
-                                     outs ? &outs[k] : nullptr, flags, &slices[k]);
+                                     outs ? &outs[k] : nullptr, flags, (int)(R % ROUNDS), &slices[k]);
             if (rc) return k == 0 ? rc : IMT_ERR_INTERNAL;       // replicas that disagree about a step are broken
         }
         const uint64_t start = n_rounds == 0 ? T : std::max<uint64_t>(T, start_of(R - 1) + sc.period);

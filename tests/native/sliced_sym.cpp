@@ -61,7 +61,7 @@ struct SymBackend : Backend {
     uint64_t tree_size() override { return cb.tree_size(rank); }
     size_t payload_bytes(size_t) override { return payload; }
     size_t unit_bytes(uint64_t sb, size_t n, unsigned q) override { return cb.unit_bytes(rank, sb, n, q); }
-    int prepare(const void*, size_t nb, size_t no, size_t na, const imt_insert_out*, unsigned, int* slice) override {
+    int prepare(const void*, size_t nb, size_t no, size_t na, const imt_insert_out*, unsigned, int, int* slice) override {
         return cb.prepare(rank, nb, no, na, slice);
     }
     int unit(int slice, unsigned q, Buffer payload_buf, Stream s) override { return cb.unit(rank, slice, q, h_id(payload_buf), h_id(s)); }
