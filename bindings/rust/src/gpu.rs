@@ -393,3 +393,32 @@ pub fn less_than_traces<F: ScalarField>(a: &[F], b: &[F], lookup_bits: usize) ->
     })?;
     Ok((0..n).map(|i| from_bytes(&trace[i * rows * 32..][..rows * 32])).collect())
 }
+
+/// f3 for `verify_non_inclusion` on its own (`src/indexed_merkle_tree.rs:127-229`, BASELINE config 3's gadget): every new
+/// advice value outside its hashes for n candidates, item-major: `rows[i]` = `imt_non_inclusion_gadget_rows(depth,
+/// lookup_bits)` elements in assignment order (`imt_non_inclusion_gadget_trace_batch`), from the witnesses
+/// [`IndexedTree::non_inclusion_witnesses`] returned.  The hash blocks in between are `path_traces(None, Some(low_leaf), ..)`;
+/// `imt_non_inclusion_column_segments` says how the two interleave, `imt_insert_gadget_lookup_rows` which rows are lookup cells.
+pub fn non_inclusion_gadget_traces<F: ScalarField>(w: &[NonInclusionWitness<F>], depth: usize, lookup_bits: usize) -> Result<Vec<Vec<F>>, ImtError> {
+    let g = context().lock().unwrap();
+    let n = w.len();
+    let rows = unsafe { imt_non_inclusion_gadget_rows(depth as u32, lookup_bits as u32) };
+    let mut low_leaf = Vec::with_capacity(n * 96);
+    let mut low_sib = Vec::with_capacity(n * depth * 32);
+    let mut vals = Vec::with_capacity(n * 32);
+    let (mut low_index, mut largest) = (Vec::with_capacity(n), Vec::with_capacity(n));
+    for x in w {
+        low_leaf.extend_from_slice(&to_bytes(&x.low_leaf[..]));
+        low_sib.extend_from_slice(&to_bytes(&x.low_leaf_proof));
+        vals.extend_from_slice(&to_bytes(&[x.new_leaf_value]));
+        low_index.push(x.low_leaf_index);
+        largest.push(x.is_new_leaf_largest as u8);
+    }
+    let mut trace = vec![0u8; n * rows * 32];
+    check(&g, unsafe {
+        imt_non_inclusion_gadget_trace_batch(g.ctx, low_leaf.as_ptr() as *const c_void, low_index.as_ptr(), low_sib.as_ptr() as *const c_void,
+                                             vals.as_ptr() as *const c_void, largest.as_ptr(), depth as u32, lookup_bits as u32, n,
+                                             trace.as_mut_ptr() as *mut c_void, IMT_FMT_CANONICAL | IMT_TRACE_ITEM_MAJOR)
+    })?;
+    Ok((0..n).map(|i| from_bytes(&trace[i * rows * 32..][..rows * 32])).collect())
+}
