@@ -114,6 +114,33 @@ private:
     imt_ctx* h_ = nullptr;
 };
 
+// f3: what the reference's is_less_than(a, b) (src/indexed_merkle_tree.rs:98-125: range.is_less_than + gate.is_equal per
+// 128-bit limb, not x4, and x4, or) assigns for these two field elements: every NEW advice value in assignment order
+// (4 (ceil(128 / lookup_bits) + 1) + 27 rows), the row that holds the result, and the rows whose cells a chip must also
+// register with the RangeChip's lookup table (the limbs of both range checks).
+struct LessThanTrace {
+    std::vector<Fr> rows;
+    std::vector<uint32_t> lookup_rows;
+    uint32_t out_row = 0;
+    bool less = false;
+};
+inline LessThanTrace is_less_than_trace(const Fr& a, const Fr& b, unsigned lookup_bits = 18, Context& ctx = Context::global()) {
+    LessThanTrace t;
+    const size_t rows = imt_less_than_trace_rows(lookup_bits);
+    if (!rows) throw Error(IMT_ERR_RANGE, "is_less_than_trace: 1 <= lookup_bits <= 28");
+    t.rows.resize(rows);
+    uint8_t lt = 0;
+    ctx.check(imt_less_than_trace_batch(ctx.get(), &a, &b, 1, lookup_bits, t.rows.data(), &lt, IMT_FMT_CANONICAL));
+    t.less = lt != 0;
+    size_t n_cells = 0, n_consts = 0, n_lk = 0;
+    ctx.check(imt_less_than_trace_layout(ctx.get(), lookup_bits, nullptr, 0, &n_cells, nullptr, 0, &n_consts, &t.out_row,
+                                         IMT_FMT_CANONICAL));
+    ctx.check(imt_less_than_lookup_rows(lookup_bits, nullptr, 0, &n_lk));
+    t.lookup_rows.resize(n_lk);
+    ctx.check(imt_less_than_lookup_rows(lookup_bits, t.lookup_rows.data(), n_lk, &n_lk));
+    return t;
+}
+
 // The native hasher of the reference's call sites.  The sponge is the reference's: T = 3, RATE = 2, two permutations
 // for 2 and for 3 absorbed elements; those are the only arities the reference uses and the only ones offered.
 class Poseidon {

@@ -60,6 +60,14 @@ static void test_hash_zero() {
     const Fr h2 = native_hasher.squeeze_and_reset();
     const auto t2 = native_hasher.hash_fix_len_array_trace({Fr::from((uint64_t)7), Fr::from((uint64_t)11)});
     CHECK(t2.rows.size() == 1208 && t2.output() == h2 && t2.out_row == 1204);
+    // f3: the comparison the gadget makes at :180 / :226, as the rows a chip assigns (63 at lookup_bits 18, the reference's
+    // tests' :436); the 18 lookup rows are 18-bit limbs
+    const auto lt = imt::is_less_than_trace(Fr::from((uint64_t)7), h2);
+    CHECK(lt.rows.size() == 63 && lt.less == (Fr::from((uint64_t)7) < h2) && lt.rows[lt.out_row] == Fr::from(lt.less));
+    CHECK(lt.lookup_rows.size() == 18);
+    for (uint32_t r : lt.lookup_rows) CHECK(lt.rows[r] < Fr::from((uint64_t)1 << 18));
+    const auto ge = imt::is_less_than_trace(h2, h2);
+    CHECK(!ge.less && ge.rows[ge.out_row] == Fr::zero());
 }
 
 // :361-478
