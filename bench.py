@@ -491,6 +491,10 @@ def bench_single_list(env):
         tp = sliced.local_transport(env.imt)
     tree = sliced.SlicedTree(env.imt, env.local_rank, DEPTH, cap, BATCH, world, first_rank=rank, n_local=1, transport=tp,
                              lag=lag, nbuf=nbuf)
+    env.live_world = tree          # for the watchdog: where the world stands when the leg hangs (imt_sliced_dump)
+    # the library's own watchdog fires first and says why: a host wait of more than this inside imt_sliced_* returns
+    # IMT_ERR_TIMEOUT with the world's state on stderr; bench.py's timer below is the net under it
+    tree.set_option(env.F.SLICED_OPT_WATCHDOG_MS, int(float(os.environ.get("IMT_BENCH_LIBRARY_WATCHDOG_S", "90")) * 1e3))
     ctx = tree.ctxs[0]
     # every rank sees the whole step: the same seed everywhere
     vals = torch.from_numpy(synth_values(steps_total * gb, 0, 1, 0x494D5403)).to(env.dev)
@@ -552,7 +556,11 @@ def bench_single_list(env):
             "schedule": {"lag_levels": i1["lag"], "round_period_ticks": i1["period"], "gathers_per_round": i1["gathers_per_round"],
                          "rounds_in_flight": i1["rounds_in_flight"], "payload_bytes": i1["payload_bytes"],
                          "driver": "libimt_hip.so (imt_sliced_step: schedule, streams, events and the collective behind the C ABI)",
-                         "transport": kind, "rccl": rccl_lib},
+                         "transport": kind, "rccl": rccl_lib,
+                         # where the world's streams sit on the runtime's hardware queues, measured by imt_sliced_create:
+                         # [round / collective / apply stream][round slot] -> queue class
+                         "queue_map": i1["queue_map"], "placement": i1["placement"], "hw_queues": i1["hw_queues"],
+                         "comm_streams": i1["comm_streams"], "streams_recreated": i1["streams_recreated"]},
             "ctx": ctx, "be": tree, "boot": boot}       # boot: the context the transport was made on, alive until it is destroyed
 
 
@@ -694,6 +702,12 @@ def main():
         limit = float(os.environ.get("IMT_BENCH_SINGLE_LIST_TIMEOUT", "240"))
 
         def give_up():
+            w = getattr(env, "live_world", None)
+            if w is not None:       # every rank: where its world stands (host-side state + event queries, no device wait)
+                try:
+                    print(f"[rank {rank}] single-list leg over its time limit; the world:\n{w.dump()}", file=sys.stderr, flush=True)
+                except Exception as e:
+                    print(f"[rank {rank}] no dump: {e!r}", file=sys.stderr, flush=True)
             if rank == 0:
                 why = f"the single-list leg did not finish within {limit:.0f} s"
                 res, _ = assemble_line(env, legs, why, (None, None, None), headline) if legs else \

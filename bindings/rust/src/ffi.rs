@@ -4,7 +4,7 @@
 //! fails when a name, the number of arguments, an integer width or a constant differs.
 #![allow(non_camel_case_types, dead_code)]
 
-use std::os::raw::{c_char, c_double, c_int, c_uint, c_void};
+use std::os::raw::{c_char, c_double, c_int, c_long, c_uint, c_void};
 
 #[repr(C)]
 pub struct imt_ctx {
@@ -69,6 +69,11 @@ pub struct imt_sliced_info {
     pub bytes_gathered: u64,
     pub host_issue_ms: c_double,
     pub host_wait_ms: c_double,
+    pub placement: c_int,
+    pub hw_queues: c_int,
+    pub comm_streams: c_int,
+    pub streams_recreated: c_int,
+    pub queue_map: [[c_int; 4]; 3],
 }
 
 /// `imt_column_segment`: a stretch of insert_leaf's advice column (imt_insert_column_segments).
@@ -104,6 +109,7 @@ pub const IMT_ERR_ARG: c_int = -9;
 pub const IMT_ERR_VALUE: c_int = -10;
 pub const IMT_ERR_FULL: c_int = -11;
 pub const IMT_ERR_INTERNAL: c_int = -12;
+pub const IMT_ERR_TIMEOUT: c_int = -13;
 
 pub const IMT_FMT_CANONICAL: c_uint = 0;
 pub const IMT_FMT_MONT256: c_uint = 1;
@@ -139,6 +145,20 @@ pub const IMT_SEG_GLUE: u32 = 0;
 pub const IMT_SEG_HASH: u32 = 1;
 pub const IMT_SLICED_ROUNDS: usize = 4;
 pub const IMT_RCCL_UNIQUE_ID_BYTES: usize = 128;
+pub const IMT_TRANSPORT_OPT_TIMEOUT_MS: c_int = 1;
+pub const IMT_TRANSPORT_OPT_HOST_POLL: c_int = 2;
+pub const IMT_SLICED_OPT_COMM_STREAMS: c_int = 1;
+pub const IMT_SLICED_OPT_COMM_PRIORITY: c_int = 2;
+pub const IMT_SLICED_OPT_ROUND_PRIORITIES: c_int = 3;
+pub const IMT_SLICED_OPT_APPLY_STREAMS: c_int = 4;
+pub const IMT_SLICED_OPT_PREP_STREAM: c_int = 5;
+pub const IMT_SLICED_OPT_VERIFY_QUEUES: c_int = 6;
+pub const IMT_SLICED_OPT_WATCHDOG_MS: c_int = 7;
+pub const IMT_SLICED_OPT_TIMING: c_int = 8;
+pub const IMT_SLICED_PLACEMENT_UNVERIFIED: c_int = 0;
+pub const IMT_SLICED_PLACEMENT_AS_CREATED: c_int = 1;
+pub const IMT_SLICED_PLACEMENT_REPAIRED: c_int = 2;
+pub const IMT_SLICED_PLACEMENT_DEGRADED: c_int = 3;
 
 pub const IMT_CELL_CONST: u8 = 0;
 pub const IMT_CELL_INPUT: u8 = 1;
@@ -246,13 +266,17 @@ extern "C" {
     pub fn imt_transport_ipc_blob_bytes() -> usize;
     pub fn imt_transport_ipc_create(ctx: *mut imt_ctx, world: c_int, rank: c_int, depth: c_uint, max_slice: usize, lag: c_int, out: *mut *mut imt_transport, blob_out: *mut c_void) -> c_int;
     pub fn imt_transport_ipc_connect(tp: *mut imt_transport, all_blobs: *const c_void) -> c_int;
-    pub fn imt_transport_destroy(tp: *mut imt_transport);
+    pub fn imt_transport_destroy(tp: *mut imt_transport) -> c_int;
+    pub fn imt_transport_set_option(tp: *mut imt_transport, option: c_int, value: c_long) -> c_int;
+    pub fn imt_transport_all_gather(tp: *mut imt_transport, send: *const c_void, recv: *mut c_void, bytes: usize, hip_stream: *mut c_void) -> c_int;
     pub fn imt_transport_last_error(tp: *const imt_transport) -> *const c_char;
     pub fn imt_sliced_create(trees: *const *mut imt_itree, n_local: c_int, world: c_int, first_rank: c_int, tp: *mut imt_transport, max_slice: usize, lag: c_int, out: *mut *mut imt_sliced) -> c_int;
     pub fn imt_sliced_step(w: *mut imt_sliced, vals: *const c_void, n: usize, outs: *const imt_insert_out, flags: c_uint, round_out: *mut u64) -> c_int;
     pub fn imt_sliced_wait(w: *mut imt_sliced, local_rank: c_int, round: u64) -> c_int;
     pub fn imt_sliced_flush(w: *mut imt_sliced) -> c_int;
+    pub fn imt_sliced_set_option(w: *mut imt_sliced, option: c_int, value: c_long) -> c_int;
     pub fn imt_sliced_get_info(w: *const imt_sliced, out: *mut imt_sliced_info) -> c_int;
+    pub fn imt_sliced_dump(w: *mut imt_sliced, out: *mut c_char, cap: usize) -> c_int;
     pub fn imt_sliced_last_error(w: *const imt_sliced) -> *const c_char;
     pub fn imt_sliced_destroy(w: *mut imt_sliced);
     // the building blocks (a host with its own scheduler)

@@ -56,6 +56,8 @@ extern "C" {
                                      src/indexed_merkle_tree.rs:190 for such an insertion */
 #define IMT_ERR_FULL (-11)        /* indexed tree capacity exhausted */
 #define IMT_ERR_INTERNAL (-12)
+#define IMT_ERR_TIMEOUT (-13)     /* a host-side wait inside imt_sliced_* ran into the world's watchdog (a peer died or
+                                     hangs); the world's state has been written to stderr, see IMT_SLICED_OPT_WATCHDOG_MS */
 
 /* flags */
 #define IMT_FMT_CANONICAL 0u
@@ -500,7 +502,10 @@ int imt_itree_batch_abort(imt_itree *t);
  *
  * One imt_sliced drives the ranks of THIS process: one (a distributed world, one process per GPU: the production form,
  * transport = RCCL) or all of them (all replicas in one process: tests and the one-GPU rehearsal, transport = local).
- * Every rank of a world must make the same sequence of imt_sliced_step / imt_sliced_flush calls with the same values. */
+ * Every rank of a world must make the same sequence of imt_sliced_step / imt_sliced_wait / imt_sliced_flush calls, with
+ * the same values and the same `round` arguments (imt_sliced_wait included: a wait may issue what is left of its round,
+ * and the order in which the collectives of overlapping rounds are issued must be the same on every rank -- with it,
+ * no placement of the library's streams on hardware queues can make two ranks wait for each other: tests/hwq_model.py). */
 #define IMT_SLICED_ROUNDS 4
 typedef struct imt_sliced imt_sliced;
 typedef struct imt_transport imt_transport;    /* how the payloads of one tick meet: an all-gather */
@@ -541,8 +546,27 @@ size_t imt_transport_ipc_blob_bytes(void);
 int imt_transport_ipc_create(imt_ctx *ctx, int world, int rank, unsigned depth, size_t max_slice, int lag,
                              imt_transport **out, void *blob_out);
 int imt_transport_ipc_connect(imt_transport *tp, const void *all_blobs /*[world][blob_bytes]*/);
-void imt_transport_destroy(imt_transport *tp);   /* after every imt_sliced that uses it, and before the imt_ctx it was created on */
+/* after every imt_sliced that uses it (IMT_ERR_ARG and nothing destroyed while one still does), and before the imt_ctx it
+ * was created on */
+int imt_transport_destroy(imt_transport *tp);
 const char *imt_transport_last_error(const imt_transport *tp);
+/* IMT_TRANSPORT_OPT_TIMEOUT_MS: how long a wait for a peer inside the IPC transport may last (GPU-side and host-side;
+ * default 60 000, at least 10) before it gives up -- the transport's error word then turns non-zero and STAYS so: the
+ * copies, acknowledgements and applies behind the wait are skipped on the device, the next imt_sliced_step / _wait /
+ * _flush returns IMT_ERR_INTERNAL and the world refuses to go on.  IMT_TRANSPORT_OPT_HOST_POLL (before
+ * imt_transport_ipc_connect): -1 decide from the PCI bus ids (ranks that share a GPU wait on the host), 0 / 1 forced. */
+#define IMT_TRANSPORT_OPT_TIMEOUT_MS 1
+#define IMT_TRANSPORT_OPT_HOST_POLL 2
+int imt_transport_set_option(imt_transport *tp, int option, long value);
+/* One small all-gather on the transport's own channel 0, enqueued on hip_stream (NULL = the stream of the context the
+ * transport was created on): recv[r * bytes, (r + 1) * bytes) = rank r's send[0, bytes), device pointers, bytes a
+ * multiple of 16 and at most 4096.  This is the ONE collective of the subtree layout (the all-gather of the per-GPU
+ * subtree roots, 32 bytes per rank and step: examples/subtree_procs_demo.c, sharded.py), offered so that a host without a
+ * collective library of its own can use the communicators this library already has (RCCL: ncclAllGather on communicator
+ * 0; IPC: peer reads behind stream-ordered flags; custom: the vtable's all_gather with channel 0, buffer 0).  Every rank
+ * calls it the same number of times in the same order; not while an imt_sliced uses the transport.  With the IPC
+ * transport between ranks that share a GPU the call waits ON THE HOST for the peers (as that transport's fence does). */
+int imt_transport_all_gather(imt_transport *tp, const void *send, void *recv, size_t bytes, void *hip_stream);
 
 /* trees[k] = the replica of rank first_rank + k (each on its own context; empty or with the same contents on every rank;
  * not placed, not partitioned); n_local = 1, or = world with the local transport.  max_slice = the largest n of a step.
@@ -550,6 +574,23 @@ const char *imt_transport_last_error(const imt_transport *tp);
  * IMT_ERR_RANGE if (world, depth, lag) would keep more than IMT_SLICED_ROUNDS steps in flight. */
 int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first_rank, imt_transport *tp,
                       size_t max_slice, int lag, imt_sliced **out);
+/* Options.  w == NULL: the defaults that imt_sliced_create calls made LATER in this process start from (every option);
+ * w != NULL: an existing world (PREP_STREAM, WATCHDOG_MS, TIMING only -- the others decide which streams exist).
+ * IMT_ERR_RANGE for a value outside the option's range, IMT_ERR_ARG for an unknown option or one that cannot be changed
+ * any more.  (tools/ may override the defaults through environment variables of the same names, IMT_SLICED_COMM_STREAMS
+ * ...; they are read once per imt_sliced_create.) */
+#define IMT_SLICED_OPT_COMM_STREAMS 1      /* 0 .. 4 streams for the collectives (0: on the round's own stream); default 4 */
+#define IMT_SLICED_OPT_COMM_PRIORITY 2     /* their HIP stream priority; default 0 = the pool of hardware queues the rounds use */
+#define IMT_SLICED_OPT_ROUND_PRIORITIES 3  /* 0 (default): the four round streams at equal priority; 1: one normal + three high */
+#define IMT_SLICED_OPT_APPLY_STREAMS 4     /* 1: other ranks' write-backs are applied on a stream of their own per round slot; default 0 */
+#define IMT_SLICED_OPT_PREP_STREAM 5       /* a step's preparation runs on 0 (default) the new round slot's collective stream, 1 its round stream, 2 the tree's side stream */
+#define IMT_SLICED_OPT_VERIFY_QUEUES 6     /* 1 (default): imt_sliced_create measures which of its streams share a hardware queue
+                                              and re-creates streams until the placement below holds; 0: take what the runtime gives */
+#define IMT_SLICED_OPT_WATCHDOG_MS 7       /* a host wait inside imt_sliced_step / _wait / _flush gives up after this long
+                                              (default 120 000; 0 = never): IMT_ERR_TIMEOUT, the world's state on stderr and in
+                                              imt_sliced_last_error, the world refuses to go on */
+#define IMT_SLICED_OPT_TIMING 8            /* 1: host time per phase on stderr at imt_sliced_destroy */
+int imt_sliced_set_option(imt_sliced *w, int option, long value);
 /* One step: vals = ALL world x n values of the step in insertion order (device pointer, identical contents on every
  * rank; format per flags), outs[k] = where local rank k's witnesses of ITS slice (insertions [rank * n, (rank + 1) * n)
  * of the step, n rows; sibling arrays [depth][n] or item-major per flags) are written; both stay untouched by the caller
@@ -559,7 +600,19 @@ int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first
  * step's number.  flags: IMT_FMT_*, IMT_SIB_ITEM_MAJOR, IMT_INPUTS_READY. */
 int imt_sliced_step(imt_sliced *w, const void *vals /*[world * n][32]*/, size_t n, const imt_insert_out *outs /*[n_local]*/,
                     unsigned flags, uint64_t *round_out);
-/* host waits until local rank k's witnesses of `round` are complete (issues what is left of that slice first) */
+/* HOW LONG imt_sliced_step BLOCKS, and why.  The call returns when the step's values have been checked on the GPU (the
+ * preparation: sort, low-leaf search, merge into the index), because IMT_ERR_VALUE must be the call's own return value
+ * and must leave every rank's tree untouched.  The preparation is short (1.5 - 2 ms at 2^16 values per rank) but is
+ * enqueued behind the hashing already in flight, and one period of ticks (a whole step's worth of hashing per rank) is
+ * issued per call and no more -- the back-pressure that keeps the hardware queues from filling up with a backlog other
+ * streams would stand behind.  At 2^16 insertions per rank and step the calling thread is therefore inside the call for
+ * about 16 - 17 ms of every 21.6 ms step: 1.4 - 3.8 ms issuing (imt_sliced_info.host_issue_ms), the rest waiting
+ * (host_wait_ms).  A host that needs its thread runs the world from a thread of its own: the calls of one world need one
+ * caller at a time, nothing else.  (Splitting the call into issue + verdict was measured and is slower at 8 ranks:
+ * docs/LAB_NOTES.md.)
+ *
+ * host waits until local rank k's witnesses of `round` are complete (issues what is left of that ROUND first -- up to the
+ * tick at which every rank's last unit of the round has been issued: the same tick on every rank) */
 int imt_sliced_wait(imt_sliced *w, int local_rank, uint64_t round);
 /* issues everything that is left of the steps in flight and waits for it: all replicas then hold the same tree, and the
  * trees may be used through the ordinary imt_itree_* calls again (roots, proofs, non-membership witnesses: every replica
@@ -574,8 +627,27 @@ typedef struct imt_sliced_info {
                                                         launch, event and collective of the step) / waiting (for the GPU: the
                                                         values check of the step, back-pressure when the host runs ahead; for
                                                         peers: the host-polled IPC transport) */
+    /* Where the world's streams sit (local rank 0's; measured at creation, IMT_SLICED_OPT_VERIFY_QUEUES).  The HIP runtime
+     * multiplexes streams onto a few in-order hardware queues per priority level; wanted: the four round streams on four
+     * different queues, slot i's collective (and apply) stream on round stream i's queue.  queue_map[k][slot] = hardware
+     * queue class (0 .. hw_queues - 1, numbered by first use) of slot's round (k = 0), collective (1) and apply (2)
+     * stream; -1 = no such stream or not measured, -2 = a queue none of the round streams is on (another priority pool). */
+    int placement;                   /* IMT_SLICED_PLACEMENT_* */
+    int hw_queues;                   /* distinct hardware queues under the four round streams (4 wanted) */
+    int comm_streams;                /* streams carrying collectives after placement (0: the round streams do) */
+    int streams_recreated;           /* streams that had to be created again to get the placement */
+    int queue_map[3][IMT_SLICED_ROUNDS];
 } imt_sliced_info;
+#define IMT_SLICED_PLACEMENT_UNVERIFIED 0  /* not measured (option off, or unequal round priorities) */
+#define IMT_SLICED_PLACEMENT_AS_CREATED 1  /* measured: as wanted, first try */
+#define IMT_SLICED_PLACEMENT_REPAIRED 2    /* measured: as wanted after re-creating streams_recreated streams */
+#define IMT_SLICED_PLACEMENT_DEGRADED 3    /* could not be had: collectives (applies) run on the round streams and / or the
+                                              round streams share queues; imt_sliced_last_error says which */
 int imt_sliced_get_info(const imt_sliced *w, imt_sliced_info *out);
+/* Where the world stands, as text (what IMT_ERR_TIMEOUT writes to stderr): the global tick issued, per rank and round
+ * slot the first tick whose unit / apply has not completed on the device, the collectives still pending with their
+ * channel.  Writes at most cap - 1 characters + NUL; returns the length of the full text.  For a host's own watchdog. */
+int imt_sliced_dump(imt_sliced *w, char *out, size_t cap);
 const char *imt_sliced_last_error(const imt_sliced *w);
 void imt_sliced_destroy(imt_sliced *w);          /* flushes first */
 

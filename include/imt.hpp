@@ -457,6 +457,15 @@ public:
         imt_sliced_get_info(w_, &o);
         return o;
     }
+    // PREP_STREAM, WATCHDOG_MS, TIMING of this world (the others: imt_sliced_set_option(nullptr, ...) before creation)
+    void set_option(int option, long value) { check(imt_sliced_set_option(w_, option, value)); }
+    // where the world stands, as text: what IMT_ERR_TIMEOUT writes to stderr
+    std::string dump() const {
+        std::string out((size_t)imt_sliced_dump(w_, nullptr, 0) + 1, '\0');
+        imt_sliced_dump(w_, &out[0], out.size());
+        out.resize(std::strlen(out.c_str()));
+        return out;
+    }
 
 private:
     Sliced(const std::vector<imt_itree*>& trees, int world, int first_rank, imt_transport* tp, bool own, size_t max_slice, int lag)

@@ -64,7 +64,9 @@ class SlicedInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("world", "n_local", "lag", "period", "gathers_per_round", "round_ticks",
                                             "rounds_in_flight")] + \
                [("payload_bytes", ctypes.c_size_t)] + [(n, ctypes.c_uint64) for n in ("rounds", "collectives", "bytes_gathered")] + \
-               [(n, ctypes.c_double) for n in ("host_issue_ms", "host_wait_ms")]
+               [(n, ctypes.c_double) for n in ("host_issue_ms", "host_wait_ms")] + \
+               [(n, ctypes.c_int) for n in ("placement", "hw_queues", "comm_streams", "streams_recreated")] + \
+               [("queue_map", (ctypes.c_int * 4) * 3)]
 
 
 class ColumnSegment(ctypes.Structure):
@@ -172,7 +174,11 @@ SIGNATURES = {
     "imt_transport_ipc_blob_bytes": (c_size_t, []),
     "imt_transport_ipc_create": (c_int, [c_void_p, c_int, c_int, c_uint, c_size_t, c_int, P(c_void_p), c_void_p]),
     "imt_transport_ipc_connect": (c_int, [c_void_p, c_void_p]),
-    "imt_transport_destroy": (None, [c_void_p]),
+    "imt_transport_destroy": (c_int, [c_void_p]),
+    "imt_transport_set_option": (c_int, [c_void_p, c_int, ctypes.c_long]),
+    "imt_transport_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "imt_sliced_set_option": (c_int, [c_void_p, c_int, ctypes.c_long]),
+    "imt_sliced_dump": (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),
     "imt_transport_last_error": (ctypes.c_char_p, [c_void_p]),
     "imt_sliced_create": (c_int, [P(c_void_p), c_int, c_int, c_int, c_void_p, c_size_t, c_int, P(c_void_p)]),
     "imt_sliced_step": (c_int, [c_void_p, c_void_p, c_size_t, P(InsertOut), c_uint, P(c_u64)]),
@@ -198,7 +204,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 # error codes / flags of include/imt.h
 IMT_OK = 0
 ERR = dict(NO_LEAVES=-1, ODD_LEAVES=-2, NOT_POW2=-3, RANGE=-4, NONCANONICAL=-5, ALLOC=-6, NO_DEVICE=-7, HIP=-8,
-           ARG=-9, VALUE=-10, FULL=-11, INTERNAL=-12)
+           ARG=-9, VALUE=-10, FULL=-11, INTERNAL=-12, TIMEOUT=-13)
 FMT_CANONICAL, FMT_MONT256, FMT_DEVICE = 0, 1, 2
 DEVICE_PTRS, SIB_ITEM_MAJOR, ROOT_PER_ITEM, PIPELINE, HOST_PREP, INPUTS_READY = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 F_RANGE_PRED, F_LOW_IN_ROOT, F_LOW_LT_NEW, F_ZERO_SLOT, F_NEXT_VAL, F_NEXT_IDX, F_NEW_ROOT, F_BAD_BIT = (
@@ -208,4 +214,8 @@ TRACE_ITEM_MAJOR = SIB_ITEM_MAJOR
 OPT_COOP_MAX_EVENTS = 1
 SEG_GLUE, SEG_HASH = 0, 1
 SLICED_ROUNDS = 4
+(SLICED_OPT_COMM_STREAMS, SLICED_OPT_COMM_PRIORITY, SLICED_OPT_ROUND_PRIORITIES, SLICED_OPT_APPLY_STREAMS, SLICED_OPT_PREP_STREAM,
+ SLICED_OPT_VERIFY_QUEUES, SLICED_OPT_WATCHDOG_MS, SLICED_OPT_TIMING) = range(1, 9)
+TRANSPORT_OPT_TIMEOUT_MS, TRANSPORT_OPT_HOST_POLL = 1, 2
+PLACEMENT = {0: "unverified", 1: "as created", 2: "repaired", 3: "degraded"}
 RCCL_UNIQUE_ID_BYTES = 128

@@ -17,7 +17,14 @@ struct FlagWait {
 void flag_set(hipStream_t s, uint64_t* flag, uint64_t value);
 void flag_wait(hipStream_t s, const FlagWait& w);
 // bytes: a multiple of 16; both pointers 16-byte aligned device-visible memory (a peer's IPC-mapped buffer included)
-void copy16(hipStream_t s, void* dst, const void* src, size_t bytes);
+// poison (may be null): a device-visible word; the copy / the store is skipped when it is non-zero (the sticky error word
+// of a transport whose wait has given up -- imt_flags.hip)
+void copy16(hipStream_t s, void* dst, const void* src, size_t bytes, const uint32_t* poison = nullptr);
+void flag_set_checked(hipStream_t s, uint64_t* flag, uint64_t value, const uint32_t* poison);
+// the hardware-queue probe: hold stream s for `ticks` of the 100 MHz wall clock and write the end time / write the time
+// the kernel ran (one wave each)
+void spin(hipStream_t s, uint64_t ticks, uint64_t* end_stamp);
+void stamp(hipStream_t s, uint64_t* out);
 
 }  // namespace launch
 }  // namespace imt

@@ -19,6 +19,7 @@
 #include <initializer_list>
 #include <new>
 #include <numeric>
+#include <thread>
 
 using namespace imt;
 
@@ -165,6 +166,8 @@ struct imt_itree {
     size_t canon_all_cap = 0;
     uint32_t* d_sorted_extra = nullptr;      // third index buffer: a step's up to three merges never write the committed one
     hipStream_t slice_prep_stream = nullptr; // where the next imt_itree_slice_prepare runs (nullptr: the side stream)
+    const uint32_t* slice_poison = nullptr;  // device-visible word of the world's transport: non-zero = skip applies
+    double slice_wait_limit_ms = 0;          // > 0: host waits inside imt_itree_slice_prepare give up after this long
     double slice_wait_ms = 0;                // host time spent waiting for the GPU inside imt_itree_slice_prepare
     bool sliced_busy = false;                // an imt_sliced world has steps in flight on this replica (until its flush)
     size_t reserved_events = 0;              // every plan set holds at least this many events (reserve_all_plans)
@@ -458,6 +461,12 @@ imt_ctx* imt_itree_ctx(const imt_itree* t) { return t ? t->ctx : nullptr; }
 unsigned imt_itree_depth(const imt_itree* t) { return t ? t->depth : 0; }
 void imt_itree_mark_sliced(imt_itree* t, bool busy) {
     if (t) t->sliced_busy = busy;
+}
+void imt_itree_set_slice_poison(imt_itree* t, const uint32_t* device_word) {
+    if (t) t->slice_poison = device_word;
+}
+void imt_itree_set_slice_wait_limit(imt_itree* t, double ms) {
+    if (t) t->slice_wait_limit_ms = ms;
 }
 void imt_itree_set_slice_prep_stream(imt_itree* t, void* hip_stream) {
     if (t) t->slice_prep_stream = (hipStream_t)hip_stream;
@@ -1690,6 +1699,27 @@ extern "C" size_t imt_itree_slice_unit_bytes(const imt_itree* t, uint64_t size_b
     return slice_unit_bytes(size_before, n, unit, t->depth);
 }
 
+// A host wait with a time limit (limit_ms <= 0: wait as long as it takes): the sliced mode's waits stand behind work
+// that stands behind collectives, i.e. behind other ranks -- a peer that died would otherwise hang the caller for good.
+// IMT_ERR_TIMEOUT leaves the stream as it is (still busy); the caller gives the world up.
+template <class Query, class Sync>
+static int bounded_wait(imt_ctx* c, double limit_ms, Query query, Sync sync, const char* what) {
+    if (limit_ms <= 0) {
+        const hipError_t e = sync();
+        return e == hipSuccess ? IMT_OK : c->hip_fail(e, what);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = query();
+        if (e == hipSuccess) return IMT_OK;
+        if (e != hipErrorNotReady) return c->hip_fail(e, what);
+        if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));     // ~0.1 ms of pure polling first
+        if ((spins & 63) == 63 &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit_ms)
+            return c->fail(IMT_ERR_TIMEOUT, "gave up after %.0f ms waiting for %s", limit_ms, what);
+    }
+}
+
 extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_before, size_t n_own, size_t n_after,
                                        const imt_insert_out* out, unsigned flags, int* slice_out, uint32_t* l0_out) {
     if (!t) return IMT_ERR_ARG;
@@ -1713,8 +1743,10 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
     if (P.open) return c->fail(IMT_ERR_ARG, "too many slices prepared ahead (%d plan sets)", imt_itree::NSETS);
     if (P.in_flight) {
         const auto w0 = std::chrono::steady_clock::now();
-        IMT_HIP(c, hipEventSynchronize(P.done));
+        rc = bounded_wait(c, t->slice_wait_limit_ms, [&] { return hipEventQuery(P.done); }, [&] { return hipEventSynchronize(P.done); },
+                          "the plan set's previous slice");
         t->slice_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        if (rc) return rc;
         P.in_flight = false;
     }
     if ((rc = plan_reserve(c, P, 2 * n_own, t->depth, t->cap))) return rc;
@@ -1805,8 +1837,10 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
     IMT_HIP(c, hipEventRecord(P.prep_done, ps));
     {
         const auto w0 = std::chrono::steady_clock::now();
-        IMT_HIP(c, hipStreamSynchronize(ps));
+        rc = bounded_wait(c, t->slice_wait_limit_ms, [&] { return hipStreamQuery(ps); }, [&] { return hipStreamSynchronize(ps); },
+                          "the step's preparation (its value check)");
         t->slice_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        if (rc) return rc;
     }
     const int perr = *t->h_err_pin;      // the same verdict on every GPU: they all see all values of the step
     if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
@@ -1948,6 +1982,7 @@ extern "C" int imt_itree_slice_apply_gathered(imt_itree* t, const void* gathered
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const unsigned depth = t->depth;
     launch::ApplyJobs jobs{};
+    jobs.poison = t->slice_poison;
     for (size_t r = 0; r < count; r++) {
         if (unit[r] < 0) continue;
         if ((unsigned)unit[r] > depth) return c->fail(IMT_ERR_RANGE, "unit %d beyond depth %u", unit[r], depth);

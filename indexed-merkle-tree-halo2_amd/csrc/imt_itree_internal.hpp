@@ -12,3 +12,8 @@ double imt_itree_take_wait_ms(imt_itree* t);
 void imt_itree_mark_sliced(imt_itree* t, bool busy);
 // the stream the NEXT imt_itree_slice_prepare calls enqueue their work on (NULL: the tree's side stream, the default)
 void imt_itree_set_slice_prep_stream(imt_itree* t, void* hip_stream);
+// the sticky error word of the world's transport (device-visible, may be NULL): applies of gathered payloads are skipped
+// once it is non-zero (a GPU-side wait for a peer gave up: the payloads are not there)
+void imt_itree_set_slice_poison(imt_itree* t, const uint32_t* device_word);
+// > 0: the host waits inside imt_itree_slice_prepare return IMT_ERR_TIMEOUT after this many milliseconds
+void imt_itree_set_slice_wait_limit(imt_itree* t, double ms);

@@ -1134,6 +1134,7 @@ k_apply_packed(const uint8_t* __restrict__ vals, const uint32_t* __restrict__ no
 // (node, value) pairs for one stored level; at and above l0 it is the one or two nodes the level's launch stored
 // (node at l0, node above) and, when the tree is full to its depth, the root
 __global__ void __launch_bounds__(BLOCK) k_apply_gathered(launch::ApplyJobs a) {
+    if (a.poison && __hip_atomic_load(a.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
     const launch::ApplyJobs::Job j = a.j[blockIdx.y];
     const size_t i = gtid();
     if (j.pairs) {

@@ -224,6 +224,8 @@ struct ApplyJobs {
         uint8_t *node_in, *node_out, *root;     // header targets (any may be NULL)
     } j[16];
     int n_jobs;
+    const uint32_t* poison;              // device-visible word (may be NULL): non-zero = a transport gave up waiting for a
+                                         // payload of this gather, nothing is applied (imt_flags.hip)
 };
 void apply_gathered(hipStream_t s, const ApplyJobs& a);
 void store_top_path(hipStream_t s, const uint8_t* top_path, uint8_t* tree_nodes, const uint64_t* tree_off, unsigned l0,

@@ -21,6 +21,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <vector>
 #include "imt_flags.hpp"
 #include "imt_itree_internal.hpp"
 #include "imt_sliced_sched.hpp"
@@ -30,56 +31,354 @@ using namespace imt::sliced;
 
 namespace {
 
+// ------------------------------------------------------------------------------------------------------- options
+// imt_sliced_set_option (include/imt.h).  The defaults are what the measurements of rounds 4 and 5 chose; the environment
+// variables of the same names (IMT_SLICED_COMM_STREAMS, ...) are read ONCE per imt_sliced_create and override them -- they
+// exist for tools/ (stream matrices, the rank emulation), not as an interface.
+struct SlicedOptions {
+    long comm_streams = ROUNDS;      // streams that carry the collectives (0 = the round's own stream)
+    long comm_priority = 0;          // their HIP priority (0 = the rounds' pool of hardware queues)
+    long round_priorities = 0;       // 0 equal, 1 = the batch pipeline's one normal + three high
+    long apply_streams = 0;          // 1 = the other ranks' write-backs are applied on a stream of their own per round slot
+    long prep_stream = 0;            // where a step's preparation is enqueued: 0 the slot's collective stream, 1 its round stream, 2 the tree's side stream
+    long verify_queues = 1;          // probe the stream -> hardware queue placement at creation and repair it
+    long watchdog_ms = 120000;       // host waits inside imt_sliced_* give up after this long (0 = never)
+    long timing = 0;                 // print the host's time per phase at destroy
+};
+SlicedOptions g_defaults;
+std::mutex g_defaults_mu;
+
+int option_field(SlicedOptions& o, int option, long** field) {
+    switch (option) {
+        case IMT_SLICED_OPT_COMM_STREAMS: *field = &o.comm_streams; return IMT_OK;
+        case IMT_SLICED_OPT_COMM_PRIORITY: *field = &o.comm_priority; return IMT_OK;
+        case IMT_SLICED_OPT_ROUND_PRIORITIES: *field = &o.round_priorities; return IMT_OK;
+        case IMT_SLICED_OPT_APPLY_STREAMS: *field = &o.apply_streams; return IMT_OK;
+        case IMT_SLICED_OPT_PREP_STREAM: *field = &o.prep_stream; return IMT_OK;
+        case IMT_SLICED_OPT_VERIFY_QUEUES: *field = &o.verify_queues; return IMT_OK;
+        case IMT_SLICED_OPT_WATCHDOG_MS: *field = &o.watchdog_ms; return IMT_OK;
+        case IMT_SLICED_OPT_TIMING: *field = &o.timing; return IMT_OK;
+    }
+    return IMT_ERR_ARG;
+}
+bool option_value_ok(int option, long v) {
+    switch (option) {
+        case IMT_SLICED_OPT_COMM_STREAMS: return v >= 0 && v <= ROUNDS;
+        case IMT_SLICED_OPT_COMM_PRIORITY: return v >= -8 && v <= 8;
+        case IMT_SLICED_OPT_PREP_STREAM: return v >= 0 && v <= 2;
+        case IMT_SLICED_OPT_WATCHDOG_MS: return v >= 0;
+        default: return v == 0 || v == 1;
+    }
+}
+SlicedOptions effective_options() {
+    SlicedOptions o;
+    {
+        std::lock_guard<std::mutex> lk(g_defaults_mu);
+        o = g_defaults;
+    }
+    auto env = [](const char* name, int option, SlicedOptions& oo) {
+        const char* e = getenv(name);
+        if (!e || !*e) return;
+        long v = atol(e);
+        if (option == IMT_SLICED_OPT_PREP_STREAM) v = !strcmp(e, "side") ? 2 : !strcmp(e, "round") ? 1 : !strcmp(e, "comm") ? 0 : v;
+        if (option == IMT_SLICED_OPT_ROUND_PRIORITIES) v = !strcmp(e, "pipe") ? 1 : v;
+        long* f = nullptr;
+        if (option_value_ok(option, v) && option_field(oo, option, &f) == IMT_OK) *f = v;
+    };
+    env("IMT_SLICED_COMM_STREAMS", IMT_SLICED_OPT_COMM_STREAMS, o);
+    env("IMT_SLICED_COMM_PRIO", IMT_SLICED_OPT_COMM_PRIORITY, o);
+    env("IMT_SLICED_ROUND_PRIO", IMT_SLICED_OPT_ROUND_PRIORITIES, o);
+    env("IMT_SLICED_APPLY_STREAMS", IMT_SLICED_OPT_APPLY_STREAMS, o);
+    env("IMT_SLICED_PREP_STREAM", IMT_SLICED_OPT_PREP_STREAM, o);
+    env("IMT_SLICED_VERIFY_QUEUES", IMT_SLICED_OPT_VERIFY_QUEUES, o);
+    env("IMT_SLICED_WATCHDOG_MS", IMT_SLICED_OPT_WATCHDOG_MS, o);
+    env("IMT_SLICED_TIMING", IMT_SLICED_OPT_TIMING, o);
+    return o;
+}
+
+// a host wait with a time limit: poll `query` (hipSuccess / hipErrorNotReady) until it is done or limit_ms have passed
+template <class Query>
+int bounded_wait(imt_ctx* ctx, long limit_ms, Query query, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = query();
+        if (e == hipSuccess) return IMT_OK;
+        if (e != hipErrorNotReady) return ctx->hip_fail(e, what);
+        if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (limit_ms > 0 && (spins & 63) == 63 &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double)limit_ms)
+            return ctx->fail(IMT_ERR_TIMEOUT, "gave up after %ld ms waiting for %s (IMT_SLICED_OPT_WATCHDOG_MS)", limit_ms, what);
+    }
+}
+
+// ------------------------------------------------------------------------- which streams share a hardware queue
+// The HIP runtime multiplexes streams onto a few in-order hardware queues per priority level (four by default: measured
+// with tools/microbench/queue_map_probe.hip -- a new stream goes to the queue with the fewest streams of its priority,
+// ties in a fixed order; high and low priority have four queues of their own each).  A queue runs what it holds in
+// submission order, one packet after the other, and an event wait blocks the whole queue: a stream that shares a queue
+// with a busy one stands behind that stream's backlog.  Where the sliced mode's streams land therefore decides how much
+// of the schedule's overlap is real (tests/hwq_model.py is the CPU model of exactly this).  The probe: hold
+// one stream with a one-wave kernel that spins for 200 us of the GPU's wall clock and notes when it ended, stamp the
+// time on every other stream; a stamp not earlier than the end was taken behind the spin -- same queue.  GPU clock
+// only; the streams are idle when it runs (creation time).
+struct QueueProbe {
+    imt_ctx* ctx = nullptr;
+    uint64_t* d = nullptr;
+    static constexpr int MAXS = 16;
+    uint64_t spin_ticks = 20000;
+    int probes = 0;
+
+    int init(imt_ctx* c) {
+        ctx = c;
+        int khz = 100000;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+        spin_ticks = (uint64_t)khz / 5;      // 200 us
+        IMT_HIP(c, hipMalloc((void**)&d, sizeof(uint64_t) * (MAXS + 1)));
+        // both kernels once, so that no first-launch cost (code object load) sits inside a measurement
+        imt::launch::spin(c->stream, 1, d + MAXS);
+        imt::launch::stamp(c->stream, d);
+        IMT_HIP(c, hipStreamSynchronize(c->stream));
+        return IMT_OK;
+    }
+    ~QueueProbe() {
+        if (d) hipFree(d);
+    }
+    // behind[j] = 1: others[j] shares a hardware queue with `busy`
+    int run(hipStream_t busy, const hipStream_t* others, int n, char* behind) {
+        if (n > MAXS) return ctx->fail(IMT_ERR_INTERNAL, "queue probe: too many streams");
+        uint64_t h[MAXS + 1];
+        IMT_HIP(ctx, hipStreamSynchronize(busy));
+        for (int j = 0; j < n; j++) IMT_HIP(ctx, hipStreamSynchronize(others[j]));
+        IMT_HIP(ctx, hipMemsetAsync(d, 0, sizeof(uint64_t) * (MAXS + 1), ctx->stream));
+        IMT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        imt::launch::spin(busy, spin_ticks, d + MAXS);
+        for (int j = 0; j < n; j++) imt::launch::stamp(others[j], d + j);
+        IMT_HIP(ctx, hipGetLastError());
+        IMT_HIP(ctx, hipStreamSynchronize(busy));
+        for (int j = 0; j < n; j++) IMT_HIP(ctx, hipStreamSynchronize(others[j]));
+        IMT_HIP(ctx, hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+        for (int j = 0; j < n; j++) behind[j] = h[j] >= h[MAXS];
+        probes++;
+        return IMT_OK;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------- one replica over HIP
 struct HipBackend : Backend {
     imt_itree* tree;
     imt_ctx* ctx;
     hipStream_t rs[ROUNDS] = {}, cs[ROUNDS] = {}, aps[ROUNDS] = {};     // round, collective and apply streams
     int n_comm = ROUNDS;
+    SlicedOptions opt;
+    // what the probe found (imt_sliced_info): hardware queue class of every stream, -1 = no such stream / not probed
+    int q_round[ROUNDS], q_comm[ROUNDS], q_apply[ROUNDS];
+    int n_queues = 0, placement = IMT_SLICED_PLACEMENT_UNVERIFIED, streams_recreated = 0;
+    std::string placement_note;
 
-    explicit HipBackend(imt_itree* t) : tree(t), ctx(imt_itree_ctx(t)) {}
-    int init() {
+    explicit HipBackend(imt_itree* t) : tree(t), ctx(imt_itree_ctx(t)) {
+        for (int i = 0; i < ROUNDS; i++) q_round[i] = q_comm[i] = q_apply[i] = -1;
+    }
+    int new_stream(hipStream_t* out, int prio) {
+        IMT_HIP(ctx, hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio));
+        return IMT_OK;
+    }
+    void adopt(hipStream_t s) { ctx->side_streams.push_back(s); }
+    // channels: how many independent channels the transport has (0 = one per round slot)
+    int init(const SlicedOptions& o, int channels) {
+        opt = o;
         int rc = ctx->set_device();
         if (rc) return rc;
         // Measured on one MI355X with in-process replicas (profiles/r04_sliced_stream_matrix.txt): the four round streams
         // at EQUAL priority (2.93-2.95 M insertions/s at world 1, 2.86 at world 2) beat the batch pipeline's scheme of one
         // normal + three high (2.49-2.64 / 2.64-2.83) -- rounds are whole slices apart here, not one level, and a
-        // high-priority round starves the others; where the collectives are enqueued (the round's own stream, one or four
-        // extra streams, normal or high priority) moves the rate by < 2 % with equal round priorities.  Default: four
-        // normal-priority streams for the collectives, so that a gather never sits in front of a hash kernel.
-        // Knobs: IMT_SLICED_COMM_STREAMS (0 = enqueue a round's gathers on the round's own stream), IMT_SLICED_COMM_PRIO,
-        // IMT_SLICED_ROUND_PRIO=pipe.
-        if (const char* e = getenv("IMT_SLICED_COMM_STREAMS")) n_comm = std::max(0, std::min(ROUNDS, atoi(e)));
+        // high-priority round starves the others.  The collectives go to four normal-priority streams of their own, each
+        // on the hardware queue of ITS round's stream (place() below): a gather then stands behind the unit that packed it
+        // (where it has to stand anyway) and in front of nothing but its own round's next unit; on another round's queue
+        // it would stand in front of that round's hash kernels (-5 ... -18 %), and in the low-priority pool (four more
+        // hardware queues, profiles/r05_emu_comm_prio.txt) the rate is 2-4 % lower as well.
+        n_comm = (int)o.comm_streams;
+        // Round slots that share a channel of the transport (an RCCL communicator) must enqueue on ONE stream, or the
+        // communicator would see its collectives in an order the GPU decides
+        if (channels > 0 && channels < ROUNDS) n_comm = channels;
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-        const char* rp = getenv("IMT_SLICED_ROUND_PRIO");
-        const bool equal = !(rp && !strcmp(rp, "pipe"));
-        int comm_prio = std::max(greatest, std::min(least, 0));
-        if (const char* e = getenv("IMT_SLICED_COMM_PRIO")) comm_prio = std::max(greatest, std::min(least, atoi(e)));
-        for (int i = 0; i < ROUNDS; i++) {
-            // different priorities for the round streams, like the batch pipeline's: the runtime may otherwise map them to
-            // one hardware queue, which serialises them
-            const int prio = equal ? 0 : std::max(greatest, std::min(least, 0 - i));
-            IMT_HIP(ctx, hipStreamCreateWithPriority(&rs[i], hipStreamNonBlocking, prio));
-            ctx->side_streams.push_back(rs[i]);
+        const bool equal = o.round_priorities == 0;
+        const int comm_prio = std::max(greatest, std::min(least, (int)o.comm_priority));
+        for (int i = 0; i < ROUNDS; i++)
+            if ((rc = new_stream(&rs[i], equal ? 0 : std::max(greatest, std::min(least, 0 - i))))) return rc;
+        for (int i = 0; i < n_comm; i++)
+            if ((rc = new_stream(&cs[i], comm_prio))) return rc;
+        // The schedule (imt_sliced_sched.hpp) lets the other ranks' write-backs be applied on a stream of their own per
+        // round slot; here they stay on the round's stream unless asked for (four more streams on the four hardware
+        // queues cost 2-4 %: tools/rank_emulation.py, profiles/r04_rank_emulation.txt).
+        if (o.apply_streams)
+            for (int i = 0; i < ROUNDS; i++)
+                if ((rc = new_stream(&aps[i], 0))) return rc;
+        if (o.verify_queues && equal) {
+            if ((rc = place(comm_prio))) return rc;
+        } else {
+            placement_note = o.verify_queues ? "not verified: unequal round priorities put the round streams into different pools"
+                                             : "not verified (IMT_SLICED_OPT_VERIFY_QUEUES = 0)";
         }
-        for (int i = 0; i < n_comm; i++) {
-            IMT_HIP(ctx, hipStreamCreateWithPriority(&cs[i], hipStreamNonBlocking, comm_prio));
-            ctx->side_streams.push_back(cs[i]);
-        }
-        // The schedule (imt_sliced_sched.hpp) lets the other ranks' write-backs be applied on a stream of their own per round
-        // slot; here they stay on the round's stream unless IMT_SLICED_APPLY_STREAMS=1.  Measured with one rank of an
-        // 8-rank run alone on the GPU (tools/rank_emulation.py, profiles/r04_rank_emulation.txt): what moved the rate was
-        // the PRECISE cross-round waits (round R + 1's unit q behind round R's apply of tick q + world * lag and its own
-        // unit q + 1, instead of behind round R's whole tick q + world * lag, which made two rounds march in lockstep):
-        // 2.66 -> 2.85 M insertions/s per rank.  Four more streams on the runtime's four hardware queues cost some of it
-        // back (2.77 / 2.67 first / last rank), helper streams placed on other rounds' queues or at high priority more.
-        const char* ae = getenv("IMT_SLICED_APPLY_STREAMS");
-        if (ae && atoi(ae) != 0)
+        for (hipStream_t* arr : {rs, cs, aps})
+            for (int i = 0; i < ROUNDS; i++)
+                if (arr[i]) adopt(arr[i]);
+        imt_itree_set_slice_wait_limit(tree, (double)o.watchdog_ms);
+        return IMT_OK;
+    }
+
+    // Verify where the streams landed and repair what can be repaired by creating streams again:
+    //   (1) the four round streams on four DIFFERENT hardware queues (two rounds on one queue take turns);
+    //   (2) a helper stream of slot i (collectives, applies) on the queue of round stream i when it lives in the rounds'
+    //       pool, on none of the rounds' queues when its priority puts it into another pool.
+    // The runtime gives a new stream the queue with the fewest streams of its priority, so whether (1) and (2) hold depends
+    // on how many streams the host (torch, RCCL, the application) created before: nothing this library controls.  Spare
+    // streams are created until a wanted place comes up (a stream that lands elsewhere is kept until the end so that the
+    // next one lands on another queue) and destroyed afterwards.  What cannot be had is reported (imt_sliced_info.placement,
+    // imt_sliced_last_error) and degrades to the collectives on the rounds' own streams.
+    int place(int comm_prio) {
+        QueueProbe pr;
+        int rc = pr.init(ctx);
+        if (rc) return rc;
+        std::vector<hipStream_t> spare;
+        auto drop_spares = [&] {
+            for (hipStream_t s : spare) hipStreamDestroy(s);
+            spare.clear();
+        };
+        char behind[QueueProbe::MAXS];
+        // ---- (1) classes of the round streams
+        int cls[ROUNDS];
+        auto classify_rounds = [&]() -> int {
+            for (int i = 0; i < ROUNDS; i++) cls[i] = -1;
+            int next = 0;
             for (int i = 0; i < ROUNDS; i++) {
-                IMT_HIP(ctx, hipStreamCreateWithPriority(&aps[i], hipStreamNonBlocking, 0));
-                ctx->side_streams.push_back(aps[i]);
+                if (cls[i] >= 0) continue;
+                cls[i] = next++;
+                if (i + 1 == ROUNDS) break;
+                int r = pr.run(rs[i], rs + i + 1, ROUNDS - i - 1, behind);
+                if (r) return r;
+                for (int j = i + 1; j < ROUNDS; j++)
+                    if (behind[j - i - 1] && cls[j] < 0) cls[j] = cls[i];
             }
+            n_queues = next;
+            return IMT_OK;
+        };
+        if ((rc = classify_rounds())) return rc;
+        for (int attempt = 0; n_queues < ROUNDS && attempt < 2 * ROUNDS; attempt++) {
+            // a round stream that shares its queue with an earlier one: create another stream and see where it lands
+            int dup = -1;
+            for (int i = 1; i < ROUNDS && dup < 0; i++)
+                for (int j = 0; j < i; j++)
+                    if (cls[i] == cls[j]) dup = i;
+            hipStream_t x;
+            if ((rc = new_stream(&x, 0))) return rc;
+            if ((rc = pr.run(x, rs, ROUNDS, behind))) return rc;
+            bool shares = false;
+            for (int j = 0; j < ROUNDS; j++) shares = shares || (behind[j] && j != dup);
+            if (!shares) {          // a queue no other round stream is on
+                spare.push_back(rs[dup]);
+                rs[dup] = x;
+                streams_recreated++;
+                if ((rc = classify_rounds())) return rc;
+            } else {
+                spare.push_back(x);
+            }
+        }
+        for (int i = 0; i < ROUNDS; i++) q_round[i] = cls[i];
+        // ---- (2) the helper streams
+        const bool same_pool = comm_prio == 0;
+        bool ok = n_queues == ROUNDS;
+        auto partner = [&](hipStream_t s, int* out) -> int {       // which round stream's queue s is on (-1: none of them)
+            int r = pr.run(s, rs, ROUNDS, behind);
+            if (r) return r;
+            *out = -1;
+            for (int j = 0; j < ROUNDS; j++)
+                if (behind[j]) { *out = j; break; }
+            return IMT_OK;
+        };
+        auto settle = [&](hipStream_t* arr, int count, int prio, bool want_partner, int* qmap) -> int {
+            // want_partner: arr[i] on round stream i's queue; else: on no round stream's queue
+            std::vector<hipStream_t> pool(arr, arr + count);
+            std::vector<hipStream_t> placed(count, nullptr);
+            int created = 0;
+            while (true) {
+                bool full = true;
+                for (int i = 0; i < count; i++) full = full && placed[i];
+                if (full) break;
+                hipStream_t s;
+                if (!pool.empty()) {
+                    s = pool.back();
+                    pool.pop_back();
+                } else {
+                    if (created >= 3 * ROUNDS) break;
+                    int r = new_stream(&s, prio);
+                    if (r) return r;
+                    created++;
+                }
+                int p = -1;
+                int r = partner(s, &p);
+                if (r) return r;
+                int slot = -1;
+                if (want_partner) {
+                    // with fewer than four queues under the rounds, the partner is the first round stream of the class
+                    for (int i = 0; i < count && slot < 0; i++)
+                        if (!placed[i] && p >= 0 && cls[i] == cls[p]) slot = i;
+                } else if (p < 0) {
+                    for (int i = 0; i < count && slot < 0; i++)
+                        if (!placed[i]) slot = i;
+                }
+                if (slot >= 0) placed[slot] = s;
+                else spare.push_back(s);
+            }
+            bool all = true;
+            for (int i = 0; i < count; i++) all = all && placed[i];
+            if (!all) {
+                for (int i = 0; i < count; i++)
+                    if (placed[i]) spare.push_back(placed[i]);
+                for (int i = 0; i < count; i++) arr[i] = nullptr;
+                return 1;           // could not be had
+            }
+            for (int i = 0; i < count; i++) {
+                if (placed[i] != arr[i]) streams_recreated++;
+                arr[i] = placed[i];
+                qmap[i] = want_partner ? cls[i] : -2;
+            }
+            return IMT_OK;
+        };
+        if (n_comm == ROUNDS) {
+            rc = settle(cs, ROUNDS, comm_prio, same_pool, q_comm);
+            if (rc < 0) return rc;
+            if (rc == 1) {
+                // the collectives go to the rounds' own streams: the same queue order, no second stream to misplace
+                n_comm = 0;
+                ok = false;
+                placement_note = "the collectives' streams could not be placed on their rounds' hardware queues: collectives are enqueued on the round streams";
+            }
+        } else if (n_comm > 0) {
+            // fewer streams than round slots (a transport with fewer channels): every stream serves several slots, there is
+            // no place that suits all of them; report where they are
+            for (int i = 0; i < n_comm; i++) {
+                int p = -1;
+                if ((rc = partner(cs[i], &p))) return rc;
+                q_comm[i] = p >= 0 ? cls[p] : -2;
+            }
+        }
+        if (aps[0]) {
+            rc = settle(aps, ROUNDS, 0, true, q_apply);
+            if (rc < 0) return rc;
+            if (rc == 1) {
+                ok = false;
+                placement_note += (placement_note.empty() ? "" : "; ");
+                placement_note += "the apply streams could not be placed: applies run on the round streams";
+            }
+        }
+        drop_spares();
+        if (n_queues < ROUNDS) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "%sthe %d round streams share %d hardware queues (GPU_MAX_HW_QUEUES?)", placement_note.empty() ? "" : "; ", ROUNDS, n_queues);
+            placement_note += buf;
+        }
+        placement = ok ? (streams_recreated ? IMT_SLICED_PLACEMENT_REPAIRED : IMT_SLICED_PLACEMENT_AS_CREATED) : IMT_SLICED_PLACEMENT_DEGRADED;
         return IMT_OK;
     }
     ~HipBackend() override {
@@ -92,6 +391,8 @@ struct HipBackend : Backend {
                     ss.erase(std::remove(ss.begin(), ss.end(), arr[i]), ss.end());
                     hipStreamDestroy(arr[i]);
                 }
+        imt_itree_set_slice_poison(tree, nullptr);
+        imt_itree_set_slice_wait_limit(tree, 0);
     }
     Stream round_stream(int slot) override { return rs[slot]; }
     Stream comm_stream(int slot) override { return n_comm ? cs[slot % n_comm] : rs[slot]; }
@@ -112,8 +413,15 @@ struct HipBackend : Backend {
         return IMT_OK;
     }
     int event_sync(Event e) override {
-        IMT_HIP(ctx, hipEventSynchronize((hipEvent_t)e));
-        return IMT_OK;
+        if (opt.watchdog_ms <= 0) {
+            IMT_HIP(ctx, hipEventSynchronize((hipEvent_t)e));
+            return IMT_OK;
+        }
+        return bounded_wait(ctx, opt.watchdog_ms, [&] { return hipEventQuery((hipEvent_t)e); }, "a round's last unit");
+    }
+    int event_query(Event e) override {
+        const hipError_t r = hipEventQuery((hipEvent_t)e);
+        return r == hipSuccess ? 1 : r == hipErrorNotReady ? 0 : -1;
     }
     int alloc(size_t bytes, Buffer* out) override {
         void* p = nullptr;
@@ -139,11 +447,10 @@ struct HipBackend : Backend {
         // preparation is also not in front of the round's own first units in stream order.  One rank of N = 2 / 4 / 8
         // alone on the GPU (tools/rank_emulation.py, first rank, modelled links): side stream 2.93 / 2.89 / 2.81, the round's
         // stream 3.02 / 2.99 / 2.77, the slot's collective stream 3.03 / 2.97 / 2.80 M insertions/s.
-        // IMT_SLICED_PREP_STREAM = comm (default) / round / side.
-        static const char* where = getenv("IMT_SLICED_PREP_STREAM");
+        // IMT_SLICED_OPT_PREP_STREAM: 0 the slot's collective stream (default), 1 its round stream, 2 the side stream.
         void* st = n_comm ? (void*)cs[slot % n_comm] : (void*)rs[slot];
-        if (where && !strcmp(where, "side")) st = nullptr;
-        if (where && !strcmp(where, "round")) st = rs[slot];
+        if (opt.prep_stream == 2) st = nullptr;
+        if (opt.prep_stream == 1) st = rs[slot];
         imt_itree_set_slice_prep_stream(tree, st);
         const int rc = imt_itree_slice_prepare(tree, vals, nb, no, na, out, flags | IMT_DEVICE_PTRS, slice, nullptr);
         imt_itree_set_slice_prep_stream(tree, nullptr);
@@ -159,7 +466,10 @@ struct HipBackend : Backend {
         if (rc) return rc;
         for (hipStream_t* arr : {rs, cs, aps})
             for (int i = 0; i < ROUNDS; i++)
-                if (arr[i]) IMT_HIP(ctx, hipStreamSynchronize(arr[i]));
+                if (arr[i]) {
+                    if (opt.watchdog_ms <= 0) IMT_HIP(ctx, hipStreamSynchronize(arr[i]));
+                    else if ((rc = bounded_wait(ctx, opt.watchdog_ms, [&] { return hipStreamQuery(arr[i]); }, "the world's streams to drain"))) return rc;
+                }
         return imt_ctx_sync(ctx);
     }
 };
@@ -174,6 +484,9 @@ struct CustomTransport : Transport {
     int all_gather(Rank& rk, int slot, int r, size_t bytes, Stream st) override {
         const int i = rk.at(slot, r);
         return ops.all_gather(ops.self, slot, r, rk.send[i], rk.recv[i], bytes, st);
+    }
+    int small_gather(const void* send, void* recv, size_t bytes, Stream st) override {
+        return ops.all_gather(ops.self, 0, 0, send, recv, bytes, st);
     }
 };
 
@@ -191,6 +504,9 @@ struct CustomTransport : Transport {
 // IMT_IPC_TIMEOUT_S (default 60) and sets an error bit, reported by the next imt_sliced_wait / _flush.
 constexpr int IPC_RING_MAX = 12;
 constexpr int IPC_NEV = ROUNDS * IPC_RING_MAX;
+// imt_transport_all_gather over IPC: a ring of small staging slots behind the send buffers, with counters of their own
+constexpr int IPC_AUX_RING = 4;
+constexpr size_t IPC_AUX_BYTES = 4096;
 
 struct IpcBlob {
     hipIpcMemHandle_t mem;
@@ -201,6 +517,7 @@ struct IpcBlob {
 };
 struct IpcShm {
     uint64_t packed[IPC_NEV], copied[IPC_NEV];
+    uint64_t aux_packed[IPC_AUX_RING], aux_copied[IPC_AUX_RING];
     uint32_t err;
 };
 constexpr size_t IPC_SHM_BYTES = (sizeof(IpcShm) + 4095) & ~(size_t)4095;
@@ -208,7 +525,7 @@ constexpr size_t IPC_SHM_BYTES = (sizeof(IpcShm) + 4095) & ~(size_t)4095;
 struct HostTimer {          // IMT_SLICED_TIMING=1: where the host's time inside the transport goes (printed at destroy)
     double ms[6] = {0};
     uint64_t n[6] = {0};
-    bool on = getenv("IMT_SLICED_TIMING") != nullptr;
+    bool on = effective_options().timing != 0;
     struct Scope {
         HostTimer& t;
         int k;
@@ -227,7 +544,9 @@ struct IpcTransport : Transport {
     HostTimer ht;
     int world, rank, ring = 0;
     size_t payload_cap = 0;
-    uint8_t* arena = nullptr;                    // [ROUNDS][ring][payload_cap]
+    uint8_t* arena = nullptr;                    // [ROUNDS][ring][payload_cap], then [IPC_AUX_RING][IPC_AUX_BYTES]
+    size_t aux_off = 0;
+    uint64_t aux_seq = 0;
     IpcShm *my_shm = nullptr, *my_shm_dev = nullptr;
     std::string shm_name;
     uint64_t seq[IPC_NEV] = {};                  // gathers issued per (slot, ring): the same on every rank
@@ -271,6 +590,15 @@ struct IpcTransport : Transport {
     IpcTransport(imt_ctx* c, int w, int r) : ctx(c), world(w), rank(r) {
         for (auto& x : issued) x.store(0);
     }
+    int clock_khz = 100000;
+    // at least 10 ms: a limit of zero (or a negative one) would make every wait give up at once
+    void set_timeout(double seconds, int khz = 0) {
+        if (khz > 0) clock_khz = khz;
+        timeout_s = !(seconds >= 0.01) ? 0.01 : seconds > 86400.0 ? 86400.0 : seconds;
+        timeout_ticks = (uint64_t)(timeout_s * 1e3 * clock_khz);
+    }
+    int host_poll_option = -1;                   // imt_transport_set_option: -1 decide from the bus ids, 0 / 1 forced
+    const uint32_t* poison_word() override { return my_shm_dev ? &my_shm_dev->err : nullptr; }
     static int ei(int slot, int r) { return slot * IPC_RING_MAX + r; }
 
     int map_page(const char* name, bool create, IpcShm** host, IpcShm** dev) {
@@ -283,10 +611,17 @@ struct IpcTransport : Transport {
         close(fd);
         if (p == MAP_FAILED) return ctx->fail(IMT_ERR_ALLOC, "mmap of the flag page %s failed", name);
         if (create) std::memset(p, 0, IPC_SHM_BYTES);
-        *host = (IpcShm*)p;
         hipError_t e = hipHostRegister(p, IPC_SHM_BYTES, hipHostRegisterMapped | hipHostRegisterPortable);
-        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)dev, p, 0);
-        if (e != hipSuccess) return ctx->hip_fail(e, "hipHostRegister(flag page)");
+        if (e != hipSuccess) {
+            munmap(p, IPC_SHM_BYTES);
+            return ctx->hip_fail(e, "hipHostRegister(flag page)");
+        }
+        if ((e = hipHostGetDevicePointer((void**)dev, p, 0)) != hipSuccess) {
+            hipHostUnregister(p);
+            munmap(p, IPC_SHM_BYTES);
+            return ctx->hip_fail(e, "hipHostGetDevicePointer(flag page)");
+        }
+        *host = (IpcShm*)p;
         return IMT_OK;
     }
     void unmap_page(IpcShm* host) {
@@ -304,11 +639,12 @@ struct IpcTransport : Transport {
         if (rc) return rc;
         int khz = 100000;                        // wall_clock64 ticks per millisecond (100 MHz on gfx9)
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
-        if (const char* e = getenv("IMT_IPC_TIMEOUT_S")) timeout_s = atof(e);
-        timeout_ticks = (uint64_t)(timeout_s * 1e3 * khz);
+        if (const char* e = getenv("IMT_IPC_TIMEOUT_S")) timeout_s = atof(e);       // tools/ only; imt_transport_set_option otherwise
+        set_timeout(timeout_s, khz);
         if (hipDeviceGetPCIBusId(my_bus, (int)sizeof my_bus, ctx->device) != hipSuccess) my_bus[0] = 0;
         payload_cap = imt_itree_slice_payload_bytes(max_slice);
-        const size_t bytes = (size_t)ROUNDS * ring * payload_cap;
+        aux_off = (size_t)ROUNDS * ring * payload_cap;
+        const size_t bytes = aux_off + IPC_AUX_RING * IPC_AUX_BYTES;
         IMT_HIP(ctx, hipMalloc((void**)&arena, bytes));
         IMT_HIP(ctx, hipMemset(arena, 0, bytes));
         std::memset(blob, 0, sizeof *blob);
@@ -316,8 +652,8 @@ struct IpcTransport : Transport {
         char name[64];
         snprintf(name, sizeof name, "/imt_ipc_%d_%d_%llx", (int)getpid(), rank,
                  (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+        shm_name = name;                         // from here on the destructor unlinks it
         if ((rc = map_page(name, true, &my_shm, &my_shm_dev))) return rc;
-        shm_name = name;
         snprintf(blob->shm_name, sizeof blob->shm_name, "%s", name);
         snprintf(blob->bus_id, sizeof blob->bus_id, "%s", my_bus);
         blob->arena_bytes = bytes;
@@ -342,7 +678,8 @@ struct IpcTransport : Transport {
             if ((rc = map_page(b.shm_name, false, &p.shm, &p.shm_dev))) return rc;
             if (my_bus[0] && !strncmp(my_bus, b.bus_id, sizeof my_bus)) host_poll = true;      // a peer on MY device
         }
-        if (const char* e = getenv("IMT_IPC_HOST_POLL")) host_poll = atoi(e) != 0;
+        if (host_poll_option >= 0) host_poll = host_poll_option != 0;
+        if (const char* e = getenv("IMT_IPC_HOST_POLL")) host_poll = atoi(e) != 0;                // tools/ only
         if (host_poll) {
             for (int slot = 0; slot < ROUNDS; slot++) IMT_HIP(ctx, hipStreamCreateWithFlags(&ws[slot], hipStreamNonBlocking));
             for (int slot = 0; slot < ROUNDS; slot++)
@@ -364,8 +701,12 @@ struct IpcTransport : Transport {
                 std::unique_lock<std::mutex> lk(mu);
                 if (pend.empty()) cv.wait(lk, [this] { return stop || !jobs.empty(); });
                 while (!jobs.empty()) { pend.push_back(jobs.front()); jobs.pop_front(); }
-                if (stop && pend.empty()) return;
-                if (stop) return;
+                if (stop) {
+                    // jobs still waiting for a peer are given up: whoever waits for them (a fence on the host) sees the
+                    // error instead of the time limit
+                    if (!pend.empty()) worker_error.store(4);
+                    return;
+                }
             }
             bool progress = false;
             for (size_t q = 0; q < pend.size();) {
@@ -379,12 +720,12 @@ struct IpcTransport : Transport {
                         if (hipStreamWaitEvent(ws[j.slot], ready_ev[j.i], 0) != hipSuccess) worker_error.store(3);
                         j.ordered = true;
                     }
-                    imt::launch::copy16(ws[j.slot], j.recv + (size_t)h * j.bytes, peers[h].arena + j.off, j.bytes);
+                    imt::launch::copy16(ws[j.slot], j.recv + (size_t)h * j.bytes, peers[h].arena + j.off, j.bytes, &my_shm_dev->err);
                     j.copied_mask |= 1u << h;
                     progress = true;
                 }
                 if (j.copied_mask == all) {
-                    imt::launch::flag_set(ws[j.slot], &my_shm_dev->copied[j.i], j.k);
+                    imt::launch::flag_set_checked(ws[j.slot], &my_shm_dev->copied[j.i], j.k, &my_shm_dev->err);
                     if (hipEventRecord(done_ev[j.i], ws[j.slot]) != hipSuccess || hipGetLastError() != hipSuccess) worker_error.store(2);
                     issued[j.i].store(j.k, std::memory_order_release);
                     pend.erase(pend.begin() + (long)q);
@@ -431,7 +772,13 @@ struct IpcTransport : Transport {
             cv.notify_all();
             worker.join();
         }
-        if (ctx->set_device()) return;
+        if (!shm_name.empty()) shm_unlink(shm_name.c_str());      // whatever else fails: the name does not stay behind
+        if (ctx->set_device()) {                                   // no device: give the host mappings back at least
+            for (auto& p : peers)
+                if (p.shm) munmap(p.shm, IPC_SHM_BYTES);
+            if (my_shm) munmap(my_shm, IPC_SHM_BYTES);
+            return;
+        }
         for (auto& w_ : ws)
             if (w_) { hipStreamSynchronize(w_); hipStreamDestroy(w_); }
         for (auto& e : done_ev)
@@ -444,7 +791,6 @@ struct IpcTransport : Transport {
         }
         if (arena) hipFree(arena);
         unmap_page(my_shm);
-        if (!shm_name.empty()) shm_unlink(shm_name.c_str());
     }
     int attach(Rank& rk) override {
         if (!connected) return ctx->fail(IMT_ERR_ARG, "imt_transport_ipc_connect first");
@@ -453,6 +799,53 @@ struct IpcTransport : Transport {
         return IMT_OK;
     }
     Buffer provide_send(Rank&, int slot, int r, size_t) override { return arena + ((size_t)slot * ring + r) * payload_cap; }
+    // The subtree layout's exchange (imt_transport_all_gather): gather number k uses staging slot (k - 1) % IPC_AUX_RING of
+    // every rank's arena.  My payload goes into my slot (once every peer has copied the slot's previous contents), my
+    // `aux_packed` says so; each peer's payload is read out of its slot once its `aux_packed` has reached k; my
+    // `aux_copied` tells the peers.  GPU-polled between different GPUs, host-polled between ranks that share one.
+    int small_gather(const void* send, void* recv, size_t bytes, Stream st_) override {
+        if (!connected) return ctx->fail(IMT_ERR_ARG, "imt_transport_ipc_connect first");
+        hipStream_t st = (hipStream_t)st_;
+        const uint64_t k = ++aux_seq;
+        const int r = (int)((k - 1) % IPC_AUX_RING);
+        uint8_t* mine = arena + aux_off + (size_t)r * IPC_AUX_BYTES;
+        auto wait_all = [&](bool copied, uint64_t value) -> int {
+            if (host_poll) {
+                for (int h = 0; h < world; h++) {
+                    if (h == rank) continue;
+                    const uint64_t* f = copied ? &peers[h].shm->aux_copied[r] : &peers[h].shm->aux_packed[r];
+                    if (!host_wait([&] { return __atomic_load_n(f, __ATOMIC_ACQUIRE) >= value; }))
+                        return ctx->fail(IMT_ERR_TIMEOUT, "IPC transport: rank %d did not reach all-gather %llu within %.0f s", h, (unsigned long long)value, timeout_s);
+                }
+                return IMT_OK;
+            }
+            imt::launch::FlagWait w{};
+            for (int d = 1; d < world; d++) {
+                const int h = (rank + d) % world;
+                w.flag[w.n++] = copied ? &peers[h].shm_dev->aux_copied[r] : &peers[h].shm_dev->aux_packed[r];
+            }
+            w.value = value;
+            w.timeout_ticks = timeout_ticks;
+            w.err = &my_shm_dev->err;
+            imt::launch::flag_wait(st, w);
+            IMT_HIP(ctx, hipGetLastError());
+            return IMT_OK;
+        };
+        int rc;
+        if (k > IPC_AUX_RING && (rc = wait_all(true, k - IPC_AUX_RING))) return rc;
+        imt::launch::copy16(st, mine, send, bytes, &my_shm_dev->err);
+        imt::launch::copy16(st, (uint8_t*)recv + (size_t)rank * bytes, send, bytes, &my_shm_dev->err);
+        imt::launch::flag_set_checked(st, &my_shm_dev->aux_packed[r], k, &my_shm_dev->err);
+        IMT_HIP(ctx, hipGetLastError());
+        if ((rc = wait_all(false, k))) return rc;
+        for (int d = 1; d < world; d++) {
+            const int h = (rank + d) % world;
+            imt::launch::copy16(st, (uint8_t*)recv + (size_t)h * bytes, peers[h].arena + aux_off + (size_t)r * IPC_AUX_BYTES, bytes, &my_shm_dev->err);
+        }
+        imt::launch::flag_set_checked(st, &my_shm_dev->aux_copied[r], k, &my_shm_dev->err);
+        IMT_HIP(ctx, hipGetLastError());
+        return IMT_OK;
+    }
     int wait_peers(hipStream_t st, int i, uint64_t k, bool copied) {
         imt::launch::FlagWait w{};
         for (int d = 1; d < world; d++) {
@@ -495,10 +888,11 @@ struct IpcTransport : Transport {
         for (int d = 1; d < world; d++) {              // start with the next rank: spread the reads over the peers
             const int h = (rank + d) % world;
             HostTimer::Scope sc(ht, 2);
-            imt::launch::copy16(st, recv + (size_t)h * bytes, peers[h].arena + off, bytes);
+            imt::launch::copy16(st, recv + (size_t)h * bytes, peers[h].arena + off, bytes, &my_shm_dev->err);
         }
         HostTimer::Scope sc(ht, 0);
-        imt::launch::flag_set(st, &my_shm_dev->copied[i], k);
+        // not published once a wait has given up: the peers must not overwrite send buffers this rank has not read
+        imt::launch::flag_set_checked(st, &my_shm_dev->copied[i], k, &my_shm_dev->err);
         IMT_HIP(ctx, hipGetLastError());
         return IMT_OK;
     }
@@ -546,8 +940,36 @@ struct imt_sliced {
     std::vector<std::unique_ptr<Rank>> ranks;
     imt_transport* tp = nullptr;
     size_t max_slice = 0;
+    SlicedOptions opt;
     std::string error;
     double host_issue_ms = 0, host_wait_ms = 0;      // wall time inside imt_sliced_step: issuing / waiting for the GPU
+    bool trees_marked = false;
+
+    void mark(bool busy) {
+        for (auto& be : bes)
+            if (be) imt_itree_mark_sliced(be->tree, busy);
+        trees_marked = busy;
+    }
+    // A host wait ran into the watchdog (IMT_ERR_TIMEOUT) or the transport gave up on a peer: write where the world stands
+    // to stderr, once per failure, and keep it for imt_sliced_last_error.  One rank's log is then enough to tell which
+    // collective of which round never completed.
+    int failed(int rc, const char* call) {
+        if (rc == IMT_OK || bes.empty()) return rc;
+        if (rc == IMT_ERR_TIMEOUT || w.poisoned) {
+            const int rank = ranks.empty() || !ranks[0] ? -1 : ranks[0]->rank;
+            imt_ctx* c0 = bes[0]->ctx;
+            std::string why = c0->last_error.empty() ? imt_transport_last_error(tp) : c0->last_error;
+            char head[256];
+            snprintf(head, sizeof head, "[imt sliced rank %d] %s failed with %d: ", rank, call, rc);
+            error = std::string(head) + why + "\n" + describe(w);
+            char tail[160];
+            snprintf(tail, sizeof tail, "  host inside imt_sliced_step so far: %.1f ms issuing, %.1f ms waiting\n", host_issue_ms, host_wait_ms);
+            error += tail;
+            fputs(error.c_str(), stderr);
+            fflush(stderr);
+        }
+        return rc;
+    }
 };
 
 extern "C" {
@@ -589,7 +1011,49 @@ int imt_transport_ipc_connect(imt_transport* tp, const void* all_blobs) {
     return t->connect((const IpcBlob*)all_blobs);
 }
 
-void imt_transport_destroy(imt_transport* tp) { delete tp; }
+int imt_transport_set_option(imt_transport* tp, int option, long value) {
+    if (!tp) return IMT_ERR_ARG;
+    IpcTransport* t = dynamic_cast<IpcTransport*>(tp->impl.get());
+    switch (option) {
+        case IMT_TRANSPORT_OPT_TIMEOUT_MS:
+            if (value <= 0) return IMT_ERR_RANGE;
+            if (t) t->set_timeout((double)value * 1e-3);
+            return IMT_OK;                              // the other transports have no wait of their own to bound
+        case IMT_TRANSPORT_OPT_HOST_POLL:
+            if (!t || t->connected || value < -1 || value > 1) return IMT_ERR_ARG;      // before imt_transport_ipc_connect
+            t->host_poll_option = (int)value;
+            return IMT_OK;
+    }
+    return IMT_ERR_ARG;
+}
+
+int imt_transport_all_gather(imt_transport* tp, const void* send, void* recv, size_t bytes, void* hip_stream) {
+    if (!tp || !send || !recv) return IMT_ERR_ARG;
+    auto fail = [&](int code, const char* msg) {
+        tp->error = msg;
+        return code;
+    };
+    if (bytes == 0 || (bytes & 15u) || bytes > IPC_AUX_BYTES) return fail(IMT_ERR_RANGE, "imt_transport_all_gather: bytes is a multiple of 16, at most 4096");
+    if (tp->users > 0) return fail(IMT_ERR_ARG, "imt_transport_all_gather: an imt_sliced is using the transport");
+    if (dynamic_cast<LocalTransport*>(tp->impl.get())) return fail(IMT_ERR_ARG, "imt_transport_all_gather: the local transport has every rank in this process (copy instead)");
+    if (!hip_stream && !tp->ctx) return fail(IMT_ERR_ARG, "imt_transport_all_gather: this transport has no context of its own, name a stream");
+    if (tp->ctx) {
+        int rc = tp->ctx->set_device();
+        if (rc) return rc;
+    }
+    tp->error.clear();
+    return tp->impl->small_gather(send, recv, bytes, hip_stream ? hip_stream : (void*)tp->ctx->stream);
+}
+
+int imt_transport_destroy(imt_transport* tp) {
+    if (!tp) return IMT_OK;
+    if (tp->users > 0) {            // an imt_sliced still holds it: destroying it now would leave that world with a dangling pointer
+        tp->error = "imt_transport_destroy: an imt_sliced still uses this transport (imt_sliced_destroy first)";
+        return IMT_ERR_ARG;
+    }
+    delete tp;
+    return IMT_OK;
+}
 
 const char* imt_transport_last_error(const imt_transport* tp) {
     if (!tp) return "";
@@ -597,18 +1061,46 @@ const char* imt_transport_last_error(const imt_transport* tp) {
     return tp->ctx ? tp->ctx->last_error.c_str() : "";
 }
 
+int imt_sliced_set_option(imt_sliced* s, int option, long value) {
+    if (!option_value_ok(option, value)) return IMT_ERR_RANGE;
+    long* f = nullptr;
+    if (!s) {                       // the defaults later imt_sliced_create calls start from
+        std::lock_guard<std::mutex> lk(g_defaults_mu);
+        int rc = option_field(g_defaults, option, &f);
+        if (rc) return rc;
+        *f = value;
+        return IMT_OK;
+    }
+    // an existing world: only what does not change its streams
+    if (option != IMT_SLICED_OPT_PREP_STREAM && option != IMT_SLICED_OPT_WATCHDOG_MS && option != IMT_SLICED_OPT_TIMING) return IMT_ERR_ARG;
+    int rc = option_field(s->opt, option, &f);
+    if (rc) return rc;
+    *f = value;
+    for (auto& be : s->bes) {
+        if (!be) continue;
+        option_field(be->opt, option, &f);
+        *f = value;
+        if (option == IMT_SLICED_OPT_WATCHDOG_MS) imt_itree_set_slice_wait_limit(be->tree, (double)value);
+    }
+    return IMT_OK;
+}
+
 void imt_sliced_destroy(imt_sliced* s) {
     if (!s) return;
-    if (getenv("IMT_SLICED_TIMING"))
+    if (s->opt.timing)
         fprintf(stderr, "[imt sliced rank %d] host ms over %llu rounds: apply %.1f  compute %.1f  send %.1f  (issue %.1f, waiting in prepare %.1f)\n",
-                s->ranks.empty() ? -1 : s->ranks[0]->rank, (unsigned long long)s->w.n_rounds, s->w.phase_ms[0], s->w.phase_ms[1], s->w.phase_ms[2],
-                s->host_issue_ms, s->host_wait_ms);
-    if (!s->ranks.empty() && s->w.n_rounds) s->w.flush();
-    for (auto& be : s->bes) {
-        be->sync();
-        imt_itree_mark_sliced(be->tree, false);
-    }
-    for (auto& r : s->ranks) r->destroy();
+                s->ranks.empty() || !s->ranks[0] ? -1 : s->ranks[0]->rank, (unsigned long long)s->w.n_rounds, s->w.phase_ms[0], s->w.phase_ms[1],
+                s->w.phase_ms[2], s->host_issue_ms, s->host_wait_ms);
+    // a poisoned world is not flushed (nothing can be issued any more); its replicas stay marked: they hold half a step
+    const bool clean = !s->w.poisoned;
+    if (clean && !s->w.ranks.empty() && s->w.n_rounds) s->w.flush();
+    for (auto& be : s->bes)
+        if (be) {
+            be->sync();                                  // bounded by the watchdog; what is still running keeps its buffers busy
+            if (clean && !s->w.poisoned) imt_itree_mark_sliced(be->tree, false);
+        }
+    for (auto& r : s->ranks)
+        if (r) r->destroy();
     if (s->tp) s->tp->users--;
     delete s;
 }
@@ -634,6 +1126,8 @@ int imt_sliced_create(imt_itree* const* trees, int n_local, int world, int first
         return c0->fail(IMT_ERR_ARG, "all ranks in one process use the local transport");
     if (n_local == 1 && world > 1 && dynamic_cast<LocalTransport*>(tp->impl.get()))
         return c0->fail(IMT_ERR_ARG, "the local transport needs every rank in this process (n_local = world)");
+    // one world per transport at a time: the transports keep per-world state (peer tables, sequence counters, ring sizes)
+    if (tp->users > 0) return c0->fail(IMT_ERR_ARG, "the transport is in use by another imt_sliced (one world per transport)");
     std::unique_ptr<imt_sliced> s(new (std::nothrow) imt_sliced());
     if (!s) return c0->fail(IMT_ERR_ALLOC, "out of host memory");
     if (!s->w.sc.init(world, (int)depth + 1, lag))
@@ -641,6 +1135,7 @@ int imt_sliced_create(imt_itree* const* trees, int n_local, int world, int first
                         lag, ROUNDS);
     s->tp = tp;
     s->max_slice = max_slice;
+    s->opt = effective_options();
     tp->users++;
     for (int k = 0; k < n_local; k++) {
         s->bes.emplace_back(new (std::nothrow) HipBackend(trees[k]));
@@ -648,13 +1143,14 @@ int imt_sliced_create(imt_itree* const* trees, int n_local, int world, int first
         HipBackend* be = s->bes.back().get();
         Rank* rk = s->ranks.back().get();
         int rc;
-        if (!be || !rk) rc = IMT_ERR_ALLOC;
-        else if (!(rc = be->init()) && !(rc = rk->init(be, tp->impl.get(), world, first_rank + k, max_slice)))
+        if (!be || !rk) rc = c0->fail(IMT_ERR_ALLOC, "out of host memory");
+        else if (!(rc = be->init(s->opt, tp->impl->channels())) && !(rc = rk->init(be, tp->impl.get(), world, first_rank + k, max_slice)))
             rc = rk->build(s->w.sc);
         if (rc) {
             imt_sliced_destroy(s.release());
             return rc;
         }
+        imt_itree_set_slice_poison(be->tree, tp->impl->poison_word());
         s->w.ranks.push_back(rk);
     }
     *out = s.release();
@@ -668,31 +1164,50 @@ int imt_sliced_step(imt_sliced* s, const void* vals, size_t n, const imt_insert_
     if (n == 0 || n > s->max_slice) return c0->fail(IMT_ERR_RANGE, "a step is world x n values with 0 < n <= max_slice = %zu", s->max_slice);
     if (flags & ~(IMT_FMT_MASK | IMT_SIB_ITEM_MAJOR | IMT_INPUTS_READY | IMT_DEVICE_PTRS))
         return c0->fail(IMT_ERR_ARG, "imt_sliced_step takes IMT_FMT_*, IMT_SIB_ITEM_MAJOR, IMT_INPUTS_READY");
+    if (s->w.poisoned) return c0->fail(IMT_ERR_INTERNAL, "this world failed earlier (imt_sliced_last_error) and cannot go on: destroy it and reload the trees from a checkpoint");
     (void)s->tp->impl->take_wait_ms();                     // waits of imt_sliced_wait / _flush are not this call's
     for (auto& be : s->bes) (void)imt_itree_take_wait_ms(be->tree);
     const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t rounds_before = s->w.n_rounds;
     const int rc = s->w.step(vals, n, outs, flags, round_out);
-    if (rc == IMT_OK)
-        for (auto& be : s->bes) imt_itree_mark_sliced(be->tree, true);
+    // the replicas are mid-step as soon as the step has been opened (the index has moved ahead of the stored tree), whether
+    // or not every tick of the period could then be issued
+    if (s->w.n_rounds != rounds_before || s->w.poisoned) s->mark(true);
     const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     double waited = s->tp->impl->take_wait_ms();           // the host-polled transport: waiting for peers' payloads
     for (auto& be : s->bes) waited += imt_itree_take_wait_ms(be->tree);
     s->host_wait_ms += waited;
     s->host_issue_ms += total - waited;
-    return rc;
+    if (rc == IMT_ERR_TIMEOUT) s->w.poisoned = true;       // the preparation's own wait gave up: the step is half open
+    return s->failed(rc, "imt_sliced_step");
 }
 
 int imt_sliced_wait(imt_sliced* s, int local_rank, uint64_t round) {
     if (!s || local_rank < 0) return IMT_ERR_ARG;
-    return s->w.wait_round((size_t)local_rank, round);
+    int rc = s->w.wait_round((size_t)local_rank, round);
+    if (rc == IMT_ERR_TIMEOUT) s->w.poisoned = true;
+    if (rc == IMT_ERR_INTERNAL && s->w.poisoned && s->bes[0]->ctx->last_error.empty())
+        s->bes[0]->ctx->fail(rc, "this world failed earlier and cannot go on");
+    return s->failed(rc, "imt_sliced_wait");
 }
 
 int imt_sliced_flush(imt_sliced* s) {
     if (!s) return IMT_ERR_ARG;
-    const int rc = s->w.flush();
-    if (rc == IMT_OK)
-        for (auto& be : s->bes) imt_itree_mark_sliced(be->tree, false);     // every replica holds the whole step now
-    return rc;
+    int rc = s->w.flush();
+    if (rc == IMT_ERR_TIMEOUT) s->w.poisoned = true;
+    if (rc == IMT_OK) s->mark(false);      // every replica holds the whole step now
+    return s->failed(rc, "imt_sliced_flush");
+}
+
+int imt_sliced_dump(imt_sliced* s, char* out, size_t cap) {
+    if (!s || (!out && cap)) return IMT_ERR_ARG;
+    const std::string d = describe(s->w);
+    if (cap) {
+        const size_t n = std::min(cap - 1, d.size());
+        memcpy(out, d.data(), n);
+        out[n] = 0;
+    }
+    return (int)std::min<size_t>(d.size(), 0x7fffffff);
 }
 
 int imt_sliced_get_info(const imt_sliced* s, imt_sliced_info* o) {
@@ -711,11 +1226,28 @@ int imt_sliced_get_info(const imt_sliced* s, imt_sliced_info* o) {
     o->bytes_gathered = s->tp->impl->bytes_moved;
     o->host_issue_ms = s->host_issue_ms;
     o->host_wait_ms = s->host_wait_ms;
+    const HipBackend& be = *s->bes[0];
+    o->placement = be.placement;
+    o->hw_queues = be.n_queues;
+    o->comm_streams = be.n_comm;
+    o->streams_recreated = be.streams_recreated;
+    for (auto& b : s->bes) {                 // the worst of the local replicas
+        if (b->placement > o->placement) o->placement = b->placement;
+        o->streams_recreated = std::max(o->streams_recreated, b->streams_recreated);
+    }
+    for (int i = 0; i < ROUNDS; i++) {
+        o->queue_map[0][i] = be.q_round[i];
+        o->queue_map[1][i] = be.q_comm[i];
+        o->queue_map[2][i] = be.q_apply[i];
+    }
     return IMT_OK;
 }
 
 const char* imt_sliced_last_error(const imt_sliced* s) {
     if (!s) return "";
+    if (!s->error.empty()) return s->error.c_str();
+    for (auto& be : s->bes)
+        if (be && be->placement == IMT_SLICED_PLACEMENT_DEGRADED && be->ctx->last_error.empty()) return be->placement_note.c_str();
     for (auto& be : s->bes)
         if (!be->ctx->last_error.empty()) return be->ctx->last_error.c_str();
     return imt_transport_last_error(s->tp);

@@ -84,6 +84,11 @@ struct RcclTransport : Transport {
         const ncclResult_t res = rccl().AllGather(rk.send[i], rk.recv[i], bytes, ncclUint8, comms[slot % n_comms], (hipStream_t)st);
         return res == ncclSuccess ? IMT_OK : fail(res, "ncclAllGather");
     }
+    int channels() const override { return n_comms; }
+    int small_gather(const void* send, void* recv, size_t bytes, Stream st) override {
+        const ncclResult_t res = rccl().AllGather(send, recv, bytes, ncclUint8, comms[0], (hipStream_t)st);
+        return res == ncclSuccess ? IMT_OK : fail(res, "ncclAllGather");
+    }
 };
 
 }  // namespace

@@ -36,6 +36,8 @@
 #include <chrono>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
+#include <string>
 #include <vector>
 #include "../../include/imt.h"
 
@@ -112,7 +114,8 @@ struct Backend {
     virtual void free_event(Event e) = 0;
     virtual int record(Event e, Stream s) = 0;
     virtual int wait(Stream s, Event e) = 0;        // HIP semantics: the latest record ISSUED before this call
-    virtual int event_sync(Event e) = 0;            // host waits
+    virtual int event_sync(Event e) = 0;            // host waits (a backend may give up: IMT_ERR_TIMEOUT)
+    virtual int event_query(Event e) { (void)e; return 1; }   // 1 complete (or never recorded), 0 not yet, < 0 an error
     virtual int alloc(size_t bytes, Buffer* out) = 0;
     virtual void free_buffer(Buffer b) = 0;
     // src may belong to another rank of the same process (the in-process transport)
@@ -143,6 +146,19 @@ struct Transport {
     virtual int all_gather(Rank& rk, int slot, int ring, size_t bytes, Stream st) = 0;
     virtual int fence(Rank& rk, int slot, int ring, Stream st) { (void)rk; (void)slot; (void)ring; (void)st; return IMT_OK; }
     virtual int poll_error() { return IMT_OK; }    // after a host-side wait: did the transport give up on a peer?
+    // How many independent channels the transport has (RCCL: its communicators; 0 = one per round slot).  Collectives of
+    // round slots that share a channel are enqueued on ONE stream (Backend::comm_stream), so a channel sees its calls in
+    // one order -- the order the hosts issue them in, which is the same on every rank (World: every tick is a function
+    // of the call sequence, never of the rank).
+    virtual int channels() const { return 0; }
+    // a device-visible word that turns non-zero when a GPU-side wait of the transport has given up (nullptr: there is no
+    // such wait); the replica's apply kernel skips its payloads then (Backend: imt_itree_set_slice_poison)
+    virtual const uint32_t* poison_word() { return nullptr; }
+    // one small all-gather outside any world (imt_transport_all_gather: the subtree layout's exchange of subtree roots)
+    virtual int small_gather(const void* send, void* recv, size_t bytes, Stream st) {
+        (void)send; (void)recv; (void)bytes; (void)st;
+        return IMT_ERR_ARG;
+    }
     virtual double take_wait_ms() { return 0; }    // host time spent WAITING for peers since the last call (not issuing)
     uint64_t collectives = 0, bytes_moved = 0;
 };
@@ -359,13 +375,25 @@ struct Rank {
 };
 
 // The ranks this process drives, in lockstep: one for a distributed world, all of them for an in-process one.
+struct World;
+std::string describe(World& w);
+
 struct World {
     std::vector<Rank*> ranks;
     Schedule sc;
     double phase_ms[4] = {0, 0, 0, 0};      // host wall time in apply / compute / send / prepare (diagnostics)
     uint64_t T = 0;                  // next global tick to issue
+    bool opened = false;             // step(): some replica has already opened the step (prepare succeeded)
     uint64_t n_rounds = 0;
     uint64_t starts[ROUNDS + 1] = {};
+    // A failure while ticks were being issued leaves the replicas mid-step with part of a tick enqueued: nothing can be
+    // resumed from there.  The world refuses every further step / wait; the trees stay marked as sliced (imt_sliced.cpp)
+    // and are reloaded from a checkpoint by the caller.
+    bool poisoned = false;
+    int poison(int rc) {
+        if (rc) poisoned = true;
+        return rc;
+    }
 
     uint64_t& start_of(uint64_t R) { return starts[R % (ROUNDS + 1)]; }
 
@@ -400,17 +428,24 @@ struct World {
     int step(const void* vals, size_t n, const imt_insert_out* outs, unsigned flags, uint64_t* round_out) {
         if (ranks.empty() || !vals) return IMT_ERR_ARG;
         if (n == 0 || n > ranks[0]->max_n) return IMT_ERR_RANGE;
+        if (poisoned) return IMT_ERR_INTERNAL;
+        // a transport that gave up on a peer (a GPU-side wait that timed out) has skipped payloads: no further step
+        if (int rc = ranks[0]->tp->poll_error()) return poison(rc);
         const uint64_t R = n_rounds;
         const uint64_t size_before = ranks[0]->be->tree_size();
         // the plan set of round R - ROUNDS - 1 is reused by round R: its slice closed long ago (its last unit was issued
         // ROUNDS rounds back); nothing to wait for on the host
         std::vector<int> slices(ranks.size(), -1);
+        opened = false;
         for (size_t k = 0; k < ranks.size(); k++) {
             Rank* rk = ranks[k];
-            if (rk->be->tree_size() != size_before) return IMT_ERR_INTERNAL;
+            if (rk->be->tree_size() != size_before) return opened ? poison(IMT_ERR_INTERNAL) : IMT_ERR_INTERNAL;
             int rc = rk->be->prepare(vals, (size_t)rk->rank * n, n, (size_t)(rk->world - 1 - rk->rank) * n,
                                      outs ? &outs[k] : nullptr, flags, (int)(R % ROUNDS), &slices[k]);
-            if (rc) return k == 0 ? rc : IMT_ERR_INTERNAL;       // replicas that disagree about a step are broken
+            // a refusal by the first replica changes nothing; replicas that disagree about a step are broken, and so is
+            // a world whose earlier replicas have already opened the step
+            if (rc) return k == 0 ? rc : poison(IMT_ERR_INTERNAL);
+            opened = true;
         }
         const uint64_t start = n_rounds == 0 ? T : std::max<uint64_t>(T, start_of(R - 1) + sc.period);
         start_of(R) = start;
@@ -424,29 +459,35 @@ struct World {
         }
         n_rounds = R + 1;
         if (round_out) *round_out = R;
-        return run_ticks(start + sc.period);
+        return poison(run_ticks(start + sc.period));
     }
 
     // issue everything that is left of the rounds in flight and wait for it
     int flush() {
         int rc;
-        if (n_rounds && (rc = run_ticks(start_of(n_rounds - 1) + sc.round_ticks))) return rc;
+        if (poisoned) return IMT_ERR_INTERNAL;
+        if (n_rounds && (rc = run_ticks(start_of(n_rounds - 1) + sc.round_ticks))) return poison(rc);
         for (Rank* rk : ranks)
-            if ((rc = rk->be->sync())) return rc;
-        return ranks.empty() ? IMT_OK : ranks[0]->tp->poll_error();
+            if ((rc = rk->be->sync())) return poison(rc);
+        return ranks.empty() ? IMT_OK : poison(ranks[0]->tp->poll_error());
     }
 
     // host waits for local rank k's witnesses of round R (its slice's last unit)
     int wait_round(size_t k, uint64_t R) {
         if (k >= ranks.size() || R >= n_rounds) return IMT_ERR_RANGE;
+        if (poisoned) return IMT_ERR_INTERNAL;
         Rank* rk = ranks[k];
         // its stream slot has been taken over by a later round, whose tick 0 was recorded on the same stream behind it
         int rc;
         if (R + ROUNDS < n_rounds) {
             rc = rk->be->event_sync(rk->tick_ev[(size_t)(R % ROUNDS) * sc.round_ticks]);
         } else {
-            // the last unit is issued at round tick units - 1 + rank * lag: make sure the schedule has got there
-            if ((rc = run_ticks(std::max<uint64_t>(T, start_of(R) + sc.units + (uint64_t)rk->rank * sc.lag)))) return rc;
+            // Rank g's last unit is issued at round tick units - 1 + g * lag.  The schedule advances to the tick at which
+            // EVERY rank's last unit of the round has been issued (its last compute tick, `gathers`), not to this rank's:
+            // the global tick, and with it the start of the next round and the order in which collectives of
+            // different rounds are issued, must be the same function of the call sequence on every rank (a world of
+            // one process per rank calls wait with the same round everywhere, never with the same rank).
+            if ((rc = run_ticks(std::max<uint64_t>(T, start_of(R) + (uint64_t)sc.gathers)))) return poison(rc);
             rc = rk->be->event_sync(rk->done_ev[R % ROUNDS]);
         }
         return rc ? rc : rk->tp->poll_error();
@@ -503,6 +544,58 @@ struct LocalTransport : Transport {
         return IMT_OK;
     }
 };
+
+// Where a world stands, for the log of a run that hangs (imt_sliced.cpp prints it when a host wait runs into the
+// watchdog; bench.py when its own gives up): the global tick the host has issued up to, and per rank and round slot the
+// round in it, how many of its ticks have been issued, and the first issued tick whose unit (tick_ev, round stream) /
+// apply (applied_ev) has NOT completed on the device, the collectives issued and not yet complete (gathered_ev) with
+// their channel, ring buffer and byte count.  A tick that stands still with its collective pending names the peer-side
+// suspect; one that stands still behind a complete collective names a local one.
+inline std::string describe(World& w) {
+    char buf[256];
+    std::string out;
+    const Schedule& sc = w.sc;
+    snprintf(buf, sizeof buf, "sliced world: %d ranks, lag %d, period %d, %d gathers / %d ticks per round; %llu rounds started, global tick %llu issued%s\n",
+             sc.world, sc.lag, sc.period, sc.gathers, sc.round_ticks, (unsigned long long)w.n_rounds, (unsigned long long)w.T,
+             w.poisoned ? " [POISONED]" : "");
+    out += buf;
+    const uint64_t first = w.n_rounds > (uint64_t)ROUNDS ? w.n_rounds - ROUNDS : 0;
+    for (Rank* rk : w.ranks) {
+        for (uint64_t R = first; R < w.n_rounds; R++) {
+            const int slot = (int)(R % ROUNDS);
+            const uint64_t st = w.start_of(R);
+            const int issued = w.T <= st ? 0 : (int)std::min<uint64_t>(w.T - st, (uint64_t)sc.round_ticks);
+            int unit_stuck = -1, apply_stuck = -1;
+            for (int rt = 0; rt < issued && (unit_stuck < 0 || apply_stuck < 0); rt++) {
+                const size_t i = (size_t)slot * sc.round_ticks + rt;
+                if (unit_stuck < 0 && rk->be->event_query(rk->tick_ev[i]) == 0) unit_stuck = rt;
+                if (apply_stuck < 0 && rk->be->event_query(rk->applied_ev[i]) == 0) apply_stuck = rt;
+            }
+            snprintf(buf, sizeof buf, "  rank %d slot %d: round %llu (start tick %llu), %d of %d ticks issued; ", rk->rank, slot,
+                     (unsigned long long)R, (unsigned long long)st, issued, sc.round_ticks);
+            out += buf;
+            if (unit_stuck < 0 && apply_stuck < 0) {
+                out += "everything issued is complete\n";
+            } else {
+                const int q = unit_stuck >= 0 ? sc.unit_of(rk->rank, unit_stuck) : -1;
+                snprintf(buf, sizeof buf, "first incomplete: unit tick %d (unit %d), apply tick %d\n", unit_stuck, q, apply_stuck);
+                out += buf;
+            }
+            for (int r = 0; r < rk->ring; r++) {
+                const int i = rk->at(slot, r);
+                if (rk->pending[i] && rk->be->event_query(rk->gathered_ev[i]) == 0) {
+                    const int ch = rk->tp->channels() > 0 ? slot % rk->tp->channels() : slot;
+                    snprintf(buf, sizeof buf, "    collective PENDING on channel %d, ring buffer %d, %zu bytes per rank\n", ch, r, rk->gather_bytes[i]);
+                    out += buf;
+                }
+            }
+        }
+    }
+    snprintf(buf, sizeof buf, "  host ms in apply / compute / send phases: %.1f / %.1f / %.1f; collectives issued %llu\n", w.phase_ms[0], w.phase_ms[1],
+             w.phase_ms[2], w.ranks.empty() ? 0ull : (unsigned long long)w.ranks[0]->tp->collectives);
+    out += buf;
+    return out;
+}
 
 }  // namespace sliced
 }  // namespace imt

@@ -125,7 +125,19 @@ class SlicedTree:
     def info(self):
         o = self.F.SlicedInfo()
         self._check(self.lib.imt_sliced_get_info(self.h, ctypes.byref(o)))
-        return {f: getattr(o, f) for f, _ in o._fields_}
+        d = {f: getattr(o, f) for f, _ in o._fields_}
+        d["queue_map"] = [[int(x) for x in row] for row in o.queue_map]       # [round / collective / apply stream][slot]
+        d["placement"] = self.F.PLACEMENT.get(d["placement"], str(d["placement"]))
+        return d
+
+    def dump(self):
+        """where the world stands (imt_sliced_dump): what a watchdog prints"""
+        buf = ctypes.create_string_buffer(1 << 14)
+        self.lib.imt_sliced_dump(self.h, buf, len(buf))
+        return buf.value.decode(errors="replace")
+
+    def set_option(self, option, value):
+        self._check(self.lib.imt_sliced_set_option(self.h, option, value))
 
     def close(self, destroy_transport=True):
         if self.h:

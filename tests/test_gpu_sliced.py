@@ -624,3 +624,231 @@ def test_slice_calls_refuse_bad_arguments(imt, ctx):
     lib.imt_transport_destroy(tp)
     for x in (t, ref, placed):
         x.close()
+
+
+# ------------------------------------------------------------------------- where the world's streams sit, and hangs
+def _hip():
+    hip = ctypes.CDLL("libamdhip64.so.7")       # the HIP runtime this process already holds
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    return hip
+
+
+@pytest.mark.parametrize("dummies", [0, 1, 2, 3, 5])
+def test_queue_placement_is_measured_and_repaired(imt, ctx, dummies):
+    """The HIP runtime gives a new stream the hardware queue with the fewest streams of its priority, so where the
+    world's eight streams land depends on how many streams the HOST created before (torch, RCCL, the application) --
+    tools/microbench/queue_map_probe.hip.  imt_sliced_create measures the placement on the device (a spinning wave on
+    one stream, time stamps on the others) and re-creates streams until the four round streams sit on four different
+    hardware queues and slot i's collective stream on round stream i's queue, whatever came before: here 0 .. 5 extra
+    streams.  The witnesses stay those of the one-GPU tree."""
+    sl = load_sliced()
+    hip = _hip()
+    extra = []
+    for _ in range(dummies):
+        s = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0        # hipStreamNonBlocking
+        extra.append(s)
+    depth, cap, batch = 32, 1 << 10, 48
+    vals = oracle_lib.synth_values(3 * batch, 0x494D5470 + dummies)
+    want, want_root = reference_run(imt, ctx, depth, cap, vals, batch)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, 1)
+    info = t.info()
+    qm = info["queue_map"]
+    assert info["placement"] in ("as created", "repaired"), (info["placement"], qm, imt.lib.imt_sliced_last_error(t.h))
+    assert info["hw_queues"] == 4 and sorted(qm[0]) == [0, 1, 2, 3], qm
+    assert qm[1] == qm[0] and info["comm_streams"] == 4, qm          # the collectives' streams: on their rounds' queues
+    assert qm[2] == [-1] * 4                                         # no apply streams by default
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    for r in range(3):
+        t.step(arr[r * batch:(r + 1) * batch])
+    t.flush()
+    for r in range(3):
+        check_round(want[r], t.outputs(r), 0, batch)
+    assert t.trees[0].root() == want_root
+    t.close()
+    for s in extra:
+        hip.hipStreamDestroy(s)
+
+
+def test_sliced_options(imt, ctx):
+    """imt_sliced_set_option: process-wide defaults for worlds created later (NULL handle), live options of a world, ranges"""
+    sl = load_sliced()
+    F, lib = imt._ffi, imt.lib
+    assert lib.imt_sliced_set_option(None, F.SLICED_OPT_COMM_STREAMS, 5) == F.ERR["RANGE"]
+    assert lib.imt_sliced_set_option(None, 99, 0) == F.ERR["ARG"]
+    try:
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_APPLY_STREAMS, 1) == 0
+        t = sl.SlicedTree(imt, 0, 32, 1 << 10, 32, 1)
+        info = t.info()
+        assert info["queue_map"][2] == info["queue_map"][0] and info["placement"] in ("as created", "repaired"), info
+        assert lib.imt_sliced_set_option(t.h, F.SLICED_OPT_APPLY_STREAMS, 0) == F.ERR["ARG"]      # decides which streams exist
+        t.set_option(F.SLICED_OPT_PREP_STREAM, 1)
+        t.set_option(F.SLICED_OPT_WATCHDOG_MS, 5000)
+        vals = oracle_lib.synth_values(64, 0x494D5479)
+        want, want_root = reference_run(imt, ctx, 32, 1 << 10, vals, 32)
+        arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+        for r in range(2):
+            t.step(arr[r * 32:(r + 1) * 32])
+        t.flush()
+        assert t.trees[0].root() == want_root
+        assert "global tick" in t.dump() and "everything issued is complete" in t.dump()
+        t.close()
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_APPLY_STREAMS, 0) == 0
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_VERIFY_QUEUES, 0) == 0
+        t = sl.SlicedTree(imt, 0, 32, 1 << 10, 32, 1)
+        assert t.info()["placement"] == "unverified" and t.info()["queue_map"][0] == [-1] * 4
+        t.close()
+    finally:
+        lib.imt_sliced_set_option(None, F.SLICED_OPT_APPLY_STREAMS, 0)
+        lib.imt_sliced_set_option(None, F.SLICED_OPT_VERIFY_QUEUES, 1)
+
+
+def test_transport_is_one_world_at_a_time(imt, ctx):
+    """a transport serves one world at a time and cannot be destroyed under it"""
+    sl = load_sliced()
+    F, lib = imt._ffi, imt.lib
+    t = sl.SlicedTree(imt, 0, 32, 1 << 10, 16, 1)
+    c2 = imt.Context(0)
+    tree2 = imt.IndexedTree(c2, 32, 1 << 10)
+    h = ctypes.c_void_p()
+    arr = (ctypes.c_void_p * 1)(tree2.h)
+    assert lib.imt_sliced_create(arr, 1, 1, 0, t.tp, 16, 0, ctypes.byref(h)) == F.ERR["ARG"]
+    assert lib.imt_transport_destroy(t.tp) == F.ERR["ARG"]           # still in use
+    send = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    assert lib.imt_transport_all_gather(t.tp, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(send.data_ptr()), 32, None) == F.ERR["ARG"]
+    tree2.close()
+    c2.close()
+    t.close()
+
+
+def test_watchdog_reports_where_the_world_stands(imt, ctx, capfd):
+    """A collective that does not complete (here: a custom transport whose fifth all-gather holds its stream for ~3 s,
+    standing in for a peer that died) must not hang the caller for good: the host wait inside the next imt_sliced_step
+    runs into the world's watchdog (set to 400 ms), the call returns IMT_ERR_TIMEOUT well before the collective ends,
+    stderr and imt_sliced_last_error name the round slot, the first tick that has not completed and the pending
+    collective with its channel, and the world refuses to go on."""
+    import time
+    sl = load_sliced()
+    F, lib = imt._ffi, imt.lib
+    hip = _hip()
+    dev = torch.device("cuda", 0)
+    # torch.cuda._sleep counts cycles of SOME clock: measure which
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.cuda._sleep(20_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    clock_hz = 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
+    calls = []
+
+    def all_gather(self_, channel, buffer, send, recv, nbytes, stream):
+        calls.append((channel, buffer))
+        if len(calls) == 5:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                torch.cuda._sleep(int(3.0 * clock_hz))
+        return 0 if hip.hipMemcpyAsync(recv, send, nbytes, 3, stream) == 0 else F.ERR["HIP"]
+
+    ops = F.TransportOps(None, F.TransportOps.ALL_GATHER(all_gather), F.TransportOps.DESTROY())
+    tp = ctypes.c_void_p()
+    assert lib.imt_transport_custom_create(ctypes.byref(ops), ctypes.byref(tp)) == 0
+    depth, cap, batch = 32, 1 << 12, 64
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, 1, transport=tp)
+    t.set_option(F.SLICED_OPT_WATCHDOG_MS, 400)
+    vals = oracle_lib.synth_values(8 * batch, 0x494D5471)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    code = None
+    for r in range(8):
+        try:
+            t.step(arr[r * batch:(r + 1) * batch])
+        except imt.ImtError as e:
+            code, msg = e.code, str(e)
+            break
+    dt = time.perf_counter() - t0
+    assert code == F.ERR["TIMEOUT"], code
+    assert dt < 2.0, f"the call came back after {dt:.2f} s"
+    err = capfd.readouterr().err
+    for text in (msg, err):
+        assert "imt_sliced_step failed with -13" in text and "collective PENDING on channel 0" in text, text
+        assert "first incomplete: unit tick" in text and "global tick" in text
+    with pytest.raises(imt.ImtError) as ei:
+        t.step(arr[:batch])
+    assert ei.value.code == F.ERR["INTERNAL"] and "cannot go on" in str(ei.value)
+    with pytest.raises(imt.ImtError):
+        t.flush()
+    torch.cuda.synchronize()            # the long collective ends; everything drains
+    t.close()
+
+
+def _poison_worker(rank, world, port, q):
+    """rank 1 stops after two steps (a rank that died, as far as rank 0 can tell) but keeps its buffers mapped"""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import imt_amd
+    F, lib = imt_amd._ffi, imt_amd.lib
+    sl = load_sliced()
+    boot = imt_amd.Context(0)
+    nb = int(lib.imt_transport_ipc_blob_bytes())
+    mine = torch.zeros(nb, dtype=torch.uint8)
+    tp = ctypes.c_void_p()
+    assert lib.imt_transport_ipc_create(boot.h, world, rank, P_DEPTH, P_BATCH, 0, ctypes.byref(tp), ctypes.c_void_p(mine.data_ptr())) == 0
+    assert lib.imt_transport_set_option(tp, F.TRANSPORT_OPT_HOST_POLL, 0) == 0         # the GPUs poll: the form real multi-GPU runs use
+    assert lib.imt_transport_set_option(tp, F.TRANSPORT_OPT_TIMEOUT_MS, 300) == 0
+    assert lib.imt_transport_set_option(tp, F.TRANSPORT_OPT_TIMEOUT_MS, 0) == F.ERR["RANGE"]
+    allb = torch.zeros(world * nb, dtype=torch.uint8)
+    dist.all_gather_into_tensor(allb, mine)
+    assert lib.imt_transport_ipc_connect(tp, ctypes.c_void_p(allb.data_ptr())) == 0
+    tree = sl.SlicedTree(imt_amd, 0, P_DEPTH, 1 << 13, P_BATCH, world, first_rank=rank, n_local=1, transport=tp)
+    vals = oracle_lib.synth_values(world * P_BATCH * 8, 0x494D5472)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    gb = world * P_BATCH
+    out = dict(rank=rank, code=None, at=None, msg="")
+    t0 = time.perf_counter()
+    try:
+        for r in range(8):
+            if rank == 1 and r == 2:
+                break
+            tree.step(arr[r * gb:(r + 1) * gb])
+            out["steps_ok"] = r + 1
+        if rank == 0:
+            tree.flush()
+    except imt_amd.ImtError as e:
+        out.update(code=e.code, at=time.perf_counter() - t0, msg=str(e)[:600])
+        try:
+            tree.step(arr[:gb])
+        except imt_amd.ImtError as e2:
+            out["again"] = e2.code
+    q.put(out)
+    dist.barrier()              # rank 1 keeps its exported buffers until rank 0 has reported
+    os._exit(0)                 # no teardown of a world whose peer is gone
+
+
+def test_a_vanished_peer_poisons_the_world_instead_of_corrupting_it(imt):
+    """GPU-polled IPC transport, two processes, rank 1 stops stepping: rank 0's wait kernels give up after the
+    transport's time limit (300 ms here), the sticky error word makes every copy / acknowledgement / apply behind them a
+    no-op on the device (csrc/imt_flags.hip), and the host hears about it at its NEXT imt_sliced_step -- not only at
+    flush -- as IMT_ERR_INTERNAL; the world then refuses further steps."""
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [mpctx.Process(target=_poison_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {o["rank"]: o for o in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    F = imt._ffi
+    r0 = got[0]
+    assert r0["code"] == F.ERR["INTERNAL"], r0
+    assert "did not arrive" in r0["msg"] and r0["at"] < 30.0, r0
+    assert r0.get("steps_ok", 0) < 8 and r0.get("again") == F.ERR["INTERNAL"], r0
+    assert got[1]["code"] is None and got[1]["steps_ok"] == 2

@@ -21,7 +21,7 @@ def c_class(t):
     base = t.rsplit(" ", 1)[0] if " " in t else t           # drop the parameter name
     base = base.replace("const ", "").strip()
     return {"int": "i32", "unsigned": "u32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64",
-            "void": "void", "uint8_t": "u8", "int32_t": "i32"}[base]
+            "void": "void", "uint8_t": "u8", "int32_t": "i32", "long": "long"}[base]
 
 
 def rust_class(t):
@@ -29,7 +29,7 @@ def rust_class(t):
     if t.startswith("*"):
         return "ptr"
     return {"c_int": "i32", "c_uint": "u32", "u32": "u32", "u64": "u64", "usize": "usize", "c_double": "f64", "u8": "u8",
-            "i32": "i32"}[t]
+            "i32": "i32", "c_long": "long"}[t]
 
 
 def c_prototypes():
@@ -191,9 +191,9 @@ def test_sliced_rs_uses_the_ffi_as_declared():
     for decl in body.split(";"):
         decl = decl.strip()
         if decl:
-            c_fields += [x.strip() for x in decl.split(" ", 1)[1].split(",")]
+            c_fields += [re.sub(r"\[.*", "", x.strip()) for x in decl.split(" ", 1)[1].split(",")]
     r = re.search(r"pub struct imt_sliced_info \{(.*?)\}", FFI, flags=re.S)
-    assert c_fields == re.findall(r"pub ([a-z_]+):", r.group(1)) and len(c_fields) == 13
+    assert c_fields == re.findall(r"pub ([a-z_]+):", r.group(1)) and len(c_fields) == 18
     m = re.search(r"typedef struct imt_transport_ops \{(.*?)\} imt_transport_ops;", HDR, flags=re.S)
     assert re.findall(r"\(\*([a-z_]+)\)", m.group(1)) == ["all_gather", "destroy"]
     r = re.search(r"pub struct imt_transport_ops \{(.*?)\n\}", FFI, flags=re.S)

@@ -1,0 +1,45 @@
+#!/bin/bash
+# GPU sessions of round 5 (one 1-GPU box per call): pick the part with $1.  Steps are chained with && and carry their own
+# timeouts; everything lands under gpurun_out/r05/ (summaries are copied into profiles/ by hand or tools/collect_profiles.sh).
+#   qmap      tools/microbench/queue_map_probe: which streams share a hardware queue (the runtime's placement rule)
+#   traces    rocprofv3 kernel traces of the sliced mode (1 / 2 / 4 in-process replicas, one emulated rank of 8), compacted
+#   tests     the whole -m gpu suite
+#   bench     bench.py N = 1 + rocprofv3 kernel stats + PMC passes for k_sweep
+#   multi     2- and 4-process rehearsals of bench.py --gpus N on the one GPU (IPC transport) + in-process replicas
+#   emu       one rank of an N = 2 / 4 / 8 single-list run alone on the GPU over a modelled transport
+#   aux       latency tables, secondary rates, kernel resources
+set -o pipefail
+O=gpurun_out/r05
+mkdir -p $O
+export TMPDIR=/tmp
+part=${1:-tests}
+trace() {   # trace NAME -- cmd...: kernel trace of cmd, compacted to $O/NAME_trace.csv.gz
+  local name=$1; shift; shift
+  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/raw_$name -o $name -- "$@" > $O/${name}_under_rocprof.txt 2> $O/${name}_rocprof.err &&
+  python tools/trace_compact.py $O/raw_$name $O/${name}_trace.csv.gz && rm -rf $O/raw_$name
+}
+case $part in
+qmap)
+  timeout -k 10 120 tools/microbench/queue_map_probe > $O/queue_map_probe.txt 2>&1 && echo "probe ok" &&
+  ( export GPU_MAX_HW_QUEUES=8; timeout -k 10 120 tools/microbench/queue_map_probe > $O/queue_map_probe_8q.txt 2>&1 ) && echo "probe (8 queues) ok"
+  cat $O/queue_map_probe.txt ;;
+traces)
+  timeout -k 10 400 python tools/sliced_costs.py 1 2 4 > $O/sliced_costs.txt 2>&1 && echo "costs ok" &&
+  trace sliced1 -- python3 tools/sliced_costs.py 1 && echo "trace 1 ok" &&
+  trace sliced2 -- python3 tools/sliced_costs.py 2 && echo "trace 2 ok" &&
+  trace sliced4 -- python3 tools/sliced_costs.py 4 && echo "trace 4 ok" &&
+  ( export EMU_RANKS=first EMU_LINK_GBPS=0 EMU_ROUNDS=12; trace emu8 -- python3 tools/rank_emulation.py 8 ) && echo "trace emu8 ok" &&
+  ( export EMU_RANKS=first EMU_ROUNDS=12; timeout -k 10 300 python tools/rank_emulation.py 8 > $O/rank_emulation_first8.txt 2>&1 ) && echo "emu ok"
+  echo "traces part exit $?"; cat $O/sliced_costs.txt ;;
+prio)   # where the collectives' streams live: the normal pool (sharing the rounds' four queues) or the low-priority pool (four queues of their own)
+  for cfg in "0 comm" "1 comm" "1 round" "0 round" "1 side"; do set -- $cfg
+    ( export EMU_RANKS=first EMU_ROUNDS=12 IMT_SLICED_COMM_PRIO=$1 IMT_SLICED_PREP_STREAM=$2; echo "== comm prio $1, prep on $2"; timeout -k 10 200 python tools/rank_emulation.py 8 4 2>&1 | grep "^N =" | cut -c1-120 ) >> $O/emu_comm_prio.txt || break
+  done
+  cat $O/emu_comm_prio.txt ;;
+tests)
+  timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "pytest rc=$?" >> $O/tests.log
+  tail -4 $O/tests.log ;;
+esac
+find $O -name "*kernel_trace.csv" -size +8M -delete
+find $O -name "*.db" -delete
+du -sh $O
