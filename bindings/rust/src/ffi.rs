@@ -155,6 +155,7 @@ pub const IMT_SLICED_OPT_PREP_STREAM: c_int = 5;
 pub const IMT_SLICED_OPT_VERIFY_QUEUES: c_int = 6;
 pub const IMT_SLICED_OPT_WATCHDOG_MS: c_int = 7;
 pub const IMT_SLICED_OPT_TIMING: c_int = 8;
+pub const IMT_SLICED_OPT_COMM_PLACEMENT: c_int = 9;
 pub const IMT_SLICED_PLACEMENT_UNVERIFIED: c_int = 0;
 pub const IMT_SLICED_PLACEMENT_AS_CREATED: c_int = 1;
 pub const IMT_SLICED_PLACEMENT_REPAIRED: c_int = 2;

@@ -590,6 +590,16 @@ int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first
                                               (default 120 000; 0 = never): IMT_ERR_TIMEOUT, the world's state on stderr and in
                                               imt_sliced_last_error, the world refuses to go on */
 #define IMT_SLICED_OPT_TIMING 8            /* 1: host time per phase on stderr at imt_sliced_destroy */
+#define IMT_SLICED_OPT_COMM_PLACEMENT 9    /* which hardware queues the collectives' streams are put on (by creating streams until one
+                                              lands there): 0 (default) queues of their OWN -- none a round stream is on, none shared --
+                                              if the runtime has any to give, else the queue of their round's stream; 1 their round's
+                                              queue; 2 their own or IMT_SLICED_PLACEMENT_DEGRADED.  On its round's queue a collective
+                                              holds up the round's next unit until the slowest rank has packed (every tick a barrier
+                                              across ranks); on its own it overlaps the next `lag` units.  The runtime has four queues
+                                              per priority level unless the host's environment says GPU_MAX_HW_QUEUES=8 (or more)
+                                              BEFORE the first HIP call: set it for multi-GPU runs (bench.py does), or give the
+                                              collectives' streams IMT_SLICED_OPT_COMM_PRIORITY 1 (the low-priority pool: 2 - 6 %
+                                              slower per rank on one GPU than normal priority) */
 int imt_sliced_set_option(imt_sliced *w, int option, long value);
 /* One step: vals = ALL world x n values of the step in insertion order (device pointer, identical contents on every
  * rank; format per flags), outs[k] = where local rank k's witnesses of ITS slice (insertions [rank * n, (rank + 1) * n)
@@ -629,9 +639,11 @@ typedef struct imt_sliced_info {
                                                         peers: the host-polled IPC transport) */
     /* Where the world's streams sit (local rank 0's; measured at creation, IMT_SLICED_OPT_VERIFY_QUEUES).  The HIP runtime
      * multiplexes streams onto a few in-order hardware queues per priority level; wanted: the four round streams on four
-     * different queues, slot i's collective (and apply) stream on round stream i's queue.  queue_map[k][slot] = hardware
+     * different queues, slot i's collective stream on a queue of its own (IMT_SLICED_OPT_COMM_PLACEMENT; else on round stream
+     * i's), its apply stream on round stream i's queue.  queue_map[k][slot] = hardware
      * queue class (0 .. hw_queues - 1, numbered by first use) of slot's round (k = 0), collective (1) and apply (2)
-     * stream; -1 = no such stream or not measured, -2 = a queue none of the round streams is on (another priority pool). */
+     * stream; 4 + slot = a queue of its own in the rounds' pool (shared with no round stream and no other helper), -2 = a
+     * queue of its own in another priority pool, -1 = no such stream or not measured. */
     int placement;                   /* IMT_SLICED_PLACEMENT_* */
     int hw_queues;                   /* distinct hardware queues under the four round streams (4 wanted) */
     int comm_streams;                /* streams carrying collectives after placement (0: the round streams do) */

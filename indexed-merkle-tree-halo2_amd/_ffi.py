@@ -215,7 +215,7 @@ OPT_COOP_MAX_EVENTS = 1
 SEG_GLUE, SEG_HASH = 0, 1
 SLICED_ROUNDS = 4
 (SLICED_OPT_COMM_STREAMS, SLICED_OPT_COMM_PRIORITY, SLICED_OPT_ROUND_PRIORITIES, SLICED_OPT_APPLY_STREAMS, SLICED_OPT_PREP_STREAM,
- SLICED_OPT_VERIFY_QUEUES, SLICED_OPT_WATCHDOG_MS, SLICED_OPT_TIMING) = range(1, 9)
+ SLICED_OPT_VERIFY_QUEUES, SLICED_OPT_WATCHDOG_MS, SLICED_OPT_TIMING, SLICED_OPT_COMM_PLACEMENT) = range(1, 10)
 TRANSPORT_OPT_TIMEOUT_MS, TRANSPORT_OPT_HOST_POLL = 1, 2
 PLACEMENT = {0: "unverified", 1: "as created", 2: "repaired", 3: "degraded"}
 RCCL_UNIQUE_ID_BYTES = 128

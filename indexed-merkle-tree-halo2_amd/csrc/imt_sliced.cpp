@@ -41,6 +41,7 @@ struct SlicedOptions {
     long round_priorities = 0;       // 0 equal, 1 = the batch pipeline's one normal + three high
     long apply_streams = 0;          // 1 = the other ranks' write-backs are applied on a stream of their own per round slot
     long prep_stream = 0;            // where a step's preparation is enqueued: 0 the slot's collective stream, 1 its round stream, 2 the tree's side stream
+    long comm_placement = 0;         // 0: the collectives' streams on queues of their own if there are any, else on their rounds'; 1: on their rounds'; 2: own or fail
     long verify_queues = 1;          // probe the stream -> hardware queue placement at creation and repair it
     long watchdog_ms = 120000;       // host waits inside imt_sliced_* give up after this long (0 = never)
     long timing = 0;                 // print the host's time per phase at destroy
@@ -58,6 +59,7 @@ int option_field(SlicedOptions& o, int option, long** field) {
         case IMT_SLICED_OPT_VERIFY_QUEUES: *field = &o.verify_queues; return IMT_OK;
         case IMT_SLICED_OPT_WATCHDOG_MS: *field = &o.watchdog_ms; return IMT_OK;
         case IMT_SLICED_OPT_TIMING: *field = &o.timing; return IMT_OK;
+        case IMT_SLICED_OPT_COMM_PLACEMENT: *field = &o.comm_placement; return IMT_OK;
     }
     return IMT_ERR_ARG;
 }
@@ -66,6 +68,7 @@ bool option_value_ok(int option, long v) {
         case IMT_SLICED_OPT_COMM_STREAMS: return v >= 0 && v <= ROUNDS;
         case IMT_SLICED_OPT_COMM_PRIORITY: return v >= -8 && v <= 8;
         case IMT_SLICED_OPT_PREP_STREAM: return v >= 0 && v <= 2;
+        case IMT_SLICED_OPT_COMM_PLACEMENT: return v >= 0 && v <= 2;
         case IMT_SLICED_OPT_WATCHDOG_MS: return v >= 0;
         default: return v == 0 || v == 1;
     }
@@ -93,6 +96,7 @@ SlicedOptions effective_options() {
     env("IMT_SLICED_VERIFY_QUEUES", IMT_SLICED_OPT_VERIFY_QUEUES, o);
     env("IMT_SLICED_WATCHDOG_MS", IMT_SLICED_OPT_WATCHDOG_MS, o);
     env("IMT_SLICED_TIMING", IMT_SLICED_OPT_TIMING, o);
+    env("IMT_SLICED_COMM_PLACEMENT", IMT_SLICED_OPT_COMM_PLACEMENT, o);
     return o;
 }
 
@@ -173,6 +177,7 @@ struct HipBackend : Backend {
     // what the probe found (imt_sliced_info): hardware queue class of every stream, -1 = no such stream / not probed
     int q_round[ROUNDS], q_comm[ROUNDS], q_apply[ROUNDS];
     int n_queues = 0, placement = IMT_SLICED_PLACEMENT_UNVERIFIED, streams_recreated = 0;
+    bool comm_own_queues = false;
     std::string placement_note;
 
     explicit HipBackend(imt_itree* t) : tree(t), ctx(imt_itree_ctx(t)) {
@@ -296,8 +301,8 @@ struct HipBackend : Backend {
                 if (behind[j]) { *out = j; break; }
             return IMT_OK;
         };
-        auto settle = [&](hipStream_t* arr, int count, int prio, bool want_partner, int* qmap) -> int {
-            // want_partner: arr[i] on round stream i's queue; else: on no round stream's queue
+        auto settle = [&](hipStream_t* arr, int count, int prio, bool want_partner, int* qmap, int max_new) -> int {
+            // want_partner: arr[i] on round stream i's queue; else: each on a queue of its own that no round stream is on
             std::vector<hipStream_t> pool(arr, arr + count);
             std::vector<hipStream_t> placed(count, nullptr);
             int created = 0;
@@ -310,7 +315,7 @@ struct HipBackend : Backend {
                     s = pool.back();
                     pool.pop_back();
                 } else {
-                    if (created >= 3 * ROUNDS) break;
+                    if (created >= max_new) break;
                     int r = new_stream(&s, prio);
                     if (r) return r;
                     created++;
@@ -324,7 +329,17 @@ struct HipBackend : Backend {
                     for (int i = 0; i < count && slot < 0; i++)
                         if (!placed[i] && p >= 0 && cls[i] == cls[p]) slot = i;
                 } else if (p < 0) {
-                    for (int i = 0; i < count && slot < 0; i++)
+                    // a queue none of the round streams is on -- and none of the helpers placed so far either: two slots'
+                    // collectives on one queue would wait for each other's peers
+                    std::vector<hipStream_t> others;
+                    for (int i = 0; i < count; i++)
+                        if (placed[i]) others.push_back(placed[i]);
+                    bool shared = false;
+                    if (!others.empty()) {
+                        if ((r = pr.run(s, others.data(), (int)others.size(), behind))) return r;
+                        for (size_t j = 0; j < others.size(); j++) shared = shared || behind[j];
+                    }
+                    for (int i = 0; i < count && slot < 0 && !shared; i++)
                         if (!placed[i]) slot = i;
                 }
                 if (slot >= 0) placed[slot] = s;
@@ -332,27 +347,52 @@ struct HipBackend : Backend {
             }
             bool all = true;
             for (int i = 0; i < count; i++) all = all && placed[i];
-            if (!all) {
+            if (!all) {         // could not be had: give the caller `count` live streams back (whichever), the rest are spares
+                std::vector<hipStream_t> have;
                 for (int i = 0; i < count; i++)
-                    if (placed[i]) spare.push_back(placed[i]);
-                for (int i = 0; i < count; i++) arr[i] = nullptr;
-                return 1;           // could not be had
+                    if (placed[i]) have.push_back(placed[i]);
+                while ((int)have.size() < count && !pool.empty()) { have.push_back(pool.back()); pool.pop_back(); }
+                while ((int)have.size() < count && !spare.empty()) { have.push_back(spare.back()); spare.pop_back(); }
+                for (int i = 0; i < count; i++) arr[i] = i < (int)have.size() ? have[i] : nullptr;
+                return 1;
             }
             for (int i = 0; i < count; i++) {
                 if (placed[i] != arr[i]) streams_recreated++;
                 arr[i] = placed[i];
-                qmap[i] = want_partner ? cls[i] : -2;
+                qmap[i] = want_partner ? cls[i] : (prio == 0 ? ROUNDS + i : -2);
             }
             return IMT_OK;
         };
         if (n_comm == ROUNDS) {
-            rc = settle(cs, ROUNDS, comm_prio, same_pool, q_comm);
-            if (rc < 0) return rc;
+            // Where the collectives' streams should sit.  A collective holds its hardware queue until every rank's has
+            // started; on its round's queue it therefore holds up the round's NEXT unit until the slowest rank has packed
+            // this tick -- every tick of every round becomes a barrier across ranks, although the schedule consumes a
+            // gather only `lag` ticks later.  On a queue of its own the gather overlaps the next units and a rank may run
+            // up to `lag` ticks ahead of its peers.  The queue model (tests/hwq_model.py, tools/hwq_calibrate.py) prices the
+            // difference at 2 / 4 / 8 GPUs: 5.1 -> 6.0, 9.5 -> 11.4, 20.6 -> 22.0 M insertions/s.  Queues of their own exist
+            // when the pool the rounds use has more than four queues (GPU_MAX_HW_QUEUES=8 in the host's environment:
+            // bench.py sets it for N > 1) or when the collectives' streams have another priority (IMT_SLICED_OPT_COMM_PRIORITY
+            // = 1: the low-priority pool; measured 2 - 6 % slower per rank than normal priority).  IMT_SLICED_OPT_COMM_PLACEMENT:
+            // 0 = queues of their own if they can be had, else their rounds' queues; 1 = their rounds' queues; 2 = own or fail.
+            rc = 1;
+            bool own = false;
+            if (!same_pool || opt.comm_placement != 1) {
+                rc = settle(cs, ROUNDS, comm_prio, false, q_comm, same_pool ? 2 * ROUNDS : 3 * ROUNDS);
+                if (rc < 0) return rc;
+                own = rc == IMT_OK;
+            }
+            if (rc == 1 && same_pool && opt.comm_placement != 2) {
+                rc = settle(cs, ROUNDS, comm_prio, true, q_comm, 3 * ROUNDS);
+                if (rc < 0) return rc;
+            }
+            comm_own_queues = own;
             if (rc == 1) {
                 // the collectives go to the rounds' own streams: the same queue order, no second stream to misplace
+                for (int i = 0; i < ROUNDS; i++)
+                    if (cs[i]) { spare.push_back(cs[i]); cs[i] = nullptr; }
                 n_comm = 0;
                 ok = false;
-                placement_note = "the collectives' streams could not be placed on their rounds' hardware queues: collectives are enqueued on the round streams";
+                placement_note = "the collectives' streams could be placed neither on queues of their own nor on their rounds' hardware queues: collectives are enqueued on the round streams";
             }
         } else if (n_comm > 0) {
             // fewer streams than round slots (a transport with fewer channels): every stream serves several slots, there is
@@ -364,9 +404,11 @@ struct HipBackend : Backend {
             }
         }
         if (aps[0]) {
-            rc = settle(aps, ROUNDS, 0, true, q_apply);
+            rc = settle(aps, ROUNDS, 0, true, q_apply, 3 * ROUNDS);
             if (rc < 0) return rc;
             if (rc == 1) {
+                for (int i = 0; i < ROUNDS; i++)
+                    if (aps[i]) { spare.push_back(aps[i]); aps[i] = nullptr; }
                 ok = false;
                 placement_note += (placement_note.empty() ? "" : "; ");
                 placement_note += "the apply streams could not be placed: applies run on the round streams";
@@ -941,9 +983,14 @@ struct imt_sliced {
     imt_transport* tp = nullptr;
     size_t max_slice = 0;
     SlicedOptions opt;
-    std::string error;
+    std::string error, first_failure;
     double host_issue_ms = 0, host_wait_ms = 0;      // wall time inside imt_sliced_step: issuing / waiting for the GPU
     bool trees_marked = false;
+
+    int refuse(const char* call) {
+        error = std::string(call) + ": this world failed earlier and cannot go on -- destroy it and reload the trees from a checkpoint.  The first failure:\n" + first_failure;
+        return IMT_ERR_INTERNAL;
+    }
 
     void mark(bool busy) {
         for (auto& be : bes)
@@ -965,6 +1012,7 @@ struct imt_sliced {
             char tail[160];
             snprintf(tail, sizeof tail, "  host inside imt_sliced_step so far: %.1f ms issuing, %.1f ms waiting\n", host_issue_ms, host_wait_ms);
             error += tail;
+            if (first_failure.empty()) first_failure = error;
             fputs(error.c_str(), stderr);
             fflush(stderr);
         }
@@ -1164,7 +1212,7 @@ int imt_sliced_step(imt_sliced* s, const void* vals, size_t n, const imt_insert_
     if (n == 0 || n > s->max_slice) return c0->fail(IMT_ERR_RANGE, "a step is world x n values with 0 < n <= max_slice = %zu", s->max_slice);
     if (flags & ~(IMT_FMT_MASK | IMT_SIB_ITEM_MAJOR | IMT_INPUTS_READY | IMT_DEVICE_PTRS))
         return c0->fail(IMT_ERR_ARG, "imt_sliced_step takes IMT_FMT_*, IMT_SIB_ITEM_MAJOR, IMT_INPUTS_READY");
-    if (s->w.poisoned) return c0->fail(IMT_ERR_INTERNAL, "this world failed earlier (imt_sliced_last_error) and cannot go on: destroy it and reload the trees from a checkpoint");
+    if (s->w.poisoned) return s->refuse("imt_sliced_step");
     (void)s->tp->impl->take_wait_ms();                     // waits of imt_sliced_wait / _flush are not this call's
     for (auto& be : s->bes) (void)imt_itree_take_wait_ms(be->tree);
     const auto t0 = std::chrono::steady_clock::now();
@@ -1184,15 +1232,15 @@ int imt_sliced_step(imt_sliced* s, const void* vals, size_t n, const imt_insert_
 
 int imt_sliced_wait(imt_sliced* s, int local_rank, uint64_t round) {
     if (!s || local_rank < 0) return IMT_ERR_ARG;
+    if (s->w.poisoned) return s->refuse("imt_sliced_wait");
     int rc = s->w.wait_round((size_t)local_rank, round);
     if (rc == IMT_ERR_TIMEOUT) s->w.poisoned = true;
-    if (rc == IMT_ERR_INTERNAL && s->w.poisoned && s->bes[0]->ctx->last_error.empty())
-        s->bes[0]->ctx->fail(rc, "this world failed earlier and cannot go on");
     return s->failed(rc, "imt_sliced_wait");
 }
 
 int imt_sliced_flush(imt_sliced* s) {
     if (!s) return IMT_ERR_ARG;
+    if (s->w.poisoned) return s->refuse("imt_sliced_flush");
     int rc = s->w.flush();
     if (rc == IMT_ERR_TIMEOUT) s->w.poisoned = true;
     if (rc == IMT_OK) s->mark(false);      // every replica holds the whole step now

@@ -487,7 +487,11 @@ struct World {
             // the global tick, and with it the start of the next round and the order in which collectives of
             // different rounds are issued, must be the same function of the call sequence on every rank (a world of
             // one process per rank calls wait with the same round everywhere, never with the same rank).
+#if IMT_SCHED_MUTATION == 7      // (the rule until round 5: this rank's own last compute tick -- the global tick then depends on the rank)
+            if ((rc = run_ticks(std::max<uint64_t>(T, start_of(R) + sc.units + (uint64_t)rk->rank * sc.lag)))) return poison(rc);
+#else
             if ((rc = run_ticks(std::max<uint64_t>(T, start_of(R) + (uint64_t)sc.gathers)))) return poison(rc);
+#endif
             rc = rk->be->event_sync(rk->done_ev[R % ROUNDS]);
         }
         return rc ? rc : rk->tp->poll_error();

@@ -44,11 +44,12 @@ CB_TYPES = [
     ("copy", ctypes.CFUNCTYPE(c_int, c_int, c_int, c_size_t, c_int, c_int, c_size_t, c_size_t, c_int)),
     ("tree_size", ctypes.CFUNCTYPE(c_u64, c_int)),
     ("unit_bytes", ctypes.CFUNCTYPE(c_size_t, c_int, c_u64, c_size_t, c_uint)),
-    ("prepare", ctypes.CFUNCTYPE(c_int, c_int, c_size_t, c_size_t, c_size_t, P(c_int))),
+    ("prepare", ctypes.CFUNCTYPE(c_int, c_int, c_size_t, c_size_t, c_size_t, c_int, P(c_int))),
     ("unit", ctypes.CFUNCTYPE(c_int, c_int, c_int, c_uint, c_int, c_int)),
     ("apply_gathered", ctypes.CFUNCTYPE(c_int, c_int, c_int, c_size_t, c_int, P(c_u64), P(c_u64), P(ctypes.c_int32), c_int)),
     ("sync", ctypes.CFUNCTYPE(c_int, c_int)),
     ("all_gather", ctypes.CFUNCTYPE(c_int, c_int, c_int, c_int, c_int, c_int, c_size_t, c_int)),
+    ("fence", ctypes.CFUNCTYPE(c_int, c_int, c_int, c_int, c_int)),
 ]
 
 
@@ -70,6 +71,12 @@ def load():
     lib.sym_world_collectives.restype = c_u64
     lib.sym_world_collectives.argtypes = [ctypes.c_void_p]
     lib.sym_world_destroy.argtypes = [ctypes.c_void_p]
+    lib.sym_world_create_channels.restype = ctypes.c_void_p
+    lib.sym_world_create_channels.argtypes = [P(Callbacks), c_int, c_int, c_size_t, c_int, c_int, c_size_t, c_int]
+    lib.sym_set_layout.argtypes = [c_int, c_int]
+    lib.sym_set_layout.restype = None
+    lib.sym_world_tick.restype = c_u64
+    lib.sym_world_tick.argtypes = [ctypes.c_void_p]
     return lib
 
 
@@ -224,7 +231,10 @@ class SymWorld:
         # like the product: smaller payloads higher up (here: the full 32 bytes for the lower half of the units, 24 above)
         return self.WORDS * 8 if q <= (self.depth + 1) // 2 else 24
 
-    def _prepare(self, rank, n_before, n_own, n_after, slice_out):
+    def _fence(self, rank, slot, ring, stream):
+        return 0
+
+    def _prepare(self, rank, n_before, n_own, n_after, slot, slice_out):
         rp = self.reps[rank]
         assert n_before == rank * n_own and n_own == self.batch and n_after == (self.world - 1 - rank) * n_own
         k = (rp.size - 1 + n_before) // self.batch

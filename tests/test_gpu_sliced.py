@@ -672,6 +672,31 @@ def test_queue_placement_is_measured_and_repaired(imt, ctx, dummies):
         hip.hipStreamDestroy(s)
 
 
+def test_collectives_get_queues_of_their_own_when_the_runtime_has_eight(imt, ctx):
+    """IMT_SLICED_OPT_COMM_PLACEMENT's default: with GPU_MAX_HW_QUEUES=8 in the host's environment (read when the HIP runtime
+    starts, hence a process of its own) the collectives' streams end up on four queues that no round stream and no other
+    helper is on -- a gather then overlaps its round's next units instead of holding them up until the slowest rank has
+    packed; with the runtime's default of four queues they sit on their rounds' queues (the test above).  Same tree either
+    way."""
+    import json
+    import subprocess
+    roots = []
+    for nq, dummies in ((8, 0), (8, 3), (None, 1)):
+        env = dict(os.environ)
+        env.pop("GPU_MAX_HW_QUEUES", None)
+        if nq:
+            env["GPU_MAX_HW_QUEUES"] = str(nq)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "placement_check.py"), str(dummies)], env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        o = json.loads(r.stdout.strip().splitlines()[-1])
+        qm = o["queue_map"]
+        assert o["placement"] in ("as created", "repaired") and o["hw_queues"] == 4 and sorted(qm[0]) == [0, 1, 2, 3], o
+        assert qm[1] == ([4, 5, 6, 7] if nq else qm[0]), o
+        roots.append(o["root"])
+    assert len(set(roots)) == 1
+
+
 def test_sliced_options(imt, ctx):
     """imt_sliced_set_option: process-wide defaults for worlds created later (NULL handle), live options of a world, ranges"""
     sl = load_sliced()
@@ -803,14 +828,14 @@ def _poison_worker(rank, world, port, q):
     allb = torch.zeros(world * nb, dtype=torch.uint8)
     dist.all_gather_into_tensor(allb, mine)
     assert lib.imt_transport_ipc_connect(tp, ctypes.c_void_p(allb.data_ptr())) == 0
-    tree = sl.SlicedTree(imt_amd, 0, P_DEPTH, 1 << 13, P_BATCH, world, first_rank=rank, n_local=1, transport=tp)
-    vals = oracle_lib.synth_values(world * P_BATCH * 8, 0x494D5472)
+    tree = sl.SlicedTree(imt_amd, 0, P_DEPTH, 1 << 14, P_BATCH, world, first_rank=rank, n_local=1, transport=tp)
+    vals = oracle_lib.synth_values(world * P_BATCH * 14, 0x494D5472)
     arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
     gb = world * P_BATCH
     out = dict(rank=rank, code=None, at=None, msg="")
     t0 = time.perf_counter()
     try:
-        for r in range(8):
+        for r in range(14):     # (a step five rounds later waits for the stuck round's plan set: the error is seen by then)
             if rank == 1 and r == 2:
                 break
             tree.step(arr[r * gb:(r + 1) * gb])
@@ -850,5 +875,5 @@ def test_a_vanished_peer_poisons_the_world_instead_of_corrupting_it(imt):
     r0 = got[0]
     assert r0["code"] == F.ERR["INTERNAL"], r0
     assert "did not arrive" in r0["msg"] and r0["at"] < 30.0, r0
-    assert r0.get("steps_ok", 0) < 8 and r0.get("again") == F.ERR["INTERNAL"], r0
+    assert r0.get("steps_ok", 0) < 14 and r0.get("again") == F.ERR["INTERNAL"], r0
     assert got[1]["code"] is None and got[1]["steps_ok"] == 2

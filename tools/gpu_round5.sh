@@ -36,6 +36,22 @@ prio)   # where the collectives' streams live: the normal pool (sharing the roun
     ( export EMU_RANKS=first EMU_ROUNDS=12 IMT_SLICED_COMM_PRIO=$1 IMT_SLICED_PREP_STREAM=$2; echo "== comm prio $1, prep on $2"; timeout -k 10 200 python tools/rank_emulation.py 8 4 2>&1 | grep "^N =" | cut -c1-120 ) >> $O/emu_comm_prio.txt || break
   done
   cat $O/emu_comm_prio.txt ;;
+couple)  # the only experiment with REAL peer coupling a one-GPU box offers: 2 (and 4) processes over IPC, the collectives'
+         # streams on their rounds' queues (default) or in the low-priority pool (queues of their own), host- and GPU-polled
+  for cfg in "0 1" "1 1" "0 0" "1 0"; do set -- $cfg
+    ( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo IMT_SLICED_COMM_PRIO=$1 IMT_IPC_HOST_POLL=$2 IMT_BENCH_MODE=single-list
+      echo "== comm prio $1 (1 = low-priority pool: own queues), IPC host poll $2"
+      timeout -k 10 300 python3 bench.py --gpus 2 --steps 16 --warmup 4 --no-cpu-baseline 2> $O/couple_$1_$2.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N=2 value', d['value'], 'verified', d['verified'], d['modes']['single_list'].get('schedule',{}).get('queue_map'))" ) >> $O/couple.txt 2>&1 || break
+  done
+  cat $O/couple.txt ;;
+own8)   # the collectives' streams on queues of their own in the NORMAL pool (GPU_MAX_HW_QUEUES=8): one emulated rank, and the
+        # placement with 0 .. 3 streams created before the world
+  ( export GPU_MAX_HW_QUEUES=8 EMU_RANKS="first last" EMU_ROUNDS=12; echo "== GPU_MAX_HW_QUEUES=8, collectives on queues of their own"; timeout -k 10 400 python tools/rank_emulation.py 8 4 2 2>&1 | grep "^N =" | cut -c1-130 ) > $O/emu_own_queues.txt &&
+  ( export GPU_MAX_HW_QUEUES=8 IMT_SLICED_COMM_PLACEMENT=1 EMU_RANKS="first" EMU_ROUNDS=12; echo "== GPU_MAX_HW_QUEUES=8, collectives on their rounds' queues"; timeout -k 10 400 python tools/rank_emulation.py 8 4 2>&1 | grep "^N =" | cut -c1-130 ) >> $O/emu_own_queues.txt &&
+  ( export EMU_RANKS="first last" EMU_ROUNDS=12; echo "== four queues (the runtime's default): collectives on their rounds' queues"; timeout -k 10 400 python tools/rank_emulation.py 8 4 2 2>&1 | grep "^N =" | cut -c1-130 ) >> $O/emu_own_queues.txt &&
+  for d in 0 1 2 3; do timeout -k 10 120 python tools/placement_check.py $d 65536 12 >> $O/placement_rates.txt 2>/dev/null || break; done &&
+  for d in 0 1 2 3; do ( export GPU_MAX_HW_QUEUES=8; timeout -k 10 120 python tools/placement_check.py $d 65536 12 >> $O/placement_rates.txt 2>/dev/null ) || break; done
+  cat $O/emu_own_queues.txt $O/placement_rates.txt ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "pytest rc=$?" >> $O/tests.log
   tail -4 $O/tests.log ;;

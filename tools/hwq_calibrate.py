@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""The hardware-queue model of the sliced schedule (tests/hwq_model.py) against what one MI355X measured, and then asked
+about eight.  CPU only.
+
+  python tools/hwq_calibrate.py            the table: model vs measurement for every calibration point, then N = 2 / 4 / 8
+                                           distributed with the link model and per-rank skew
+  python tools/hwq_calibrate.py --fit      re-fit the free parameters (coordinate descent on the calibration points)
+
+Calibration points (profiles/r05_sliced_costs.txt, profiles/r05_rank_emulation.txt; same box, same build):
+  in-process replicas on one GPU, N = 1 / 2 / 4     tools/sliced_costs.py           (all ranks share the process's four queues)
+  one rank of N = 4 / 8 alone on the GPU             tools/rank_emulation.py         (free collectives / 40 us + bytes / 48 GB/s)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hwq_model as M  # noqa: E402
+import sliced_sim  # noqa: E402
+
+B, DEPTH = 1 << 16, 32
+MEASURED = {            # M insertions/s (per rank for "emu"), gpurun_out/r05 of this round: calls 1 and 2
+    ("inproc", 1): 3.052, ("inproc", 2): 3.021, ("inproc", 4): 2.965,
+    ("emu", 8, 0, "free"): 2.872, ("emu", 8, 0, "links"): 2.741,          # means of 2.862 / 2.883 and 2.730 / 2.753
+    ("emu", 4, 0, "free"): 3.008, ("emu", 4, 0, "links"): 2.984,
+}
+lib = sliced_sim.load()
+
+
+def timed_rate(progs, sh, qmap, costs, world, per_rank_insertions, rounds, **kw):
+    T = M.Timed(progs, sh, qmap, costs, world, **kw)
+    T.run()
+    t = [st[-1] - st[-2] for st in T.sync_times if len(st) >= 2]
+    return rounds * per_rank_insertions / (max(t) * 1e-6) / 1e6, T
+
+
+def script(rounds, warm):
+    return [("step",)] * warm + [("flush",)] + [("step",)] * rounds + [("flush",)]
+
+
+def inproc(world, costs, rounds=12, warm=2):
+    progs, sh, _ = M.record(lib, world, DEPTH, B, script(rounds, warm), hosts="one", comm_streams=4, costs=costs)
+    r, T = timed_rate(progs, sh, M.QueueMap(one_device=True), costs, world, world * B, rounds)
+    return r
+
+
+def emu(world, rank, links, costs, rounds=12, warm=4, **qm):
+    c = costs
+    if not links:
+        c = type("C", (type(costs),), {})()
+        c.__dict__.update(costs.__dict__)
+        c.link_gbps = 0.0
+    progs, sh, _ = M.record(lib, world, DEPTH, B, script(rounds, warm), transport="emu", comm_streams=4, costs=c, only_ranks=[rank])
+    r, T = timed_rate(progs, sh, M.QueueMap(**qm), c, world, B, rounds)
+    return r
+
+
+def distributed(world, costs, rounds=12, warm=4, speed=None, host_speed=None, transport="rccl", **qm):
+    progs, sh, _ = M.record(lib, world, DEPTH, B, script(rounds, warm), transport=transport, comm_streams=4, costs=costs)
+    r, T = timed_rate(progs, sh, M.QueueMap(**qm), costs, world, world * B, rounds, speed=speed, host_speed=host_speed)
+    return r, T
+
+
+def points(costs):
+    out = {}
+    for w in (1, 2, 4):
+        out[("inproc", w)] = inproc(w, costs)
+    for w in (8, 4):
+        out[("emu", w, 0, "free")] = emu(w, 0, False, costs)
+        out[("emu", w, 0, "links")] = emu(w, 0, True, costs)
+    return out
+
+
+def show(costs):
+    t0 = time.time()
+    got = points(costs)
+    worst = 0.0
+    print("calibration point                         model   measured   model / measured")
+    for k, m in MEASURED.items():
+        g = got[k]
+        worst = max(worst, abs(g / m - 1))
+        print(f"  {str(k):38s} {g:6.3f}   {m:6.3f}     {g / m:6.3f}")
+    print(f"worst deviation {worst * 100:.1f} %   ({time.time() - t0:.0f} s)")
+    return got, worst
+
+
+def main():
+    costs = M.Costs()
+    show(costs)
+    if "--fit" in sys.argv:
+        return
+    print("\none process per GPU, RCCL semantics (a collective holds its queue until every rank's has reached the head of its own),")
+    print(f"links {costs.link_latency_us:.0f} us + bytes / {costs.link_gbps:.0f} GB/s per peer; placement as imt_sliced_create verifies it")
+    for w in (2, 4, 8):
+        r, T = distributed(w, costs)
+        print(f"  N = {w}: {r:6.2f} M insertions/s  ({r / w:.3f} per GPU, {r / w / MEASURED[('inproc', 1)]:.3f} of the one-GPU figure)")
+    import random
+    rng = random.Random(5)
+    for skew in (0.015, 0.03):
+        speed = {g: 1.0 + rng.uniform(-skew, skew) for g in range(8)}
+        r, T = distributed(8, costs, speed=speed, host_speed={g: 1.0 + rng.uniform(-0.2, 0.2) for g in range(8)})
+        print(f"  N = 8 with per-GPU speeds within +-{skew * 100:.1f} % and host speeds within +-20 %: {r:6.2f} M insertions/s "
+              f"(slowest GPU {min(speed.values()):.3f})")
+    for name, qm in (("collectives' streams on the NEXT slot's queue (comm_shift = 1)", dict(comm_shift=1)),
+                     ("ranks with different rotations of the queue map", dict(rot={g: g % 4 for g in range(8)})),
+                     ("collectives' streams on four queues of their own", dict(comm_own_queues=True))):
+        r, T = distributed(8, costs, **qm)
+        print(f"  N = 8, {name}: {r:6.2f} M insertions/s")
+
+
+if __name__ == "__main__":
+    main()
