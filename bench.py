@@ -679,6 +679,13 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1 or args.gpus & (args.gpus - 1):
         raise SystemExit("--gpus must be a power of two (slices / subtrees of equal size)")
+    if args.gpus > 1:
+        # Eight hardware queues per priority level instead of the runtime's four (read when the HIP runtime starts: nothing
+        # has touched the GPU yet, here or in the ranks this process may launch): imt_sliced_create then finds queues of
+        # their OWN for the collectives' streams, so that a gather overlaps its round's next units instead of holding them
+        # up until the slowest rank has packed (include/imt.h: IMT_SLICED_OPT_COMM_PLACEMENT).  The placement
+        # found is on the line: schedule.queue_map.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     env = Env(args)

@@ -84,6 +84,10 @@ class Costs:
     sigma = (1.0, 0.55, 0.25)
     small_counts_us = 100.0
     tail = 0.15
+    # more than four hardware queues in use on a device (GPU_MAX_HW_QUEUES=8: the collectives' streams on queues of their
+    # own): the hash kernels run this much slower -- measured, not explained (one emulated rank, eight queues against four:
+    # profiles/r05_emu_own_queues.txt; round 4 saw the same with the streams merely spread over eight queues)
+    many_queues = 0.96
     # the link model of a collective between different GPUs: latency + bytes per peer / rate (one xGMI link per peer)
     link_latency_us, link_gbps = 40.0, 48.0
 
@@ -631,6 +635,8 @@ class Timed:
                     s += 1
         sp = self.speed.get(dev, 1.0)
         c = self.c
+        if len(self.dev_q.get(dev, ())) > 4 and not self.qmap.shared_gpu and not self.qmap.one_device:
+            sp *= c.many_queues
         rho = (c.rho_busy if s else c.rho)
         return rho[min(h, len(rho) - 1)] * sp, c.sigma[min(h, len(c.sigma) - 1)] * sp, h
 

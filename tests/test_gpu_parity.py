@@ -837,6 +837,18 @@ def test_c_example_runs(imt):
     for args in (["2", "ipc", "6", "256"], ["3", "ipc", "5", "100"], ["1", "rccl", "4", "128"]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0 and "replicas equal" in r.stdout and "root " in r.stdout, (args, r.stdout + r.stderr)
+    # examples/subtree_procs_demo.c: north_star's layout (placed subtrees by leaf-index range, ONE all-gather of subtree roots
+    # per step through the library's own communicators: imt_transport_all_gather) from a plain-C multi-process host: every
+    # witness lifted to depth 32 passes insert_leaf's constraints (imt_insert_witness_batch), the roots of all ranks and
+    # steps form one chain -- two and four ranks sharing this GPU over IPC, one rank over RCCL
+    exe = os.path.join(root, "examples", "subtree_procs_demo")
+    r = subprocess.run(["gcc", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "examples", "subtree_procs_demo.c"), "-L", csrc, "-limt_hip", "-Wl,-rpath," + csrc, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for args in (["2", "ipc", "5", "192"], ["4", "ipc", "4", "96"], ["1", "rccl", "3", "128"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "the roots form one chain" in r.stdout and "witnesses lifted to depth 32" in r.stdout, (args, r.stdout + r.stderr)
 
 
 def test_c_abi_survives_null_and_nonsense_arguments(imt):

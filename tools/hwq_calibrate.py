@@ -24,6 +24,10 @@ MEASURED = {            # M insertions/s (per rank for "emu"), gpurun_out/r05 of
     ("inproc", 1): 3.052, ("inproc", 2): 3.021, ("inproc", 4): 2.965,
     ("emu", 8, 0, "free"): 2.872, ("emu", 8, 0, "links"): 2.741,          # means of 2.862 / 2.883 and 2.730 / 2.753
     ("emu", 4, 0, "free"): 3.008, ("emu", 4, 0, "links"): 2.984,
+    # the collectives' streams on queues of their own (GPU_MAX_HW_QUEUES=8; profiles/r05_emu_own_queues.txt)
+    ("emu-own", 8, 0, "free"): 2.732, ("emu-own", 8, 0, "links"): 2.724,
+    ("emu-own", 4, 0, "free"): 2.927, ("emu-own", 4, 0, "links"): 2.902,
+    ("emu-own", 2, 0, "free"): 2.951, ("emu-own", 2, 0, "links"): 2.955,
 }
 lib = sliced_sim.load()
 
@@ -69,6 +73,9 @@ def points(costs):
     for w in (8, 4):
         out[("emu", w, 0, "free")] = emu(w, 0, False, costs)
         out[("emu", w, 0, "links")] = emu(w, 0, True, costs)
+    for w in (8, 4, 2):
+        out[("emu-own", w, 0, "free")] = emu(w, 0, False, costs, comm_own_queues=True)
+        out[("emu-own", w, 0, "links")] = emu(w, 0, True, costs, comm_own_queues=True)
     return out
 
 
@@ -92,19 +99,21 @@ def main():
         return
     print("\none process per GPU, RCCL semantics (a collective holds its queue until every rank's has reached the head of its own),")
     print(f"links {costs.link_latency_us:.0f} us + bytes / {costs.link_gbps:.0f} GB/s per peer; placement as imt_sliced_create verifies it")
-    for w in (2, 4, 8):
-        r, T = distributed(w, costs)
-        print(f"  N = {w}: {r:6.2f} M insertions/s  ({r / w:.3f} per GPU, {r / w / MEASURED[('inproc', 1)]:.3f} of the one-GPU figure)")
+    for own in (True, False):
+        print("  collectives' streams on queues of their own (the library's placement when the runtime has eight queues):" if own else
+              "  collectives' streams on their rounds' queues (four queues):")
+        for w in (2, 4, 8):
+            r, T = distributed(w, costs, comm_own_queues=own)
+            print(f"    N = {w}: {r:6.2f} M insertions/s  ({r / w:.3f} per GPU, {r / w / MEASURED[('inproc', 1)]:.3f} of the one-GPU figure)")
     import random
     rng = random.Random(5)
     for skew in (0.015, 0.03):
         speed = {g: 1.0 + rng.uniform(-skew, skew) for g in range(8)}
-        r, T = distributed(8, costs, speed=speed, host_speed={g: 1.0 + rng.uniform(-0.2, 0.2) for g in range(8)})
+        r, T = distributed(8, costs, speed=speed, host_speed={g: 1.0 + rng.uniform(-0.2, 0.2) for g in range(8)}, comm_own_queues=True)
         print(f"  N = 8 with per-GPU speeds within +-{skew * 100:.1f} % and host speeds within +-20 %: {r:6.2f} M insertions/s "
               f"(slowest GPU {min(speed.values()):.3f})")
-    for name, qm in (("collectives' streams on the NEXT slot's queue (comm_shift = 1)", dict(comm_shift=1)),
-                     ("ranks with different rotations of the queue map", dict(rot={g: g % 4 for g in range(8)})),
-                     ("collectives' streams on four queues of their own", dict(comm_own_queues=True))):
+    for name, qm in (("four queues, collectives' streams on the NEXT slot's queue (comm_shift = 1)", dict(comm_shift=1)),
+                     ("four queues, ranks with different rotations of the queue map", dict(rot={g: g % 4 for g in range(8)}))):
         r, T = distributed(8, costs, **qm)
         print(f"  N = 8, {name}: {r:6.2f} M insertions/s")
 
