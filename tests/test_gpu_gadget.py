@@ -208,3 +208,89 @@ def test_the_two_traces_cover_the_whole_advice_column_of_insert_leaf(imt, ctx, o
             roots.append(out)
     assert roots[-1] == imt.to_int(res["new_root"][i])             # :313
     assert roots[1 + depth - 1] == imt.to_int(res["old_root"][i])  # the low leaf's path ends in the old root :196-204
+
+
+def test_limbs_logic_at_the_references_size(imt, ctx):
+    """The reference's own test of the limb formula, test_limbs_logic (/root/reference/src/indexed_merkle_tree.rs:597-630), at
+    its own size: 10^7 random pairs -- here through the GPU kernels that stand for the circuit's is_less_than: the f3 trace
+    kernel's result row (imt_less_than_trace_batch: lt_out and the column's output cell) and the relation checker's range
+    predicates (k_non_membership_pred through imt_non_membership_batch: low.val < new, new < next), against 256-bit integer
+    comparison (numpy on four 64-bit limbs; exact Python integers on a sample of every chunk).  The reference draws
+    254-bit integers; field elements have to be < p, so a draw >= p is halved.  A twentieth of the pairs share their high
+    limb, a hundredth are equal, and a hundredth have a_r == b_q -- the one case where the formula AS TYPED in the
+    reference's test (`are_lsb_eq = a_r == b_q`, :615) differs from the circuit's (`is_equal(a_r, b_r)`, :112): the
+    kernels follow the circuit."""
+    import ctypes
+    import torch
+    F, lib = imt._ffi, imt.lib
+    total, chunk = 10_000_000, 1_000_000
+    rows = int(lib.imt_less_than_trace_rows(18))
+    _, _, out_row = ctx.less_than_layout(18)
+    dev = torch.device("cuda", 0)
+    p_limbs = np.array([(P >> (64 * k)) & (2 ** 64 - 1) for k in range(4)], dtype=np.uint64)
+
+    def lt256(x, y):                     # [n, 4] little-endian uint64 limbs
+        res = np.zeros(x.shape[0], bool)
+        decided = np.zeros(x.shape[0], bool)
+        for k in (3, 2, 1, 0):
+            res |= ~decided & (x[:, k] < y[:, k])
+            decided |= x[:, k] != y[:, k]
+        return res
+
+    def draw(rng, n):
+        v = rng.integers(0, 2 ** 64, size=(n, 4), dtype=np.uint64)
+        v[:, 3] >>= np.uint64(2)                                          # 254 bits
+        big = ~lt256(v, np.broadcast_to(p_limbs, v.shape))                # >= p: halve (a 253-bit value is < p)
+        carry = (v[big, 1:] & np.uint64(1)) << np.uint64(63)
+        v[big] >>= np.uint64(1)
+        v[big, :3] |= carry
+        return v
+
+    trace = torch.empty((rows, chunk, 32), dtype=torch.uint8, device=dev)
+    lt = torch.empty(chunk, dtype=torch.uint8, device=dev)
+    fail = torch.empty(chunk, dtype=torch.uint8, device=dev)
+    leaf = torch.zeros((chunk, 3, 32), dtype=torch.uint8, device=dev)
+    zeros64 = torch.zeros(chunk, dtype=torch.int64, device=dev)
+    zeros8 = torch.zeros(chunk, dtype=torch.uint8, device=dev)
+    root = torch.zeros(32, dtype=torch.uint8, device=dev)
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    rng = np.random.default_rng(597)
+    seen = dict(lt=0, eq=0, same_high=0, typo=0)
+    for c in range(total // chunk):
+        a, b = draw(rng, chunk), draw(rng, chunk)
+        k = np.arange(chunk)
+        s = k % 20 == 7
+        b[s, 2:] = a[s, 2:]                                               # same high limb: the low limbs decide
+        s = k % 100 == 13
+        b[s] = a[s]
+        s = k % 100 == 57
+        a[s, :2] = b[s, 2:]                                               # a_r == b_q
+        want = lt256(a, b)
+        ab, bb = np.ascontiguousarray(a).view(np.uint8).reshape(chunk, 32), np.ascontiguousarray(b).view(np.uint8).reshape(chunk, 32)
+        ta, tb = torch.from_numpy(ab).to(dev), torch.from_numpy(bb).to(dev)
+        ctx._check(lib.imt_less_than_trace_batch(ctx.h, P_(ta), P_(tb), chunk, 18, P_(trace), P_(lt), F.DEVICE_PTRS))
+        # the relation checker: low leaf {val = a, next_val = a}, candidate b, not the largest:
+        #   IMT_F_LOW_LT_NEW clear <=> a < b;  IMT_F_RANGE_PRED clear <=> b < a
+        leaf[:, 0] = ta
+        leaf[:, 1] = ta
+        fail.zero_()
+        ctx._check(lib.imt_non_membership_batch(ctx.h, P_(root), P_(leaf), P_(zeros64), None, 0, P_(tb), P_(zeros8), chunk, P_(fail), None,
+                                                F.DEVICE_PTRS))
+        ctx.sync()
+        got = lt.cpu().numpy().astype(bool)
+        cell = trace[out_row].cpu().numpy()
+        f = fail.cpu().numpy()
+        assert (got == want).all(), f"chunk {c}: lt_out differs at {np.nonzero(got != want)[0][:5]}"
+        assert (cell[:, 0].astype(bool) == want).all() and not cell[:, 1:].any()          # the column's output cell is the bit
+        assert (((f & F.F_LOW_LT_NEW) == 0) == want).all()
+        assert (((f & F.F_RANGE_PRED) == 0) == lt256(b, a)).all()
+        # exact integers on a sample, boundary classes included
+        for j in list(range(0, chunk, 97))[:3000] + [7, 13, 57, 107, 113, 157]:
+            x, y = int.from_bytes(ab[j].tobytes(), "little"), int.from_bytes(bb[j].tobytes(), "little")
+            assert x < P and y < P and bool(got[j]) == (x < y)
+        seen["lt"] += int(want.sum())
+        seen["eq"] += int((~want & ~lt256(b, a)).sum())
+        seen["same_high"] += int((a[:, 2:] == b[:, 2:]).all(axis=1).sum())
+        seen["typo"] += int((a[:, :2] == b[:, 2:]).all(axis=1).sum())
+    assert seen["eq"] >= total // 100 and seen["same_high"] >= total // 20 and seen["typo"] >= total // 100
+    assert 0.4 * total < seen["lt"] < 0.6 * total

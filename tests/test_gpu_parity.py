@@ -1303,6 +1303,36 @@ def test_config3_non_membership_2pow20_properties(imt, ctx):
     assert (fail & imt._ffi.F_LOW_LT_NEW).all()
 
 
+def test_config3_mixed_batch_2pow20_against_the_oracle_digest(imt, ctx):
+    """BASELINE config 3 at its full size AGAINST THE ORACLE, item by item: 2^20 verify_non_inclusion items against the
+    config-2 tree, a mixed batch (tests/golden/config3_mix.py: honest ones, members shown with their own leaf or their
+    predecessor, zero, a wrong is_largest, a forged sibling, a wrong path position, a changed preimage).  The CPU oracle's
+    fail mask and recomputed root of every item were computed in the build container
+    (tests/golden/make_config3_digest.py, ~35 M CPU hashes) and committed as digests; so were the honest witnesses
+    (low index, preimage, is_largest, all 32 siblings of all 2^20 items), which pins imt_itree_non_membership_witness at
+    this size too.  /root/reference/src/indexed_merkle_tree.rs:127-229."""
+    import hashlib
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import config3_mix as C
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_oracle_digest.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    t = imt.IndexedTree(ctx, C.DEPTH, 1 << 17)
+    t.insert_batch(oracle_lib.synth_values(C.N_TREE, C.TREE_SEED), proofs=False)
+    root = t.root()
+    assert str(root) == gold["tree_root"]
+    cand = C.candidates()
+    low, leaves, sib, largest = t.non_membership_witness(cand)
+    assert sha(low.astype("<u8")) == gold["sha256_honest_low_index"] and sha(leaves) == gold["sha256_honest_low_leaf"]
+    assert sha(largest) == gold["sha256_honest_is_largest"] and sha(sib) == gold["sha256_honest_siblings"]
+    cls = C.mix(cand, low, leaves, sib, largest)
+    fail, rout = ctx.non_membership(imt.to_bytes(root), leaves, low, sib, C.DEPTH, cand, largest, want_root=True)
+    per_class = {str(c): {f"0x{int(k):02x}": int((fail[cls == c] == k).sum()) for k in np.unique(fail[cls == c])} for c in sorted(set(cls.tolist()))}
+    assert per_class == {c: v["masks"] for c, v in gold["per_class"].items()}, per_class       # says WHICH class differs, if one does
+    assert sha(fail) == gold["sha256_fail_masks"]
+    assert sha(rout) == gold["sha256_recomputed_roots"]
+    t.close()
+
+
 def _load_sharded():
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
