@@ -72,18 +72,25 @@ def lags_around_default(lib, world, depth):
 def test_hw_queue_model_progress(lib, world, depth, transport):
     """every run drains, whatever the queue map and however the hosts and queues are interleaved"""
     rounds = 6 if world < 8 else 5
-    seeds = range(int(os.environ.get("IMT_SIM_SEEDS", "2")))
+    full = os.environ.get("IMT_SIM_FULL") == "1"            # the whole grid (minutes); the default is a covering sample
+    seeds = range(int(os.environ.get("IMT_SIM_SEEDS", "2" if full else "1")))
     runs = 0
+    all_maps = [M.QueueMap(K=4, rot={g: off for g in range(world)}) for off in range(4)]
+    all_maps += [M.QueueMap(K=4, rot={g: g % 4 for g in range(world)}),              # another rotation on every rank
+                 M.QueueMap(K=4, comm_shift=1), M.QueueMap(K=4, comm_shift=2, apply_shift=1),
+                 M.QueueMap(K=2), M.QueueMap(K=1), M.QueueMap(K=4, comm_own_queues=True)]
+    combo = 0
     for lag in lags_around_default(lib, world, depth):
         for apply_streams in (False, True):
             for comm_streams in ((4, 0) if transport == "rccl" else (4,)):
                 sc = script(rounds, waits=(lag is None), flush_at=(2,) if apply_streams else ())
-                maps = [M.QueueMap(K=4, rot={g: off for g in range(world)}) for off in range(4)]
-                maps += [M.QueueMap(K=4, rot={g: g % 4 for g in range(world)}),              # another rotation on every rank
-                         M.QueueMap(K=4, comm_shift=1), M.QueueMap(K=4, comm_shift=2, apply_shift=1),
-                         M.QueueMap(K=2), M.QueueMap(K=1), M.QueueMap(K=4, comm_own_queues=True)]
-                if world == 8 and (lag is not None or apply_streams or comm_streams == 0):
-                    maps = maps[3:6]        # the big world: a sample
+                if full:
+                    maps = all_maps
+                elif lag is None and not apply_streams and comm_streams == 4:
+                    maps = all_maps if world < 8 else all_maps[:1] + all_maps[4:]       # the product's layout: every map
+                else:
+                    maps = [all_maps[(combo + k) % len(all_maps)] for k in (0, 5)]       # the others: two maps each, rotating
+                combo += 1
                 for qm in maps:
                     for seed in seeds:
                         progs, sh, _ = M.record(lib, world, depth, 4, sc, lag=lag, transport=transport, comm_streams=comm_streams,
@@ -92,7 +99,7 @@ def test_hw_queue_model_progress(lib, world, depth, transport):
                         assert n > 0
                         check_replicas(sh, world, rounds, depth)
                         runs += 1
-    assert runs >= 30
+    assert runs >= 12
 
 
 @pytest.mark.parametrize("channels", [1, 2, 3])

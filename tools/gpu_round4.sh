@@ -9,7 +9,7 @@
 #   aux       secondary rates and latency tables, kernel resources
 #   emu       one rank of an N = 2 / 4 / 8 single-list run alone on the GPU over a modelled transport (timing emulation)
 set -o pipefail
-O=gpurun_out/r04
+O=${ROUND_DIR:-gpurun_out/r04}
 mkdir -p $O
 export TMPDIR=/tmp
 part=${1:-tests}

@@ -55,6 +55,8 @@ own8)   # the collectives' streams on queues of their own in the NORMAL pool (GP
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "pytest rc=$?" >> $O/tests.log
   tail -4 $O/tests.log ;;
+bench|multi|scale|soak|emu|aux)   # the standing parts: tools/gpu_round4.sh writing into this round's directory
+  ROUND_DIR=$O bash tools/gpu_round4.sh $part ;;
 esac
 find $O -name "*kernel_trace.csv" -size +8M -delete
 find $O -name "*.db" -delete
