@@ -464,6 +464,38 @@ def bench_subtrees(env):
     return res
 
 
+def stalling_transport(env):
+    """IMT_BENCH_SLICED_TRANSPORT=stall, for the test of what a hang looks like from outside: a caller-supplied transport
+    (imt_transport_custom_create) for a world of one whose all-gather number IMT_BENCH_STALL_AT (40) holds its stream for
+    IMT_BENCH_STALL_S (8) seconds -- a peer that never arrives, as far as the library can tell.  The library's watchdog
+    (IMT_BENCH_LIBRARY_WATCHDOG_S) must turn that into IMT_ERR_TIMEOUT with the world's state on stderr, and the bench
+    into `"value": null` and a non-zero exit status, long before the collective ends."""
+    import ctypes
+    F, lib = env.F, env.lib
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.cuda._sleep(20_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    hz = 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
+    state = dict(calls=0, at=int(os.environ.get("IMT_BENCH_STALL_AT", "40")), s=float(os.environ.get("IMT_BENCH_STALL_S", "8")))
+
+    def all_gather(self_, channel, buffer, send, recv, nbytes, stream):
+        state["calls"] += 1
+        if state["calls"] == state["at"]:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=env.dev)):
+                torch.cuda._sleep(int(state["s"] * hz))
+        return 0 if hip.hipMemcpyAsync(recv, send, nbytes, 3, stream) == 0 else F.ERR["HIP"]
+
+    ops = F.TransportOps(None, F.TransportOps.ALL_GATHER(all_gather), F.TransportOps.DESTROY())
+    env.keep_alive = (ops, all_gather)          # the callback outlives this function
+    tp = ctypes.c_void_p()
+    assert lib.imt_transport_custom_create(ctypes.byref(ops), ctypes.byref(tp)) == 0
+    return tp
+
+
 def bench_single_list(env):
     """N > 1 (or IMT_BENCH_FORCE_DIST): ONE depth-32 tree on all ranks, time-sliced, through the C ABI: imt_sliced_step per
     step; the schedule, its streams / events and the all-gather (RCCL: ncclAllGather called by the library on its own
@@ -487,6 +519,8 @@ def bench_single_list(env):
                                    device=env.dev if env.backend == "nccl" else None)
     elif kind == "ipc":
         tp = sliced.ipc_transport(env.imt, boot, dist, world, rank, DEPTH, BATCH, lag, device=env.dev if env.backend == "nccl" else None)
+    elif kind == "stall":        # TEST ONLY (tests/test_gpu_sharded_procs.py): a collective that stops completing, world 1
+        tp = stalling_transport(env)
     else:
         tp = sliced.local_transport(env.imt)
     tree = sliced.SlicedTree(env.imt, env.local_rank, DEPTH, cap, BATCH, world, first_rank=rank, n_local=1, transport=tp,

@@ -305,3 +305,36 @@ def test_bench_rccl_calls_with_one_rank():
     # the sliced single-list leg issued its all-gathers through RCCL (asynchronous, waited for on the round's stream)
     assert res["modes"]["single_list"]["verified"] is True and res["modes"]["single_list"]["collectives_per_step"] >= 32
     assert res["modes"]["subtrees"]["verified"] is True
+
+
+def test_bench_says_where_a_hung_collective_stands():
+    """What the first real multi-GPU run shows if a collective never completes: bench.py with a
+    transport whose 40th all-gather holds its stream for 8 s (IMT_BENCH_SLICED_TRANSPORT=stall; one rank through the N > 1
+    code path) and the library's watchdog at 1 s -- the single-list leg ends with IMT_ERR_TIMEOUT, stderr carries the
+    world's state (global tick, the first incomplete tick per round slot, the pending collective and its channel), the
+    line has `"value": null` with the reason and the subtree leg's figures under `modes` only, the exit status is
+    non-zero, all of it well inside the 8 s the collective takes."""
+    import json
+    import socket
+    import subprocess
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, IMT_BENCH_FORCE_DIST="1", IMT_BENCH_NO_TRACE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", IMT_BENCH_COLLECTIVE="gloo",
+               IMT_BENCH_DEVICE="0", IMT_BENCH_SLICED_TRANSPORT="stall", IMT_BENCH_LIBRARY_WATCHDOG_S="1", IMT_BENCH_STALL_S="8")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["value"] is None and res["verified"] is False and "ImtError" in res["value_failed"] and "-13" in res["value_failed"]
+    assert res["modes"]["subtrees"]["verified"] is True
+    for text in ("imt_sliced_step failed with -13", "collective PENDING on channel", "first incomplete: unit tick", "global tick"):
+        assert text in r.stderr, r.stderr[-3000:]

@@ -52,6 +52,15 @@ own8)   # the collectives' streams on queues of their own in the NORMAL pool (GP
   for d in 0 1 2 3; do timeout -k 10 120 python tools/placement_check.py $d 65536 12 >> $O/placement_rates.txt 2>/dev/null || break; done &&
   for d in 0 1 2 3; do ( export GPU_MAX_HW_QUEUES=8; timeout -k 10 120 python tools/placement_check.py $d 65536 12 >> $O/placement_rates.txt 2>/dev/null ) || break; done
   cat $O/emu_own_queues.txt $O/placement_rates.txt ;;
+rehearse)  # what changed the multi-process rehearsals on the one GPU since round 4: the watchdog's polling waits, eight queues
+  for cfg in "8 120000" "4 120000" "8 0" "4 0"; do set -- $cfg
+    for n in 2 4; do
+      ( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo GPU_MAX_HW_QUEUES=$1 IMT_BENCH_LIBRARY_WATCHDOG_S=$(( $2 / 1000 )) IMT_BENCH_MODE=single-list
+        echo "== N=$n GPU_MAX_HW_QUEUES=$1 watchdog $2 ms"
+        timeout -k 10 400 python3 bench.py --gpus $n --steps 12 --warmup 3 --no-cpu-baseline 2> $O/rehearse.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['modes']['single_list']; print('value', round(d['value']/1e6,3), 'verified', d['verified'], s['schedule']['queue_map'][1], 'host wait ms', round(s.get('host_wait_ms_per_step',0),1), 'issue', round(s['host_call_ms_per_step'],1))" ) >> $O/rehearse.txt 2>&1 || break 2
+    done
+  done
+  cat $O/rehearse.txt ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "pytest rc=$?" >> $O/tests.log
   tail -4 $O/tests.log ;;
