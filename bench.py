@@ -719,7 +719,10 @@ def main():
         # their OWN for the collectives' streams, so that a gather overlaps its round's next units instead of holding them
         # up until the slowest rank has packed (include/imt.h: IMT_SLICED_OPT_COMM_PLACEMENT).  The placement
         # found is on the line: schedule.queue_map.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # (Not in the one-GPU rehearsal, IMT_BENCH_DEVICE: N processes x 8+ queues oversubscribe ONE device's hardware queue
+        # slots -- 4 processes: 1.3 against 1.7 M/s, profiles/r05_rehearsal_queues.txt.)
+        if "IMT_BENCH_DEVICE" not in os.environ:
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     env = Env(args)
