@@ -180,6 +180,7 @@ struct Rank {
     std::vector<Buffer> send, recv;             // [ROUNDS][ring]
     std::vector<char> send_owned;
     std::vector<size_t> gather_bytes;           // [ROUNDS][ring] bytes per rank of the collective in flight
+    std::vector<char> issued;                   // [ROUNDS][ring] a collective has ever been issued on this buffer pair (diagnostics)
     std::vector<char> pending;                  // [ROUNDS][ring] a collective has been issued and not yet consumed
     std::vector<char> send_busy;                // [ROUNDS][ring] ... and the send buffer not yet known to be free again
     std::vector<Event> tick_ev;                 // [ROUNDS][round_ticks] round stream: the tick's unit is computed and packed
@@ -214,6 +215,7 @@ struct Rank {
         send_owned.assign(nb, 0);
         gather_bytes.assign(nb, payload_cap);
         pending.assign(nb, 0);
+        issued.assign(nb, 0);
         send_busy.assign(nb, 0);
         packed_ev.assign(nb, nullptr);
         gathered_ev.assign(nb, nullptr);
@@ -366,6 +368,7 @@ struct Rank {
                 (rc = tp->all_gather(*this, slot, r, mx, cs)) || (rc = be->record(gathered_ev[i], cs)))
                 return rc;
             pending[i] = 1;
+            issued[i] = 1;
             send_busy[i] = 1;
             tp->collectives++;
             tp->bytes_moved += mx * (uint64_t)world;
@@ -587,9 +590,11 @@ inline std::string describe(World& w) {
             }
             for (int r = 0; r < rk->ring; r++) {
                 const int i = rk->at(slot, r);
-                if (rk->pending[i] && rk->be->event_query(rk->gathered_ev[i]) == 0) {
+                // (the latest collective issued on this buffer pair: complete for everyone, or still waiting for a peer)
+                if (rk->issued[i] && rk->be->event_query(rk->gathered_ev[i]) == 0) {
                     const int ch = rk->tp->channels() > 0 ? slot % rk->tp->channels() : slot;
-                    snprintf(buf, sizeof buf, "    collective PENDING on channel %d, ring buffer %d, %zu bytes per rank\n", ch, r, rk->gather_bytes[i]);
+                    snprintf(buf, sizeof buf, "    collective NOT COMPLETE on channel %d, ring buffer %d, %zu bytes per rank%s\n", ch, r, rk->gather_bytes[i],
+                             rk->pending[i] ? " (its apply not yet issued)" : "");
                     out += buf;
                 }
             }

@@ -336,5 +336,5 @@ def test_bench_says_where_a_hung_collective_stands():
     res = json.loads(lines[0])
     assert res["value"] is None and res["verified"] is False and "ImtError" in res["value_failed"] and "-13" in res["value_failed"]
     assert res["modes"]["subtrees"]["verified"] is True
-    for text in ("imt_sliced_step failed with -13", "collective PENDING on channel", "first incomplete: unit tick", "global tick"):
+    for text in ("failed with -13", "collective NOT COMPLETE on channel", "first incomplete: unit tick", "global tick"):
         assert text in r.stderr, r.stderr[-3000:]

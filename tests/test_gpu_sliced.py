@@ -797,7 +797,7 @@ def test_watchdog_reports_where_the_world_stands(imt, ctx, capfd):
     assert dt < 2.0, f"the call came back after {dt:.2f} s"
     err = capfd.readouterr().err
     for text in (msg, err):
-        assert "imt_sliced_step failed with -13" in text and "collective PENDING on channel 0" in text, text
+        assert "imt_sliced_step failed with -13" in text and "collective NOT COMPLETE on channel 0" in text, text
         assert "first incomplete: unit tick" in text and "global tick" in text
     with pytest.raises(imt.ImtError) as ei:
         t.step(arr[:batch])
