@@ -37,6 +37,27 @@ import os
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 
+
+def _n_gpus_asked():
+    import sys
+    n = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv) and sys.argv[i + 1].isdigit():
+            n = max(n, int(sys.argv[i + 1]))
+        elif a.startswith("--gpus=") and a[7:].isdigit():
+            n = max(n, int(a[7:]))
+    return n
+
+
+# Eight hardware queues per priority level instead of the runtime's four, for runs with one GPU per rank (the runtime
+# reads this when it starts, so it is set here, before `import torch` loads it): imt_sliced_create then finds queues of
+# their OWN for the collectives' streams, so that a gather overlaps its round's next units instead of holding them up
+# until the slowest rank has packed (include/imt.h: IMT_SLICED_OPT_COMM_PLACEMENT).  The placement found is
+# on the line: schedule.queue_map.  Not in the one-GPU rehearsal (IMT_BENCH_DEVICE): N processes x 8+ queues
+# oversubscribe ONE device's hardware queue slots (4 processes: 1.3 against 1.7 M/s, profiles/r05_rehearsal_queues.txt).
+if _n_gpus_asked() > 1 and "IMT_BENCH_DEVICE" not in os.environ:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import argparse  # noqa: E402
 import ctypes  # noqa: E402
 import json  # noqa: E402
@@ -713,16 +734,6 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1 or args.gpus & (args.gpus - 1):
         raise SystemExit("--gpus must be a power of two (slices / subtrees of equal size)")
-    if args.gpus > 1:
-        # Eight hardware queues per priority level instead of the runtime's four (read when the HIP runtime starts: nothing
-        # has touched the GPU yet, here or in the ranks this process may launch): imt_sliced_create then finds queues of
-        # their OWN for the collectives' streams, so that a gather overlaps its round's next units instead of holding them
-        # up until the slowest rank has packed (include/imt.h: IMT_SLICED_OPT_COMM_PLACEMENT).  The placement
-        # found is on the line: schedule.queue_map.
-        # (Not in the one-GPU rehearsal, IMT_BENCH_DEVICE: N processes x 8+ queues oversubscribe ONE device's hardware queue
-        # slots -- 4 processes: 1.3 against 1.7 M/s, profiles/r05_rehearsal_queues.txt.)
-        if "IMT_BENCH_DEVICE" not in os.environ:
-            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     env = Env(args)
