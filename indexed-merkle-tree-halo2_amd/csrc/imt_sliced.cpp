@@ -196,11 +196,10 @@ struct HipBackend : Backend {
         // Measured on one MI355X with in-process replicas (profiles/r04_sliced_stream_matrix.txt): the four round streams
         // at EQUAL priority (2.93-2.95 M insertions/s at world 1, 2.86 at world 2) beat the batch pipeline's scheme of one
         // normal + three high (2.49-2.64 / 2.64-2.83) -- rounds are whole slices apart here, not one level, and a
-        // high-priority round starves the others.  The collectives go to four normal-priority streams of their own, each
-        // on the hardware queue of ITS round's stream (place() below): a gather then stands behind the unit that packed it
-        // (where it has to stand anyway) and in front of nothing but its own round's next unit; on another round's queue
-        // it would stand in front of that round's hash kernels (-5 ... -18 %), and in the low-priority pool (four more
-        // hardware queues, profiles/r05_emu_comm_prio.txt) the rate is 2-4 % lower as well.
+        // high-priority round starves the others.  The collectives go to four normal-priority streams of their own; WHERE
+        // those sit on the runtime's hardware queues is place()'s business (queues of their own if the runtime has any to
+        // give, else their rounds' queues; never another round's queue, where a gather would stand in front of that
+        // round's hash kernels: -5 ... -18 % in round 4's emulation).
         n_comm = (int)o.comm_streams;
         // Round slots that share a channel of the transport (an RCCL communicator) must enqueue on ONE stream, or the
         // communicator would see its collectives in an order the GPU decides
@@ -245,7 +244,11 @@ struct HipBackend : Backend {
         QueueProbe pr;
         int rc = pr.init(ctx);
         if (rc) return rc;
-        std::vector<hipStream_t> spare;
+        struct Spares : std::vector<hipStream_t> {      // streams that landed on the wrong queue: alive until the end (they keep
+            ~Spares() {                                  // the next creation off their queue), destroyed on every way out
+                for (hipStream_t s : *this) hipStreamDestroy(s);
+            }
+        } spare;
         auto drop_spares = [&] {
             for (hipStream_t s : spare) hipStreamDestroy(s);
             spare.clear();
@@ -712,8 +715,8 @@ struct IpcTransport : Transport {
         for (int h = 0; h < world; h++) {
             if (h == rank) continue;
             const IpcBlob& b = all[h];
-            if (b.rank != h || b.world != world || b.ring != ring)
-                return ctx->fail(IMT_ERR_ARG, "IPC blob %d does not describe rank %d of this world", h, h);
+            if (b.rank != h || b.world != world || b.ring != ring || b.arena_bytes != aux_off + IPC_AUX_RING * IPC_AUX_BYTES)
+                return ctx->fail(IMT_ERR_ARG, "IPC blob %d does not describe rank %d of this world (same depth, max_slice and lag on every rank)", h, h);
             if (b.pid == (int)getpid()) return ctx->fail(IMT_ERR_ARG, "the IPC transport joins PROCESSES; ranks of one process use the local transport");
             Peer& p = peers[h];
             IMT_HIP(ctx, hipIpcOpenMemHandle((void**)&p.arena, b.mem, hipIpcMemLazyEnablePeerAccess));
@@ -1218,15 +1221,15 @@ int imt_sliced_step(imt_sliced* s, const void* vals, size_t n, const imt_insert_
     const auto t0 = std::chrono::steady_clock::now();
     const uint64_t rounds_before = s->w.n_rounds;
     const int rc = s->w.step(vals, n, outs, flags, round_out);
+    if (rc == IMT_ERR_TIMEOUT) s->w.poisoned = true;       // the preparation's own wait gave up: its kernels are still in flight
     // the replicas are mid-step as soon as the step has been opened (the index has moved ahead of the stored tree), whether
-    // or not every tick of the period could then be issued
+    // or not every tick of the period could then be issued -- and stay closed to ordinary calls once the world has failed
     if (s->w.n_rounds != rounds_before || s->w.poisoned) s->mark(true);
     const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     double waited = s->tp->impl->take_wait_ms();           // the host-polled transport: waiting for peers' payloads
     for (auto& be : s->bes) waited += imt_itree_take_wait_ms(be->tree);
     s->host_wait_ms += waited;
     s->host_issue_ms += total - waited;
-    if (rc == IMT_ERR_TIMEOUT) s->w.poisoned = true;       // the preparation's own wait gave up: the step is half open
     return s->failed(rc, "imt_sliced_step");
 }
 
