@@ -60,6 +60,32 @@ def emu(world, rank, links, costs, rounds=12, warm=4, **qm):
     return r
 
 
+def emu_variant(world, rank, costs, lag=None, comm_streams=4, apply_streams=False, rounds=12, warm=4, **qm):
+    progs, sh, _ = M.record(lib, world, DEPTH, B, script(rounds, warm), lag=lag, transport="emu", comm_streams=comm_streams,
+                            apply_streams=apply_streams, costs=costs, only_ranks=[rank])
+    r, T = timed_rate(progs, sh, M.QueueMap(**qm), costs, world, B, rounds)
+    return r
+
+
+# Held out: variants of the emulated rank 0 of 8 (modelled links) that round 4 measured (profiles/r04_rank_emulation.txt,
+# "AFTER (precise waits)" block) and that no parameter was set from.  As ratios to the default of the same session.
+HELD_OUT = [("lag 3 instead of 2", dict(lag=3), 2.376 / 2.817),
+            ("collectives on the round streams (comm_streams = 0)", dict(comm_streams=0), 2.839 / 2.817),
+            ("applies on streams of their own", dict(apply_streams=True), 2.708 / 2.817),
+            ("the LAST rank instead of the first (r05: 2.817 / 2.731)", dict(rank=7), 2.817 / 2.731)]
+
+
+def show_held_out(costs):
+    base = emu_variant(8, 0, costs)
+    print("\nheld-out variants of one emulated rank of 8 (ratio to the default; no parameter was fitted to these)")
+    print("  variant                                                    model   measured")
+    for name, kw, meas in HELD_OUT:
+        kw = dict(kw)
+        rank = kw.pop("rank", 0)
+        v = emu_variant(8, rank, costs, **kw)
+        print(f"  {name:58s} {v / base:6.3f}   {meas:6.3f}")
+
+
 def distributed(world, costs, rounds=12, warm=4, speed=None, host_speed=None, transport="rccl", **qm):
     progs, sh, _ = M.record(lib, world, DEPTH, B, script(rounds, warm), transport=transport, comm_streams=4, costs=costs)
     r, T = timed_rate(progs, sh, M.QueueMap(**qm), costs, world, world * B, rounds, speed=speed, host_speed=host_speed)
@@ -95,6 +121,7 @@ def show(costs):
 def main():
     costs = M.Costs()
     show(costs)
+    show_held_out(costs)
     if "--fit" in sys.argv:
         return
     print("\none process per GPU, RCCL semantics (a collective holds its queue until every rank's has reached the head of its own),")
