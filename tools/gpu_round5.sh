@@ -61,6 +61,18 @@ rehearse)  # what changed the multi-process rehearsals on the one GPU since roun
     done
   done
   cat $O/rehearse.txt ;;
+polled4)  # the 4-process GPU-polled rehearsal collapses because a waiting kernel holds a round's queue -- then
+          # it should recover when the collectives' streams have queues of their own (low-priority pool; four queues per process)
+  for cfg in "0 0" "1 0" "0 1" "1 1"; do set -- $cfg
+    ( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo IMT_SLICED_COMM_PRIO=$1 IMT_IPC_HOST_POLL=$2 IMT_BENCH_MODE=single-list
+      echo "== N=4, collectives' streams priority $1 (1 = low-priority pool: queues of their own), IPC host poll $2"
+      timeout -k 10 400 python3 bench.py --gpus 4 --steps 10 --warmup 3 --no-cpu-baseline 2> $O/polled4.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['modes']['single_list']; print('value', round(d['value']/1e6,3), 'verified', d['verified'], s['schedule']['queue_map'][1])" ) >> $O/polled4.txt 2>&1 || break
+  done
+  cat $O/polled4.txt ;;
+longsoak)
+  SOAK_SECONDS=420 timeout -k 10 600 python tools/sliced_soak.py > $O/sliced_soak_420s.txt 2>&1 && echo "sliced soak ok" &&
+  SOAK_SECONDS=240 timeout -k 10 400 python tools/differential_soak.py > $O/differential_soak_240s.txt 2>&1 && echo "soak ok"
+  tail -2 $O/sliced_soak_420s.txt $O/differential_soak_240s.txt ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "pytest rc=$?" >> $O/tests.log
   tail -4 $O/tests.log ;;
