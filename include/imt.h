@@ -585,7 +585,11 @@ int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first
 #define IMT_SLICED_OPT_APPLY_STREAMS 4     /* 1: other ranks' write-backs are applied on a stream of their own per round slot; default 0 */
 #define IMT_SLICED_OPT_PREP_STREAM 5       /* a step's preparation runs on 0 (default) the new round slot's collective stream, 1 its round stream, 2 the tree's side stream */
 #define IMT_SLICED_OPT_VERIFY_QUEUES 6     /* 1 (default): imt_sliced_create measures which of its streams share a hardware queue
-                                              and re-creates streams until the placement below holds; 0: take what the runtime gives */
+                                              and re-creates streams until the placement below holds; 0: take what the runtime gives.
+                                              The measurement (a few milliseconds: a wave spinning 200 us on one stream, GPU-clock
+                                              stamps on the others) wants the process's OTHER streams idle -- work queued elsewhere
+                                              on a shared hardware queue delays a stamp and reads as "shares a queue"; the result is
+                                              then a more cautious placement (imt_sliced_info.placement), never a wrong tree */
 #define IMT_SLICED_OPT_WATCHDOG_MS 7       /* a host wait inside imt_sliced_step / _wait / _flush gives up after this long
                                               (default 120 000; 0 = never): IMT_ERR_TIMEOUT, the world's state on stderr and in
                                               imt_sliced_last_error, the world refuses to go on */
