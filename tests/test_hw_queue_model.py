@@ -87,7 +87,7 @@ def test_hw_queue_model_progress(lib, world, depth, transport):
                 if full:
                     maps = all_maps
                 elif lag is None and not apply_streams and comm_streams == 4:
-                    maps = all_maps if world < 8 else all_maps[:1] + all_maps[4:]       # the product's layout: every map
+                    maps = all_maps if world < 8 else [all_maps[0], all_maps[4], all_maps[5], all_maps[9]]       # the product's layout: every map (a sample at world 8)
                 else:
                     maps = [all_maps[(combo + k) % len(all_maps)] for k in (0, 5)]       # the others: two maps each, rotating
                 combo += 1
