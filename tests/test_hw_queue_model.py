@@ -99,7 +99,7 @@ def test_hw_queue_model_progress(lib, world, depth, transport):
                         assert n > 0
                         check_replicas(sh, world, rounds, depth)
                         runs += 1
-    assert runs >= 12
+    assert runs >= 8
 
 
 @pytest.mark.parametrize("channels", [1, 2, 3])
