@@ -133,6 +133,7 @@ class Recorder:
         assert self.h, "sym_world_create failed"
         self.channels = channels
         self.sched = sliced_sim.Schedule(lib, world, depth + 1, lag)
+        self.worker = []                    # "ipc-host": the program of this rank's worker thread (a second host)
         self.seq = {}                       # (slot, ring) -> collectives issued (IPC counters)
         self.chan_seq = {}                  # channel -> collectives issued
 
@@ -340,6 +341,31 @@ class Recorder:
                 self.kernel(SMALL, rank, stream, c.copy_base_us + real / 1e6 * c.copy_us_per_mb + real / (c.link_gbps * 1e3), fx, f"peer read from rank {h}")
             self.op(Pkt(FSET, rank, stream, key=("copied", rank, slot, ring, n), work=c.fill_us, what="copied"), c.issue_kernel_us)
             rp.send_of[(slot, ring)] = sbuf
+        elif self.transport == "ipc-host":     # host-polled: ranks that share a GPU; nothing on the device waits for a peer
+            n = self.seq.get((slot, ring), 0) + 1
+            self.seq[(slot, ring)] = n
+            self.op(Pkt(FSET, rank, stream, key=("packed", rank, slot, ring, n), work=c.fill_us, what="packed"), c.issue_kernel_us)
+            ready = self.sh.new_token()         # the receive buffer is free once the stream gets here
+            self.op(Pkt(REC, rank, stream, tok=ready, work=c.bar_us, what="receive buffer free"), c.issue_event_us)
+            ws = 3 * ROUNDS + slot              # the worker's stream of this round slot
+            w = self.worker
+            self.prog.append(("setflag", ("job", rank, slot, ring, n)))      # the main thread hands the job to the worker
+            w.append(("waitflags", [("job", rank, slot, ring, n)]))
+            w.append(("waitflags", [("packed", h, slot, ring, n) for h in range(self.world) if h != rank]))
+            w.append(("op", Pkt(WAIT, rank, ws, tok=ready, work=c.bar_us, what="receive buffer free"), c.issue_event_us))
+            for d in range(1, self.world):
+                h = (rank + d) % self.world
+
+                def fx(h=h):
+                    sb = self.sh.ranks[h].send_of[(slot, ring)]
+                    rbuf[h * words:h * words + min(words, self.WORDS)] = sb[:min(words, self.WORDS)]
+                w.append(("op", Pkt(SMALL, rank, ws, work=c.copy_base_us + real / 1e6 * c.copy_us_per_mb, fx=fx, what=f"peer read from rank {h}"), c.issue_kernel_us))
+            w.append(("op", Pkt(FSET, rank, ws, key=("copied", rank, slot, ring, n), work=c.fill_us, what="copied"), c.issue_kernel_us))
+            done = self.sh.new_token()
+            w.append(("op", Pkt(REC, rank, ws, tok=done, work=c.bar_us, what="gather done"), c.issue_event_us))
+            w.append(("setflag", ("issued", rank, slot, ring, n)))
+            rp.send_of[(slot, ring)] = sbuf
+            rp.done_of[(slot, ring)] = done
         else:                                   # "emu": tools/rank_emulation.py -- a modelled wait, then own payload into every slot
             if c.link_gbps > 0:
                 self.op(Pkt(SLEEP, rank, stream, work=c.link_latency_us + real / (c.link_gbps * 1e3), what="modelled collective"), c.issue_kernel_us + 12.0)
@@ -347,6 +373,14 @@ class Recorder:
                 self.kernel(SMALL, rank, stream, c.copy_base_us + real / 1e6 * c.copy_us_per_mb, None, "slot fill")
 
     def _fence(self, rank, slot, ring, stream):
+        if self.transport == "ipc-host":        # the HOST waits: the worker has enqueued my gather's copies, every peer has copied my payload
+            n = self.seq.get((slot, ring), 0)
+            if n:
+                self.prog.append(("waitflags", [("issued", rank, slot, ring, n)]))
+                self.op(Pkt(WAIT, rank, stream, tok=self.sh.ranks[rank].done_of[(slot, ring)], work=self.costs.bar_us, what="gather done"),
+                        self.costs.issue_event_us)
+                self.prog.append(("waitflags", [("copied", h, slot, ring, n) for h in range(self.world) if h != rank]))
+            return 0
         if self.transport != "ipc":
             return 0
         n = self.seq.get((slot, ring), 0)
@@ -360,7 +394,7 @@ class RankState:
     def __init__(self, depth, batch, world):
         self.units = depth + 1
         self.events, self.buffers, self.slices = {}, {}, {}
-        self.send_of = {}
+        self.send_of, self.done_of = {}, {}
         self.levels = [[] for _ in range(depth)]
         self.computed = []
         self.size, self.next_id = 1, 0
@@ -410,7 +444,7 @@ def record(lib, world, depth, batch, script, lag=None, hosts="per-rank", transpo
                     rec.wait(0 if hosts != "one" else call[1] % world, call[-1])
                 elif call[0] == "flush":
                     rec.flush()
-        progs = [rec.prog for rec in recs]
+        progs = [rec.prog for rec in recs] + [rec.worker for rec in recs if rec.worker]
     finally:
         lib.sym_set_layout(ROUNDS, 1)
     for rec in recs:
@@ -431,10 +465,10 @@ class QueueMap:
         self.shared_gpu = shared_gpu                    # one PROCESS per rank, all on device 0 (the rehearsal): queues per process
 
     def __call__(self, rank, stream):
-        kind, slot = divmod(stream, ROUNDS)
-        shift = (0, self.comm_shift, self.apply_shift)[kind]
+        kind, slot = divmod(stream, ROUNDS)           # 0 round, 1 collective, 2 apply, 3 the host-polled transport's worker
+        shift = (0, self.comm_shift, self.apply_shift, self.comm_shift)[kind]
         q = (slot + shift + self.rot.get(rank, 0)) % self.K
-        if kind == 1 and self.comm_own_queues:
+        if kind in (1, 3) and self.comm_own_queues:
             q += self.K
         if self.shared_gpu:
             return 0, q + 2 * self.K * rank
@@ -471,7 +505,9 @@ def replay_adversarial(progs, sh, qmap, seed=0, world=None, max_steps=50_000_000
             return e[1] in done
         if e[0] == "sync":
             return pending.get(e[1], 0) == 0
-        return True                     # "op", "mark"
+        if e[0] == "waitflags":
+            return all(k in flags for k in e[1])
+        return True                     # "op", "mark", "setflag"
 
     def head(qid):
         lst = queues[qid]
@@ -557,6 +593,8 @@ def replay_adversarial(progs, sh, qmap, seed=0, world=None, max_steps=50_000_000
                     heads[qid] = 0
                 queues[qid].append(p)
                 pending[p.rank] = pending.get(p.rank, 0) + 1
+            elif e[0] == "setflag":
+                flags.add(e[1])
         elif kind == "q":
             run_pkt(head(x), x)
         else:
@@ -605,7 +643,7 @@ class Timed:
         self.dev_wait = {}                      # dev -> [qid] whose head kernel waits for room on the device
         self.done_at = {}                       # token -> time
         self.waiters = {}                       # token -> [("q", qid) | ("h", host)]
-        self.flags, self.flag_waiters = set(), {}
+        self.flags, self.flag_waiters, self.host_flag_waiters = set(), {}, {}
         self.pending, self.sync_waiters = {}, {}
         self.coll = {}                          # key -> {rank: qid}
         self.heap, self.n = [], 0
@@ -780,9 +818,7 @@ class Timed:
                 else:
                     self.at(self.now, "host", x)
         elif p.kind == FSET:
-            self.flags.add(p.key)
-            for q in self.flag_waiters.pop(p.key, ()):
-                self.at(self.now, "unblock", q)
+            self.set_flag(p.key)
         if self.pending[p.rank] == 0:
             for h in self.sync_waiters.pop(p.rank, ()):
                 self.at(self.now, "host", h)
@@ -791,6 +827,13 @@ class Timed:
         # the next packet of the queue: a kernel behind a kernel starts after the launch gap
         self.at(self.now + self.c.gap_us, "head", qid)
         self.reschedule(dev)
+
+    def set_flag(self, key):
+        self.flags.add(key)
+        for q in self.flag_waiters.pop(key, ()):
+            self.at(self.now, "unblock", q)
+        for h in self.host_flag_waiters.pop(key, ()):
+            self.at(self.now + 20.0, "host", h)          # a polling host thread notices within its polling interval
 
     # ---- hosts
     def run_host(self, h):
@@ -818,6 +861,17 @@ class Timed:
                 self.pcs[h] += 1
                 self.sync_times[h].append(max(self.now, self.host_t[h]))
                 continue
+            if e[0] == "setflag":
+                self.pcs[h] += 1
+                self.set_flag(e[1])
+                continue
+            if e[0] == "waitflags":
+                missing = [k for k in e[1] if k not in self.flags]
+                if not missing:
+                    self.pcs[h] += 1
+                    continue
+                self.host_flag_waiters.setdefault(missing[0], []).append(h)
+                return
             if e[0] == "sync":
                 if self.pending.get(e[1], 0) == 0:
                     self.pcs[h] += 1

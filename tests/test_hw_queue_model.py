@@ -1,8 +1,8 @@
 """CPU: the multi-GPU single-list schedule of libimt_hip.so (csrc/imt_sliced_sched.hpp, the code imt_sliced_step runs) on a
 model of the HIP runtime's HARDWARE QUEUES (tests/hwq_model.py): K in-order queues per device shared by all streams of a
 process, event waits that block their whole queue, collectives that hold their queue until every peer's matching
-collective has reached the head of ITS queue (RCCL; the GPU-polled IPC transport's flag waits likewise), one host per
-rank, each advancing on its own.
+collective has reached the head of ITS queue (RCCL; the GPU-polled IPC transport's flag waits likewise; the host-polled
+form with a worker thread per rank), one host per rank, each advancing on its own.
 
  * progress: world 2 / 4 / 8, depth 32 at world 8, the default lag and one more / less, every rotation of the queue map
    (and a different one per rank), the helper streams on their own or on the round streams, collectives' streams moved
@@ -100,6 +100,27 @@ def test_hw_queue_model_progress(lib, world, depth, transport):
                         check_replicas(sh, world, rounds, depth)
                         runs += 1
     assert runs >= 8
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_hw_queue_model_progress_host_polled_and_depth_32(lib, world):
+    """the HOST-polled form of the IPC transport (ranks that share a GPU: a worker thread per rank watches the peers'
+    counters and enqueues each payload's copies; the issuing host waits in the fence for the worker and for the peers'
+    acknowledgements -- hosts wait for hosts, nothing on the device waits for a peer), two hosts per rank; and the
+    other transports at depth 32 for the small worlds"""
+    runs = 0
+    for depth, transports in ((8, ("ipc-host",)), (32, ("ipc-host", "rccl", "ipc"))):
+        for transport in transports:
+            for k, qm in enumerate((M.QueueMap(K=4), M.QueueMap(K=4, rot={g: g % 4 for g in range(world)}), M.QueueMap(K=1),
+                                    M.QueueMap(K=4, comm_own_queues=True), M.QueueMap(K=4, comm_shift=1))):
+                if depth == 32 and k % 2:
+                    continue
+                progs, sh, _ = M.record(lib, world, depth, 4, script(6, waits=True, flush_at=(2,)), transport=transport, real_sizes=False)
+                assert len(progs) == (2 * world if transport == "ipc-host" else world)
+                M.replay_adversarial(progs, sh, qm, seed=17 * runs + world, world=world)
+                check_replicas(sh, world, 6, depth)
+                runs += 1
+    assert runs >= 12
 
 
 @pytest.mark.parametrize("channels", [1, 2, 3])
