@@ -73,6 +73,32 @@ impl SlicedTree {
         unsafe { imt_sliced_get_info(self.w, &mut o) };
         o
     }
+    /// the live options of this world: `IMT_SLICED_OPT_PREP_STREAM`, `_WATCHDOG_MS`, `_TIMING`.  The others decide which
+    /// streams exist and are process-wide defaults for worlds created later: `SlicedTree::set_default_option`.
+    pub fn set_option(&mut self, option: i32, value: i64) -> Result<(), i32> {
+        let rc = unsafe { imt_sliced_set_option(self.w, option, value as std::os::raw::c_long) };
+        if rc == IMT_OK { Ok(()) } else { Err(rc) }
+    }
+    pub fn set_default_option(option: i32, value: i64) -> Result<(), i32> {
+        let rc = unsafe { imt_sliced_set_option(std::ptr::null_mut(), option, value as std::os::raw::c_long) };
+        if rc == IMT_OK { Ok(()) } else { Err(rc) }
+    }
+    /// where the world stands, as text: what an `IMT_ERR_TIMEOUT` writes to stderr (for a host's own watchdog)
+    pub fn dump(&mut self) -> String {
+        let n = unsafe { imt_sliced_dump(self.w, std::ptr::null_mut(), 0) };
+        let mut buf = vec![0u8; n.max(0) as usize + 1];
+        unsafe { imt_sliced_dump(self.w, buf.as_mut_ptr() as *mut std::os::raw::c_char, buf.len()) };
+        let end = buf.iter().position(|&b| b == 0).unwrap_or(buf.len());
+        String::from_utf8_lossy(&buf[..end]).into_owned()
+    }
+    /// the subtree layout's one collective on this transport (32 bytes per rank: the subtree roots), when no world uses it
+    ///
+    /// # Safety
+    /// `send` / `recv` are device-addressable, `recv` holds `world * bytes`.
+    pub unsafe fn all_gather(tp: *mut imt_transport, send: *const c_void, recv: *mut c_void, bytes: usize, stream: *mut c_void) -> Result<(), i32> {
+        let rc = imt_transport_all_gather(tp, send, recv, bytes, stream);
+        if rc == IMT_OK { Ok(()) } else { Err(rc) }
+    }
 }
 
 impl Drop for SlicedTree {
