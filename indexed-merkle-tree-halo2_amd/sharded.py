@@ -133,11 +133,14 @@ class ShardedIndexedTree:
     """step(vals) inserts this rank's batch and finishes -- root exchange + lift -- the PREVIOUS step,
     whose depth-D witnesses it returns; flush() finishes the last one."""
 
-    def __init__(self, backend, depth, world=1, rank=0, dist=None, via_host=False):
+    def __init__(self, backend, depth, world=1, rank=0, dist=None, via_host=False, transport=None):
+        """transport: an imt_transport handle (RCCL or IPC, include/imt.h) -- the root exchange then goes through the
+        LIBRARY's communicators (imt_transport_all_gather: what a host without torch.distributed uses, e.g.
+        examples/subtree_procs_demo.c) instead of `dist`"""
         if world & (world - 1):
             raise ValueError("world size must be a power of two")
         self.backend, self.depth, self.world, self.rank, self.dist = backend, depth, world, rank, dist
-        self.via_host = via_host
+        self.via_host, self.transport = via_host, transport
         self.k = world.bit_length() - 1
         self.sub_height = depth - self.k
         self.pending = None
@@ -173,6 +176,13 @@ class ShardedIndexedTree:
 
     def gather_roots(self, mine):
         """[world, 32]: every rank's subtree root -- the one collective of the path"""
+        if self.transport is not None and self.world > 1:      # the library's own collective, on the backend's stream
+            be = self.backend
+            out = torch.empty((self.world, 32), dtype=torch.uint8, device=mine.device)
+            src = mine.contiguous()
+            be.ctx._check(be.imt.lib.imt_transport_all_gather(self.transport, ctypes.c_void_p(src.data_ptr()),
+                                                              ctypes.c_void_p(out.data_ptr()), 32, None))
+            return out
         if self.dist is None:
             return mine.reshape(1, 32).clone()
         if self.via_host:       # gloo rehearsal: through host memory

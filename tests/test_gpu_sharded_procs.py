@@ -98,7 +98,7 @@ def _sub_vals(rank, world, seed):
     return [v for v in raw if v % world == rank][:SUB_N * SUB_STEPS]
 
 
-def _sub_worker(rank, world, port, depth, q):
+def _sub_worker(rank, world, port, depth, q, library_gather=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -106,7 +106,14 @@ def _sub_worker(rank, world, port, depth, q):
     sharded = _load_sharded()
     k = world.bit_length() - 1
     be = sharded.GpuBackend(imt_amd, 0, depth, world, rank, 64, SUB_N, pipeline=True, nbuf=2)
-    tree = sharded.ShardedIndexedTree(be, depth, world, rank, dist, via_host=True)
+    tp = None
+    if library_gather:      # the root exchange through the library's own communicators (imt_transport_all_gather over IPC);
+        import importlib.util      # gloo only carries the IPC handle blobs
+        spec = importlib.util.spec_from_file_location("imt_sliced", os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "sliced.py"))
+        sl = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sl)
+        tp = sl.ipc_transport(imt_amd, be.ctx, dist, world, rank, depth, 1)
+    tree = sharded.ShardedIndexedTree(be, depth, world, rank, dist, via_host=True, transport=tp)
     vals = _sub_vals(rank, world, 0x494D5450 + depth)
     finished, roots, fails = [], [], []
 
@@ -140,17 +147,21 @@ def _sub_worker(rank, world, port, depth, q):
     nm_fail = be.ctx.non_membership(tree.global_root.cpu().numpy(), leaves, low, sib, depth, imt_amd.to_bytes(cand), largest)
     assert sib.shape == (depth, 16, 32) and not nm_fail.any() and ((low >> (depth - k)) == rank).all()
     q.put((rank, finished, roots, fails))
-    dist.barrier()
+    dist.barrier()              # nobody unmaps what a peer may still read
+    if tp is not None:
+        assert imt_amd.lib.imt_transport_destroy(tp) == 0
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("depth", [8, 32])
-def test_subtree_mode_on_two_ranks(imt, ctx, oracle, depth):
+@pytest.mark.parametrize("depth,library_gather", [(8, False), (32, False), (32, True)])
+def test_subtree_mode_on_two_ranks(imt, ctx, oracle, depth, library_gather):
+    """library_gather: the one collective of the layout through imt_transport_all_gather (the library's IPC transport)
+    instead of torch.distributed -- what sharded.py shares with examples/subtree_procs_demo.c"""
     world = 2
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
-    port = 29800 + (os.getpid() % 1000) + depth
-    procs = [mpctx.Process(target=_sub_worker, args=(r, world, port, depth, q)) for r in range(world)]
+    port = 29800 + (os.getpid() % 1000) + depth + (50 if library_gather else 0)
+    procs = [mpctx.Process(target=_sub_worker, args=(r, world, port, depth, q, library_gather)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda x: x[0])
