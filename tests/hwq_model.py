@@ -45,13 +45,14 @@ KIND_NAME = {REC: "record", WAIT: "wait", HASH: "hash", SMALL: "small", COLL: "c
 
 class Pkt:
     """one packet of a hardware queue"""
-    __slots__ = ("kind", "rank", "stream", "tok", "work", "fx", "key", "what", "left", "started", "t0")
+    __slots__ = ("kind", "rank", "stream", "tok", "work", "fx", "key", "what", "left", "started", "t0", "heavy")
 
     def __init__(self, kind, rank, stream, tok=None, work=0.0, fx=None, key=None, what=""):
         self.kind, self.rank, self.stream, self.tok, self.work, self.fx, self.key, self.what = kind, rank, stream, tok, work, fx, key, what
         self.left = work
         self.started = False
         self.t0 = 0.0
+        self.heavy = False          # a SMALL kernel that takes real capacity from the hash kernels while it runs (a preparation's sorts)
 
     def __repr__(self):
         return f"<{KIND_NAME[self.kind]} {self.what} rank {self.rank} stream {self.stream}>"
@@ -74,20 +75,19 @@ class Costs:
     # The device: `resident_max` hash kernels fit at a time (k_sweep: 2 048 waves of 64 lanes = 2 per SIMD, and the traces
     # show the regime change at two: with two sweeps running a 4-us kernel takes 80 - 300 us, i.e. it waits for wave slots
     # until a sweep retires; a third sweep "runs" for 1.6 - 1.9 ms of which it waits about half).  Resident hash kernels
-    # share the device (rate rho[r] each, r of them resident; rho_busy while a SMALL kernel of at least small_counts_us of
-    # work -- the sorts and merges of a preparation -- runs as well); a SMALL kernel runs at sigma[r].  Whatever reaches the
+    # share the device (rate rho[r] each, r of them resident; rho_busy while a kernel of a step's preparation -- its sorts
+    # and merges -- runs as well); a SMALL kernel runs at sigma[r].  Whatever reaches the
     # head of its queue while the device is full waits, first come first served, until a resident kernel has retired --
     # a SMALL kernel only until one has reached the last `tail` of its work (a retiring kernel's waves end one by one).
     resident_max = 2
     rho = (1.0, 0.95, 0.56)
     rho_busy = (1.0, 0.62, 0.49)
     sigma = (1.0, 0.55, 0.25)
-    small_counts_us = 100.0
     tail = 0.15
     # more than four hardware queues in use on a device (GPU_MAX_HW_QUEUES=8: the collectives' streams on queues of their
     # own): the hash kernels run this much slower -- measured, not explained (one emulated rank, eight queues against four:
     # profiles/r05_emu_own_queues.txt; round 4 saw the same with the streams merely spread over eight queues)
-    many_queues = 0.96
+    many_queues = 0.955
     # the link model of a collective between different GPUs: latency + bytes per peer / rate (one xGMI link per peer)
     link_latency_us, link_gbps = 40.0, 48.0
 
@@ -239,10 +239,14 @@ class Recorder:
         # the step's preparation on the new round slot's collective stream (the product's default), then the host waits for
         # its verdict
         sc = self.costs.scaled(n_own)
-        stream = self.sh.comm_stream(slot)
+        stream = 4 * ROUNDS if self.sh.prep_own_stream else self.sh.comm_stream(slot)
         tok = self.sh.new_token()
         work = (c.prep_us[0] + c.prep_us[1] * (self.world - 1)) * sc
-        self.op(Pkt(SMALL, rank, stream, work=work, what="preparation"), c.issue_kernel_us * c.prep_kernels)
+        # some sixty dependent small kernels: each has to get onto the device on its own
+        for j in range(c.prep_kernels):
+            pk = Pkt(SMALL, rank, stream, work=work / c.prep_kernels, what="preparation" if j == 0 else "preparation (cont.)")
+            pk.heavy = True
+            self.op(pk, c.issue_kernel_us)
         self.op(Pkt(REC, rank, stream, tok=tok, work=c.bar_us, what="prepared"), c.issue_event_us)
         rp.slices[sid]["prep"] = tok
         self.prog.append(("wait", tok))
@@ -405,10 +409,11 @@ class RankState:
 class Shared:
     """what the hosts of one world share: the ranks' symbolic replicas, the token counter, the stream layout"""
 
-    def __init__(self, comm_streams=ROUNDS, apply_streams=False):
+    def __init__(self, comm_streams=ROUNDS, apply_streams=False, prep_own_stream=False):
         self.ranks = {}
         self.tokens = 0
         self.comm_streams, self.apply_streams = comm_streams, apply_streams
+        self.prep_own_stream = prep_own_stream          # the preparation on a stream (and hardware queue) of its own
 
     def new_rank(self, r, depth, batch, world):
         self.ranks[r] = RankState(depth, batch, world)
@@ -422,14 +427,14 @@ class Shared:
 
 
 def record(lib, world, depth, batch, script, lag=None, hosts="per-rank", transport="rccl", comm_streams=ROUNDS, apply_streams=False,
-           channels=0, costs=None, real_sizes=True, rank_scripts=None, only_ranks=None):
+           channels=0, costs=None, real_sizes=True, rank_scripts=None, only_ranks=None, prep_own_stream=False):
     """run `script` (a list of ("step",) / ("wait", R) / ("flush",)) on every host and return (programs, shared).
     hosts = "per-rank": one host per rank, collectives through `transport` ("rccl", "ipc", "emu"); "one": all ranks in one
     process, the product's in-process transport (copies ordered by events).  rank_scripts: per-rank scripts instead
     (unequal call sequences: what the contract forbids).  only_ranks: record these ranks only ("emu")."""
     costs = costs or Costs()
     lib.sym_set_layout(comm_streams, 1 if apply_streams else 0)
-    sh = Shared(comm_streams, apply_streams)
+    sh = Shared(comm_streams, apply_streams, prep_own_stream)
     try:
         if hosts == "one":
             recs = [Recorder(sh, lib, world, depth, batch, lag, 0, world, "local", costs, real_sizes=real_sizes)]
@@ -466,6 +471,8 @@ class QueueMap:
 
     def __call__(self, rank, stream):
         kind, slot = divmod(stream, ROUNDS)           # 0 round, 1 collective, 2 apply, 3 the host-polled transport's worker
+        if kind == 4:                                 # the preparation's own stream: a queue nothing else of the world is on
+            return (0 if (self.one_device or self.shared_gpu) else rank), 3 * self.K + (rank if (self.one_device or self.shared_gpu) else 0)
         shift = (0, self.comm_shift, self.apply_shift, self.comm_shift)[kind]
         q = (slot + shift + self.rot.get(rank, 0)) % self.K
         if kind in (1, 3) and self.comm_own_queues:
@@ -669,7 +676,7 @@ class Timed:
             if p is not None and p.started:
                 if p.kind == HASH:
                     h += 1
-                elif p.kind == SMALL and p.work >= self.c.small_counts_us:
+                elif p.kind == SMALL and p.heavy:
                     s += 1
         sp = self.speed.get(dev, 1.0)
         c = self.c

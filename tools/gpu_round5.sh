@@ -73,6 +73,10 @@ longsoak)
   SOAK_SECONDS=420 timeout -k 10 600 python tools/sliced_soak.py > $O/sliced_soak_420s.txt 2>&1 && echo "sliced soak ok" &&
   SOAK_SECONDS=240 timeout -k 10 400 python tools/differential_soak.py > $O/differential_soak_240s.txt 2>&1 && echo "soak ok"
   tail -2 $O/sliced_soak_420s.txt $O/differential_soak_240s.txt ;;
+issue)   # when does the host ISSUE a step's preparation, and when does it run? (rocprofv3 kernel + HIP runtime trace of one emulated rank of 8)
+  ( export EMU_RANKS=first EMU_LINK_GBPS=0 EMU_ROUNDS=6; timeout -k 10 400 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $O/raw_issue -o issue -- python3 tools/rank_emulation.py 8 > $O/issue_under_rocprof.txt 2> $O/issue_rocprof.err ) &&
+  python tools/trace_issue_lag.py $O/raw_issue "prep::k_scatter" "k_convert" > $O/issue_lag.txt 2>&1; rm -rf $O/raw_issue
+  cat $O/issue_lag.txt | head -60 ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "pytest rc=$?" >> $O/tests.log
   tail -4 $O/tests.log ;;

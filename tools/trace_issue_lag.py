@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""rocprofv3 --kernel-trace --hip-runtime-trace CSVs -> for every kernel, when the HOST issued it (the hipLaunchKernel /
+hipModuleLaunchKernel / hipMemcpyAsync ... call with the same correlation id) and when it RAN: where a kernel that starts
+late was held up -- issued late (the host was elsewhere) or issued early and stuck in its hardware queue.
+Prints, per kernel name pattern given, the distribution of (start - issue) and lists the first kernels of every step's
+preparation.  Usage: python tools/trace_issue_lag.py <dir> [pattern ...]"""
+import csv
+import glob
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", re.sub(r"^void ", "", name))
+    m = re.match(r"([A-Za-z_0-9:<>~ ,]+?)\(", name)
+    base = m.group(1) if m else name
+    if "trampoline_kernel" in name:
+        m = re.search(r"wrapped_([a-z_]+)_config", name)
+        base = "rocprim::" + (m.group(1) if m else "kernel")
+    return base.replace("imt::", "").strip()
+
+
+def main():
+    d = sys.argv[1]
+    pats = sys.argv[2:] or ["prep::k_scatter"]
+    api = {}
+    for f in glob.glob(os.path.join(d, "**", "*hip_api_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f, newline="")):
+            api[r["Correlation_Id"]] = (r["Function"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]))
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f, newline="")):
+            a = api.get(r["Correlation_Id"])
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), int(r.get("Queue_Id", 0) or 0),
+                         int(r.get("Stream_Id", 0) or 0), a[1] if a else None, a[0] if a else "?"))
+    rows.sort()
+    t0 = rows[0][0]
+    print(f"{len(rows)} dispatches, {sum(1 for r in rows if r[5] is not None)} matched to an API call")
+    sweeps = [(r[0], r[1]) for r in rows if r[2] == "k_sweep"]
+    for pat in pats:
+        sel = [r for r in rows if pat in r[2] and r[5] is not None]
+        print(f"== {pat}: {len(sel)} dispatches; issued -> started (us), and how many k_sweep launches ran in between")
+        for r in sel[:40]:
+            between = sum(1 for a, b in sweeps if a < r[0] and b > r[5])
+            print(f"   issued at {(r[5] - t0) / 1e3:10.1f} us   started {(r[0] - r[5]) / 1e3:9.1f} us later on queue {r[3]} stream {r[4]} ({between} sweeps overlapped the wait)")
+
+
+if __name__ == "__main__":
+    main()
