@@ -25,9 +25,24 @@ def main():
     d = sys.argv[1]
     pats = sys.argv[2:] or ["prep::k_scatter"]
     api = {}
+    calls = []
     for f in glob.glob(os.path.join(d, "**", "*hip_api_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f, newline="")):
             api[r["Correlation_Id"]] = (r["Function"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]))
+            calls.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Function"], r["Thread_Id"]))
+    calls.sort()
+    if calls:
+        import collections
+        t00 = calls[0][0]
+        tot = collections.Counter()
+        for a, b, fn, th in calls:
+            tot[fn] += b - a
+        print("host time per HIP call (ms, whole run):", {k: round(v / 1e6, 1) for k, v in tot.most_common(8)})
+        print("HIP calls that took longer than 0.5 ms (the host blocked inside), second half of the run:")
+        half = (calls[-1][1] + t00) // 2
+        for a, b, fn, th in calls:
+            if a > half and b - a > 500_000:
+                print(f"   {fn:28s} thread {th} at {(a - t00) / 1e3:10.1f} us for {(b - a) / 1e3:8.1f} us")
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f, newline="")):
