@@ -29,20 +29,27 @@ def main():
     for f in glob.glob(os.path.join(d, "**", "*hip_api_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f, newline="")):
             api[r["Correlation_Id"]] = (r["Function"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]))
-            calls.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Function"], r["Thread_Id"]))
+            calls.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Function"], r["Thread_Id"], r["Correlation_Id"]))
     calls.sort()
+    kname = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f, newline="")):
+            kname[r["Correlation_Id"]] = (short(r["Kernel_Name"]), int(r.get("Queue_Id", 0) or 0), int(r.get("Stream_Id", 0) or 0),
+                                          int(r["Start_Timestamp"]), int(r["End_Timestamp"]))
     if calls:
         import collections
         t00 = calls[0][0]
         tot = collections.Counter()
-        for a, b, fn, th in calls:
+        for a, b, fn, th, cid in calls:
             tot[fn] += b - a
         print("host time per HIP call (ms, whole run):", {k: round(v / 1e6, 1) for k, v in tot.most_common(8)})
-        print("HIP calls that took longer than 0.5 ms (the host blocked inside), second half of the run:")
-        half = (calls[-1][1] + t00) // 2
-        for a, b, fn, th in calls:
-            if a > half and b - a > 500_000:
-                print(f"   {fn:28s} thread {th} at {(a - t00) / 1e3:10.1f} us for {(b - a) / 1e3:8.1f} us")
+        print("kernel launches / copies / event calls that held the host for more than 0.5 ms (what was launched, when it then ran):")
+        for a, b, fn, th, cid in calls:
+            if b - a > 500_000 and fn in ("hipLaunchKernel", "hipModuleLaunchKernel", "hipMemcpyAsync", "hipMemsetAsync", "hipEventRecord",
+                                          "hipStreamWaitEvent", "hipExtLaunchKernel", "hipEventSynchronize", "hipStreamSynchronize", "hipStreamQuery"):
+                k = kname.get(cid)
+                what = f"{k[0]} on queue {k[1]} stream {k[2]}, ran {(k[3] - b) / 1e3:.1f} us after the call returned" if k else ""
+                print(f"   {fn:22s} at {(a - t00) / 1e3:10.1f} us for {(b - a) / 1e3:8.1f} us  {what}")
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f, newline="")):
