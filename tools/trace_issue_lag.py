@@ -60,6 +60,25 @@ def main():
     t0 = rows[0][0]
     print(f"{len(rows)} dispatches, {sum(1 for r in rows if r[5] is not None)} matched to an API call")
     sweeps = [(r[0], r[1]) for r in rows if r[2] == "k_sweep"]
+    # ---- per step: when the host issued the preparation, when the device finished it, when the host issued the step's
+    # hash launches -- the host's loop against the device's
+    scat = [r for r in rows if r[2] == "prep::k_scatter" and r[5] is not None]
+    steps = [scat[i] for i in range(len(scat)) if i == 0 or scat[i][5] - scat[i - 1][5] > 5_000_000]
+    print("per step (ms from the step's first preparation launch): preparation done on the device | host issues the period's hash launches from .. to | "
+          "k_sweep launches of the period | device idle (no k_sweep running) inside the step")
+    for i, st in enumerate(steps[:-1]):
+        a, b = st[5], steps[i + 1][5]
+        prep_end = max((r[1] for r in rows if r[2] == "k_merge_level" and a <= r[5] < b), default=None)
+        sw = [r for r in rows if r[2] == "k_sweep" and r[5] is not None and a <= r[5] < b]
+        ev = sorted([(r[0], 1) for r in rows if r[2] == "k_sweep" and r[1] > a and r[0] < b] + [(r[1], -1) for r in rows if r[2] == "k_sweep" and r[1] > a and r[0] < b])
+        h, last, idle = 0, a, 0
+        for t, dd in ev:
+            if h == 0:
+                idle += max(0, min(t, b) - max(last, a))
+            h += dd
+            last = t
+        if sw and prep_end:
+            print(f"   step {i}: period {(b - a) / 1e6:6.2f} | {(prep_end - a) / 1e6:6.2f} | {(sw[0][5] - a) / 1e6:6.2f} .. {(sw[-1][5] - a) / 1e6:6.2f} | {len(sw):3d} | {idle / 1e6:5.2f}")
     for pat in pats:
         sel = [r for r in rows if pat in r[2] and r[5] is not None]
         print(f"== {pat}: {len(sel)} dispatches; issued -> started (us), and how many k_sweep launches ran in between")
