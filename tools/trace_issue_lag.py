@@ -79,6 +79,21 @@ def main():
             last = t
         if sw and prep_end:
             print(f"   step {i}: period {(b - a) / 1e6:6.2f} | {(prep_end - a) / 1e6:6.2f} | {(sw[0][5] - a) / 1e6:6.2f} .. {(sw[-1][5] - a) / 1e6:6.2f} | {len(sw):3d} | {idle / 1e6:5.2f}")
+    if len(steps) >= 4 and calls:
+        import collections
+        a, b = steps[-4][5], steps[-1][5]
+        agg = collections.defaultdict(lambda: [0, 0, 0])
+        for c0, c1, fn, th, cid in calls:
+            if a <= c0 < b:
+                g = agg[fn]
+                g[0] += 1
+                g[1] += c1 - c0
+                g[2] = max(g[2], c1 - c0)
+        print(f"the host's HIP calls over the last three steps ({(b - a) / 1e6:.1f} ms): function: calls, total ms, longest us")
+        for fn, g in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
+            print(f"   {fn:28s} {g[0]:6d} {g[1] / 1e6:8.2f} {g[2] / 1e3:9.1f}")
+        inside = sum(g[1] for g in agg.values())
+        print(f"   inside HIP calls {inside / 1e6:.1f} ms of {(b - a) / 1e6:.1f} ms")
     for pat in pats:
         sel = [r for r in rows if pat in r[2] and r[5] is not None]
         print(f"== {pat}: {len(sel)} dispatches; issued -> started (us), and how many k_sweep launches ran in between")
