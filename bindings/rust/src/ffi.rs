@@ -74,7 +74,6 @@ pub struct imt_sliced_info {
     pub comm_streams: c_int,
     pub streams_recreated: c_int,
     pub queue_map: [[c_int; 4]; 3],
-    pub prep_queue: c_int,
 }
 
 /// `imt_column_segment`: a stretch of insert_leaf's advice column (imt_insert_column_segments).
@@ -274,7 +273,6 @@ extern "C" {
     pub fn imt_transport_last_error(tp: *const imt_transport) -> *const c_char;
     pub fn imt_sliced_create(trees: *const *mut imt_itree, n_local: c_int, world: c_int, first_rank: c_int, tp: *mut imt_transport, max_slice: usize, lag: c_int, out: *mut *mut imt_sliced) -> c_int;
     pub fn imt_sliced_step(w: *mut imt_sliced, vals: *const c_void, n: usize, outs: *const imt_insert_out, flags: c_uint, round_out: *mut u64) -> c_int;
-    pub fn imt_sliced_announce(w: *mut imt_sliced, next_vals: *const c_void, n: usize, next_outs: *const imt_insert_out, flags: c_uint) -> c_int;
     pub fn imt_sliced_wait(w: *mut imt_sliced, local_rank: c_int, round: u64) -> c_int;
     pub fn imt_sliced_flush(w: *mut imt_sliced) -> c_int;
     pub fn imt_sliced_set_option(w: *mut imt_sliced, option: c_int, value: c_long) -> c_int;

@@ -60,14 +60,6 @@ impl SlicedTree {
         let rc = imt_sliced_step(self.w, vals, n, out, flags, &mut round);
         if rc == IMT_OK { Ok(round) } else { Err(rc) }
     }
-    /// tell the world the NEXT step's arguments before stepping the current one: its preparation then runs a period ahead
-    ///
-    /// # Safety
-    /// as for `step`; the next `step` must be called with exactly these arguments.
-    pub unsafe fn announce(&mut self, next_vals: *const c_void, n: usize, next_out: &imt_insert_out, flags: u32) -> Result<(), i32> {
-        let rc = imt_sliced_announce(self.w, next_vals, n, next_out, flags);
-        if rc == IMT_OK { Ok(()) } else { Err(rc) }
-    }
     pub fn wait(&mut self, round: u64) -> Result<(), i32> {
         let rc = unsafe { imt_sliced_wait(self.w, 0, round) };
         if rc == IMT_OK { Ok(()) } else { Err(rc) }

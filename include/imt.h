@@ -614,20 +614,6 @@ int imt_sliced_set_option(imt_sliced *w, int option, long value);
  * step's number.  flags: IMT_FMT_*, IMT_SIB_ITEM_MAJOR, IMT_INPUTS_READY. */
 int imt_sliced_step(imt_sliced *w, const void *vals /*[world * n][32]*/, size_t n, const imt_insert_out *outs /*[n_local]*/,
                     unsigned flags, uint64_t *round_out);
-/* Optional, and worth 4 - 5 % at eight GPUs: tell the world the arguments of the NEXT step before stepping the current one
- * (next_vals / next_outs / flags exactly as they will be passed to that imt_sliced_step; the same on every rank, like
- * every call of the contract above).  The current imt_sliced_step then enqueues the next step's preparation right after
- * its own value check, a whole period before it is needed -- a preparation is some sixty small dependent kernels that
- * crawl while the device is full of hash kernels, and without the announcement the host stands waiting for it at the
- * start of every step while the device runs dry.  On a hardware queue of its own when the runtime has one
- * (imt_sliced_info.prep_queue: eight queues, GPU_MAX_HW_QUEUES=8), else behind the next round slot's previous round.
- * Call order:   imt_sliced_announce(step k + 1);  imt_sliced_step(step k);  imt_sliced_announce(step k + 2);
- * imt_sliced_step(step k + 1); ...  -- an announcement always names the step AFTER the one stepped next.  That step must
- * then be called with exactly the announced arguments (IMT_ERR_ARG and the announcement dropped otherwise); bad values
- * are still refused by THAT call, nothing changed.  A refused or failed step, a flush and destroy drop announcements.
- * One step ahead, not two (IMT_ERR_ARG). */
-int imt_sliced_announce(imt_sliced *w, const void *next_vals /*[world * n][32]*/, size_t n, const imt_insert_out *next_outs /*[n_local]*/,
-                        unsigned flags);
 /* HOW LONG imt_sliced_step BLOCKS, and why.  The call returns when the step's values have been checked on the GPU (the
  * preparation: sort, low-leaf search, merge into the index), because IMT_ERR_VALUE must be the call's own return value
  * and must leave every rank's tree untouched.  The preparation is short (1.5 - 2 ms at 2^16 values per rank) but is
@@ -667,8 +653,6 @@ typedef struct imt_sliced_info {
     int comm_streams;                /* streams carrying collectives after placement (0: the round streams do) */
     int streams_recreated;           /* streams that had to be created again to get the placement */
     int queue_map[3][IMT_SLICED_ROUNDS];
-    int prep_queue;                  /* the stream announced steps are prepared on (imt_sliced_announce): 8 = on a hardware queue
-                                        of its own; -1 = none could be had: the next round slot's collective stream is used */
 } imt_sliced_info;
 #define IMT_SLICED_PLACEMENT_UNVERIFIED 0  /* not measured (option off, or unequal round priorities) */
 #define IMT_SLICED_PLACEMENT_AS_CREATED 1  /* measured: as wanted, first try */

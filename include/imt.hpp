@@ -450,10 +450,6 @@ public:
         check(imt_sliced_step(w_, vals, n, outs, flags, &round));
         return round;
     }
-    // the NEXT step's arguments, told before the current one is stepped: its preparation then runs a period ahead
-    void announce(const void* next_vals, size_t n, const imt_insert_out* next_outs, unsigned flags = 0) {
-        check(imt_sliced_announce(w_, next_vals, n, next_outs, flags));
-    }
     void wait(uint64_t round, int local_rank = 0) { check(imt_sliced_wait(w_, local_rank, round)); }
     void flush() { check(imt_sliced_flush(w_)); }
     imt_sliced_info info() const {

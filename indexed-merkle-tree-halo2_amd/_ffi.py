@@ -66,7 +66,7 @@ class SlicedInfo(ctypes.Structure):
                [("payload_bytes", ctypes.c_size_t)] + [(n, ctypes.c_uint64) for n in ("rounds", "collectives", "bytes_gathered")] + \
                [(n, ctypes.c_double) for n in ("host_issue_ms", "host_wait_ms")] + \
                [(n, ctypes.c_int) for n in ("placement", "hw_queues", "comm_streams", "streams_recreated")] + \
-               [("queue_map", (ctypes.c_int * 4) * 3), ("prep_queue", ctypes.c_int)]
+               [("queue_map", (ctypes.c_int * 4) * 3)]
 
 
 class ColumnSegment(ctypes.Structure):
@@ -182,7 +182,6 @@ SIGNATURES = {
     "imt_transport_last_error": (ctypes.c_char_p, [c_void_p]),
     "imt_sliced_create": (c_int, [P(c_void_p), c_int, c_int, c_int, c_void_p, c_size_t, c_int, P(c_void_p)]),
     "imt_sliced_step": (c_int, [c_void_p, c_void_p, c_size_t, P(InsertOut), c_uint, P(c_u64)]),
-    "imt_sliced_announce": (c_int, [c_void_p, c_void_p, c_size_t, P(InsertOut), c_uint]),
     "imt_sliced_wait": (c_int, [c_void_p, c_int, c_u64]),
     "imt_sliced_flush": (c_int, [c_void_p]),
     "imt_sliced_get_info": (c_int, [c_void_p, P(SlicedInfo)]),

@@ -168,20 +168,7 @@ struct imt_itree {
     hipStream_t slice_prep_stream = nullptr; // where the next imt_itree_slice_prepare runs (nullptr: the side stream)
     const uint32_t* slice_poison = nullptr;  // device-visible word of the world's transport: non-zero = skip applies
     double slice_wait_limit_ms = 0;          // > 0: host waits inside imt_itree_slice_prepare give up after this long
-    // a slice's preparation that has been ISSUED and not yet committed (imt_itree_slice_prepare_issue / _commit: the sliced
-    // world enqueues the NEXT step's preparation one call ahead, so that its value check is done when the step is called)
-    struct SlicePending {
-        bool active = false;
-        int set = 0;
-        hipStream_t stream = nullptr;
-        uint64_t M0 = 0, M_own = 0;
-        size_t n_all = 0, n_own = 0;
-        unsigned L0 = 0, fmt = 0, flags = 0;
-        imt_insert_out out = {};
-        bool has_out = false;
-    } slice_pending;
     double slice_wait_ms = 0;                // host time spent waiting for the GPU inside imt_itree_slice_prepare
-    double slice_backpressure_ms = 0;        // ... the part of it spent waiting for the plan set's previous slice (all-time total)
     bool sliced_busy = false;                // an imt_sliced world has steps in flight on this replica (until its flush)
     size_t reserved_events = 0;              // every plan set holds at least this many events (reserve_all_plans)
 };
@@ -475,7 +462,6 @@ unsigned imt_itree_depth(const imt_itree* t) { return t ? t->depth : 0; }
 void imt_itree_mark_sliced(imt_itree* t, bool busy) {
     if (t) t->sliced_busy = busy;
 }
-double imt_itree_slice_backpressure_ms(const imt_itree* t) { return t ? t->slice_backpressure_ms : 0; }
 void imt_itree_set_slice_poison(imt_itree* t, const uint32_t* device_word) {
     if (t) t->slice_poison = device_word;
 }
@@ -1734,16 +1720,11 @@ static int bounded_wait(imt_ctx* c, double limit_ms, Query query, Sync sync, con
     }
 }
 
-// imt_itree_slice_prepare in two halves (imt_itree_internal.hpp): _issue enqueues the whole preparation and returns, _commit
-// waits for its value check and -- if the values are good -- commits the index and opens the slice.  Nothing that the
-// preparation writes is visible to anybody before the commit (the merges go to the spare index buffers, the tables into a
-// plan set that is not in use), so an issued preparation can also be dropped (_abandon).  One at a time.
-int imt_itree_slice_prepare_issue(imt_itree* t, const void* vals, size_t n_before, size_t n_own, size_t n_after,
-                                  const imt_insert_out* out, unsigned flags) {
+extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_before, size_t n_own, size_t n_after,
+                                       const imt_insert_out* out, unsigned flags, int* slice_out, uint32_t* l0_out) {
     if (!t) return IMT_ERR_ARG;
     imt_ctx* c = t->ctx;
-    if (t->slice_pending.active) return c->fail(IMT_ERR_ARG, "a slice's preparation is already issued (commit or abandon it first)");
-    if (!vals || n_own == 0) return c->fail(IMT_ERR_ARG, "null / empty slice");
+    if (!vals || n_own == 0 || !slice_out) return c->fail(IMT_ERR_ARG, "null / empty slice");
     if (!(flags & IMT_DEVICE_PTRS)) return c->fail(IMT_ERR_ARG, "imt_itree_slice_prepare takes device pointers");
     if ((flags & IMT_FMT_MASK) == 3) return c->fail(IMT_ERR_ARG, "unknown field-element format");
     if (t->index_base || t->part_mod > 1) return c->fail(IMT_ERR_ARG, "a placed / partitioned tree is not sliced");
@@ -1764,9 +1745,7 @@ int imt_itree_slice_prepare_issue(imt_itree* t, const void* vals, size_t n_befor
         const auto w0 = std::chrono::steady_clock::now();
         rc = bounded_wait(c, t->slice_wait_limit_ms, [&] { return hipEventQuery(P.done); }, [&] { return hipEventSynchronize(P.done); },
                           "the plan set's previous slice");
-        const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
-        t->slice_wait_ms += waited;
-        t->slice_backpressure_ms += waited;
+        t->slice_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
         if (rc) return rc;
         P.in_flight = false;
     }
@@ -1856,56 +1835,13 @@ int imt_itree_slice_prepare_issue(imt_itree* t, const void* vals, size_t n_befor
     for (auto& pl : t->plan)
         if (&pl != &P && pl.in_flight && !pl.sliced) IMT_HIP(c, hipStreamWaitEvent(ps, pl.done, 0));
     IMT_HIP(c, hipEventRecord(P.prep_done, ps));
-    auto& pd = t->slice_pending;
-    pd.active = true;
-    pd.set = set;
-    pd.stream = ps;
-    pd.M0 = M0;
-    pd.M_own = M_own;
-    pd.n_all = n_all;
-    pd.n_own = n_own;
-    pd.L0 = L0;
-    pd.fmt = fmt;
-    pd.flags = flags;
-    pd.has_out = out != nullptr;
-    pd.out = out ? *out : imt_insert_out{};
-    return IMT_OK;
-}
-
-int imt_itree_slice_prepare_abandon(imt_itree* t) {
-    if (!t || !t->slice_pending.active) return IMT_OK;
-    imt_ctx* c = t->ctx;
-    int rc = c->set_device();
-    if (rc) return rc;
-    hipStream_t ps = t->slice_pending.stream;
-    rc = bounded_wait(c, t->slice_wait_limit_ms, [&] { return hipStreamQuery(ps); }, [&] { return hipStreamSynchronize(ps); },
-                      "an abandoned preparation");
-    t->slice_pending.active = false;
-    return rc;
-}
-
-int imt_itree_slice_prepare_commit(imt_itree* t, int* slice_out, uint32_t* l0_out) {
-    if (!t) return IMT_ERR_ARG;
-    imt_ctx* c = t->ctx;
-    auto& pd = t->slice_pending;
-    if (!pd.active || !slice_out) return c->fail(IMT_ERR_ARG, "no preparation has been issued");
-    int rc = c->set_device();
-    if (rc) return rc;
-    const int set = pd.set;
-    PlanSet& P = t->plan[set];
-    hipStream_t ps = pd.stream;
-    const uint64_t M0 = pd.M0, M_own = pd.M_own;
-    const size_t n_all = pd.n_all, n_own = pd.n_own;
-    const unsigned L0 = pd.L0, fmt = pd.fmt, flags = pd.flags;
-    const imt_insert_out* out = pd.has_out ? &pd.out : nullptr;
     {
         const auto w0 = std::chrono::steady_clock::now();
         rc = bounded_wait(c, t->slice_wait_limit_ms, [&] { return hipStreamQuery(ps); }, [&] { return hipStreamSynchronize(ps); },
                           "the step's preparation (its value check)");
         t->slice_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
-        if (rc) return rc;           // (IMT_ERR_TIMEOUT: still pending; the world gives up)
+        if (rc) return rc;
     }
-    pd.active = false;
     const int perr = *t->h_err_pin;      // the same verdict on every GPU: they all see all values of the step
     if (perr & prep::ERR_NONCANONICAL) return c->fail(IMT_ERR_NONCANONICAL, "a value is not reduced (>= p)");
     if (perr & prep::ERR_ZERO) return c->fail(IMT_ERR_VALUE, "value 0 cannot be inserted");
@@ -1929,14 +1865,6 @@ int imt_itree_slice_prepare_commit(imt_itree* t, int* slice_out, uint32_t* l0_ou
     *slice_out = set;
     if (l0_out) *l0_out = L0;
     return IMT_OK;
-}
-
-extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_before, size_t n_own, size_t n_after,
-                                       const imt_insert_out* out, unsigned flags, int* slice_out, uint32_t* l0_out) {
-    if (!t) return IMT_ERR_ARG;
-    if (!slice_out) return t->ctx->fail(IMT_ERR_ARG, "null / empty slice");
-    int rc = imt_itree_slice_prepare_issue(t, vals, n_before, n_own, n_after, out, flags);
-    return rc ? rc : imt_itree_slice_prepare_commit(t, slice_out, l0_out);
 }
 
 extern "C" int imt_itree_slice_unit(imt_itree* t, int slice, unsigned unit, void* payload, void* hip_stream) {

@@ -17,13 +17,3 @@ void imt_itree_set_slice_prep_stream(imt_itree* t, void* hip_stream);
 void imt_itree_set_slice_poison(imt_itree* t, const uint32_t* device_word);
 // > 0: the host waits inside imt_itree_slice_prepare return IMT_ERR_TIMEOUT after this many milliseconds
 void imt_itree_set_slice_wait_limit(imt_itree* t, double ms);
-// all-time host milliseconds inside imt_itree_slice_prepare spent waiting for the plan set's previous slice to finish
-// (back-pressure), as opposed to the step's own value check
-double imt_itree_slice_backpressure_ms(const imt_itree* t);
-// imt_itree_slice_prepare in two halves: issue enqueues a slice's whole preparation and returns; commit waits for its value
-// check (IMT_ERR_VALUE / NONCANONICAL: nothing changed) and opens the slice; abandon waits for an issued preparation and
-// drops it.  One issued preparation at a time; its index is built on the state the PREVIOUS commit left.
-int imt_itree_slice_prepare_issue(imt_itree* t, const void* vals, size_t n_before, size_t n_own, size_t n_after,
-                                  const imt_insert_out* out, unsigned flags);
-int imt_itree_slice_prepare_commit(imt_itree* t, int* slice_out, uint32_t* l0_out);
-int imt_itree_slice_prepare_abandon(imt_itree* t);

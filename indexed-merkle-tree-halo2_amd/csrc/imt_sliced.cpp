@@ -172,8 +172,6 @@ struct HipBackend : Backend {
     imt_itree* tree;
     imt_ctx* ctx;
     hipStream_t rs[ROUNDS] = {}, cs[ROUNDS] = {}, aps[ROUNDS] = {};     // round, collective and apply streams
-    hipStream_t pre = nullptr;       // announced steps' preparations, when a hardware queue nothing else of the world is on could be had
-    int q_pre = -1;
     int n_comm = ROUNDS;
     SlicedOptions opt;
     // what the probe found (imt_sliced_info): hardware queue class of every stream, -1 = no such stream / not probed
@@ -229,7 +227,6 @@ struct HipBackend : Backend {
         for (hipStream_t* arr : {rs, cs, aps})
             for (int i = 0; i < ROUNDS; i++)
                 if (arr[i]) adopt(arr[i]);
-        if (pre) adopt(pre);
         imt_itree_set_slice_wait_limit(tree, (double)o.watchdog_ms);
         return IMT_OK;
     }
@@ -420,26 +417,6 @@ struct HipBackend : Backend {
                 placement_note += "the apply streams could not be placed: applies run on the round streams";
             }
         }
-        // a stream for the preparations of ANNOUNCED steps (imt_sliced_announce): they are issued a whole period before they are
-        // needed and must not stand in front of (or behind) a round's packets -- only a queue of its own will do
-        if (same_pool && comm_own_queues) {
-            for (int tries = 0; tries < 2 * ROUNDS && !pre; tries++) {
-                hipStream_t x;
-                if ((rc = new_stream(&x, 0))) return rc;
-                std::vector<hipStream_t> all(rs, rs + ROUNDS);
-                for (int i = 0; i < ROUNDS; i++)
-                    if (cs[i]) all.push_back(cs[i]);
-                if ((rc = pr.run(x, all.data(), (int)all.size(), behind))) return rc;
-                bool shared = false;
-                for (size_t j = 0; j < all.size(); j++) shared = shared || behind[j];
-                if (!shared) {
-                    pre = x;
-                    q_pre = 2 * ROUNDS;
-                } else {
-                    spare.push_back(x);
-                }
-            }
-        }
         drop_spares();
         if (n_queues < ROUNDS) {
             char buf[160];
@@ -459,11 +436,6 @@ struct HipBackend : Backend {
                     ss.erase(std::remove(ss.begin(), ss.end(), arr[i]), ss.end());
                     hipStreamDestroy(arr[i]);
                 }
-        if (pre) {
-            hipStreamSynchronize(pre);
-            ss.erase(std::remove(ss.begin(), ss.end(), pre), ss.end());
-            hipStreamDestroy(pre);
-        }
         imt_itree_set_slice_poison(tree, nullptr);
         imt_itree_set_slice_wait_limit(tree, 0);
     }
@@ -529,18 +501,6 @@ struct HipBackend : Backend {
         imt_itree_set_slice_prep_stream(tree, nullptr);
         return rc;
     }
-    // An announced step's preparation: on the stream with a hardware queue of its own when there is one; else on the new
-    // round slot's collective stream like any other preparation (it then stands behind that slot's previous round and the
-    // head start is worth less).
-    int prepare_issue(const void* vals, size_t nb, size_t no, size_t na, const imt_insert_out* out, unsigned flags, int slot) override {
-        void* st = pre ? (void*)pre : (n_comm ? (void*)cs[slot % n_comm] : (void*)rs[slot]);
-        imt_itree_set_slice_prep_stream(tree, st);
-        const int rc = imt_itree_slice_prepare_issue(tree, vals, nb, no, na, out, flags | IMT_DEVICE_PTRS);
-        imt_itree_set_slice_prep_stream(tree, nullptr);
-        return rc;
-    }
-    int prepare_commit(int* slice) override { return imt_itree_slice_prepare_commit(tree, slice, nullptr); }
-    int prepare_abandon() override { return imt_itree_slice_prepare_abandon(tree); }
     int unit(int slice, unsigned q, Buffer payload, Stream s) override { return imt_itree_slice_unit(tree, slice, q, payload, s); }
     int apply_gathered(Buffer g, size_t stride, int count, const uint64_t* sb, const uint64_t* n, const int32_t* units,
                        Stream s) override {
@@ -555,10 +515,6 @@ struct HipBackend : Backend {
                     if (opt.watchdog_ms <= 0) IMT_HIP(ctx, hipStreamSynchronize(arr[i]));
                     else if ((rc = bounded_wait(ctx, opt.watchdog_ms, [&] { return hipStreamQuery(arr[i]); }, "the world's streams to drain"))) return rc;
                 }
-        if (pre) {
-            if (opt.watchdog_ms <= 0) IMT_HIP(ctx, hipStreamSynchronize(pre));
-            else if ((rc = bounded_wait(ctx, opt.watchdog_ms, [&] { return hipStreamQuery(pre); }, "the world's streams to drain"))) return rc;
-        }
         return imt_ctx_sync(ctx);
     }
 };
@@ -1183,13 +1139,11 @@ int imt_sliced_set_option(imt_sliced* s, int option, long value) {
 void imt_sliced_destroy(imt_sliced* s) {
     if (!s) return;
     if (s->opt.timing)
-        fprintf(stderr, "[imt sliced rank %d] host ms over %llu rounds: apply %.1f  compute %.1f  send %.1f  (issue %.1f, waiting in prepare %.1f of which "
-                        "%.1f for a plan set's previous slice)\n",
+        fprintf(stderr, "[imt sliced rank %d] host ms over %llu rounds: apply %.1f  compute %.1f  send %.1f  (issue %.1f, waiting in prepare %.1f)\n",
                 s->ranks.empty() || !s->ranks[0] ? -1 : s->ranks[0]->rank, (unsigned long long)s->w.n_rounds, s->w.phase_ms[0], s->w.phase_ms[1],
-                s->w.phase_ms[2], s->host_issue_ms, s->host_wait_ms, s->bes.empty() || !s->bes[0] ? 0.0 : imt_itree_slice_backpressure_ms(s->bes[0]->tree));
+                s->w.phase_ms[2], s->host_issue_ms, s->host_wait_ms);
     // a poisoned world is not flushed (nothing can be issued any more); its replicas stay marked: they hold half a step
     const bool clean = !s->w.poisoned;
-    if (!s->w.ranks.empty()) s->w.drop_announced();
     if (clean && !s->w.ranks.empty() && s->w.n_rounds) s->w.flush();
     for (auto& be : s->bes)
         if (be) {
@@ -1279,19 +1233,6 @@ int imt_sliced_step(imt_sliced* s, const void* vals, size_t n, const imt_insert_
     return s->failed(rc, "imt_sliced_step");
 }
 
-int imt_sliced_announce(imt_sliced* s, const void* next_vals, size_t n, const imt_insert_out* next_outs, unsigned flags) {
-    if (!s) return IMT_ERR_ARG;
-    imt_ctx* c0 = s->bes[0]->ctx;
-    if (!next_vals) return c0->fail(IMT_ERR_ARG, "null vals");
-    if (n == 0 || n > s->max_slice) return c0->fail(IMT_ERR_RANGE, "a step is world x n values with 0 < n <= max_slice = %zu", s->max_slice);
-    if (flags & ~(IMT_FMT_MASK | IMT_SIB_ITEM_MAJOR | IMT_INPUTS_READY | IMT_DEVICE_PTRS))
-        return c0->fail(IMT_ERR_ARG, "imt_sliced_announce takes what imt_sliced_step takes");
-    if (s->w.poisoned) return s->refuse("imt_sliced_announce");
-    const int rc = s->w.announce(next_vals, n, next_outs, flags);
-    if (rc == IMT_ERR_ARG) return c0->fail(rc, "a step is already announced: one step ahead, not two");
-    return rc;
-}
-
 int imt_sliced_wait(imt_sliced* s, int local_rank, uint64_t round) {
     if (!s || local_rank < 0) return IMT_ERR_ARG;
     if (s->w.poisoned) return s->refuse("imt_sliced_wait");
@@ -1350,7 +1291,6 @@ int imt_sliced_get_info(const imt_sliced* s, imt_sliced_info* o) {
         o->queue_map[1][i] = be.q_comm[i];
         o->queue_map[2][i] = be.q_apply[i];
     }
-    o->prep_queue = be.q_pre;
     return IMT_OK;
 }
 

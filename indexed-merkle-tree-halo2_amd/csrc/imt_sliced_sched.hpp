@@ -37,7 +37,6 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
-#include <cstring>
 #include <string>
 #include <vector>
 #include "../../include/imt.h"
@@ -127,24 +126,6 @@ struct Backend {
     // slot = the round slot the step will run in (R % ROUNDS): a backend may prepare on that round's stream
     virtual int prepare(const void* vals, size_t n_before, size_t n_own, size_t n_after, const imt_insert_out* out,
                         unsigned flags, int slot, int* slice) = 0;
-    // The same in two halves, for a step announced one call ahead (World::announce): issue enqueues the preparation and
-    // returns, commit waits for its value check and opens the slice, abandon drops an issued one.  The defaults defer the
-    // whole preparation to the commit (a backend without the split behaves exactly as if nothing had been announced).
-    virtual int prepare_issue(const void* vals, size_t n_before, size_t n_own, size_t n_after, const imt_insert_out* out,
-                              unsigned flags, int slot) {
-        d_vals = vals; d_nb = n_before; d_no = n_own; d_na = n_after; d_flags = flags; d_slot = slot;
-        d_has_out = out != nullptr;
-        if (out) d_out = *out;
-        return IMT_OK;
-    }
-    virtual int prepare_commit(int* slice) { return prepare(d_vals, d_nb, d_no, d_na, d_has_out ? &d_out : nullptr, d_flags, d_slot, slice); }
-    virtual int prepare_abandon() { return IMT_OK; }
-    const void* d_vals = nullptr;
-    size_t d_nb = 0, d_no = 0, d_na = 0;
-    unsigned d_flags = 0;
-    int d_slot = 0;
-    bool d_has_out = false;
-    imt_insert_out d_out = {};
     virtual int unit(int slice, unsigned q, Buffer payload, Stream s) = 0;
     virtual int apply_gathered(Buffer gathered, size_t stride, int count, const uint64_t* size_before, const uint64_t* n,
                                const int32_t* units, Stream s) = 0;
@@ -406,46 +387,6 @@ struct World {
     double phase_ms[4] = {0, 0, 0, 0};      // host wall time in apply / compute / send / prepare (diagnostics)
     uint64_t T = 0;                  // next global tick to issue
     bool opened = false;             // step(): some replica has already opened the step (prepare succeeded)
-    // The NEXT step, announced before the current one is stepped (announce): its preparation is issued inside the current
-    // step, right after that step's own value check, a whole period before it is needed -- a preparation is some sixty
-    // small dependent kernels that crawl while the device is full of hash kernels (16 ms at 8 ranks, measured), and the
-    // host used to stand waiting for it at the start of every step while the device ran dry.
-    struct Announced {
-        bool active = false, issued = false;
-        const void* vals = nullptr;
-        size_t n = 0;
-        unsigned flags = 0;
-        bool has_outs = false;
-        std::vector<imt_insert_out> outs;
-    };
-    Announced next;                  // issued: the step the NEXT step() call has to be (its preparation is in flight)
-    Announced queued;                // told, not yet issued: the step after the next step() call
-    // call order of a host that announces:   announce(step k + 1);  step(step k);   announce(step k + 2);  step(step k + 1); ...
-    int announce(const void* vals, size_t n, const imt_insert_out* outs, unsigned flags) {
-        if (ranks.empty() || !vals) return IMT_ERR_ARG;
-        if (n == 0 || n > ranks[0]->max_n) return IMT_ERR_RANGE;
-        if (poisoned) return IMT_ERR_INTERNAL;
-        if (queued.active) return IMT_ERR_ARG;               // one step ahead, not two
-        queued.active = true;
-        queued.issued = false;
-        queued.vals = vals;
-        queued.n = n;
-        queued.flags = flags;
-        queued.has_outs = outs != nullptr;
-        queued.outs.assign(outs ? outs : nullptr, outs ? outs + ranks.size() : nullptr);
-        return IMT_OK;
-    }
-    int drop_announced() {
-        int rc = IMT_OK;
-        if (next.active)
-            for (Rank* rk : ranks) {
-                const int r = rk->be->prepare_abandon();
-                if (r && !rc) rc = r;
-            }
-        next.active = next.issued = false;
-        queued.active = false;
-        return rc;
-    }
     uint64_t n_rounds = 0;
     uint64_t starts[ROUNDS + 1] = {};
     // A failure while ticks were being issued leaves the replicas mid-step with part of a tick enqueued: nothing can be
@@ -499,28 +440,11 @@ struct World {
         // ROUNDS rounds back); nothing to wait for on the host
         std::vector<int> slices(ranks.size(), -1);
         opened = false;
-        // this step was announced a call ago and its preparation issued then: the same arguments, or it is another step
-        bool mine = false;
-        if (next.active) {
-            bool same = next.vals == vals && next.n == n && next.flags == flags && next.has_outs == (outs != nullptr);
-            for (size_t k = 0; same && outs && k < ranks.size(); k++) same = std::memcmp(&next.outs[k], &outs[k], sizeof(imt_insert_out)) == 0;
-            if (!same) {
-                drop_announced();
-                return IMT_ERR_ARG;
-            }
-            mine = true;
-            next.active = next.issued = false;
-        }
-        Announced ahead = queued;        // told for the step AFTER this one: issued below, once this one is committed and its ticks are out
-        queued.active = false;
         for (size_t k = 0; k < ranks.size(); k++) {
             Rank* rk = ranks[k];
             if (rk->be->tree_size() != size_before) return opened ? poison(IMT_ERR_INTERNAL) : IMT_ERR_INTERNAL;
-            int rc = mine ? rk->be->prepare_commit(&slices[k])
-                          : rk->be->prepare(vals, (size_t)rk->rank * n, n, (size_t)(rk->world - 1 - rk->rank) * n,
-                                            outs ? &outs[k] : nullptr, flags, (int)(R % ROUNDS), &slices[k]);
-            if (rc && mine && k == 0)            // refused: the other replicas' issued preparations are dropped with it
-                for (size_t j = 1; j < ranks.size(); j++) ranks[j]->be->prepare_abandon();
+            int rc = rk->be->prepare(vals, (size_t)rk->rank * n, n, (size_t)(rk->world - 1 - rk->rank) * n,
+                                     outs ? &outs[k] : nullptr, flags, (int)(R % ROUNDS), &slices[k]);
             // a refusal by the first replica changes nothing; replicas that disagree about a step are broken, and so is
             // a world whose earlier replicas have already opened the step
             if (rc) return k == 0 ? rc : poison(IMT_ERR_INTERNAL);
@@ -538,34 +462,13 @@ struct World {
         }
         n_rounds = R + 1;
         if (round_out) *round_out = R;
-        if (int rc = poison(run_ticks(start + sc.period))) return rc;
-        if (ahead.active) {
-            // the announced next step, on the index this step has just committed -- AFTER this step's ticks: reserving its
-            // plan set may have to wait for an old slice's last unit, and that wait must not hold this period's launches up
-            for (size_t k = 0; k < ranks.size(); k++) {
-                Rank* rk = ranks[k];
-                int rc = rk->be->prepare_issue(ahead.vals, (size_t)rk->rank * ahead.n, ahead.n, (size_t)(rk->world - 1 - rk->rank) * ahead.n,
-                                               ahead.has_outs ? &ahead.outs[k] : nullptr, ahead.flags, (int)((R + 1) % ROUNDS));
-                if (rc == IMT_ERR_TIMEOUT) return poison(rc);
-                if (rc) {                // (a capacity / argument error of the NEXT step: that step reports it when it is stepped)
-                    for (size_t j = 0; j < k; j++) ranks[j]->be->prepare_abandon();
-                    ahead.active = false;
-                    break;
-                }
-            }
-            if (ahead.active) {
-                next = ahead;
-                next.issued = true;
-            }
-        }
-        return IMT_OK;
+        return poison(run_ticks(start + sc.period));
     }
 
     // issue everything that is left of the rounds in flight and wait for it
     int flush() {
         int rc;
         if (poisoned) return IMT_ERR_INTERNAL;
-        if ((rc = drop_announced())) return poison(rc);      // an announced step that has not come: its preparation is dropped
         if (n_rounds && (rc = run_ticks(start_of(n_rounds - 1) + sc.round_ticks))) return poison(rc);
         for (Rank* rk : ranks)
             if ((rc = rk->be->sync())) return poison(rc);

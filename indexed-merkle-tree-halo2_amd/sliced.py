@@ -87,21 +87,12 @@ class SlicedTree:
         if rc:
             raise self.imt.ImtError(rc, self.lib.imt_sliced_last_error(self.h).decode())
 
-    def _outs(self, round_no):
-        slot = round_no % len(self.sets)
-        return (self.F.InsertOut * self.n_local)(*[self.F.InsertOut(**{k: t.data_ptr() for k, t in s.items()}) for s in self.sets[slot]])
-
-    def step(self, vals, flags=0, next_vals=None):
-        """next_vals: the values of the step AFTER this one (imt_sliced_announce): its preparation is enqueued inside this call, a
-        whole period before it is needed; the next step() must then be called with exactly that tensor and these flags"""
+    def step(self, vals, flags=0):
         n = vals.shape[0] // self.world
         if vals.shape[0] != n * self.world or not 0 < n <= self.batch:
             raise ValueError(f"a step is world x n values, 0 < n <= batch = {self.batch} (a shorter step has shorter slices)")
-        if next_vals is not None:
-            nn = next_vals.shape[0] // self.world
-            self._next_outs = self._outs(len(self.rounds) + 1)          # kept alive until that step has been made
-            self._check(self.lib.imt_sliced_announce(self.h, ctypes.c_void_p(next_vals.data_ptr()), nn, self._next_outs, self.fmt | flags))
-        outs = self._outs(len(self.rounds))
+        slot = len(self.rounds) % len(self.sets)
+        outs = (self.F.InsertOut * self.n_local)(*[self.F.InsertOut(**{k: t.data_ptr() for k, t in s.items()}) for s in self.sets[slot]])
         R = ctypes.c_uint64()
         size_before = self.size()
         self._check(self.lib.imt_sliced_step(self.h, ctypes.c_void_p(vals.data_ptr()), n, outs, self.fmt | flags, ctypes.byref(R)))

@@ -171,11 +171,9 @@ void* sym_world_create_channels(const sym_callbacks* cb, int world, int first_ra
     sw->w.ranks.push_back(rk);
     return sw.release();
 }
-static const char sym_dummy_vals = 0;
-int sym_world_step(void* h, size_t n, uint64_t* round_out) { return ((SymWorld*)h)->w.step(&sym_dummy_vals, n, nullptr, 0, round_out); }
-// imt_sliced_announce: the next step's arguments one call ahead (the symbolic backend defers the preparation to the commit)
-int sym_world_announce(void* h, size_t n, int other_args) {
-    return ((SymWorld*)h)->w.announce(other_args ? (const void*)(&sym_dummy_vals + 1) : (const void*)&sym_dummy_vals, n, nullptr, 0);
+int sym_world_step(void* h, size_t n, uint64_t* round_out) {
+    static const char dummy = 0;
+    return ((SymWorld*)h)->w.step(&dummy, n, nullptr, 0, round_out);
 }
 int sym_world_flush(void* h) { return ((SymWorld*)h)->w.flush(); }
 int sym_world_run_all(void* h) {       // issue everything, wait for nothing

@@ -75,7 +75,6 @@ def load():
     lib.sym_world_create_channels.argtypes = [P(Callbacks), c_int, c_int, c_size_t, c_int, c_int, c_size_t, c_int]
     lib.sym_set_layout.argtypes = [c_int, c_int]
     lib.sym_set_layout.restype = None
-    lib.sym_world_announce.argtypes = [ctypes.c_void_p, c_size_t, c_int]
     lib.sym_world_tick.restype = c_u64
     lib.sym_world_tick.argtypes = [ctypes.c_void_p]
     return lib
@@ -307,10 +306,6 @@ class SymWorld:
         self._check(self.lib.sym_world_step(self.h, self.batch, ctypes.byref(R)))
         self.rounds += 1
         return int(R.value)
-
-    def announce(self, other_args=False):
-        """the next step's arguments, told before the current step (imt_sliced_announce)"""
-        return self.lib.sym_world_announce(self.h, self.batch, 1 if other_args else 0)
 
     def flush(self):
         self._check(self.lib.sym_world_flush(self.h))

@@ -877,50 +877,3 @@ def test_a_vanished_peer_poisons_the_world_instead_of_corrupting_it(imt):
     assert "did not arrive" in r0["msg"] and r0["at"] < 30.0, r0
     assert r0.get("steps_ok", 0) < 14 and r0.get("again") == F.ERR["INTERNAL"], r0
     assert got[1]["code"] is None and got[1]["steps_ok"] == 2
-
-
-@pytest.mark.parametrize("world,batch", [(1, 200), (2, 128), (4, 72)])
-def test_announced_steps_equal_the_one_gpu_tree(imt, ctx, world, batch):
-    """imt_sliced_announce: every step's arguments told one step ahead, so that its preparation is enqueued inside the step
-    before it -- the same witnesses and roots as the one-GPU tree; an announced step with a duplicate value is refused by ITS
-    step call and changes nothing; a step call with other arguments than the announced ones is IMT_ERR_ARG; a flush in the
-    middle drops an announcement"""
-    sl = load_sliced()
-    F = imt._ffi
-    depth, cap, rounds = 32, 1 << 13, 7
-    gb = world * batch
-    vals = oracle_lib.synth_values(gb * rounds, 0x494D5480 + world)
-    want, want_root = reference_run(imt, ctx, depth, cap, vals, gb)
-    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
-    chunks = [arr[r * gb:(r + 1) * gb].contiguous() for r in range(rounds)]
-    bad = chunks[3].clone()
-    bad[5] = bad[4]                                              # a duplicate inside step 3
-    t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world)
-    assert t.info()["prep_queue"] in (-1, 8)
-    t.step(chunks[0], next_vals=chunks[1])
-    t.step(chunks[1], next_vals=chunks[2])
-    t.step(chunks[2], next_vals=bad)                             # the bad step is announced ... and prepared ahead
-    size = t.size()
-    with pytest.raises(ValueError):
-        t.rounds.append(None)                                    # (step() records the round only on success: keep the slot arithmetic honest)
-        try:
-            t.rounds.pop()
-            t.step(bad)                                          # ... and refused by its own call
-        finally:
-            pass
-    assert t.size() == size
-    t.step(chunks[3], next_vals=chunks[4])                       # the same round number again, good values
-    with pytest.raises(imt.ImtError) as ei:
-        t.step(chunks[5])                                        # not the announced step
-    assert ei.value.code == F.ERR["ARG"]
-    t.step(chunks[4])                                            # the announcement was dropped: an ordinary step
-    t.flush()
-    t.step(chunks[5], next_vals=chunks[6])
-    t.flush()                                                    # drops the announcement of step 6 (its preparation was in flight)
-    t.step(chunks[6])
-    t.flush()
-    for r in range(rounds):
-        for k in range(world):
-            check_round(want[r], t.outputs(r, k), k * batch, (k + 1) * batch)
-    assert all(tr.root() == want_root for tr in t.trees)
-    t.close()

@@ -158,37 +158,6 @@ def test_gloo_ranks_line_up(world, depth, lag):
     assert res[0][2] > 0
 
 
-def test_announced_steps(lib):
-    """imt_sliced_announce in the schedule code.  A host that announces calls  announce(step k + 1); step(step k);
-    announce(step k + 2); step(step k + 1) ...: every step's preparation is issued inside the step before it and committed
-    by its own step() -- the same results as without; a step() with other arguments than the announced ones is refused and
-    the announcement dropped; two announcements without a step in between are refused; a flush drops announcements"""
-    for world, depth in ((1, 8), (2, 8), (4, 5)):
-        sim = sliced_sim.Sim(immediate=False, seed=world)
-        w = sliced_sim.SymWorld(lib, sim, world, depth, 4)
-        assert w.announce() == 0 and w.announce() == -9           # one step ahead, not two
-        for r in range(6):
-            assert w.step() == r                                   # commits what was announced for it (r >= 1), issues the next
-            if r % 3 != 2:
-                assert w.announce() == 0                           # told one step ahead; every third step is not announced
-        rounds = 6
-        w.flush()                                                  # drops what is still announced (issued and told)
-        assert w.step() == rounds                                  # an ordinary step after it
-        rounds += 1
-        assert w.announce(other_args=True) == 0
-        assert w.step() == rounds                                  # issues the announced (other) arguments for the step after this one
-        rounds += 1
-        R = sliced_sim.c_u64()
-        assert lib.sym_world_step(w.h, w.batch, ctypes.byref(R)) == -9      # IMT_ERR_ARG: not the announced step; announcement dropped
-        assert w.step() == rounds                                  # and the world goes on
-        rounds += 1
-        w.flush()
-        for rank, rp in w.reps.items():
-            assert sorted(rp.computed) == [(r * world + rank, q) for r in range(rounds) for q in range(depth + 1)]
-            assert all(lvl == list(range(rounds * world)) for lvl in rp.levels)
-        w.close()
-
-
 def test_small_schedules_exhaustively(lib):
     """every admissible (world <= 8, depth in 1..8, lag in 1..7) schedule, with flushes at changing places, under the
     adversarial stream scheduler: the corner cases of the tick arithmetic (a world larger than the tree is deep, a lag

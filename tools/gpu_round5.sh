@@ -77,12 +77,6 @@ issue)   # when does the host ISSUE a step's preparation, and when does it run? 
   ( export EMU_RANKS=first EMU_LINK_GBPS=0 EMU_ROUNDS=6; timeout -k 10 400 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $O/raw_issue -o issue -- python3 tools/rank_emulation.py 8 > $O/issue_under_rocprof.txt 2> $O/issue_rocprof.err ) &&
   python tools/trace_issue_lag.py $O/raw_issue "prep::k_scatter" "k_convert" > $O/issue_lag.txt 2>&1; rm -rf $O/raw_issue
   cat $O/issue_lag.txt | head -60 ;;
-announce)   # imt_sliced_announce on one emulated rank: every step told one step ahead (eight queues: the preparation on a queue of its own)
-  for cfg in "8 0" "8 1" "unset 0" "unset 1"; do set -- $cfg
-    ( if [ $1 != unset ]; then export GPU_MAX_HW_QUEUES=$1; fi; export EMU_ANNOUNCE=$2 EMU_RANKS="first last" EMU_ROUNDS=16
-      echo "== GPU_MAX_HW_QUEUES=$1, steps announced one step ahead: $2"; timeout -k 10 400 python tools/rank_emulation.py 8 4 2 1 2>&1 | grep "^N =" | cut -c1-130 ) >> $O/emu_announce.txt || break
-  done
-  cat $O/emu_announce.txt ;;
 tests)
   timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "pytest rc=$?" >> $O/tests.log
   tail -4 $O/tests.log ;;

@@ -92,10 +92,8 @@ def one_rank(world, rank, link, lat):
     c0, m0 = tp.calls, tp.model_ms
     i0 = t.info()
     t0 = time.perf_counter()
-    announce = os.environ.get("EMU_ANNOUNCE", "0") != "0"       # imt_sliced_announce: every step told one step ahead
     for r in range(WARM, steps):
-        nxt = vals[(r + 1) * gb:(r + 2) * gb] if announce and r + 1 < steps else None
-        t.step(vals[r * gb:(r + 1) * gb], F.INPUTS_READY, next_vals=nxt)
+        t.step(vals[r * gb:(r + 1) * gb], F.INPUTS_READY)
     t.flush()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
