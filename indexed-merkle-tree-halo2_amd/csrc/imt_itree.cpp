@@ -169,6 +169,7 @@ struct imt_itree {
     const uint32_t* slice_poison = nullptr;  // device-visible word of the world's transport: non-zero = skip applies
     double slice_wait_limit_ms = 0;          // > 0: host waits inside imt_itree_slice_prepare give up after this long
     double slice_wait_ms = 0;                // host time spent waiting for the GPU inside imt_itree_slice_prepare
+    double slice_backpressure_ms = 0;        // ... the part of it spent waiting for the plan set's previous slice (all-time total)
     bool sliced_busy = false;                // an imt_sliced world has steps in flight on this replica (until its flush)
     size_t reserved_events = 0;              // every plan set holds at least this many events (reserve_all_plans)
 };
@@ -462,6 +463,7 @@ unsigned imt_itree_depth(const imt_itree* t) { return t ? t->depth : 0; }
 void imt_itree_mark_sliced(imt_itree* t, bool busy) {
     if (t) t->sliced_busy = busy;
 }
+double imt_itree_slice_backpressure_ms(const imt_itree* t) { return t ? t->slice_backpressure_ms : 0; }
 void imt_itree_set_slice_poison(imt_itree* t, const uint32_t* device_word) {
     if (t) t->slice_poison = device_word;
 }
@@ -1745,7 +1747,9 @@ extern "C" int imt_itree_slice_prepare(imt_itree* t, const void* vals, size_t n_
         const auto w0 = std::chrono::steady_clock::now();
         rc = bounded_wait(c, t->slice_wait_limit_ms, [&] { return hipEventQuery(P.done); }, [&] { return hipEventSynchronize(P.done); },
                           "the plan set's previous slice");
-        t->slice_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        t->slice_wait_ms += waited;
+        t->slice_backpressure_ms += waited;
         if (rc) return rc;
         P.in_flight = false;
     }

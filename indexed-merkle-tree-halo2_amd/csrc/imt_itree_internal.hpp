@@ -17,3 +17,6 @@ void imt_itree_set_slice_prep_stream(imt_itree* t, void* hip_stream);
 void imt_itree_set_slice_poison(imt_itree* t, const uint32_t* device_word);
 // > 0: the host waits inside imt_itree_slice_prepare return IMT_ERR_TIMEOUT after this many milliseconds
 void imt_itree_set_slice_wait_limit(imt_itree* t, double ms);
+// all-time host milliseconds inside imt_itree_slice_prepare spent waiting for the plan set's previous slice to finish
+// (back-pressure), as opposed to the step's own value check
+double imt_itree_slice_backpressure_ms(const imt_itree* t);

@@ -1139,9 +1139,10 @@ int imt_sliced_set_option(imt_sliced* s, int option, long value) {
 void imt_sliced_destroy(imt_sliced* s) {
     if (!s) return;
     if (s->opt.timing)
-        fprintf(stderr, "[imt sliced rank %d] host ms over %llu rounds: apply %.1f  compute %.1f  send %.1f  (issue %.1f, waiting in prepare %.1f)\n",
+        fprintf(stderr, "[imt sliced rank %d] host ms over %llu rounds: apply %.1f  compute %.1f  send %.1f  (issue %.1f, waiting in prepare %.1f of which "
+                        "%.1f for a plan set's previous slice)\n",
                 s->ranks.empty() || !s->ranks[0] ? -1 : s->ranks[0]->rank, (unsigned long long)s->w.n_rounds, s->w.phase_ms[0], s->w.phase_ms[1],
-                s->w.phase_ms[2], s->host_issue_ms, s->host_wait_ms);
+                s->w.phase_ms[2], s->host_issue_ms, s->host_wait_ms, s->bes.empty() || !s->bes[0] ? 0.0 : imt_itree_slice_backpressure_ms(s->bes[0]->tree));
     // a poisoned world is not flushed (nothing can be issued any more); its replicas stay marked: they hold half a step
     const bool clean = !s->w.poisoned;
     if (clean && !s->w.ranks.empty() && s->w.n_rounds) s->w.flush();
