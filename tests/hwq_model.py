@@ -80,7 +80,7 @@ class Costs:
     # head of its queue while the device is full waits, first come first served, until a resident kernel has retired --
     # a SMALL kernel only until one has reached the last `tail` of its work (a retiring kernel's waves end one by one).
     resident_max = 2
-    rho = (1.0, 0.95, 0.56)
+    rho = (1.0, 0.96, 0.56)
     rho_busy = (1.0, 0.62, 0.49)
     sigma = (1.0, 0.55, 0.25)
     tail = 0.15
@@ -690,7 +690,7 @@ class Timed:
         res = [x for q in self.dev_q.get(dev, ()) if (x := self.running.get(q)) is not None and x.started and x.kind == HASH]
         if len(res) < self.c.resident_max:
             return True
-        if p.kind in (SMALL, COLL):             # (a collective's kernel is a few workgroups: it gets in like a small kernel)
+        if p.kind in (SMALL, COLL, SLEEP):      # (a collective's kernel, or the emulation's one-wave sleep, gets in like a small kernel)
             return any(x.left <= self.c.tail * x.work for x in res)
         return False
 
@@ -738,7 +738,7 @@ class Timed:
         self.dev_ver[dev] = self.dev_ver.get(dev, 0) + 1
         rh, rs, _ = self.rates(dev)
         best = None
-        waiting_small = any((x := self.running.get(q)) is not None and not x.started and x.kind in (SMALL, COLL) for q in self.dev_wait.get(dev, ()))
+        waiting_small = any((x := self.running.get(q)) is not None and not x.started and x.kind in (SMALL, COLL, SLEEP) for q in self.dev_wait.get(dev, ()))
         for q in self.dev_q.get(dev, ()):
             p = self.running.get(q)
             if p is None or not p.started:
