@@ -280,7 +280,10 @@ struct HipBackend : Backend {
                     if (cls[i] == cls[j]) dup = i;
             hipStream_t x;
             if ((rc = new_stream(&x, 0))) return rc;
-            if ((rc = pr.run(x, rs, ROUNDS, behind))) return rc;
+            if ((rc = pr.run(x, rs, ROUNDS, behind))) {
+                hipStreamDestroy(x);
+                return rc;
+            }
             bool shares = false;
             for (int j = 0; j < ROUNDS; j++) shares = shares || (behind[j] && j != dup);
             if (!shares) {          // a queue no other round stream is on
@@ -314,6 +317,7 @@ struct HipBackend : Backend {
                 for (int i = 0; i < count; i++) full = full && placed[i];
                 if (full) break;
                 hipStream_t s;
+                bool fresh = false;
                 if (!pool.empty()) {
                     s = pool.back();
                     pool.pop_back();
@@ -322,10 +326,14 @@ struct HipBackend : Backend {
                     int r = new_stream(&s, prio);
                     if (r) return r;
                     created++;
+                    fresh = true;
                 }
                 int p = -1;
                 int r = partner(s, &p);
-                if (r) return r;
+                if (r) {
+                    if (fresh) hipStreamDestroy(s);     // (the caller's own streams stay in arr: ~HipBackend destroys them)
+                    return r;
+                }
                 int slot = -1;
                 if (want_partner) {
                     // with fewer than four queues under the rounds, the partner is the first round stream of the class
@@ -1301,7 +1309,7 @@ const char* imt_sliced_last_error(const imt_sliced* s) {
     for (auto& be : s->bes)
         if (be && be->placement == IMT_SLICED_PLACEMENT_DEGRADED && be->ctx->last_error.empty()) return be->placement_note.c_str();
     for (auto& be : s->bes)
-        if (!be->ctx->last_error.empty()) return be->ctx->last_error.c_str();
+        if (be && !be->ctx->last_error.empty()) return be->ctx->last_error.c_str();
     return imt_transport_last_error(s->tp);
 }
 
