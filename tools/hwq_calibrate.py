@@ -75,7 +75,30 @@ HELD_OUT = [("lag 3 instead of 2", dict(lag=3), 2.376 / 2.817),
             ("the LAST rank instead of the first (r05: 2.817 / 2.731)", dict(rank=7), 2.817 / 2.731)]
 
 
+# Held out as well (round 5, profiles/r05_prep_repeated_experiment.txt): the bulk of a step's preparation enqueued TWICE per step by a
+# throw-away build (the sort, the gap search, the sparse-table levels and the index merge: 1.8 x its device time, 1.85 x
+# its launches).  (queues of their own?, modelled links?) -> measured ratio, means of two runs each.
+PREP_TWICE = {(True, True): (2.669 + 2.629) / (2.734 + 2.702), (True, False): (2.613 + 2.687) / (2.735 + 2.702),
+              (False, True): (2.709 + 2.726) / (2.761 + 2.765), (False, False): (2.795 + 2.801) / (2.895 + 2.890)}
+PREP_TWICE_BATCH_PIPELINE = (3.057 + 3.056) / (3.079 + 3.082)        # python bench.py: the one-GPU batch pipeline (no model of it here)
+
+
+def prep_twice(costs):
+    c = type("C", (type(costs),), {})()
+    c.__dict__.update(costs.__dict__)
+    c.prep_us = (costs.prep_us[0] * 1.8, costs.prep_us[1] * 2)
+    c.prep_kernels = int(costs.prep_kernels * 1.85)
+    return c
+
+
 def show_held_out(costs):
+    print("\nheld out: a step's preparation enqueued twice, one emulated rank of 8 (ratio to once)")
+    print("  collectives' streams on       links      model   measured")
+    c2 = prep_twice(costs)
+    for (own, links), meas in PREP_TWICE.items():
+        v = emu(8, 0, links, c2, comm_own_queues=own) / emu(8, 0, links, costs, comm_own_queues=own)
+        print(f"  {'queues of their own' if own else 'their rounds queues':28s}  {'48 GB/s' if links else 'free   '}   {v:6.3f}   {meas:6.3f}")
+    print(f"  (the one-GPU batch pipeline of bench.py, which this model does not describe: measured {PREP_TWICE_BATCH_PIPELINE:.3f})")
     base = emu_variant(8, 0, costs)
     print("\nheld-out variants of one emulated rank of 8 (ratio to the default; no parameter was fitted to these)")
     print("  variant                                                    model   measured")
