@@ -38,25 +38,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 
 
-def _n_gpus_asked():
-    import sys
-    n = int(os.environ.get("WORLD_SIZE", "1") or 1)
-    for i, a in enumerate(sys.argv):
-        if a == "--gpus" and i + 1 < len(sys.argv) and sys.argv[i + 1].isdigit():
-            n = max(n, int(sys.argv[i + 1]))
-        elif a.startswith("--gpus=") and a[7:].isdigit():
-            n = max(n, int(a[7:]))
-    return n
-
-
-# Eight hardware queues per priority level instead of the runtime's four, for runs with one GPU per rank (the runtime
-# reads this when it starts, so it is set here, before `import torch` loads it): imt_sliced_create then finds queues of
-# their OWN for the collectives' streams, so that a gather overlaps its round's next units instead of holding them up
-# until the slowest rank has packed (include/imt.h: IMT_SLICED_OPT_COMM_PLACEMENT).  The placement found is
-# on the line: schedule.queue_map.  Not in the one-GPU rehearsal (IMT_BENCH_DEVICE): N processes x 8+ queues
-# oversubscribe ONE device's hardware queue slots (4 processes: 1.3 against 1.7 M/s, profiles/r05_rehearsal_queues.txt).
-if _n_gpus_asked() > 1 and "IMT_BENCH_DEVICE" not in os.environ:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Nothing about the runtime's hardware queues is set here any more: with one process per GPU imt_sliced_create puts its
+# round streams into the HIGH-priority pool of queues, its collectives' streams into the LOW one and leaves the normal
+# pool to the host's and RCCL's own streams (include/imt.h: IMT_SLICED_OPT_POOLS) -- a gather then overlaps
+# its round's next units, and no foreign stream can sit on a round's queue.  The placement found is on the line:
+# schedule.pools / schedule.queue_map.  Not in the one-GPU rehearsal (IMT_BENCH_DEVICE): N processes x 12 queues would
+# oversubscribe ONE device's hardware queue slots (4 processes x 8: 1.3 against 1.7 M/s, profiles/r05_rehearsal_queues.txt).
 
 import argparse  # noqa: E402
 import ctypes  # noqa: E402
@@ -544,6 +531,8 @@ def bench_single_list(env):
         tp = stalling_transport(env)
     else:
         tp = sliced.local_transport(env.imt)
+    if "IMT_BENCH_DEVICE" in os.environ and "IMT_SLICED_POOLS" not in os.environ:      # the rehearsal: ranks share ONE device
+        lib.imt_sliced_set_option(None, env.F.SLICED_OPT_POOLS, 0)
     tree = sliced.SlicedTree(env.imt, env.local_rank, DEPTH, cap, BATCH, world, first_rank=rank, n_local=1, transport=tp,
                              lag=lag, nbuf=nbuf)
     env.live_world = tree          # for the watchdog: where the world stands when the leg hangs (imt_sliced_dump)
@@ -614,7 +603,7 @@ def bench_single_list(env):
                          "transport": kind, "rccl": rccl_lib,
                          # where the world's streams sit on the runtime's hardware queues, measured by imt_sliced_create:
                          # [round / collective / apply stream][round slot] -> queue class
-                         "queue_map": i1["queue_map"], "placement": i1["placement"], "hw_queues": i1["hw_queues"],
+                         "pools": i1["pools"], "queue_map": i1["queue_map"], "placement": i1["placement"], "hw_queues": i1["hw_queues"],
                          "comm_streams": i1["comm_streams"], "streams_recreated": i1["streams_recreated"]},
             "ctx": ctx, "be": tree, "boot": boot}       # boot: the context the transport was made on, alive until it is destroyed
 

@@ -74,6 +74,7 @@ pub struct imt_sliced_info {
     pub comm_streams: c_int,
     pub streams_recreated: c_int,
     pub queue_map: [[c_int; 4]; 3],
+    pub pools: c_int,
 }
 
 /// `imt_column_segment`: a stretch of insert_leaf's advice column (imt_insert_column_segments).
@@ -156,6 +157,7 @@ pub const IMT_SLICED_OPT_VERIFY_QUEUES: c_int = 6;
 pub const IMT_SLICED_OPT_WATCHDOG_MS: c_int = 7;
 pub const IMT_SLICED_OPT_TIMING: c_int = 8;
 pub const IMT_SLICED_OPT_COMM_PLACEMENT: c_int = 9;
+pub const IMT_SLICED_OPT_POOLS: c_int = 10;
 pub const IMT_SLICED_PLACEMENT_UNVERIFIED: c_int = 0;
 pub const IMT_SLICED_PLACEMENT_AS_CREATED: c_int = 1;
 pub const IMT_SLICED_PLACEMENT_REPAIRED: c_int = 2;

@@ -581,7 +581,8 @@ int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first
  * ...; they are read once per imt_sliced_create.) */
 #define IMT_SLICED_OPT_COMM_STREAMS 1      /* 0 .. 4 streams for the collectives (0: on the round's own stream); default 4 */
 #define IMT_SLICED_OPT_COMM_PRIORITY 2     /* their HIP stream priority; default 0 = the pool of hardware queues the rounds use */
-#define IMT_SLICED_OPT_ROUND_PRIORITIES 3  /* 0 (default): the four round streams at equal priority; 1: one normal + three high */
+#define IMT_SLICED_OPT_ROUND_PRIORITIES 3  /* the four round streams: 0 (default) all at normal priority; 1 one normal + three high
+                                              (not verified); 2 all LOW; 3 all HIGH -- a pool of hardware queues per priority */
 #define IMT_SLICED_OPT_APPLY_STREAMS 4     /* 1: other ranks' write-backs are applied on a stream of their own per round slot; default 0 */
 #define IMT_SLICED_OPT_PREP_STREAM 5       /* a step's preparation runs on 0 (default) the new round slot's collective stream, 1 its round stream, 2 the tree's side stream */
 #define IMT_SLICED_OPT_VERIFY_QUEUES 6     /* 1 (default): imt_sliced_create measures which of its streams share a hardware queue
@@ -603,7 +604,18 @@ int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first
                                               per priority level unless the host's environment says GPU_MAX_HW_QUEUES=8 (or more)
                                               BEFORE the first HIP call: set it for multi-GPU runs (bench.py does), or give the
                                               collectives' streams IMT_SLICED_OPT_COMM_PRIORITY 1 (the low-priority pool: 2 - 6 %
-                                              slower per rank on one GPU than normal priority) */
+                                              slower per rank on one GPU than normal priority) -- or IMT_SLICED_OPT_POOLS */
+#define IMT_SLICED_OPT_POOLS 10            /* 1: three priority pools -- round streams HIGH, collectives' streams LOW, the preparation
+                                              on the round's stream (sets ROUND_PRIORITIES 3, COMM_PRIORITY lowest, PREP_STREAM 1); 0:
+                                              everything in the normal pool, as the options above say; -1 (default): 1 for a world of
+                                              more than one rank with one rank in this process, else 0.  The runtime keeps a set of
+                                              hardware queues per priority, and everybody else's streams are in the normal one -- the
+                                              host's, and RCCL's: a communicator creates three of its own and brackets every
+                                              collective with one (the user's stream waits for it, it waits for the kernel).  Sharing
+                                              a round's queue, such a stream puts the round behind every collective and the collective
+                                              behind the round's backlog, and this library can neither see nor move it; in the HIGH
+                                              pool the rounds are alone.  Needs no GPU_MAX_HW_QUEUES.  One rank of 2 / 4 / 8 alone on
+                                              a GPU: within 1 % of one pool */
 int imt_sliced_set_option(imt_sliced *w, int option, long value);
 /* One step: vals = ALL world x n values of the step in insertion order (device pointer, identical contents on every
  * rank; format per flags), outs[k] = where local rank k's witnesses of ITS slice (insertions [rank * n, (rank + 1) * n)
@@ -653,6 +665,7 @@ typedef struct imt_sliced_info {
     int comm_streams;                /* streams carrying collectives after placement (0: the round streams do) */
     int streams_recreated;           /* streams that had to be created again to get the placement */
     int queue_map[3][IMT_SLICED_ROUNDS];
+    int pools;                       /* IMT_SLICED_OPT_POOLS as resolved: 1 = rounds HIGH / collectives LOW / RCCL and the host normal */
 } imt_sliced_info;
 #define IMT_SLICED_PLACEMENT_UNVERIFIED 0  /* not measured (option off, or unequal round priorities) */
 #define IMT_SLICED_PLACEMENT_AS_CREATED 1  /* measured: as wanted, first try */

@@ -66,7 +66,7 @@ class SlicedInfo(ctypes.Structure):
                [("payload_bytes", ctypes.c_size_t)] + [(n, ctypes.c_uint64) for n in ("rounds", "collectives", "bytes_gathered")] + \
                [(n, ctypes.c_double) for n in ("host_issue_ms", "host_wait_ms")] + \
                [(n, ctypes.c_int) for n in ("placement", "hw_queues", "comm_streams", "streams_recreated")] + \
-               [("queue_map", (ctypes.c_int * 4) * 3)]
+               [("queue_map", (ctypes.c_int * 4) * 3), ("pools", ctypes.c_int)]
 
 
 class ColumnSegment(ctypes.Structure):
@@ -215,7 +215,7 @@ OPT_COOP_MAX_EVENTS = 1
 SEG_GLUE, SEG_HASH = 0, 1
 SLICED_ROUNDS = 4
 (SLICED_OPT_COMM_STREAMS, SLICED_OPT_COMM_PRIORITY, SLICED_OPT_ROUND_PRIORITIES, SLICED_OPT_APPLY_STREAMS, SLICED_OPT_PREP_STREAM,
- SLICED_OPT_VERIFY_QUEUES, SLICED_OPT_WATCHDOG_MS, SLICED_OPT_TIMING, SLICED_OPT_COMM_PLACEMENT) = range(1, 10)
+ SLICED_OPT_VERIFY_QUEUES, SLICED_OPT_WATCHDOG_MS, SLICED_OPT_TIMING, SLICED_OPT_COMM_PLACEMENT, SLICED_OPT_POOLS) = range(1, 11)
 TRANSPORT_OPT_TIMEOUT_MS, TRANSPORT_OPT_HOST_POLL = 1, 2
 PLACEMENT = {0: "unverified", 1: "as created", 2: "repaired", 3: "degraded"}
 RCCL_UNIQUE_ID_BYTES = 128

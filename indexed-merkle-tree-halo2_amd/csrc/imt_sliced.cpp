@@ -38,10 +38,11 @@ namespace {
 struct SlicedOptions {
     long comm_streams = ROUNDS;      // streams that carry the collectives (0 = the round's own stream)
     long comm_priority = 0;          // their HIP priority (0 = the rounds' pool of hardware queues)
-    long round_priorities = 0;       // 0 equal, 1 = the batch pipeline's one normal + three high
+    long round_priorities = 0;       // 0 all normal, 1 = the batch pipeline's one normal + three high, 2 all LOW, 3 all HIGH
     long apply_streams = 0;          // 1 = the other ranks' write-backs are applied on a stream of their own per round slot
     long prep_stream = 0;            // where a step's preparation is enqueued: 0 the slot's collective stream, 1 its round stream, 2 the tree's side stream
     long comm_placement = 0;         // 0: the collectives' streams on queues of their own if there are any, else on their rounds'; 1: on their rounds'; 2: own or fail
+    long pools = -1;                 // 1: three priority pools (rounds HIGH, collectives LOW, preparation on the round stream); 0: one pool; -1: 1 for one process per GPU
     long verify_queues = 1;          // probe the stream -> hardware queue placement at creation and repair it
     long watchdog_ms = 120000;       // host waits inside imt_sliced_* give up after this long (0 = never)
     long timing = 0;                 // print the host's time per phase at destroy
@@ -60,6 +61,7 @@ int option_field(SlicedOptions& o, int option, long** field) {
         case IMT_SLICED_OPT_WATCHDOG_MS: *field = &o.watchdog_ms; return IMT_OK;
         case IMT_SLICED_OPT_TIMING: *field = &o.timing; return IMT_OK;
         case IMT_SLICED_OPT_COMM_PLACEMENT: *field = &o.comm_placement; return IMT_OK;
+        case IMT_SLICED_OPT_POOLS: *field = &o.pools; return IMT_OK;
     }
     return IMT_ERR_ARG;
 }
@@ -68,7 +70,9 @@ bool option_value_ok(int option, long v) {
         case IMT_SLICED_OPT_COMM_STREAMS: return v >= 0 && v <= ROUNDS;
         case IMT_SLICED_OPT_COMM_PRIORITY: return v >= -8 && v <= 8;
         case IMT_SLICED_OPT_PREP_STREAM: return v >= 0 && v <= 2;
+        case IMT_SLICED_OPT_ROUND_PRIORITIES: return v >= 0 && v <= 3;
         case IMT_SLICED_OPT_COMM_PLACEMENT: return v >= 0 && v <= 2;
+        case IMT_SLICED_OPT_POOLS: return v >= -1 && v <= 1;
         case IMT_SLICED_OPT_WATCHDOG_MS: return v >= 0;
         default: return v == 0 || v == 1;
     }
@@ -84,7 +88,7 @@ SlicedOptions effective_options() {
         if (!e || !*e) return;
         long v = atol(e);
         if (option == IMT_SLICED_OPT_PREP_STREAM) v = !strcmp(e, "side") ? 2 : !strcmp(e, "round") ? 1 : !strcmp(e, "comm") ? 0 : v;
-        if (option == IMT_SLICED_OPT_ROUND_PRIORITIES) v = !strcmp(e, "pipe") ? 1 : v;
+        if (option == IMT_SLICED_OPT_ROUND_PRIORITIES) v = !strcmp(e, "pipe") ? 1 : !strcmp(e, "low") ? 2 : !strcmp(e, "high") ? 3 : v;
         long* f = nullptr;
         if (option_value_ok(option, v) && option_field(oo, option, &f) == IMT_OK) *f = v;
     };
@@ -97,6 +101,7 @@ SlicedOptions effective_options() {
     env("IMT_SLICED_WATCHDOG_MS", IMT_SLICED_OPT_WATCHDOG_MS, o);
     env("IMT_SLICED_TIMING", IMT_SLICED_OPT_TIMING, o);
     env("IMT_SLICED_COMM_PLACEMENT", IMT_SLICED_OPT_COMM_PLACEMENT, o);
+    env("IMT_SLICED_POOLS", IMT_SLICED_OPT_POOLS, o);
     return o;
 }
 
@@ -173,6 +178,7 @@ struct HipBackend : Backend {
     imt_ctx* ctx;
     hipStream_t rs[ROUNDS] = {}, cs[ROUNDS] = {}, aps[ROUNDS] = {};     // round, collective and apply streams
     int n_comm = ROUNDS;
+    int round_prio = 0;                       // HIP priority of the (equal-priority) round streams
     SlicedOptions opt;
     // what the probe found (imt_sliced_info): hardware queue class of every stream, -1 = no such stream / not probed
     int q_round[ROUNDS], q_comm[ROUNDS], q_apply[ROUNDS];
@@ -206,10 +212,17 @@ struct HipBackend : Backend {
         if (channels > 0 && channels < ROUNDS) n_comm = channels;
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-        const bool equal = o.round_priorities == 0;
+        // The four round streams at ONE priority (equal): normal, or -- a pool of hardware queues per priority level -- all
+        // LOW / all HIGH: a pool nobody else in the process creates streams in (torch, RCCL: normal priority), so that no
+        // foreign stream can share a round's queue.  That matters with RCCL: a communicator owns internal streams
+        // (ncclCommInitRank creates three, normal priority: tools/microbench/rccl_streams_probe.hip) and brackets every
+        // collective with one of them -- the user's stream waits for it, it waits for the kernel -- so on a round's queue it
+        // would put the round behind every collective of that communicator, and the collective behind the round's backlog
+        const bool equal = o.round_priorities != 1;
+        round_prio = o.round_priorities == 2 ? least : o.round_priorities == 3 ? greatest : 0;
         const int comm_prio = std::max(greatest, std::min(least, (int)o.comm_priority));
         for (int i = 0; i < ROUNDS; i++)
-            if ((rc = new_stream(&rs[i], equal ? 0 : std::max(greatest, std::min(least, 0 - i))))) return rc;
+            if ((rc = new_stream(&rs[i], equal ? round_prio : std::max(greatest, std::min(least, 0 - i))))) return rc;
         for (int i = 0; i < n_comm; i++)
             if ((rc = new_stream(&cs[i], comm_prio))) return rc;
         // The schedule (imt_sliced_sched.hpp) lets the other ranks' write-backs be applied on a stream of their own per
@@ -217,7 +230,7 @@ struct HipBackend : Backend {
         // queues cost 2-4 %: tools/rank_emulation.py, profiles/r04_rank_emulation.txt).
         if (o.apply_streams)
             for (int i = 0; i < ROUNDS; i++)
-                if ((rc = new_stream(&aps[i], 0))) return rc;
+                if ((rc = new_stream(&aps[i], equal ? round_prio : 0))) return rc;
         if (o.verify_queues && equal) {
             if ((rc = place(comm_prio))) return rc;
         } else {
@@ -279,7 +292,7 @@ struct HipBackend : Backend {
                 for (int j = 0; j < i; j++)
                     if (cls[i] == cls[j]) dup = i;
             hipStream_t x;
-            if ((rc = new_stream(&x, 0))) return rc;
+            if ((rc = new_stream(&x, round_prio))) return rc;
             if ((rc = pr.run(x, rs, ROUNDS, behind))) {
                 hipStreamDestroy(x);
                 return rc;
@@ -297,7 +310,7 @@ struct HipBackend : Backend {
         }
         for (int i = 0; i < ROUNDS; i++) q_round[i] = cls[i];
         // ---- (2) the helper streams
-        const bool same_pool = comm_prio == 0;
+        const bool same_pool = comm_prio == round_prio;
         bool ok = n_queues == ROUNDS;
         auto partner = [&](hipStream_t s, int* out) -> int {       // which round stream's queue s is on (-1: none of them)
             int r = pr.run(s, rs, ROUNDS, behind);
@@ -370,7 +383,7 @@ struct HipBackend : Backend {
             for (int i = 0; i < count; i++) {
                 if (placed[i] != arr[i]) streams_recreated++;
                 arr[i] = placed[i];
-                qmap[i] = want_partner ? cls[i] : (prio == 0 ? ROUNDS + i : -2);
+                qmap[i] = want_partner ? cls[i] : (prio == round_prio ? ROUNDS + i : -2);
             }
             return IMT_OK;
         };
@@ -415,7 +428,7 @@ struct HipBackend : Backend {
             }
         }
         if (aps[0]) {
-            rc = settle(aps, ROUNDS, 0, true, q_apply, 3 * ROUNDS);
+            rc = settle(aps, ROUNDS, round_prio, true, q_apply, 3 * ROUNDS);
             if (rc < 0) return rc;
             if (rc == 1) {
                 for (int i = 0; i < ROUNDS; i++)
@@ -1196,6 +1209,22 @@ int imt_sliced_create(imt_itree* const* trees, int n_local, int world, int first
     s->tp = tp;
     s->max_slice = max_slice;
     s->opt = effective_options();
+    // Priority pools (IMT_SLICED_OPT_POOLS).  The runtime keeps a set of hardware queues PER stream priority, and everything
+    // else in a process lives in the normal one: the host's streams, and RCCL's -- a communicator creates three streams of
+    // its own (tools/microbench/rccl_streams_probe.hip) and brackets every collective with one of them (the user's stream
+    // waits for it, it waits for the kernel).  On a round's queue such a stream puts the round's hash kernels behind every
+    // collective of that communicator and the collective behind the round's backlog: 15 - 30 % in the queue model
+    // (profiles/r05_hwq_model.txt), and nothing this library could see or repair.  So for one process per GPU the round
+    // streams go to the HIGH-priority pool, where no foreign stream is, the collectives' streams to the LOW one (a gather
+    // overlaps its round's next units: IMT_SLICED_OPT_COMM_PLACEMENT's reason), and the preparation to the round's stream
+    // (it would crawl at low priority).  One rank of 2 / 4 / 8 alone on the GPU: within 1 % of everything in one pool
+    // (profiles/r05_emu_priority_pools.txt).  Replicas of one process have no peers to wait for: one pool.
+    if (s->opt.pools < 0) s->opt.pools = (n_local == 1 && world > 1) ? 1 : 0;
+    if (s->opt.pools == 1) {
+        s->opt.round_priorities = 3;
+        s->opt.comm_priority = 8;        // clamped to the lowest the device has
+        s->opt.prep_stream = 1;
+    }
     tp->users++;
     for (int k = 0; k < n_local; k++) {
         s->bes.emplace_back(new (std::nothrow) HipBackend(trees[k]));
@@ -1291,6 +1320,7 @@ int imt_sliced_get_info(const imt_sliced* s, imt_sliced_info* o) {
     o->hw_queues = be.n_queues;
     o->comm_streams = be.n_comm;
     o->streams_recreated = be.streams_recreated;
+    o->pools = (int)s->opt.pools;
     for (auto& b : s->bes) {                 // the worst of the local replicas
         if (b->placement > o->placement) o->placement = b->placement;
         o->streams_recreated = std::max(o->streams_recreated, b->streams_recreated);

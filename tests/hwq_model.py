@@ -239,7 +239,7 @@ class Recorder:
         # the step's preparation on the new round slot's collective stream (the product's default), then the host waits for
         # its verdict
         sc = self.costs.scaled(n_own)
-        stream = 4 * ROUNDS if self.sh.prep_own_stream else self.sh.comm_stream(slot)
+        stream = 4 * ROUNDS if self.sh.prep_own_stream else slot if self.sh.prep_on_round else self.sh.comm_stream(slot)
         tok = self.sh.new_token()
         work = (c.prep_us[0] + c.prep_us[1] * (self.world - 1)) * sc
         # some sixty dependent small kernels: each has to get onto the device on its own
@@ -328,8 +328,17 @@ class Recorder:
             ch = slot % self.channels if self.channels else slot
             n = self.chan_seq.get(ch, 0)
             self.chan_seq[ch] = n + 1
+            dev = 5 * ROUNDS + ch
+            if self.sh.rccl_internal:              # ncclLaunchPrepare: the user's stream waits for deviceStream
+                t0 = self.sh.new_token()
+                self.op(Pkt(REC, rank, dev, tok=t0, work=c.bar_us, what=f"RCCL deviceStream {ch}: record"), c.issue_event_us)
+                self.op(Pkt(WAIT, rank, stream, tok=t0, work=c.bar_us, what=f"RCCL: wait for deviceStream {ch}"), c.issue_event_us)
             self.op(Pkt(COLL, rank, stream, key=(ch, n), work=(real, words, sbuf, rbuf), what=f"all-gather {n} on channel {ch} ({nbytes} B)"),
                     c.issue_kernel_us)
+            if self.sh.rccl_internal:              # ncclLaunchFinish: deviceStream waits for the kernel
+                t1 = self.sh.new_token()
+                self.op(Pkt(REC, rank, stream, tok=t1, work=c.bar_us, what=f"RCCL: all-gather {n} of channel {ch} launched"), c.issue_event_us)
+                self.op(Pkt(WAIT, rank, dev, tok=t1, work=c.bar_us, what=f"RCCL deviceStream {ch}: wait for all-gather {n}"), c.issue_event_us)
         elif self.transport == "ipc":          # GPU-polled: flags in shared host memory, peer reads
             n = self.seq.get((slot, ring), 0) + 1
             self.seq[(slot, ring)] = n
@@ -409,11 +418,17 @@ class RankState:
 class Shared:
     """what the hosts of one world share: the ranks' symbolic replicas, the token counter, the stream layout"""
 
-    def __init__(self, comm_streams=ROUNDS, apply_streams=False, prep_own_stream=False):
+    def __init__(self, comm_streams=ROUNDS, apply_streams=False, prep_own_stream=False, rccl_internal=False, prep_on_round=False):
         self.ranks = {}
         self.tokens = 0
         self.comm_streams, self.apply_streams = comm_streams, apply_streams
         self.prep_own_stream = prep_own_stream          # the preparation on a stream (and hardware queue) of its own
+        self.prep_on_round = prep_on_round              # ... on the new round's own stream (IMT_SLICED_OPT_PREP_STREAM 1: what the priority pools use)
+        # RCCL's own stream per communicator (`deviceStream`; ncclCommInitRank creates three streams per communicator in the
+        # normal-priority pool: tools/microbench/rccl_streams_probe.hip).  NCCL's eager launch brackets every collective
+        # with it: the user's stream waits for an event recorded on deviceStream, and deviceStream then waits for an event
+        # recorded on the user's stream behind the kernel -- a barrier packet on whatever hardware queue deviceStream shares
+        self.rccl_internal = rccl_internal
 
     def new_rank(self, r, depth, batch, world):
         self.ranks[r] = RankState(depth, batch, world)
@@ -427,14 +442,15 @@ class Shared:
 
 
 def record(lib, world, depth, batch, script, lag=None, hosts="per-rank", transport="rccl", comm_streams=ROUNDS, apply_streams=False,
-           channels=0, costs=None, real_sizes=True, rank_scripts=None, only_ranks=None, prep_own_stream=False):
+           channels=0, costs=None, real_sizes=True, rank_scripts=None, only_ranks=None, prep_own_stream=False, rccl_internal=False,
+           prep_on_round=False):
     """run `script` (a list of ("step",) / ("wait", R) / ("flush",)) on every host and return (programs, shared).
     hosts = "per-rank": one host per rank, collectives through `transport` ("rccl", "ipc", "emu"); "one": all ranks in one
     process, the product's in-process transport (copies ordered by events).  rank_scripts: per-rank scripts instead
     (unequal call sequences: what the contract forbids).  only_ranks: record these ranks only ("emu")."""
     costs = costs or Costs()
     lib.sym_set_layout(comm_streams, 1 if apply_streams else 0)
-    sh = Shared(comm_streams, apply_streams, prep_own_stream)
+    sh = Shared(comm_streams, apply_streams, prep_own_stream, rccl_internal, prep_on_round)
     try:
         if hosts == "one":
             recs = [Recorder(sh, lib, world, depth, batch, lag, 0, world, "local", costs, real_sizes=real_sizes)]
@@ -464,13 +480,19 @@ class QueueMap:
     streams onto ANOTHER round's queue (what an unverified creation order may give), `one_device` puts every rank on
     device 0 (the in-process rehearsal: all replicas of a process share the process's K queues)."""
 
-    def __init__(self, K=4, rot=None, comm_shift=0, apply_shift=0, one_device=False, comm_own_queues=False, shared_gpu=False):
+    def __init__(self, K=4, rot=None, comm_shift=0, apply_shift=0, one_device=False, comm_own_queues=False, shared_gpu=False, rccl_dev=None):
         self.K, self.rot, self.comm_shift, self.apply_shift, self.one_device = K, rot or {}, comm_shift, apply_shift, one_device
         self.comm_own_queues = comm_own_queues          # the collectives' streams in another priority pool: K more queues
         self.shared_gpu = shared_gpu                    # one PROCESS per rank, all on device 0 (the rehearsal): queues per process
+        # hardware queue of RCCL's deviceStream per channel: a list (the same on every rank) or {rank: list}; numbers >= 2 K
+        # are queues that nothing of the world is on
+        self.rccl_dev = rccl_dev
 
     def __call__(self, rank, stream):
         kind, slot = divmod(stream, ROUNDS)           # 0 round, 1 collective, 2 apply, 3 the host-polled transport's worker
+        if kind == 5:                                 # RCCL's deviceStream of channel `slot`
+            lst = self.rccl_dev[rank] if isinstance(self.rccl_dev, dict) else self.rccl_dev
+            return (0 if (self.one_device or self.shared_gpu) else rank), lst[slot]
         if kind == 4:                                 # the preparation's own stream: a queue nothing else of the world is on
             return (0 if (self.one_device or self.shared_gpu) else rank), 3 * self.K + (rank if (self.one_device or self.shared_gpu) else 0)
         shift = (0, self.comm_shift, self.apply_shift, self.comm_shift)[kind]

@@ -400,7 +400,7 @@ def _worker(rank, world, port, q, host_poll):
     dist.barrier()                      # nobody closes its exported buffers while a peer may still read them
     tree.close()
     boot.close()
-    q.put((rank, res, root, info["collectives"], info["bytes_gathered"]))
+    q.put((rank, res, root, info["collectives"], info["bytes_gathered"], {k: info[k] for k in ("pools", "queue_map", "placement")}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -426,9 +426,12 @@ def test_processes_over_ipc_equal_one_gpu_tree(imt, ctx, world, host_poll):
         assert p.exitcode == 0
     vals = oracle_lib.synth_values(world * P_BATCH * P_ROUNDS, 0x494D5461)
     want, want_root = reference_run(imt, ctx, P_DEPTH, 1 << 13, vals, world * P_BATCH)
-    for rank, res, root, ncoll, nbytes in got:
+    for rank, res, root, ncoll, nbytes, place in got:
         assert root == want_root
         assert ncoll > 0 and nbytes > 0
+        # one process per rank: the rounds in the HIGH-priority pool, the collectives in the LOW one (IMT_SLICED_OPT_POOLS)
+        assert place["pools"] == 1 and sorted(place["queue_map"][0]) == [0, 1, 2, 3] and place["queue_map"][1] == [-2] * 4, place
+        assert place["placement"] in ("as created", "repaired"), place
         for r in range(P_ROUNDS):
             for k in FIELDS:
                 w = np.asarray(want[r][k])
@@ -725,9 +728,34 @@ def test_sliced_options(imt, ctx):
         t = sl.SlicedTree(imt, 0, 32, 1 << 10, 32, 1)
         assert t.info()["placement"] == "unverified" and t.info()["queue_map"][0] == [-1] * 4
         t.close()
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_VERIFY_QUEUES, 1) == 0
+        # three priority pools (what one process per GPU gets by default): the rounds alone on four queues of the HIGH
+        # pool, the collectives' streams on four of the LOW one, the same tree
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, 2) == F.ERR["RANGE"]
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, 1) == 0
+        t = sl.SlicedTree(imt, 0, 32, 1 << 10, 32, 2, n_local=2)
+        info = t.info()
+        assert info["pools"] == 1 and sorted(info["queue_map"][0]) == [0, 1, 2, 3] and info["queue_map"][1] == [-2] * 4, info
+        assert info["placement"] in ("as created", "repaired") and info["comm_streams"] == 4, info
+        vals2 = oracle_lib.synth_values(2 * 32 * 5, 0x494D547A)
+        want2, want_root2 = reference_run(imt, ctx, 32, 1 << 10, vals2, 64)
+        arr2 = torch.from_numpy(oracle_lib.ints_to_arr(vals2)).cuda()
+        for r in range(5):
+            t.step(arr2[r * 64:(r + 1) * 64])
+        t.flush()
+        for r in range(2, 5):
+            for k in range(2):
+                check_round(want2[r], t.outputs(r, k), k * 32, (k + 1) * 32)
+        assert t.trees[0].root() == want_root2 and t.trees[1].root() == want_root2
+        t.close()
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, -1) == 0
+        t = sl.SlicedTree(imt, 0, 32, 1 << 10, 32, 2, n_local=2)           # replicas of one process: one pool
+        assert t.info()["pools"] == 0 and t.info()["queue_map"][1] == t.info()["queue_map"][0]
+        t.close()
     finally:
         lib.imt_sliced_set_option(None, F.SLICED_OPT_APPLY_STREAMS, 0)
         lib.imt_sliced_set_option(None, F.SLICED_OPT_VERIFY_QUEUES, 1)
+        lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, -1)
 
 
 def test_transport_is_one_world_at_a_time(imt, ctx):

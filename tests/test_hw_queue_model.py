@@ -102,6 +102,46 @@ def test_hw_queue_model_progress(lib, world, depth, transport):
     assert runs >= 8
 
 
+@pytest.mark.parametrize("world,depth", [(2, 8), (4, 8), (8, 32), (3, 5)])
+def test_hw_queue_model_progress_with_rccls_own_streams(lib, world, depth):
+    """RCCL brackets every collective with a stream of the communicator's own (the user's stream waits for an event of
+    it, it waits for an event behind the kernel: tools/microbench/rccl_streams_probe.hip finds three streams per
+    communicator in the normal-priority pool): wherever those streams sit -- a queue nothing else is on, their own
+    slot's queue, ANOTHER round's queue, all four on one round's queue, a different place on every rank -- every run
+    drains and every unit sees exactly the earlier slices.  (Both waits point at something issued earlier on the same
+    rank, so the progress argument of DESIGN 8a covers them; what they cost is the next test.)"""
+    rounds = 6 if world < 8 else 5
+    maps = [M.QueueMap(K=4, rccl_dev=[0, 1, 2, 3]), M.QueueMap(K=4, rccl_dev=[1, 2, 3, 0]), M.QueueMap(K=4, rccl_dev=[2, 2, 2, 2]),
+            M.QueueMap(K=4, comm_own_queues=True, rccl_dev=[8, 9, 10, 11]), M.QueueMap(K=4, comm_own_queues=True, rccl_dev=[6, 3, 0, 5]),
+            M.QueueMap(K=4, comm_own_queues=True, rccl_dev={g: [(g + c) % 8 for c in range(4)] for g in range(world)}),
+            M.QueueMap(K=1, rccl_dev=[0, 0, 0, 0]), M.QueueMap(K=2, comm_shift=1, rccl_dev=[1, 0, 1, 0])]
+    runs = 0
+    for lag in lags_around_default(lib, world, depth):
+        for comm_streams, channels in ((4, 0), (0, 0), (4, 2)):
+            sc = script(rounds, waits=(lag is None), flush_at=(2,) if comm_streams == 0 else ())
+            for qm in (maps if (lag is None and world < 8) else maps[runs % 3::3]):
+                progs, sh, _ = M.record(lib, world, depth, 4, sc, lag=lag, transport="rccl", comm_streams=comm_streams, channels=channels,
+                                        real_sizes=False, rccl_internal=True)
+                assert M.replay_adversarial(progs, sh, qm, seed=4001 + runs, world=world) > 0
+                check_replicas(sh, world, rounds, depth)
+                runs += 1
+    assert runs >= 12
+
+
+def test_hw_queue_model_rccls_own_streams_must_stay_off_the_rounds_queues(lib):
+    """in time: one of RCCL's streams on a round's hardware queue puts that round's hash kernels behind every collective
+    of its communicator and the collective behind the round's backlog -- the reason for the three priority pools
+    (IMT_SLICED_OPT_POOLS: rounds HIGH, collectives LOW, everybody else's streams normal)"""
+    import hwq_calibrate as C
+    costs = M.Costs()
+    pools, _ = C.distributed(4, costs, rounds=6, warm=3, comm_own_queues=True, prep_on_round=True, rccl_dev=[8, 9, 10, 11])
+    crowded, _ = C.distributed(4, costs, rounds=6, warm=3, comm_own_queues=True, prep_on_round=True, rccl_dev=[8, 8, 8, 8])
+    one_pool, _ = C.distributed(4, costs, rounds=6, warm=3, rccl_dev=[1, 2, 3, 0])
+    eight, _ = C.distributed(4, costs, rounds=6, warm=3, comm_own_queues=True, rccl_dev=[1, 2, 3, 0])
+    assert crowded > 0.97 * pools                 # RCCL's streams sharing ONE queue among themselves: harmless
+    assert one_pool < 0.85 * pools and eight < 0.85 * pools, (pools, one_pool, eight)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_hw_queue_model_progress_host_polled_and_depth_32(lib, world):
     """the HOST-polled form of the IPC transport (ranks that share a GPU: a worker thread per rank watches the peers'

@@ -193,7 +193,7 @@ def test_sliced_rs_uses_the_ffi_as_declared():
         if decl:
             c_fields += [re.sub(r"\[.*", "", x.strip()) for x in decl.split(" ", 1)[1].split(",")]
     r = re.search(r"pub struct imt_sliced_info \{(.*?)\}", FFI, flags=re.S)
-    assert c_fields == re.findall(r"pub ([a-z_]+):", r.group(1)) and len(c_fields) == 18
+    assert c_fields == re.findall(r"pub ([a-z_]+):", r.group(1)) and len(c_fields) == 19
     m = re.search(r"typedef struct imt_transport_ops \{(.*?)\} imt_transport_ops;", HDR, flags=re.S)
     assert re.findall(r"\(\*([a-z_]+)\)", m.group(1)) == ["all_gather", "destroy"]
     r = re.search(r"pub struct imt_transport_ops \{(.*?)\n\}", FFI, flags=re.S)

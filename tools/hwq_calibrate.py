@@ -49,13 +49,14 @@ def inproc(world, costs, rounds=12, warm=2):
     return r
 
 
-def emu(world, rank, links, costs, rounds=12, warm=4, **qm):
+def emu(world, rank, links, costs, rounds=12, warm=4, prep_on_round=False, **qm):
     c = costs
     if not links:
         c = type("C", (type(costs),), {})()
         c.__dict__.update(costs.__dict__)
         c.link_gbps = 0.0
-    progs, sh, _ = M.record(lib, world, DEPTH, B, script(rounds, warm), transport="emu", comm_streams=4, costs=c, only_ranks=[rank])
+    progs, sh, _ = M.record(lib, world, DEPTH, B, script(rounds, warm), transport="emu", comm_streams=4, costs=c, only_ranks=[rank],
+                            prep_on_round=prep_on_round)
     r, T = timed_rate(progs, sh, M.QueueMap(**qm), c, world, B, rounds)
     return r
 
@@ -109,8 +110,9 @@ def show_held_out(costs):
         print(f"  {name:58s} {v / base:6.3f}   {meas:6.3f}")
 
 
-def distributed(world, costs, rounds=12, warm=4, speed=None, host_speed=None, transport="rccl", **qm):
-    progs, sh, _ = M.record(lib, world, DEPTH, B, script(rounds, warm), transport=transport, comm_streams=4, costs=costs)
+def distributed(world, costs, rounds=12, warm=4, speed=None, host_speed=None, transport="rccl", comm_streams=4, prep_on_round=False, **qm):
+    progs, sh, _ = M.record(lib, world, DEPTH, B, script(rounds, warm), transport=transport, comm_streams=comm_streams, costs=costs,
+                            rccl_internal=qm.get("rccl_dev") is not None, prep_on_round=prep_on_round)
     r, T = timed_rate(progs, sh, M.QueueMap(**qm), costs, world, world * B, rounds, speed=speed, host_speed=host_speed)
     return r, T
 
@@ -147,25 +149,45 @@ def main():
     show_held_out(costs)
     if "--fit" in sys.argv:
         return
-    print("\none process per GPU, RCCL semantics (a collective holds its queue until every rank's has reached the head of its own),")
-    print(f"links {costs.link_latency_us:.0f} us + bytes / {costs.link_gbps:.0f} GB/s per peer; placement as imt_sliced_create verifies it")
-    for own in (True, False):
-        print("  collectives' streams on queues of their own (the library's placement when the runtime has eight queues):" if own else
-              "  collectives' streams on their rounds' queues (four queues):")
-        for w in (2, 4, 8):
-            r, T = distributed(w, costs, comm_own_queues=own)
-            print(f"    N = {w}: {r:6.2f} M insertions/s  ({r / w:.3f} per GPU, {r / w / MEASURED[('inproc', 1)]:.3f} of the one-GPU figure)")
+    print("\none process per GPU, RCCL semantics (a collective holds its queue until every rank's has reached the head of its own; every")
+    print("communicator brackets its collectives with a stream of its own, tools/microbench/rccl_streams_probe.hip),")
+    print(f"links {costs.link_latency_us:.0f} us + bytes / {costs.link_gbps:.0f} GB/s per peer")
+    POOLS = dict(comm_own_queues=True, prep_on_round=True)
+
+    def line(w, r):
+        return f"N = {w}: {r:6.2f} ({r / w / MEASURED[('inproc', 1)]:.3f})"
+
+    def row(label, worlds=(2, 4, 8), **qm):
+        print(f"  {label:92s} " + "   ".join(line(w, distributed(w, costs, **qm)[0]) for w in worlds), flush=True)
+
+    print("M insertions/s (and the fraction of N x the one-GPU figure)")
+    print(" three priority pools -- the library's placement for one process per GPU (IMT_SLICED_OPT_POOLS): rounds HIGH, collectives LOW")
+    row("RCCL's streams in the normal pool, one queue each", rccl_dev=[8, 9, 10, 11], **POOLS)
+    row("RCCL's four streams on ONE queue of the normal pool", rccl_dev=[8, 8, 8, 8], **POOLS)
+    row("(without RCCL's own streams: the IPC transport)", **POOLS)
+    print(" one pool of four queues, collectives' streams on their rounds' queues (IMT_SLICED_OPT_POOLS 0, the runtime's defaults)")
+    row("no stream of RCCL's own (the IPC transport)")
+    row("RCCL's stream of channel c on round c's queue", rccl_dev=[0, 1, 2, 3])
+    row("RCCL's stream of channel c on ANOTHER round's queue", rccl_dev=[1, 2, 3, 0])
+    print(" one pool of eight queues, collectives' streams on queues of their own (GPU_MAX_HW_QUEUES=8: this round's earlier default)")
+    row("no stream of RCCL's own", comm_own_queues=True)
+    row("RCCL's stream of channel c on its collective stream's queue", comm_own_queues=True, rccl_dev=[4, 5, 6, 7])
+    row("RCCL's stream of channel c on round c's queue", comm_own_queues=True, rccl_dev=[0, 1, 2, 3])
+    row("RCCL's stream of channel c on another round's queue", comm_own_queues=True, rccl_dev=[1, 2, 3, 0])
+    row("RCCL's streams where a round-robin over eight queues puts them (6, 3, 0, 5)", comm_own_queues=True, rccl_dev=[6, 3, 0, 5])
     import random
     rng = random.Random(5)
+    print(" three priority pools, N = 8, GPUs and hosts of unequal speed")
     for skew in (0.015, 0.03):
         speed = {g: 1.0 + rng.uniform(-skew, skew) for g in range(8)}
-        r, T = distributed(8, costs, speed=speed, host_speed={g: 1.0 + rng.uniform(-0.2, 0.2) for g in range(8)}, comm_own_queues=True)
-        print(f"  N = 8 with per-GPU speeds within +-{skew * 100:.1f} % and host speeds within +-20 %: {r:6.2f} M insertions/s "
+        r, T = distributed(8, costs, speed=speed, host_speed={g: 1.0 + rng.uniform(-0.2, 0.2) for g in range(8)}, rccl_dev=[8, 9, 10, 11], **POOLS)
+        print(f"  per-GPU speeds within +-{skew * 100:.1f} % and host speeds within +-20 %: {r:6.2f} M insertions/s "
               f"(slowest GPU {min(speed.values()):.3f})")
-    for name, qm in (("four queues, collectives' streams on the NEXT slot's queue (comm_shift = 1)", dict(comm_shift=1)),
-                     ("four queues, ranks with different rotations of the queue map", dict(rot={g: g % 4 for g in range(8)}))):
+    print(" one pool of four queues, N = 8, no stream of RCCL's own")
+    for name, qm in (("collectives' streams on the NEXT slot's queue (comm_shift = 1)", dict(comm_shift=1)),
+                     ("ranks with different rotations of the queue map", dict(rot={g: g % 4 for g in range(8)}))):
         r, T = distributed(8, costs, **qm)
-        print(f"  N = 8, {name}: {r:6.2f} M insertions/s")
+        print(f"  {name}: {r:6.2f} M insertions/s")
 
 
 if __name__ == "__main__":
