@@ -602,9 +602,8 @@ int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first
                                               holds up the round's next unit until the slowest rank has packed (every tick a barrier
                                               across ranks); on its own it overlaps the next `lag` units.  The runtime has four queues
                                               per priority level unless the host's environment says GPU_MAX_HW_QUEUES=8 (or more)
-                                              BEFORE the first HIP call: set it for multi-GPU runs (bench.py does), or give the
-                                              collectives' streams IMT_SLICED_OPT_COMM_PRIORITY 1 (the low-priority pool: 2 - 6 %
-                                              slower per rank on one GPU than normal priority) -- or IMT_SLICED_OPT_POOLS */
+                                              BEFORE the first HIP call; queues in ANOTHER priority pool are what
+                                              IMT_SLICED_OPT_POOLS (below, the default for one process per GPU) arranges */
 #define IMT_SLICED_OPT_POOLS 10            /* 1: three priority pools -- round streams HIGH, collectives' streams LOW, the preparation
                                               on the round's stream (sets ROUND_PRIORITIES 3, COMM_PRIORITY lowest, PREP_STREAM 1); 0:
                                               everything in the normal pool, as the options above say; -1 (default): 1 for a world of

@@ -394,8 +394,8 @@ struct HipBackend : Backend {
             // gather only `lag` ticks later.  On a queue of its own the gather overlaps the next units and a rank may run
             // up to `lag` ticks ahead of its peers.  The queue model (tests/hwq_model.py, tools/hwq_calibrate.py) prices the
             // difference at 2 / 4 / 8 GPUs: 5.2 -> 5.7, 9.9 -> 10.9, 20.5 -> 21.1 M insertions/s.  Queues of their own exist
-            // when the pool the rounds use has more than four queues (GPU_MAX_HW_QUEUES=8 in the host's environment:
-            // bench.py sets it for N > 1) or when the collectives' streams have another priority (IMT_SLICED_OPT_COMM_PRIORITY
+            // when the pool the rounds use has more than four queues (GPU_MAX_HW_QUEUES=8 in the host's environment)
+            // or when the collectives' streams have another priority (IMT_SLICED_OPT_POOLS, or IMT_SLICED_OPT_COMM_PRIORITY
             // = 1: the low-priority pool; measured 2 - 6 % slower per rank than normal priority).  IMT_SLICED_OPT_COMM_PLACEMENT:
             // 0 = queues of their own if they can be had, else their rounds' queues; 1 = their rounds' queues; 2 = own or fail.
             rc = 1;
