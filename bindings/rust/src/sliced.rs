@@ -74,7 +74,8 @@ impl SlicedTree {
         o
     }
     /// the live options of this world: `IMT_SLICED_OPT_PREP_STREAM`, `_WATCHDOG_MS`, `_TIMING`.  The others decide which
-    /// streams exist and are process-wide defaults for worlds created later: `SlicedTree::set_default_option`.
+    /// streams exist and are process-wide defaults for worlds created later: `SlicedTree::set_default_option`
+    /// (e.g. `IMT_SLICED_OPT_POOLS` 0 for a host that uses high- or low-priority HIP streams of its own on the device).
     pub fn set_option(&mut self, option: i32, value: i64) -> Result<(), i32> {
         let rc = unsafe { imt_sliced_set_option(self.w, option, value as std::os::raw::c_long) };
         if rc == IMT_OK { Ok(()) } else { Err(rc) }
