@@ -52,6 +52,13 @@ __global__ void k_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+__global__ void k_copy16_multi(imt::launch::CopyJobs jobs, size_t n16, const uint32_t* poison) {
+    if (poisoned(poison)) return;
+    uint4* __restrict__ dst = (uint4*)jobs.dst[blockIdx.y];
+    const uint4* __restrict__ src = (const uint4*)jobs.src[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // ---- which streams share a hardware queue (imt_sliced.cpp: QueueProbe) ----
 // k_spin holds its stream's hardware queue for `ticks` of the 100 MHz wall clock and writes when it ended; k_stamp
 // writes when it RAN.  A stamp taken on another stream that is not earlier than the spin's end could not start before
@@ -76,6 +83,15 @@ void copy16(hipStream_t s, void* dst, const void* src, size_t bytes, const uint3
     if (!n16) return;
     const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, 512);
     hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n16, poison);
+}
+
+void copy16_multi(hipStream_t s, const CopyJobs& jobs, size_t bytes, const uint32_t* poison) {
+    const size_t n16 = bytes / 16;
+    if (!n16 || jobs.n <= 0) return;
+    // enough loads in flight per peer to keep a link busy (64 blocks x 256 lanes x 16 B = 256 KB), no more: the copy shares
+    // the device with the hash kernels
+    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, 64);
+    hipLaunchKernelGGL(k_copy16_multi, dim3(blocks, (unsigned)jobs.n), dim3(256), 0, s, jobs, n16, poison);
 }
 
 void flag_set_checked(hipStream_t s, uint64_t* flag, uint64_t value, const uint32_t* poison) {

@@ -20,6 +20,14 @@ void flag_wait(hipStream_t s, const FlagWait& w);
 // poison (may be null): a device-visible word; the copy / the store is skipped when it is non-zero (the sticky error word
 // of a transport whose wait has given up -- imt_flags.hip)
 void copy16(hipStream_t s, void* dst, const void* src, size_t bytes, const uint32_t* poison = nullptr);
+// the payloads of SEVERAL peers in one launch (blockIdx.y = peer): every peer is read over its own xGMI link, so the
+// links work side by side instead of one after the other (seven copies of 4.7 MB at N = 8: one link time, not seven)
+struct CopyJobs {
+    void* dst[FLAG_WAIT_MAX];
+    const void* src[FLAG_WAIT_MAX];
+    int n;
+};
+void copy16_multi(hipStream_t s, const CopyJobs& jobs, size_t bytes, const uint32_t* poison);
 void flag_set_checked(hipStream_t s, uint64_t* flag, uint64_t value, const uint32_t* poison);
 // the hardware-queue probe: hold stream s for `ticks` of the 100 MHz wall clock and write the end time / write the time
 // the kernel ran (one wave each)

@@ -951,10 +951,15 @@ struct IpcTransport : Transport {
         }
         int rc = wait_peers(st, i, k, false);
         if (rc) return rc;
-        for (int d = 1; d < world; d++) {              // start with the next rank: spread the reads over the peers
-            const int h = (rank + d) % world;
+        {                                              // every peer's payload in ONE launch: the peers' links side by side
+            imt::launch::CopyJobs jobs{};
+            for (int d = 1; d < world; d++) {
+                const int h = (rank + d) % world;
+                jobs.dst[jobs.n] = recv + (size_t)h * bytes;
+                jobs.src[jobs.n++] = peers[h].arena + off;
+            }
             HostTimer::Scope sc(ht, 2);
-            imt::launch::copy16(st, recv + (size_t)h * bytes, peers[h].arena + off, bytes, &my_shm_dev->err);
+            imt::launch::copy16_multi(st, jobs, bytes, &my_shm_dev->err);
         }
         HostTimer::Scope sc(ht, 0);
         // not published once a wait has given up: the peers must not overwrite send buffers this rank has not read

@@ -345,13 +345,13 @@ class Recorder:
             self.op(Pkt(FSET, rank, stream, key=("packed", rank, slot, ring, n), work=c.fill_us, what="packed"), c.issue_kernel_us)
             self.op(Pkt(FWAIT, rank, stream, key=[("packed", h, slot, ring, n) for h in range(self.world) if h != rank], work=c.fill_us,
                         what=f"wait packed {n} of ({slot},{ring})"), c.issue_kernel_us)
-            for d in range(1, self.world):
-                h = (rank + d) % self.world
-
-                def fx(h=h):
-                    sb = self.sh.ranks[h].send_of[(slot, ring)]
-                    rbuf[h * words:h * words + min(words, self.WORDS)] = sb[:min(words, self.WORDS)]
-                self.kernel(SMALL, rank, stream, c.copy_base_us + real / 1e6 * c.copy_us_per_mb + real / (c.link_gbps * 1e3), fx, f"peer read from rank {h}")
+            def fx():                              # k_copy16_multi: every peer's payload in one launch, the links side by side
+                for h in range(self.world):
+                    if h != rank:
+                        sb = self.sh.ranks[h].send_of[(slot, ring)]
+                        rbuf[h * words:h * words + min(words, self.WORDS)] = sb[:min(words, self.WORDS)]
+            self.kernel(SMALL, rank, stream, c.copy_base_us + (self.world - 1) * real / 1e6 * c.copy_us_per_mb + real / (c.link_gbps * 1e3), fx,
+                        "peer reads")
             self.op(Pkt(FSET, rank, stream, key=("copied", rank, slot, ring, n), work=c.fill_us, what="copied"), c.issue_kernel_us)
             rp.send_of[(slot, ring)] = sbuf
         elif self.transport == "ipc-host":     # host-polled: ranks that share a GPU; nothing on the device waits for a peer
