@@ -164,9 +164,10 @@ def main():
     print(" three priority pools -- the library's placement for one process per GPU (IMT_SLICED_OPT_POOLS): rounds HIGH, collectives LOW")
     row("RCCL's streams in the normal pool, one queue each", rccl_dev=[8, 9, 10, 11], **POOLS)
     row("RCCL's four streams on ONE queue of the normal pool", rccl_dev=[8, 8, 8, 8], **POOLS)
-    row("(without RCCL's own streams: the IPC transport)", **POOLS)
+    row("the IPC transport instead (counters polled by the GPUs, the peers' payloads read in one launch)", transport="ipc", **POOLS)
     print(" one pool of four queues, collectives' streams on their rounds' queues (IMT_SLICED_OPT_POOLS 0, the runtime's defaults)")
-    row("no stream of RCCL's own (the IPC transport)")
+    row("no stream of RCCL's own (the model before this was known)")
+    row("the IPC transport", transport="ipc")
     row("RCCL's stream of channel c on round c's queue", rccl_dev=[0, 1, 2, 3])
     row("RCCL's stream of channel c on ANOTHER round's queue", rccl_dev=[1, 2, 3, 0])
     print(" one pool of eight queues, collectives' streams on queues of their own (GPU_MAX_HW_QUEUES=8: this round's earlier default)")
