@@ -522,9 +522,30 @@ def bench_single_list(env):
     # ranks share the device and exchange payloads by direct peer copies over HIP IPC handles
     kind = os.environ.get("IMT_BENCH_SLICED_TRANSPORT", "rccl" if env.backend == "nccl" else ("ipc" if world > 1 else "local"))
     boot = env.imt.Context(env.local_rank)
+    transport_note = None
     if kind == "rccl":
-        tp = sliced.rccl_transport(env.imt, boot, dist, world, rank, n_comms=int(os.environ.get("IMT_BENCH_RCCL_COMMS", "4")),
-                                   device=env.dev if env.backend == "nccl" else None)
+        # RCCL inside the library; if its creation FAILS on any rank (a box without a usable RCCL, communicators that cannot
+        # be set up) every rank falls back to the library's other transport for ranks on different GPUs -- peer reads over
+        # HIP IPC handles -- and the line says so.  (A rank that hangs in ncclCommInitRank is the watchdog's business.)
+        tp, why = None, ""
+        try:
+            tp = sliced.rccl_transport(env.imt, boot, dist, world, rank, n_comms=int(os.environ.get("IMT_BENCH_RCCL_COMMS", "4")),
+                                       device=env.dev if env.backend == "nccl" else None)
+        except Exception as e:            # noqa: BLE001 -- whatever it was, the ranks must agree on what to do next
+            why = repr(e)
+        if world > 1:
+            bad = torch.tensor([0 if tp is not None else 1], dtype=torch.int32, device=env.dev if env.backend == "nccl" else "cpu")
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()):
+                if tp is not None:
+                    lib.imt_transport_destroy(tp)
+                tp, kind = None, "ipc"
+                transport_note = f"RCCL transport could not be created on some rank ({why or 'another rank'}): fell back to IPC peer reads"
+                print(f"[bench rank {rank}] {transport_note}", file=sys.stderr, flush=True)
+        elif tp is None:
+            raise RuntimeError(why)
+    if kind == "rccl":
+        pass
     elif kind == "ipc":
         tp = sliced.ipc_transport(env.imt, boot, dist, world, rank, DEPTH, BATCH, lag, device=env.dev if env.backend == "nccl" else None)
     elif kind == "stall":        # TEST ONLY (tests/test_gpu_sharded_procs.py): a collective that stops completing, world 1
@@ -600,7 +621,7 @@ def bench_single_list(env):
             "schedule": {"lag_levels": i1["lag"], "round_period_ticks": i1["period"], "gathers_per_round": i1["gathers_per_round"],
                          "rounds_in_flight": i1["rounds_in_flight"], "payload_bytes": i1["payload_bytes"],
                          "driver": "libimt_hip.so (imt_sliced_step: schedule, streams, events and the collective behind the C ABI)",
-                         "transport": kind, "rccl": rccl_lib,
+                         "transport": kind, "transport_note": transport_note, "rccl": rccl_lib,
                          # where the world's streams sit on the runtime's hardware queues, measured by imt_sliced_create:
                          # [round / collective / apply stream][round slot] -> queue class
                          "pools": i1["pools"], "queue_map": i1["queue_map"], "placement": i1["placement"], "hw_queues": i1["hw_queues"],

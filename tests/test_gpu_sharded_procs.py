@@ -242,6 +242,15 @@ def test_bench_gpus2_as_typed_rehearsal():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                         capture_output=True, text=True, timeout=300, env=env2, cwd=ROOT)
     assert r2.returncode != 0 and "does not match WORLD_SIZE" in (r2.stdout + r2.stderr)
+    # an RCCL transport that cannot be created (here: more communicators than the library takes) -> every rank falls back
+    # to the IPC transport, the line says so, the figure stands
+    env3 = dict(env, IMT_BENCH_SLICED_TRANSPORT="rccl", IMT_BENCH_RCCL_COMMS="9", IMT_BENCH_MODE="single-list")
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                        capture_output=True, text=True, timeout=600, env=env3, cwd=ROOT)
+    assert r3.returncode == 0, r3.stdout[-2000:] + r3.stderr[-4000:]
+    res3 = json.loads([l for l in r3.stdout.splitlines() if l.startswith("{")][0])
+    sch = res3["modes"]["single_list"]["schedule"]
+    assert res3["verified"] is True and sch["transport"] == "ipc" and "fell back" in sch["transport_note"], sch
 
 
 def test_bench_gpus4_as_typed_rehearsal():
