@@ -6,7 +6,11 @@ the rule: a new stream goes to the queue with the fewest streams of its priority
 other, and an event wait is a barrier packet that blocks the WHOLE queue -- every stream on it -- until the event has
 happened.  A collective (an RCCL kernel, or the wait kernel of the GPU-polled IPC transport) holds its queue until every
 peer's matching collective runs.  So whether a schedule makes progress, and how fast, depends on where its streams sit
-and on what the OTHER ranks' hosts have issued -- neither of which the per-stream simulator sees.
+and on what the OTHER ranks' hosts have issued -- neither of which the per-stream simulator sees.  And on other people's
+streams: RCCL brackets every collective with a stream of the communicator's own (`rccl_internal`: the user's stream waits
+for it, it waits for the kernel), which sits on SOME hardware queue of the normal-priority pool
+(tools/microbench/rccl_streams_probe.hip) -- the reason the library keeps its round streams in another pool when there is
+one process per GPU (IMT_SLICED_OPT_POOLS; here: QueueMap(comm_own_queues=True, rccl_dev=[queues >= 2 K])).
 
 What.  Two steps.
   1. RECORD.  The product's schedule code (csrc/imt_sliced_sched.hpp, compiled by tests/native/sliced_sym.cpp) is driven
