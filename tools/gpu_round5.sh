@@ -31,6 +31,9 @@ traces)
   ( export EMU_RANKS=first EMU_LINK_GBPS=0 EMU_ROUNDS=12; trace emu8 -- python3 tools/rank_emulation.py 8 ) && echo "trace emu8 ok" &&
   ( export EMU_RANKS=first EMU_ROUNDS=12; timeout -k 10 300 python tools/rank_emulation.py 8 > $O/rank_emulation_first8.txt 2>&1 ) && echo "emu ok"
   echo "traces part exit $?"; cat $O/sliced_costs.txt ;;
+poolstrace)  # one rank of 8 with the three priority pools (the library's default for one process per GPU), modelled links: the kernel trace
+  ( export EMU_RANKS=first EMU_ROUNDS=12; trace emu8_pools -- python3 tools/rank_emulation.py 8 ) && echo "trace emu8 pools ok"
+  tail -3 $O/emu8_pools_under_rocprof.txt | cut -c1-160 ;;
 prio)   # where the collectives' streams live: the normal pool (sharing the rounds' four queues) or the low-priority pool (four queues of their own)
   for cfg in "0 comm" "1 comm" "1 round" "0 round" "1 side"; do set -- $cfg
     ( export EMU_RANKS=first EMU_ROUNDS=12 IMT_SLICED_COMM_PRIO=$1 IMT_SLICED_PREP_STREAM=$2; echo "== comm prio $1, prep on $2"; timeout -k 10 200 python tools/rank_emulation.py 8 4 2>&1 | grep "^N =" | cut -c1-120 ) >> $O/emu_comm_prio.txt || break
