@@ -605,9 +605,11 @@ int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first
                                               BEFORE the first HIP call; queues in ANOTHER priority pool are what
                                               IMT_SLICED_OPT_POOLS (below, the default for one process per GPU) arranges */
 #define IMT_SLICED_OPT_POOLS 10            /* 1: three priority pools -- round streams HIGH, collectives' streams LOW, the preparation
-                                              on the round's stream (sets ROUND_PRIORITIES 3, COMM_PRIORITY lowest, PREP_STREAM 1); 0:
-                                              everything in the normal pool, as the options above say; -1 (default): 1 for a world of
-                                              more than one rank with one rank in this process, else 0.  The runtime keeps a set of
+                                              on the round's stream (sets ROUND_PRIORITIES 3, COMM_PRIORITY lowest, PREP_STREAM 1); 2:
+                                              round AND collectives' streams HIGH, the collectives' on their rounds' queues (4 % more per
+                                              rank on one GPU, but every tick a barrier across ranks: COMM_PLACEMENT); 0: everything in
+                                              the normal pool, as the options above say; -1 (default): 1 for a world of more than one
+                                              rank with one rank in this process, else 0.  The runtime keeps a set of
                                               hardware queues per priority, and everybody else's streams are in the normal one -- the
                                               host's, and RCCL's: a communicator creates three of its own and brackets every
                                               collective with one (the user's stream waits for it, it waits for the kernel).  Sharing

@@ -42,7 +42,7 @@ struct SlicedOptions {
     long apply_streams = 0;          // 1 = the other ranks' write-backs are applied on a stream of their own per round slot
     long prep_stream = 0;            // where a step's preparation is enqueued: 0 the slot's collective stream, 1 its round stream, 2 the tree's side stream
     long comm_placement = 0;         // 0: the collectives' streams on queues of their own if there are any, else on their rounds'; 1: on their rounds'; 2: own or fail
-    long pools = -1;                 // 1: three priority pools (rounds HIGH, collectives LOW, preparation on the round stream); 0: one pool; -1: 1 for one process per GPU
+    long pools = -1;                 // 1: three priority pools (rounds HIGH, collectives LOW, preparation on the round stream); 2: rounds AND collectives HIGH; 0: one pool; -1: 1 for one process per GPU
     long verify_queues = 1;          // probe the stream -> hardware queue placement at creation and repair it
     long watchdog_ms = 120000;       // host waits inside imt_sliced_* give up after this long (0 = never)
     long timing = 0;                 // print the host's time per phase at destroy
@@ -72,7 +72,7 @@ bool option_value_ok(int option, long v) {
         case IMT_SLICED_OPT_PREP_STREAM: return v >= 0 && v <= 2;
         case IMT_SLICED_OPT_ROUND_PRIORITIES: return v >= 0 && v <= 3;
         case IMT_SLICED_OPT_COMM_PLACEMENT: return v >= 0 && v <= 2;
-        case IMT_SLICED_OPT_POOLS: return v >= -1 && v <= 1;
+        case IMT_SLICED_OPT_POOLS: return v >= -1 && v <= 2;
         case IMT_SLICED_OPT_WATCHDOG_MS: return v >= 0;
         default: return v == 0 || v == 1;
     }
@@ -1229,6 +1229,13 @@ int imt_sliced_create(imt_itree* const* trees, int n_local, int world, int first
         s->opt.round_priorities = 3;
         s->opt.comm_priority = 8;        // clamped to the lowest the device has
         s->opt.prep_stream = 1;
+    } else if (s->opt.pools == 2) {
+        // the one-pool layout moved into the HIGH pool: the collectives' streams on their rounds' queues -- no foreign stream
+        // on a round's queue either, no barrier packet between a round and its gathers (same queue: in order), 4 % more
+        // per rank on one GPU than the three pools, but every tick a barrier across ranks again (IMT_SLICED_OPT_COMM_PLACEMENT)
+        s->opt.round_priorities = 3;
+        s->opt.comm_priority = -8;       // clamped to the highest
+        s->opt.comm_placement = 1;
     }
     tp->users++;
     for (int k = 0; k < n_local; k++) {

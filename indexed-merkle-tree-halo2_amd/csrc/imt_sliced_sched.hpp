@@ -57,6 +57,13 @@ constexpr int ROUNDS = 4;            // rounds in flight = slices a tree keeps o
 #else
 #define IMT_SCHED_OWN_READ_SLACK 0
 #endif
+// -DIMT_SCHED_ALL_WAITS: issue every wait, also those another wait on the same stream implies (A/B builds; see
+// wait_previous_round)
+#ifdef IMT_SCHED_ALL_WAITS
+#define IMT_SCHED_SKIP_IMPLIED 0
+#else
+#define IMT_SCHED_SKIP_IMPLIED 1
+#endif
 
 struct Schedule {
     int world = 0, units = 0, lag = 0;
@@ -185,8 +192,12 @@ struct Rank {
     std::vector<char> send_busy;                // [ROUNDS][ring] ... and the send buffer not yet known to be free again
     std::vector<Event> tick_ev;                 // [ROUNDS][round_ticks] round stream: the tick's unit is computed and packed
     std::vector<Event> applied_ev;              // [ROUNDS][round_ticks] apply stream: the tick's (and every earlier) apply is done
-    std::vector<Event> packed_ev, gathered_ev;  // [ROUNDS][ring]
-    std::vector<Event> consumed_ev;             // [ROUNDS][ring] apply stream: the receive buffer's payloads have been applied
+    std::vector<Event> gathered_ev;             // [ROUNDS][ring] the collective's stream: the gather into recv[i] is complete
+    // [ROUNDS][ring] "the send buffer is packed" = the tick event of the tick that packed it: an ALIAS into tick_ev (not
+    // owned), set when the tick is issued.  (Until round 5 a separate event, recorded right in front of the tick event on
+    // the same stream -- one barrier packet more between two hash kernels, for nothing.)  Likewise "the receive buffer's
+    // payloads have been applied" is the apply event of the tick that applied them (phase_send).
+    std::vector<Event> packed_ev;
     Event done_ev[ROUNDS] = {};
     Round rounds[ROUNDS + 1];                   // round R at R % (ROUNDS + 1)
     uint64_t n_rounds = 0;
@@ -219,7 +230,6 @@ struct Rank {
         send_busy.assign(nb, 0);
         packed_ev.assign(nb, nullptr);
         gathered_ev.assign(nb, nullptr);
-        consumed_ev.assign(nb, nullptr);
         tick_ev.assign((size_t)ROUNDS * sc.round_ticks, nullptr);
         applied_ev.assign((size_t)ROUNDS * sc.round_ticks, nullptr);
         w_units.resize(world);
@@ -236,9 +246,7 @@ struct Rank {
                     send_owned[i] = 1;
                 }
                 if ((rc = be->alloc(payload_cap * world, &recv[i]))) return rc;
-                if ((rc = be->new_event(&packed_ev[i])) || (rc = be->new_event(&gathered_ev[i])) ||
-                    (rc = be->new_event(&consumed_ev[i])))
-                    return rc;
+                if ((rc = be->new_event(&gathered_ev[i]))) return rc;
             }
         for (auto& e : tick_ev)
             if ((rc = be->new_event(&e))) return rc;
@@ -254,9 +262,7 @@ struct Rank {
         for (size_t i = 0; i < send.size(); i++) {
             if (send[i] && send_owned[i]) be->free_buffer(send[i]);
             if (recv[i]) be->free_buffer(recv[i]);
-            if (packed_ev[i]) be->free_event(packed_ev[i]);
             if (gathered_ev[i]) be->free_event(gathered_ev[i]);
-            if (consumed_ev[i]) be->free_event(consumed_ev[i]);
         }
         for (auto e : tick_ev)
             if (e) be->free_event(e);
@@ -276,13 +282,25 @@ struct Rank {
     // apply of tick u + world * lag (the last slice's unit u is gathered at tick u + (world - 1) lag and applied `lag`
     // later), this rank's own by its unit u -- and this rank's round R - 1 has READ the level (its unit u + 1, which
     // computes level u from it).  Both streams of round R - 1 are in order, so one event of each covers everything before.
+    //
+    // Every wait is a barrier packet on the waiting stream's hardware queue, and a round's stream carries them BETWEEN two
+    // of its hash kernels: ten packets a tick cost 150 us in which the round does not hash (rocprofv3 traces of one rank of
+    // eight, docs/LAB_NOTES.md), so a wait that another one implies is not issued: when round R - 1 applies on its round
+    // stream (the default), its tick event of tick `own` lies BEFORE its apply event of the later tick u + period on that
+    // one stream, and waiting for the latter is enough.
     int wait_previous_round(Stream st, uint64_t R, int u) {
-        const size_t base = (size_t)((R - 1) % ROUNDS) * sc.round_ticks;
+        const int pslot = (int)((R - 1) % ROUNDS);
+        const size_t base = (size_t)pslot * sc.round_ticks;
         int rc;
         if ((rc = be->wait(st, applied_ev[base + u + sc.period]))) return rc;
         const int own = std::min(u + 1 + IMT_SCHED_OWN_READ_SLACK, sc.units - 1) + rank * sc.lag;
+        if (IMT_SCHED_SKIP_IMPLIED && be->apply_stream(pslot) == be->round_stream(pslot) && own < u + sc.period) return IMT_OK;
         return be->wait(st, tick_ev[base + own]);
     }
+    // the previous-round wait phase_apply issued on the round's own stream at (R, rt), and up to which unit it reaches:
+    // phase_compute of the same tick, behind it on the same stream, needs no second one
+    uint64_t memo_R = ~(uint64_t)0;
+    int memo_rt = -1, memo_u = -1;
 
     // gathered payloads of tick rt - lag -> this replica, on the round's APPLY stream: an apply waits for a collective and
     // for the previous round's applies, not for this rank's own hashing, so the round's units are never queued behind it
@@ -305,10 +323,21 @@ struct Rank {
         int top = -1;
         for (int g = 0; g < world; g++) top = std::max(top, (int)w_units[g]);
         if (top < 0) return be->record(done, ast);
-        if (R >= 1 && IMT_SCHED_MUTATION != 2)
+        if (R >= 1 && IMT_SCHED_MUTATION != 2) {
             // a write-back of round R lands on a node after every write-back round R - 1 made to that level and after
-            // that round's last look at it
-            if ((rc = wait_previous_round(ast, R, top))) return rc;
+            // that round's last look at it.  On the round's own stream the unit of this tick comes right behind and
+            // needs the same of round R - 1 for ITS level (a later tick of that round: it implies this one): one wait
+            // for both.
+            int u = top;
+            const bool same = IMT_SCHED_SKIP_IMPLIED && ast == be->round_stream(slot);
+            if (same && IMT_SCHED_MUTATION != 1) u = std::max(u, sc.unit_of(rank, rt));
+            if ((rc = wait_previous_round(ast, R, u))) return rc;
+            if (same) {
+                memo_R = R;
+                memo_rt = rt;
+                memo_u = u;
+            }
+        }
         for (int g = 0; g < world; g++) {
             w_sb[g] = rd.size_before + (uint64_t)g * rd.n;
             w_n[g] = rd.n;
@@ -317,10 +346,8 @@ struct Rank {
         // collective that also carries this rank's own unit of that tick, u + (g - rank) lag >= u + 1 -- the unit that read
         // level u - 1 -- so the collective cannot complete before that read; an EARLIER slice's payload writes levels this
         // rank's units have not reached, and those wait for this apply (phase_compute).
-        if ((rc = be->apply_gathered(recv[i], gather_bytes[i], world, w_sb.data(), w_n.data(), w_units.data(), ast)) ||
-            (rc = be->record(consumed_ev[i], ast)))
-            return rc;
-        return be->record(done, ast);
+        if ((rc = be->apply_gathered(recv[i], gather_bytes[i], world, w_sb.data(), w_n.data(), w_units.data(), ast))) return rc;
+        return be->record(done, ast);        // also "recv[i] has been read" for the collective that will refill it (phase_send)
     }
 
     // this rank's unit of the tick, packed into the tick's send buffer
@@ -331,9 +358,11 @@ struct Rank {
         const int i = at(slot, rt % ring);
         int rc;
         if (q >= 0) {
-            // the earlier slices' write-backs of this tick (the previous slice's level q - 1 arrives exactly now)
-            if (IMT_SCHED_MUTATION != 4 && (rc = be->wait(st, applied_ev[(size_t)slot * sc.round_ticks + rt]))) return rc;
-            if (q >= 1 && R >= 1 && IMT_SCHED_MUTATION != 1)
+            // the earlier slices' write-backs of this tick (the previous slice's level q - 1 arrives exactly now); applies
+            // on the round's own stream are in front of the unit anyway
+            const bool same = IMT_SCHED_SKIP_IMPLIED && be->apply_stream(slot) == st;
+            if (!same && IMT_SCHED_MUTATION != 4 && (rc = be->wait(st, applied_ev[(size_t)slot * sc.round_ticks + rt]))) return rc;
+            if (q >= 1 && R >= 1 && IMT_SCHED_MUTATION != 1 && !(same && memo_R == R && memo_rt == rt && memo_u >= q))
                 // level q - 1 of every slice of round R - 1 must be in this replica, and that round done reading it
                 if ((rc = wait_previous_round(st, R, q))) return rc;
             if (send_busy[i]) {     // the unit packs into a send buffer an earlier collective may still be reading
@@ -343,14 +372,15 @@ struct Rank {
             if ((rc = be->unit(round(R).slice, (unsigned)q, send[i], st))) return rc;
             if (q == sc.units - 1 && (rc = be->record(done_ev[slot], st))) return rc;
         }
-        if (sc.has_gather(rt) && (rc = be->record(packed_ev[i], st))) return rc;
-        return IMT_OK;
+        // the tick's event: unit computed and packed (and what the tick's collective waits for)
+        Event tick = tick_ev[(size_t)slot * sc.round_ticks + rt];
+        if (sc.has_gather(rt)) packed_ev[i] = tick;
+        return be->record(tick, st);
     }
 
-    // the tick's collective (asynchronous, consumed `lag` ticks later) and the tick's event
+    // the tick's collective (asynchronous, consumed `lag` ticks later)
     int phase_send(uint64_t R, int rt) {
         const int slot = (int)(R % ROUNDS);
-        Stream st = be->round_stream(slot);
         int rc;
         if (sc.has_gather(rt)) {
             const int r = rt % ring, i = at(slot, r);
@@ -363,8 +393,13 @@ struct Rank {
                 if (w_units[g] >= 0) mx = std::max(mx, be->unit_bytes(rd.size_before + (uint64_t)g * rd.n, rd.n, (unsigned)w_units[g]));
             gather_bytes[i] = mx;
             Stream cs = be->comm_stream(slot);
-            // the receive buffer is free once its previous payloads have been applied (another stream's business now)
-            if ((IMT_SCHED_MUTATION != 5 && (rc = be->wait(cs, consumed_ev[i]))) || (rc = be->wait(cs, packed_ev[i])) ||
+            // the receive buffer is free once its previous payloads have been applied (another stream's business now):
+            // those of this round's tick rt - ring, applied at tick rt - ring + lag = rt - 1; for the round's first gathers
+            // those of the slot's previous round, the last of which its last tick applied (applies are in order)
+            Event freed = nullptr;
+            if (rt >= ring) freed = applied_ev[(size_t)slot * sc.round_ticks + rt - 1];
+            else if (R >= (uint64_t)ROUNDS) freed = applied_ev[(size_t)slot * sc.round_ticks + sc.round_ticks - 1];
+            if ((IMT_SCHED_MUTATION != 5 && freed && (rc = be->wait(cs, freed))) || (rc = be->wait(cs, packed_ev[i])) ||
                 (rc = tp->all_gather(*this, slot, r, mx, cs)) || (rc = be->record(gathered_ev[i], cs)))
                 return rc;
             pending[i] = 1;
@@ -373,7 +408,7 @@ struct Rank {
             tp->collectives++;
             tp->bytes_moved += mx * (uint64_t)world;
         }
-        return be->record(tick_ev[(size_t)slot * sc.round_ticks + rt], st);
+        return IMT_OK;
     }
 };
 

@@ -73,7 +73,7 @@ class Costs:
     copy_base_us, copy_us_per_mb = 2.4, 1.0        # device-to-device copies (blit kernel): launch + bytes
     prep_us = (1500.0, 70.0)    # a step's preparation: base + per further rank's slice (index work for N x n values)
     prep_kernels = 60           # ... issued as this many launches by the host
-    bar_us = 3.6                # a barrier packet (event record / stream wait) once it is at the head of its queue
+    bar_us = 2.5                # a barrier packet (event record / stream wait) once it is at the head of its queue (3.6 measured alone; the fit)
     gap_us = 0.0                # between two kernels of one queue (the trace shows them back to back)
     issue_kernel_us, issue_event_us = 3.2, 1.6     # host time per launch / per event call
     # The device: `resident_max` hash kernels fit at a time (k_sweep: 2 048 waves of 64 lanes = 2 per SIMD, and the traces
@@ -91,7 +91,7 @@ class Costs:
     # more than four hardware queues in use on a device (GPU_MAX_HW_QUEUES=8: the collectives' streams on queues of their
     # own): the hash kernels run this much slower -- measured, not explained (one emulated rank, eight queues against four:
     # profiles/r05_emu_own_queues.txt; round 4 saw the same with the streams merely spread over eight queues)
-    many_queues = 0.955
+    many_queues = 0.94
     # the link model of a collective between different GPUs: latency + bytes per peer / rate (one xGMI link per peer)
     link_latency_us, link_gbps = 40.0, 48.0
 

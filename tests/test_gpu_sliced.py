@@ -731,7 +731,12 @@ def test_sliced_options(imt, ctx):
         assert lib.imt_sliced_set_option(None, F.SLICED_OPT_VERIFY_QUEUES, 1) == 0
         # three priority pools (what one process per GPU gets by default): the rounds alone on four queues of the HIGH
         # pool, the collectives' streams on four of the LOW one, the same tree
-        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, 2) == F.ERR["RANGE"]
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, 3) == F.ERR["RANGE"]
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, 2) == 0      # rounds and collectives in the HIGH pool, on shared queues
+        t = sl.SlicedTree(imt, 0, 32, 1 << 10, 32, 1)
+        info = t.info()
+        assert info["pools"] == 2 and sorted(info["queue_map"][0]) == [0, 1, 2, 3] and info["queue_map"][1] == info["queue_map"][0], info
+        t.close()
         assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, 1) == 0
         t = sl.SlicedTree(imt, 0, 32, 1 << 10, 32, 2, n_local=2)
         info = t.info()
