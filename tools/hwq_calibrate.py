@@ -175,6 +175,8 @@ def main():
     row("RCCL's streams in the normal pool, one queue each", rccl_dev=[8, 9, 10, 11], **POOLS)
     row("RCCL's four streams on ONE queue of the normal pool", rccl_dev=[8, 8, 8, 8], **POOLS)
     row("the IPC transport instead (counters polled by the GPUs, the peers' payloads read in one launch)", transport="ipc", **POOLS)
+    print(" round AND collectives' streams in the HIGH pool, the collectives' on their rounds' queues (IMT_SLICED_OPT_POOLS 2)")
+    row("RCCL's streams in the normal pool (the model misses this layout's emulated rank of 8 by -5 %)", rccl_dev=[8, 9, 10, 11])
     print(" one pool of four queues, collectives' streams on their rounds' queues (IMT_SLICED_OPT_POOLS 0, the runtime's defaults)")
     row("no stream of RCCL's own (the model before this was known)")
     row("the IPC transport", transport="ipc")
@@ -192,6 +194,13 @@ def main():
     for skew in (0.015, 0.03):
         speed = {g: 1.0 + rng.uniform(-skew, skew) for g in range(8)}
         r, T = distributed(8, costs, speed=speed, host_speed={g: 1.0 + rng.uniform(-0.2, 0.2) for g in range(8)}, rccl_dev=[8, 9, 10, 11], **POOLS)
+        print(f"  per-GPU speeds within +-{skew * 100:.1f} % and host speeds within +-20 %: {r:6.2f} M insertions/s "
+              f"(slowest GPU {min(speed.values()):.3f})")
+    print(" IMT_SLICED_OPT_POOLS 2, N = 8, GPUs and hosts of unequal speed (every tick a barrier across ranks: host jitter gets through)")
+    rng = random.Random(5)
+    for skew in (0.015, 0.03):
+        speed = {g: 1.0 + rng.uniform(-skew, skew) for g in range(8)}
+        r, T = distributed(8, costs, speed=speed, host_speed={g: 1.0 + rng.uniform(-0.2, 0.2) for g in range(8)}, rccl_dev=[8, 9, 10, 11])
         print(f"  per-GPU speeds within +-{skew * 100:.1f} % and host speeds within +-20 %: {r:6.2f} M insertions/s "
               f"(slowest GPU {min(speed.values()):.3f})")
     print(" one pool of four queues, N = 8, no stream of RCCL's own")
