@@ -399,7 +399,10 @@ struct Rank {
             Event freed = nullptr;
             if (rt >= ring) freed = applied_ev[(size_t)slot * sc.round_ticks + rt - 1];
             else if (R >= (uint64_t)ROUNDS) freed = applied_ev[(size_t)slot * sc.round_ticks + sc.round_ticks - 1];
-            if ((IMT_SCHED_MUTATION != 5 && freed && (rc = be->wait(cs, freed))) || (rc = be->wait(cs, packed_ev[i])) ||
+            // (applies on the round's own stream: both of those events lie in front of this tick's event on that stream,
+            // which the collective waits for anyway)
+            const bool implied = IMT_SCHED_SKIP_IMPLIED && be->apply_stream(slot) == be->round_stream(slot);
+            if ((IMT_SCHED_MUTATION != 5 && freed && !implied && (rc = be->wait(cs, freed))) || (rc = be->wait(cs, packed_ev[i])) ||
                 (rc = tp->all_gather(*this, slot, r, mx, cs)) || (rc = be->record(gathered_ev[i], cs)))
                 return rc;
             pending[i] = 1;
