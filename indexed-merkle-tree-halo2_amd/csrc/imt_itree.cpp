@@ -168,6 +168,8 @@ struct imt_itree {
     hipStream_t slice_prep_stream = nullptr; // where the next imt_itree_slice_prepare runs (nullptr: the side stream)
     const uint32_t* slice_poison = nullptr;  // device-visible word of the world's transport: non-zero = skip applies
     double slice_wait_limit_ms = 0;          // > 0: host waits inside imt_itree_slice_prepare give up after this long
+    hipEvent_t slice_tail_event = nullptr;   // one shot (imt_itree_set_slice_tail_event)
+    bool slice_tail_attached = false;
     double slice_wait_ms = 0;                // host time spent waiting for the GPU inside imt_itree_slice_prepare
     double slice_backpressure_ms = 0;        // ... the part of it spent waiting for the plan set's previous slice (all-time total)
     bool sliced_busy = false;                // an imt_sliced world has steps in flight on this replica (until its flush)
@@ -464,6 +466,19 @@ void imt_itree_mark_sliced(imt_itree* t, bool busy) {
     if (t) t->sliced_busy = busy;
 }
 double imt_itree_slice_backpressure_ms(const imt_itree* t) { return t ? t->slice_backpressure_ms : 0; }
+void imt_itree_set_slice_tail_event(imt_itree* t, void* hip_event) {
+    if (t) {
+        t->slice_tail_event = (hipEvent_t)hip_event;
+        t->slice_tail_attached = false;
+    }
+}
+bool imt_itree_take_slice_tail_attached(imt_itree* t) {
+    if (!t) return false;
+    const bool a = t->slice_tail_attached;
+    t->slice_tail_attached = false;
+    t->slice_tail_event = nullptr;
+    return a;
+}
 void imt_itree_set_slice_poison(imt_itree* t, const uint32_t* device_word) {
     if (t) t->slice_poison = device_word;
 }
@@ -1908,9 +1923,13 @@ extern "C" int imt_itree_slice_unit(imt_itree* t, int slice, unsigned unit, void
         if (pl) {       // the write-back, and what the other replicas need to repeat it: (node, value) pairs, packed
             const size_t cap = slice_pairs(P.slice_size_before, n, l);
             IMT_HIP(c, hipMemsetAsync(pl + SLICE_COUNT_AT, 0, 4, s));
+            // the pack is the last kernel of this unit (unless it is the round's last, or a profile brackets it): it can
+            // signal the tick's event itself
+            hipEvent_t tail = (l + 1 != depth && pf < 0) ? t->slice_tail_event : nullptr;
             launch::pack_writeback(s, vin, P.d_from + off, P.d_nodeb + off, (uint32_t)E, t->d_nodes + t->h_off[l] * 32,
                                    pl + SLICE_HDR, (uint32_t*)(pl + SLICE_HDR + cap * 32), (uint32_t*)(pl + SLICE_COUNT_AT),
-                                   (uint32_t)cap);
+                                   (uint32_t)cap, tail);
+            if (tail) t->slice_tail_attached = true;
         } else {
             launch::writeback(s, vin, P.d_from + off, P.d_nodeb + off, t->d_nodes + t->h_off[l] * 32, (uint32_t)E);
         }
@@ -2024,7 +2043,12 @@ extern "C" int imt_itree_slice_apply_gathered(imt_itree* t, const void* gathered
         }
         if (jobs.n_jobs >= 15) { launch::apply_gathered(s, jobs); jobs.n_jobs = 0; }
     }
-    launch::apply_gathered(s, jobs);
+    if (jobs.n_jobs && t->slice_tail_event) {
+        launch::apply_gathered(s, jobs, t->slice_tail_event);
+        t->slice_tail_attached = true;
+    } else {
+        launch::apply_gathered(s, jobs);
+    }
     return IMT_OK;
 }
 

@@ -17,6 +17,11 @@ void imt_itree_set_slice_prep_stream(imt_itree* t, void* hip_stream);
 void imt_itree_set_slice_poison(imt_itree* t, const uint32_t* device_word);
 // > 0: the host waits inside imt_itree_slice_prepare return IMT_ERR_TIMEOUT after this many milliseconds
 void imt_itree_set_slice_wait_limit(imt_itree* t, double ms);
+// One shot: the NEXT imt_itree_slice_unit / imt_itree_slice_apply_gathered makes its last kernel signal `hip_event` when that
+// kernel is the last thing the call enqueues (the pack of a level below l0; the apply of at least one payload) --
+// imt_itree_take_slice_tail_attached then says true, and the caller needs no hipEventRecord behind the call.
+void imt_itree_set_slice_tail_event(imt_itree* t, void* hip_event);
+bool imt_itree_take_slice_tail_attached(imt_itree* t);
 // all-time host milliseconds inside imt_itree_slice_prepare spent waiting for the plan set's previous slice to finish
 // (back-pressure), as opposed to the step's own value check
 double imt_itree_slice_backpressure_ms(const imt_itree* t);

@@ -11,6 +11,8 @@
 // a5/a8/a9 path_root, a13 non_membership, a14 insert_witness, a15 sweep_* (index logic in imt_sweep.hpp;
 // the hash-free batch preparation is a separate translation unit, imt_prep.hip).
 #include <algorithm>
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "imt_device.hpp"
 #include "imt_trace_device.hpp"
@@ -1420,22 +1422,27 @@ void extract(hipStream_t s, const ExtractParams& p) {
     hipLaunchKernelGGL(k_extract, dim3(nblk(threads)), dim3(BLOCK), 0, s, a);
 }
 void pack_writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const uint32_t* node_below, uint32_t total,
-                    uint8_t* tree_l, uint8_t* out_vals, uint32_t* out_nodes, uint32_t* counter, uint32_t cap) {
+                    uint8_t* tree_l, uint8_t* out_vals, uint32_t* out_nodes, uint32_t* counter, uint32_t cap, hipEvent_t done) {
     if (!total) return;
-    hipLaunchKernelGGL(k_pack_writeback, dim3(nblk(total)), dim3(BLOCK), 0, s, val_l, from, node_below, total, tree_l,
-                       out_vals, out_nodes, counter, cap);
+    if (done)
+        hipExtLaunchKernelGGL(k_pack_writeback, dim3(nblk(total)), dim3(BLOCK), 0, s, nullptr, done, 0, val_l, from, node_below, total,
+                              tree_l, out_vals, out_nodes, counter, cap);
+    else
+        hipLaunchKernelGGL(k_pack_writeback, dim3(nblk(total)), dim3(BLOCK), 0, s, val_l, from, node_below, total, tree_l,
+                           out_vals, out_nodes, counter, cap);
 }
 void apply_packed(hipStream_t s, const uint8_t* vals, const uint32_t* nodes, const uint32_t* counter, uint32_t cap,
                   uint8_t* tree_l, uint64_t len_l) {
     if (!cap) return;
     hipLaunchKernelGGL(k_apply_packed, dim3(nblk(cap)), dim3(BLOCK), 0, s, vals, nodes, counter, cap, tree_l, len_l);
 }
-void apply_gathered(hipStream_t s, const ApplyJobs& a) {
+void apply_gathered(hipStream_t s, const ApplyJobs& a, hipEvent_t done) {
     if (!a.n_jobs) return;
     uint32_t widest = 3;
     for (int k = 0; k < a.n_jobs; k++)
         if (a.j[k].pairs && a.j[k].cap > widest) widest = a.j[k].cap;
-    hipLaunchKernelGGL(k_apply_gathered, dim3(nblk(widest), a.n_jobs), dim3(BLOCK), 0, s, a);
+    if (done) hipExtLaunchKernelGGL(k_apply_gathered, dim3(nblk(widest), a.n_jobs), dim3(BLOCK), 0, s, nullptr, done, 0, a);
+    else hipLaunchKernelGGL(k_apply_gathered, dim3(nblk(widest), a.n_jobs), dim3(BLOCK), 0, s, a);
 }
 void store_top_path(hipStream_t s, const uint8_t* top_path, uint8_t* tree_nodes, const uint64_t* tree_off, unsigned l0,
                     unsigned depth) {

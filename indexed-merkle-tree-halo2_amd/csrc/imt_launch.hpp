@@ -210,7 +210,8 @@ void extract(hipStream_t s, const ExtractParams& p);
 // time-sliced single list: the (node, value) pairs k_writeback would write, packed behind an atomic counter (at most
 // `cap` of them), and their application to a replica's stored level
 void pack_writeback(hipStream_t s, const uint8_t* val_l, const uint32_t* from, const uint32_t* node_below, uint32_t total,
-                    uint8_t* tree_l, uint8_t* out_vals, uint32_t* out_nodes, uint32_t* counter, uint32_t cap);
+                    uint8_t* tree_l, uint8_t* out_vals, uint32_t* out_nodes, uint32_t* counter, uint32_t cap,
+                    hipEvent_t done = nullptr);
 void apply_packed(hipStream_t s, const uint8_t* vals, const uint32_t* nodes, const uint32_t* counter, uint32_t cap,
                   uint8_t* tree_l, uint64_t len_l);
 // every payload of one all-gather applied by one launch (imt_itree_slice_apply_gathered)
@@ -227,7 +228,9 @@ struct ApplyJobs {
     const uint32_t* poison;              // device-visible word (may be NULL): non-zero = a transport gave up waiting for a
                                          // payload of this gather, nothing is applied (imt_flags.hip)
 };
-void apply_gathered(hipStream_t s, const ApplyJobs& a);
+// done (here and in pack_writeback): the event the kernel's own completion signals (hipExtLaunchKernelGGL's stop event) --
+// what a hipEventRecord right behind the launch would mark, without the marker packet
+void apply_gathered(hipStream_t s, const ApplyJobs& a, hipEvent_t done = nullptr);
 void store_top_path(hipStream_t s, const uint8_t* top_path, uint8_t* tree_nodes, const uint64_t* tree_off, unsigned l0,
                     unsigned depth);
 

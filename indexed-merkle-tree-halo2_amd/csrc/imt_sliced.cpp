@@ -523,6 +523,20 @@ struct HipBackend : Backend {
         return rc;
     }
     int unit(int slice, unsigned q, Buffer payload, Stream s) override { return imt_itree_slice_unit(tree, slice, q, payload, s); }
+    // the unit's last kernel (the pack) / the apply kernel signals the event itself where it can: no marker packet behind it
+    int unit_record(int slice, unsigned q, Buffer payload, Stream s, Event ev) override {
+        imt_itree_set_slice_tail_event(tree, ev);
+        const int rc = imt_itree_slice_unit(tree, slice, q, payload, s);
+        const bool attached = imt_itree_take_slice_tail_attached(tree);
+        return rc ? rc : attached ? IMT_OK : record(ev, s);
+    }
+    int apply_record(Buffer g, size_t stride, int count, const uint64_t* sb, const uint64_t* n, const int32_t* units, Stream s,
+                     Event ev) override {
+        imt_itree_set_slice_tail_event(tree, ev);
+        const int rc = imt_itree_slice_apply_gathered(tree, g, stride, (size_t)count, sb, n, units, s);
+        const bool attached = imt_itree_take_slice_tail_attached(tree);
+        return rc ? rc : attached ? IMT_OK : record(ev, s);
+    }
     int apply_gathered(Buffer g, size_t stride, int count, const uint64_t* sb, const uint64_t* n, const int32_t* units,
                        Stream s) override {
         return imt_itree_slice_apply_gathered(tree, g, stride, (size_t)count, sb, n, units, s);

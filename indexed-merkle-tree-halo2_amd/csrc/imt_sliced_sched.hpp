@@ -137,6 +137,18 @@ struct Backend {
     virtual int apply_gathered(Buffer gathered, size_t stride, int count, const uint64_t* size_before, const uint64_t* n,
                                const int32_t* units, Stream s) = 0;
     virtual int sync() = 0;                         // host waits for everything this rank has enqueued
+    // unit / apply followed by "record `ev` on s".  A backend that can make the LAST kernel of the call signal the event
+    // itself saves the marker packet a record costs on the hardware queue between two hash kernels (the HIP backend:
+    // hipExtLaunchKernelGGL's stop event; tools/microbench/ext_launch_event.hip).
+    virtual int unit_record(int slice, unsigned q, Buffer payload, Stream s, Event ev) {
+        int rc = unit(slice, q, payload, s);
+        return rc ? rc : record(ev, s);
+    }
+    virtual int apply_record(Buffer gathered, size_t stride, int count, const uint64_t* size_before, const uint64_t* n,
+                             const int32_t* units, Stream s, Event ev) {
+        int rc = apply_gathered(gathered, stride, count, size_before, n, units, s);
+        return rc ? rc : record(ev, s);
+    }
 };
 
 struct Rank;
@@ -346,8 +358,8 @@ struct Rank {
         // collective that also carries this rank's own unit of that tick, u + (g - rank) lag >= u + 1 -- the unit that read
         // level u - 1 -- so the collective cannot complete before that read; an EARLIER slice's payload writes levels this
         // rank's units have not reached, and those wait for this apply (phase_compute).
-        if ((rc = be->apply_gathered(recv[i], gather_bytes[i], world, w_sb.data(), w_n.data(), w_units.data(), ast))) return rc;
-        return be->record(done, ast);        // also "recv[i] has been read" for the collective that will refill it (phase_send)
+        // (`done` is also "recv[i] has been read" for the collective that will refill it: phase_send)
+        return be->apply_record(recv[i], gather_bytes[i], world, w_sb.data(), w_n.data(), w_units.data(), ast, done);
     }
 
     // this rank's unit of the tick, packed into the tick's send buffer
@@ -369,13 +381,13 @@ struct Rank {
                 if ((rc = be->wait(st, gathered_ev[i])) || (IMT_SCHED_MUTATION != 3 && (rc = tp->fence(*this, slot, rt % ring, st)))) return rc;
                 send_busy[i] = 0;
             }
-            if ((rc = be->unit(round(R).slice, (unsigned)q, send[i], st))) return rc;
-            if (q == sc.units - 1 && (rc = be->record(done_ev[slot], st))) return rc;
         }
         // the tick's event: unit computed and packed (and what the tick's collective waits for)
         Event tick = tick_ev[(size_t)slot * sc.round_ticks + rt];
         if (sc.has_gather(rt)) packed_ev[i] = tick;
-        return be->record(tick, st);
+        if (q < 0) return be->record(tick, st);
+        if ((rc = be->unit_record(round(R).slice, (unsigned)q, send[i], st, tick))) return rc;
+        return q == sc.units - 1 ? be->record(done_ev[slot], st) : IMT_OK;
     }
 
     // the tick's collective (asynchronous, consumed `lag` ticks later)
