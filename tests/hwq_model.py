@@ -91,7 +91,7 @@ class Costs:
     # more than four hardware queues in use on a device (GPU_MAX_HW_QUEUES=8: the collectives' streams on queues of their
     # own): the hash kernels run this much slower -- measured, not explained (one emulated rank, eight queues against four:
     # profiles/r05_emu_own_queues.txt; round 4 saw the same with the streams merely spread over eight queues)
-    many_queues = 0.94
+    many_queues = 0.97
     # the link model of a collective between different GPUs: latency + bytes per peer / rate (one xGMI link per peer)
     link_latency_us, link_gbps = 40.0, 48.0
 

@@ -21,22 +21,19 @@ import sliced_sim  # noqa: E402
 
 B, DEPTH = 1 << 16, 32
 MEASURED = {            # M insertions/s (per rank for "emu"): ONE box, one session, the round's final build (profiles/r05_calibration_session.txt)
-    ("inproc", 1): 3.022, ("inproc", 2): 3.017, ("inproc", 4): 2.975,
+    ("inproc", 1): 2.950, ("inproc", 2): 2.943, ("inproc", 4): 2.911,
     # one rank of N alone on the GPU, everything in the normal pool's four queues (IMT_SLICED_POOLS=0): means of two runs
-    ("emu", 8, 0, "free"): 2.709, ("emu", 8, 0, "links"): 2.852,
-    ("emu", 4, 0, "free"): 2.978, ("emu", 4, 0, "links"): 2.960,
+    ("emu", 8, 0, "free"): 2.875, ("emu", 8, 0, "links"): 2.843,
+    ("emu", 4, 0, "free"): 2.937, ("emu", 4, 0, "links"): 2.929,
     # the three priority pools (what one process per GPU gets): round streams HIGH, collectives LOW, preparation on the round stream
-    ("emu-own", 8, 0, "free"): 2.514, ("emu-own", 8, 0, "links"): 2.741,
-    ("emu-own", 4, 0, "free"): 2.821, ("emu-own", 4, 0, "links"): 2.810,
-    ("emu-own", 2, 0, "free"): 2.867, ("emu-own", 2, 0, "links"): 2.918,
+    ("emu-own", 8, 0, "free"): 2.799, ("emu-own", 8, 0, "links"): 2.810,
+    ("emu-own", 4, 0, "free"): 2.890, ("emu-own", 4, 0, "links"): 2.870,
+    ("emu-own", 2, 0, "free"): 2.925, ("emu-own", 2, 0, "links"): 2.925,
 }
-# Points the model is NOT fitted to, and why.  Shown in the table all the same.
-EXCLUDED = {
-    ("emu", 8, 0, "free"): "at N = 8 the emulation is SLOWER without its modelled link time (the eight slot copies then start the moment the pack ends, in front of the next sweep); the model says faster",
-    ("emu-own", 8, 0, "free"): "the same",
-}
-# ... and one it is fitted to but misses by more than the others: the bound the test holds it to
-KNOWN_MISS = {("emu", 8, 0, "links"): 0.065}       # one pool at N = 8: the model prices the gather in the round's queue too high (-5 %)
+# Points the model is NOT fitted to, and why (none at present).  Shown in the table all the same.
+EXCLUDED = {}
+# ... and points it is fitted to but misses by more than the others: the bound the test holds them to
+KNOWN_MISS = {("emu", 8, 0, "links"): 0.08}     # one pool at N = 8: the model prices the gather's time in the round's queue too high (-6 %)
 lib = sliced_sim.load()
 
 
@@ -125,7 +122,18 @@ def distributed(world, costs, rounds=12, warm=4, speed=None, host_speed=None, tr
     return r, T
 
 
-def points(costs):
+def points(costs, box=True):
+    """the model's value for every calibration point; box=True: scaled to the speed of the box the session ran on (boxes
+    differ by +-1.5 %, this one by -3 %: kernel durations in Costs are a typical box's) -- the scale is the one-GPU
+    in-process point, which is therefore matched by construction"""
+    out = _points(costs)
+    if box:
+        k = MEASURED[("inproc", 1)] / out[("inproc", 1)]
+        out = {key: v * k for key, v in out.items()}
+    return out
+
+
+def _points(costs):
     out = {}
     for w in (1, 2, 4):
         out[("inproc", w)] = inproc(w, costs)
@@ -164,8 +172,10 @@ def main():
     print(f"links {costs.link_latency_us:.0f} us + bytes / {costs.link_gbps:.0f} GB/s per peer")
     POOLS = dict(comm_own_queues=True, prep_on_round=True)
 
+    one_gpu = inproc(1, costs)                     # the model's own one-GPU figure (a typical box: Costs' kernel durations)
+
     def line(w, r):
-        return f"N = {w}: {r:6.2f} ({r / w / MEASURED[('inproc', 1)]:.3f})"
+        return f"N = {w}: {r:6.2f} ({r / w / one_gpu:.3f})"
 
     def row(label, worlds=(2, 4, 8), **qm):
         print(f"  {label:92s} " + "   ".join(line(w, distributed(w, costs, **qm)[0]) for w in worlds), flush=True)
@@ -176,7 +186,7 @@ def main():
     row("RCCL's four streams on ONE queue of the normal pool", rccl_dev=[8, 8, 8, 8], **POOLS)
     row("the IPC transport instead (counters polled by the GPUs, the peers' payloads read in one launch)", transport="ipc", **POOLS)
     print(" round AND collectives' streams in the HIGH pool, the collectives' on their rounds' queues (IMT_SLICED_OPT_POOLS 2)")
-    row("RCCL's streams in the normal pool (the model misses this layout's emulated rank of 8 by -5 %)", rccl_dev=[8, 9, 10, 11])
+    row("RCCL's streams in the normal pool (the model misses this layout's emulated rank of 8 by -6 %)", rccl_dev=[8, 9, 10, 11])
     print(" one pool of four queues, collectives' streams on their rounds' queues (IMT_SLICED_OPT_POOLS 0, the runtime's defaults)")
     row("no stream of RCCL's own (the model before this was known)")
     row("the IPC transport", transport="ipc")

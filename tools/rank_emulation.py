@@ -50,11 +50,12 @@ class _Raw:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
-# How the slots are filled.  "memcpy": one hipMemcpyAsync per slot (the first version of this tool: 8 calls of ~35 us each
-# per collective at N = 8, 13 ms of HOST time per step -- the emulation's own host then issues as fast as it can and no
-# faster, which a C++ host calling ncclAllGather once per collective does not suffer from); "fused" (default): ONE
-# broadcast copy kernel for all slots.
-FILL = os.environ.get("EMU_FILL", "fused")
+# How the slots are filled.  "memcpy" (default): one hipMemcpyAsync per slot, eight short full-width blit kernels per
+# collective at N = 8 -- what the queue model's emulated transport describes and was calibrated with.  "fused": ONE
+# broadcast copy kernel for all slots (a torch elementwise copy of 38 MB): cheaper for the host, but one fat low-priority
+# kernel competes with the hashing -- 2.2 - 2.5 against 2.6 - 2.7 M/s at N = 8 -- and without the modelled link time it
+# starts the moment the pack ends (then "free collectives" come out SLOWER than modelled links).
+FILL = os.environ.get("EMU_FILL", "memcpy")
 
 
 class ModelTransport:
