@@ -3,6 +3,8 @@
 # timeouts; everything lands under gpurun_out/r05/ (summaries are copied into profiles/ by hand or tools/collect_profiles.sh).
 #   qmap      tools/microbench/queue_map_probe: which streams share a hardware queue (the runtime's placement rule)
 #   traces    rocprofv3 kernel traces of the sliced mode (1 / 2 / 4 in-process replicas, one emulated rank of 8), compacted
+#   poolstrace  the same for one emulated rank of 8 with the library's default for one process per GPU (three priority pools)
+#   prio / couple / own8 / rehearse / polled4 / longsoak / issue   the round's experiments (see the case labels)
 #   tests     the whole -m gpu suite
 #   bench     bench.py N = 1 + rocprofv3 kernel stats + PMC passes for k_sweep
 #   multi     2- and 4-process rehearsals of bench.py --gpus N on the one GPU (IPC transport) + in-process replicas
