@@ -92,9 +92,9 @@ def test_the_simulator_catches_planted_mutations(tmp_path):
     code passes the same runs"""
     src = os.path.join(ROOT, "tests", "native", "sliced_sym.cpp")
 
-    def outcome(mutation):
-        so = str(tmp_path / f"libslicedsym_m{mutation}.so")
-        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", f"-DIMT_SCHED_MUTATION={mutation}", "-o", so, src],
+    def outcome(mutation, extra=()):
+        so = str(tmp_path / f"libslicedsym_m{mutation}{len(extra)}.so")
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", f"-DIMT_SCHED_MUTATION={mutation}", *extra, "-o", so, src],
                        check=True)
         mlib = ctypes.CDLL(so)
         for name in ("sym_schedule", "sym_unit_of", "sym_payload_units", "sym_world_create", "sym_world_step", "sym_world_flush",
@@ -111,6 +111,8 @@ def test_the_simulator_catches_planted_mutations(tmp_path):
         return "passed"
 
     assert outcome(0) == "passed"
+    # the A/B build that issues every wait, also those another wait on the same stream implies (docs/LAB_NOTES.md)
+    assert outcome(0, ("-DIMT_SCHED_ALL_WAITS",)) == "passed"
     for m in (1, 2, 3, 4, 5, 6):
         assert outcome(m) == "caught", f"mutation {m} went unnoticed"
 
