@@ -306,7 +306,8 @@ struct Rank {
         int rc;
         if ((rc = be->wait(st, applied_ev[base + u + sc.period]))) return rc;
         const int own = std::min(u + 1 + IMT_SCHED_OWN_READ_SLACK, sc.units - 1) + rank * sc.lag;
-        if (IMT_SCHED_SKIP_IMPLIED && be->apply_stream(pslot) == be->round_stream(pslot) && own < u + sc.period) return IMT_OK;
+        // (mutation 9: ... taken for implied also when that round applies on ANOTHER stream)
+        if (IMT_SCHED_SKIP_IMPLIED && (IMT_SCHED_MUTATION == 9 || be->apply_stream(pslot) == be->round_stream(pslot)) && own < u + sc.period) return IMT_OK;
         return be->wait(st, tick_ev[base + own]);
     }
     // the previous-round wait phase_apply issued on the round's own stream at (R, rt), and up to which unit it reaches:
@@ -342,12 +343,13 @@ struct Rank {
             // for both.
             int u = top;
             const bool same = IMT_SCHED_SKIP_IMPLIED && ast == be->round_stream(slot);
-            if (same && IMT_SCHED_MUTATION != 1) u = std::max(u, sc.unit_of(rank, rt));
+            if (same && IMT_SCHED_MUTATION != 1 && IMT_SCHED_MUTATION != 8) u = std::max(u, sc.unit_of(rank, rt));
             if ((rc = wait_previous_round(ast, R, u))) return rc;
             if (same) {
                 memo_R = R;
                 memo_rt = rt;
-                memo_u = u;
+                // (mutation 8: the note claims the unit's level although only the payloads' level was waited for)
+                memo_u = IMT_SCHED_MUTATION == 8 ? std::max(u, sc.unit_of(rank, rt)) : u;
             }
         }
         for (int g = 0; g < world; g++) {

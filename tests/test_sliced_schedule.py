@@ -92,8 +92,8 @@ def test_the_simulator_catches_planted_mutations(tmp_path):
     code passes the same runs"""
     src = os.path.join(ROOT, "tests", "native", "sliced_sym.cpp")
 
-    def outcome(mutation, extra=()):
-        so = str(tmp_path / f"libslicedsym_m{mutation}{len(extra)}.so")
+    def outcome(mutation, extra=(), apply_on_round=False):
+        so = str(tmp_path / f"libslicedsym_m{mutation}{len(extra)}{int(apply_on_round)}.so")
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", f"-DIMT_SCHED_MUTATION={mutation}", *extra, "-o", so, src],
                        check=True)
         mlib = ctypes.CDLL(so)
@@ -102,6 +102,9 @@ def test_the_simulator_catches_planted_mutations(tmp_path):
             ref = getattr(sliced_sim.load(), name)
             fn = getattr(mlib, name)
             fn.argtypes, fn.restype = ref.argtypes, ref.restype
+        mlib.sym_set_layout.argtypes, mlib.sym_set_layout.restype = [ctypes.c_int, ctypes.c_int], None
+        if apply_on_round:              # the product's default layout: applies on the round's own stream
+            mlib.sym_set_layout(sliced_sim.ROUNDS, 0)
         for world, depth, lag in ((2, 8, None), (4, 8, None), (8, 8, 1), (3, 5, 2)):
             for seed in range(6):
                 try:
@@ -115,6 +118,12 @@ def test_the_simulator_catches_planted_mutations(tmp_path):
     assert outcome(0, ("-DIMT_SCHED_ALL_WAITS",)) == "passed"
     for m in (1, 2, 3, 4, 5, 6):
         assert outcome(m) == "caught", f"mutation {m} went unnoticed"
+    # the waits that are NOT issued because another one implies them (round 5): the unmodified code passes in the layout
+    # where they are dropped (applies on the round's stream); a note that claims more than was waited for (8) is caught
+    # there, a tick event taken for implied although the previous round applies on another stream (9) in the other
+    assert outcome(0, apply_on_round=True) == "passed"
+    assert outcome(8, apply_on_round=True) == "caught", "mutation 8 went unnoticed"
+    assert outcome(9) == "caught", "mutation 9 went unnoticed"
 
 
 def _worker(rank, world, port, depth, lag, q):
