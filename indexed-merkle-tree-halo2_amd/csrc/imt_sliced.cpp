@@ -1351,7 +1351,7 @@ int imt_sliced_get_info(const imt_sliced* s, imt_sliced_info* o) {
         if (b->placement > o->placement) o->placement = b->placement;
         o->streams_recreated = std::max(o->streams_recreated, b->streams_recreated);
     }
-    for (int i = 0; i < ROUNDS; i++) {
+    for (int i = 0; i < ROUNDS && i < IMT_SLICED_ROUNDS; i++) {
         o->queue_map[0][i] = be.q_round[i];
         o->queue_map[1][i] = be.q_comm[i];
         o->queue_map[2][i] = be.q_apply[i];

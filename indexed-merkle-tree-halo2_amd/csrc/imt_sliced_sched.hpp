@@ -44,7 +44,10 @@
 namespace imt {
 namespace sliced {
 
-constexpr int ROUNDS = 4;            // rounds in flight = slices a tree keeps open (its plan sets minus one)
+#ifndef IMT_SLICED_ROUNDS_BUILD       // (experiment builds only: more steps in flight need -DIMT_NPIPE to match and break include/imt.h's layout)
+#define IMT_SLICED_ROUNDS_BUILD 4
+#endif
+constexpr int ROUNDS = IMT_SLICED_ROUNDS_BUILD;   // rounds in flight = slices a tree keeps open (its plan sets minus one)
 
 // Test hook (tests/test_sliced_schedule.py::test_the_simulator_catches_planted_mutations): a build with
 // -DIMT_SCHED_MUTATION=k drops one ordering rule, and the adversarial simulator must notice.  0 in every product build.
