@@ -175,6 +175,180 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=dict(os.environ)).returncode
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1: every rank the launcher starts (the driver's torch.distributed.run, or launch_ranks above) is a SUPERVISOR that
+# never touches the GPU.  It runs the measurement in a CHILD process (the worker: this file again with IMT_BENCH_WORKER=1
+# and the same RANK / LOCAL_RANK / WORLD_SIZE), and if the single-list leg of an attempt hangs, fails or does not verify
+# on ANY rank, all supervisors start FRESH children with the next (transport, stream layout) of the plan: a process that
+# has a hung collective on its GPU is never reused, nothing is ever exec'ed over a process that has initialised the GPU.
+# The first hardware run of the single list may be the only one; a surprise in RCCL must not leave it without a number.
+# `value` is the single list's figure from the first attempt that verifies on every rank -- never the subtrees' -- and
+# the line carries `attempts`: what each attempt ran with and how it ended.
+ATTEMPT_LAYOUTS = ("pools", "one-pool")
+
+
+def attempts_plan(backend):
+    """[(transport, layout)] in the order tried.  layout "pools" = the library's default for one process per GPU (round
+    streams HIGH, collectives LOW: IMT_SLICED_OPT_POOLS 1); "one-pool" = everything in the normal pool with every
+    collective ON ITS ROUND'S OWN STREAM (IMT_SLICED_OPT_POOLS 0, COMM_STREAMS 0): no wait ever crosses a hardware queue
+    of this library -- the layout the queue model proves cannot stall on placement, every tick a barrier across ranks.
+    IMT_BENCH_ATTEMPTS="rccl:pools,ipc:one-pool" overrides; IMT_BENCH_SLICED_TRANSPORT alone = that one attempt."""
+    spec = os.environ.get("IMT_BENCH_ATTEMPTS")
+    if spec:
+        plan = []
+        for item in spec.split(","):
+            kind, _, layout = item.strip().partition(":")
+            layout = layout or "pools"
+            if layout not in ATTEMPT_LAYOUTS:
+                raise SystemExit(f"IMT_BENCH_ATTEMPTS: layout {layout!r} is not one of {ATTEMPT_LAYOUTS}")
+            plan.append((kind, layout))
+        return plan
+    if os.environ.get("IMT_BENCH_SLICED_TRANSPORT"):
+        return [(os.environ["IMT_BENCH_SLICED_TRANSPORT"], os.environ.get("IMT_BENCH_LAYOUT", "pools"))]
+    if backend == "nccl":
+        return [("rccl", "pools"), ("ipc", "pools"), ("rccl", "one-pool"), ("ipc", "one-pool")]
+    return [("ipc", "pools"), ("ipc", "one-pool")]
+
+
+def is_supervisor(args):
+    if "WORLD_SIZE" not in os.environ or os.environ.get("IMT_BENCH_WORKER") or os.environ.get("IMT_BENCH_NO_SUPERVISOR"):
+        return False
+    return int(os.environ["WORLD_SIZE"]) > 1 or bool(os.environ.get("IMT_BENCH_FORCE_DIST"))
+
+
+def supervise(args, worker_cmd=None):
+    """One rank's supervisor (see above).  Returns the process's exit status.  Never calls into HIP: `import torch` and a
+    gloo process group over the launcher's rendezvous are all it uses.  worker_cmd: the worker's command line (default:
+    this file with the same arguments; tests/test_bench_supervisor.py passes a stand-in to exercise the retry logic
+    without a GPU)."""
+    import datetime
+    import signal
+    import socket
+    import subprocess
+    import threading
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    backend = os.environ.get("IMT_BENCH_COLLECTIVE", "nccl")
+    plan = attempts_plan(backend)
+    limit = float(os.environ.get("IMT_BENCH_ATTEMPT_TIMEOUT", "600"))
+    sys.stdout.flush()
+    keep = os.dup(1)                 # gloo announces its connections on stdout, which belongs to the ONE JSON line
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=limit + 300))
+    finally:
+        os.dup2(keep, 1)
+        os.close(keep)
+    store = dist.distributed_c10d._get_default_store()
+    attempts, kept_subtrees, line, all_ok = [], None, None, False
+    for k, (kind, layout) in enumerate(plan):
+        port = [None]
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port[0] = sk.getsockname()[1]
+        dist.broadcast_object_list(port, src=0)
+        env = dict(os.environ, IMT_BENCH_WORKER="1", IMT_BENCH_ATTEMPT=str(k), MASTER_PORT=str(port[0]),
+                   IMT_BENCH_SLICED_TRANSPORT=kind, IMT_BENCH_LAYOUT=layout)
+        for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+            env.pop(v, None)         # the workers rendezvous on a port of their own: rank 0's worker hosts the store
+        if kept_subtrees is not None and "IMT_BENCH_MODE" not in os.environ:
+            env["IMT_BENCH_MODE"] = "single-list"       # the other leg has been measured and verified: not again
+        cmd = worker_cmd or ([sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
+                              "--warmup", str(args.warmup)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
+        t0 = time.perf_counter()
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, errors="replace",
+                                 start_new_session=True)
+        out_lines, err_tail = [], []
+
+        def drain(pipe, keep_lines, relay):
+            for ln in pipe:
+                keep_lines.append(ln)
+                if relay:
+                    sys.stderr.write(ln)
+                    sys.stderr.flush()
+                    del keep_lines[:-60]
+        th = [threading.Thread(target=drain, args=(child.stdout, out_lines, False), daemon=True),
+              threading.Thread(target=drain, args=(child.stderr, err_tail, True), daemon=True)]
+        for t in th:
+            t.start()
+        how, peer_failed_at = None, None
+        key = f"imt_bench/attempt{k}/failed"
+        while child.poll() is None:
+            time.sleep(0.25)
+            now = time.perf_counter()
+            if now - t0 > limit:
+                how = f"killed by its supervisor after {limit:.0f} s"
+            elif peer_failed_at is None and store.check([key]):
+                peer_failed_at = now          # a peer's worker is gone: what is left of this one cannot finish a collective
+            elif peer_failed_at is not None and now - peer_failed_at > float(os.environ.get("IMT_BENCH_PEER_GRACE", "15")):
+                how = "killed by its supervisor: a peer's worker had failed"
+            if how:
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)      # exactly the process group this supervisor started
+                except ProcessLookupError:
+                    pass
+                child.wait()
+        for t in th:
+            t.join(timeout=5)
+        rc = child.returncode
+        if rc != 0:
+            store.set(key, b"1")
+        got = None
+        for ln in out_lines:
+            if ln.startswith("{"):
+                try:
+                    got = json.loads(ln)
+                except ValueError:
+                    pass
+        mine_ok = rc == 0 and (rank != 0 or (got is not None and got.get("value") is not None and got.get("verified") is True))
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "rc": rc, "ok": bool(mine_ok), "how": how,
+                                      "tail": None if mine_ok else "".join(err_tail)[-1500:]})
+        all_ok = all(x["ok"] for x in seen)
+        if rank == 0:
+            if got is not None:
+                line = got
+                sub = (got.get("modes") or {}).get("subtrees")
+                if sub and sub.get("verified") and kept_subtrees is None:
+                    kept_subtrees = sub
+            bad = [x for x in seen if not x["ok"]]
+            why = None
+            if not all_ok:
+                why = (got or {}).get("value_failed") or "; ".join(f"rank {x['rank']}: exit status {x['rc']}" + (f" ({x['how']})" if x["how"] else "")
+                                                                   for x in bad)
+            sch = ((got or {}).get("modes") or {}).get("single_list", {}).get("schedule") or {}
+            attempts.append({"attempt": k, "transport": sch.get("transport", kind), "asked_for": kind, "layout": layout,
+                             "pools": sch.get("pools"), "comm_streams": sch.get("comm_streams"),
+                             "outcome": "verified" if all_ok else "failed", "why": why,
+                             "exit_status": [x["rc"] for x in seen], "seconds": round(time.perf_counter() - t0, 1),
+                             "preflight": (got or {}).get("preflight"),
+                             # what the first worker that ended BY ITSELF said last (one killed for its peer's sake knows less)
+                             "dump_tail": None if all_ok or not bad else sorted(bad, key=lambda x: x["how"] is not None)[0]["tail"]})
+        flag = [kept_subtrees is not None]
+        dist.broadcast_object_list(flag, src=0)
+        if flag[0] and kept_subtrees is None:
+            kept_subtrees = {}       # every supervisor sets the same IMT_BENCH_MODE for the next attempt
+        if all_ok:
+            break
+    if rank == 0:
+        if line is None:
+            line = {"metric": METRIC, "value": None, "unit": "insertions/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "verified": False, "value_failed": "no attempt printed a line"}
+        if not all_ok:
+            line["value"], line["verified"], line["ms_per_step"] = None, False, None
+            line.setdefault("value_failed", attempts[-1]["why"] if attempts else "no attempt")
+        if kept_subtrees and "subtrees" not in line.setdefault("modes", {}):
+            line["modes"]["subtrees"] = dict(kept_subtrees, measured_in_attempt=0)
+        line["attempts"] = attempts
+        print(json.dumps(line), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if all_ok else 1
+
+
 def load_module(name):
     import importlib.util
     spec = importlib.util.spec_from_file_location("imt_" + name, os.path.join(ROOT, "indexed-merkle-tree-halo2_amd",
@@ -504,6 +678,30 @@ def stalling_transport(env):
     return tp
 
 
+PREFLIGHT_STEPS, PREFLIGHT_N = 2, 1 << 10
+
+
+def slices_verify(env, ctx, tree, R, n, is_last_round):
+    """round R of a sliced world, this rank's slice: its witnesses through the witness kernels; the slices chain (rank g's
+    first old root = rank g - 1's last new root); for the last round issued every replica's root = the last new root"""
+    world, dist = env.world, env.dist
+    o = tree.outputs(R)
+    ok = witness_check(env, ctx, o, o["first_insertion"], n)
+    ends = torch.stack([o["old_root"][0], o["new_root"][n - 1], torch.from_numpy(env.imt.to_bytes(tree.trees[0].root())).to(env.dev)])
+    if dist is not None and world > 1:
+        allends = torch.empty((world,) + tuple(ends.shape), dtype=torch.uint8, device=env.red_dev)
+        dist.all_gather_into_tensor(allends.view(-1), ends.to(env.red_dev).reshape(-1))
+        allends = allends.cpu()
+    else:
+        allends = ends.cpu().unsqueeze(0)
+    for g in range(1, world):
+        ok = ok and bool((allends[g, 0] == allends[g - 1, 1]).all())
+    if is_last_round:
+        for g in range(world):
+            ok = ok and bool((allends[g, 2] == allends[world - 1, 1]).all())
+    return ok
+
+
 def bench_single_list(env):
     """N > 1 (or IMT_BENCH_FORCE_DIST): ONE depth-32 tree on all ranks, time-sliced, through the C ABI: imt_sliced_step per
     step; the schedule, its streams / events and the all-gather (RCCL: ncclAllGather called by the library on its own
@@ -513,7 +711,7 @@ def bench_single_list(env):
     sliced = load_module("sliced")
     steps_total = args.warmup + args.steps
     gb = BATCH * world
-    cap = 1 << (steps_total * gb).bit_length()
+    cap = 1 << (steps_total * gb + PREFLIGHT_STEPS * PREFLIGHT_N * world).bit_length()
     # one witness set per round when that fits comfortably (0.29 GB each): rounds from the middle of the timed region can
     # then be verified afterwards as they were written, nothing is rewritten
     nbuf = steps_total if steps_total <= 40 else 5
@@ -552,18 +750,43 @@ def bench_single_list(env):
         tp = stalling_transport(env)
     else:
         tp = sliced.local_transport(env.imt)
+    layout = os.environ.get("IMT_BENCH_LAYOUT", "pools")
     if "IMT_BENCH_DEVICE" in os.environ and "IMT_SLICED_POOLS" not in os.environ:      # the rehearsal: ranks share ONE device
         lib.imt_sliced_set_option(None, env.F.SLICED_OPT_POOLS, 0)
+    if layout == "one-pool":       # a later attempt's layout (attempts_plan): nothing of this library waits across queues
+        lib.imt_sliced_set_option(None, env.F.SLICED_OPT_POOLS, 0)
+        lib.imt_sliced_set_option(None, env.F.SLICED_OPT_COMM_STREAMS, 0)
     tree = sliced.SlicedTree(env.imt, env.local_rank, DEPTH, cap, BATCH, world, first_rank=rank, n_local=1, transport=tp,
-                             lag=lag, nbuf=nbuf)
+                             lag=lag, nbuf=nbuf + PREFLIGHT_STEPS)
     env.live_world = tree          # for the watchdog: where the world stands when the leg hangs (imt_sliced_dump)
-    # the library's own watchdog fires first and says why: a host wait of more than this inside imt_sliced_* returns
-    # IMT_ERR_TIMEOUT with the world's state on stderr; bench.py's timer below is the net under it
-    tree.set_option(env.F.SLICED_OPT_WATCHDOG_MS, int(float(os.environ.get("IMT_BENCH_LIBRARY_WATCHDOG_S", "90")) * 1e3))
     ctx = tree.ctxs[0]
     # every rank sees the whole step: the same seed everywhere
     vals = torch.from_numpy(synth_values(steps_total * gb, 0, 1, 0x494D5403)).to(env.dev)
+    # ---- preflight: two short steps (2^10 insertions per rank) through the SAME world, transport and streams as the timed
+    # steps, under a short library watchdog, verified on the spot.  A collective that never completes, a rank that does
+    # not arrive or witnesses that do not chain across ranks cost 20 s and a dump here instead of the leg's whole limit.
+    lib_watchdog_ms = int(float(os.environ.get("IMT_BENCH_LIBRARY_WATCHDOG_S", "90")) * 1e3)
+    tree.set_option(env.F.SLICED_OPT_WATCHDOG_MS, min(lib_watchdog_ms, int(float(os.environ.get("IMT_BENCH_PREFLIGHT_WATCHDOG_S", "20")) * 1e3)))
+    tp0 = time.perf_counter()
+    pvals = torch.from_numpy(synth_values(PREFLIGHT_STEPS * PREFLIGHT_N * world, 0, 1, 0x494D54F0)).to(env.dev)
     torch.cuda.synchronize()
+    for i in range(PREFLIGHT_STEPS):
+        tree.step(pvals[i * PREFLIGHT_N * world:(i + 1) * PREFLIGHT_N * world], env.F.INPUTS_READY)
+    tree.flush()
+    pre_ok = True
+    for i in range(PREFLIGHT_STEPS):
+        pre_ok = pre_ok and slices_verify(env, ctx, tree, i, PREFLIGHT_N, i == PREFLIGHT_STEPS - 1)
+    pre_ok = env.all_true(pre_ok)
+    env.preflight = {"steps": PREFLIGHT_STEPS, "insertions_per_rank_and_step": PREFLIGHT_N, "verified": pre_ok,
+                     "seconds": round(time.perf_counter() - tp0, 2)}
+    if not pre_ok:
+        raise RuntimeError("preflight: the witnesses of two 2^10-insertion steps on this world do not verify")
+    if getattr(env, "preflight_timer", None) is not None:
+        env.preflight_timer.cancel()
+    # the library's own watchdog fires first and says why: a host wait of more than this inside imt_sliced_* returns
+    # IMT_ERR_TIMEOUT with the world's state on stderr; bench.py's timer is the net under it
+    tree.set_option(env.F.SLICED_OPT_WATCHDOG_MS, lib_watchdog_ms)
+    R0 = PREFLIGHT_STEPS            # round number of step 0
 
     for i in range(args.warmup):
         tree.step(vals[i * gb:(i + 1) * gb], env.F.INPUTS_READY)
@@ -587,23 +810,9 @@ def bench_single_list(env):
     i1 = tree.info()
     # ---- verification: the last round's witnesses of THIS rank's slice through the witness kernels; the slices chain
     # (rank g's first old root = rank g - 1's last new root); every replica holds the same root = the last new root
-    R = steps_total - 1
-    o = tree.outputs(R)
-    ok = witness_check(env, ctx, o, o["first_insertion"], BATCH)
+    ok = slices_verify(env, ctx, tree, R0 + steps_total - 1, BATCH, True)
     if nbuf == steps_total and args.steps >= 3:       # ... and a round from the middle of the timed region
-        om = tree.outputs(args.warmup + args.steps // 2)
-        ok = ok and witness_check(env, ctx, om, om["first_insertion"], BATCH)
-    ends = torch.stack([o["old_root"][0], o["new_root"][-1], torch.from_numpy(env.imt.to_bytes(tree.trees[0].root())).to(env.dev)])
-    if dist is not None and world > 1:
-        allends = torch.empty((world,) + tuple(ends.shape), dtype=torch.uint8, device=env.red_dev)
-        dist.all_gather_into_tensor(allends.view(-1), ends.to(env.red_dev).reshape(-1))
-        allends = allends.cpu()
-    else:
-        allends = ends.cpu().unsqueeze(0)
-    for g in range(1, world):
-        ok = ok and bool((allends[g, 0] == allends[g - 1, 1]).all())
-    for g in range(world):
-        ok = ok and bool((allends[g, 2] == allends[world - 1, 1]).all())
+        ok = ok and slices_verify(env, ctx, tree, R0 + args.warmup + args.steps // 2, BATCH, False)
     verified = env.all_true(ok)
     kern, pipe_ms = sweep_lines(prof, args.steps)
     rccl_lib = None
@@ -746,6 +955,8 @@ def main():
         raise SystemExit("--gpus must be a power of two (slices / subtrees of equal size)")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
+    if is_supervisor(args):
+        sys.exit(supervise(args))
     env = Env(args)
     rank, dist = env.rank, env.dist
     # N > 1: "both" (default; `value` = single-list), or one of "single-list" / "subtrees" alone
@@ -766,35 +977,53 @@ def main():
         import threading
         limit = float(os.environ.get("IMT_BENCH_SINGLE_LIST_TIMEOUT", "240"))
 
-        def give_up():
+        pre_limit = min(limit, float(os.environ.get("IMT_BENCH_PREFLIGHT_TIMEOUT", "75")))
+
+        def give_up(why):
             w = getattr(env, "live_world", None)
             if w is not None:       # every rank: where its world stands (host-side state + event queries, no device wait)
                 try:
                     print(f"[rank {rank}] single-list leg over its time limit; the world:\n{w.dump()}", file=sys.stderr, flush=True)
                 except Exception as e:
                     print(f"[rank {rank}] no dump: {e!r}", file=sys.stderr, flush=True)
+            else:
+                print(f"[rank {rank}] {why}; no world exists yet (transport creation / imt_sliced_create)", file=sys.stderr, flush=True)
             if rank == 0:
-                why = f"the single-list leg did not finish within {limit:.0f} s"
                 res, _ = assemble_line(env, legs, why, (None, None, None), headline) if legs else \
-                    ({"metric": METRIC, "value": None, "verified": False, "value_failed": why, "n_gpus": env.world}, False)
+                    ({"metric": METRIC, "value": None, "verified": False, "value_failed": why, "n_gpus": env.world,
+                      "value_is": headline, "modes": {"single_list": {"error": why}}}, False)
                 print(json.dumps(res), flush=True)
             os._exit(1)
-        watchdog = threading.Timer(limit, give_up)
+        watchdog = threading.Timer(limit, give_up, args=(f"the single-list leg did not finish within {limit:.0f} s",))
         watchdog.daemon = True
         watchdog.start()
+        # the transport's creation (ncclCommInitRank on every rank), imt_sliced_create and the preflight have a shorter
+        # limit of their own: bench_single_list cancels it once the preflight has verified
+        env.preflight_timer = threading.Timer(pre_limit, give_up, args=(
+            f"the single-list leg did not finish its preflight (transport, world, two short steps) within {pre_limit:.0f} s",))
+        env.preflight_timer.daemon = True
+        env.preflight_timer.start()
         try:
             legs["single-list"] = bench_single_list(env)
         except Exception as e:      # the line says what happened; the status says it failed
             import traceback
             print(f"[rank {rank}] the single-list leg failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
-            if "subtrees" not in legs:
-                raise
             failed = f"{type(e).__name__}: {e}"
         watchdog.cancel()
+        env.preflight_timer.cancel()
     ok = True
     if rank == 0:
-        probe_leg = legs.get(headline) or next(iter(legs.values()))
-        res, ok = assemble_line(env, legs, failed, device_probes(env, probe_leg["ctx"]), headline)
+        if legs:
+            probe_leg = legs.get(headline) or next(iter(legs.values()))
+            # no device probes after a failed leg: the device may be the thing that hangs
+            probes = device_probes(env, probe_leg["ctx"]) if failed is None else (None, None, None)
+            res, ok = assemble_line(env, legs, failed, probes, headline)
+        else:
+            res, ok = {"metric": METRIC, "value": None, "unit": "insertions/s", "n_gpus": env.world, "steps": args.steps,
+                       "warmup": args.warmup, "ms_per_step": None, "verified": False, "value_failed": failed,
+                       "value_is": headline, "modes": {"single_list": {"error": failed}}}, False
+        if getattr(env, "preflight", None) is not None:
+            res["preflight"] = env.preflight
         print(json.dumps(res), flush=True)
     if failed is not None:
         os._exit(1)                 # a process group that has failed is not torn down gracefully

@@ -206,6 +206,10 @@ int orc_sparse_insert(orc_sparse *t, const uint8_t val[32], uint64_t *low_idx,
                       uint8_t new_root[32], uint8_t *low_proof, uint8_t *new_proof);
 /* low-leaf search only (predecessor by canonical integer order) */
 int orc_sparse_find_low(const orc_sparse *t, const uint8_t val[32], uint64_t *low_idx);
+/* Rebuild a fresh tree from the preimages of its first n leaves: hash_nullifier_pre_images (:662-671) +
+ * IndexedMerkleTree::new (src/utils.rs:38-51) with every other slot empty.  -10 unless the preimages are one sorted
+ * list starting at the sentinel.  For starting a sequential run at a checkpoint. */
+int orc_sparse_load(orc_sparse *t, const uint8_t *preimages /*[n][3][32]*/, uint64_t n);
 
 #ifdef __cplusplus
 }

@@ -181,3 +181,58 @@ int orc_sparse_insert(orc_sparse *t, const uint8_t val[32], uint64_t *low_idx,
     t->size++;
     return ORC_OK;
 }
+
+/* The test module's "rebuild from the preimages": hash_nullifier_pre_images (:662-671) + IndexedMerkleTree::new
+ * (src/utils.rs:38-51), on a tree whose first n leaves hold preimages[n][3][32] and whose other slots are empty
+ * (H(0,0,0), :373-376).  The list is taken as given except for what orc_sparse_insert relies on: leaf 0 is the sentinel
+ * (val 0), values are canonical and pairwise different, every next_val / next_idx names the next larger value's leaf
+ * (0 / 0 at the largest).  Used to start a sequential run at a checkpoint (tests/golden/make_config4_digest.py, which
+ * also checks that the root loaded here equals the root the sequential run before it ended with).  -10: not such a list. */
+static const orc_sparse *g_sort_tree;
+static int cmp_leaf_by_val(const void *x, const void *y) {
+    uint64_t a = *(const uint64_t *)x, b = *(const uint64_t *)y;
+    return cmp_bytes(g_sort_tree->pre + 96 * a, g_sort_tree->pre + 96 * b);
+}
+
+int orc_sparse_load(orc_sparse *t, const uint8_t *preimages, uint64_t n) {
+    if (n < 1 || n > t->cap || t->size != 1) return ORC_ERR_RANGE;
+    memcpy(t->pre, preimages, 96 * n);
+    for (uint64_t i = 0; i < n; i++) t->sorted[i] = i;
+    g_sort_tree = t;
+    qsort(t->sorted, n, sizeof *t->sorted, cmp_leaf_by_val);
+    if (t->sorted[0] != 0) return -10;
+    for (int k = 0; k < 32; k++) if (t->pre[k]) return -10;
+    for (uint64_t j = 0; j < n; j++) {
+        const uint8_t *me = t->pre + 96 * t->sorted[j];
+        uint8_t want_idx[32];
+        ofr_t chk;
+        if (ofr_from_bytes(&chk, me)) return -10;
+        if (j + 1 < n) {
+            const uint8_t *nx = t->pre + 96 * t->sorted[j + 1];
+            if (cmp_bytes(me, nx) == 0) return -10;
+            put_u64(want_idx, t->index_base + t->sorted[j + 1]);
+            if (memcmp(me + 32, nx, 32) || memcmp(me + 64, want_idx, 32)) return -10;
+        } else {
+            memset(want_idx, 0, 32);
+            if (memcmp(me + 32, want_idx, 32) || memcmp(me + 64, want_idx, 32)) return -10;
+        }
+    }
+    for (uint64_t i = 0; i < n; i++) {                       /* :662-671 */
+        ofr_t a, b, c;
+        const uint8_t *q = t->pre + 96 * i;
+        ofr_from_bytes(&a, q); ofr_from_bytes(&b, q + 32); ofr_from_bytes(&c, q + 64);
+        orc_hash3_fr(&t->lvl[0][i], &a, &b, &c);
+    }
+    uint64_t filled = n;                                     /* utils.rs:38-51, only where a child is not all-empty */
+    for (unsigned l = 0; l < t->depth; l++) {
+        uint64_t parents = (filled + 1) / 2;
+        for (uint64_t k = 0; k < parents; k++) {
+            const ofr_t *left = &t->lvl[l][2 * k];
+            const ofr_t *right = 2 * k + 1 < t->nlen[l] ? &t->lvl[l][2 * k + 1] : &t->zero[l];
+            orc_hash2_fr(&t->lvl[l + 1][k], left, right);
+        }
+        filled = parents;
+    }
+    t->size = n;
+    return ORC_OK;
+}

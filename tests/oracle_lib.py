@@ -274,6 +274,11 @@ class Oracle:
                     interim_root=int.from_bytes(ir.raw, "little"), new_root=int.from_bytes(nr.raw, "little"),
                     low_proof=lp, new_proof=npf)
 
+    def sparse_load(self, h, preimages):
+        """hash_nullifier_pre_images + IndexedMerkleTree::new over the first n leaves (oracle/sparse.c orc_sparse_load)"""
+        pre = np.ascontiguousarray(preimages, dtype=np.uint8).reshape(-1, 3, 32)
+        return self.lib.orc_sparse_load(h, pre.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(pre.shape[0]))
+
     def sparse_proof(self, h, depth, index):
         out = np.empty((depth, 32), np.uint8)
         assert self.lib.orc_sparse_proof(h, ctypes.c_uint64(index), out.ctypes.data_as(ctypes.c_void_p)) == 0

@@ -1,0 +1,115 @@
+"""bench.py's supervisor (the GPU-free process every launched rank is): the retry logic over attempts
+in FRESH worker processes, exercised without a GPU -- two supervisors over gloo, the worker replaced by
+tests/helpers/fake_bench_worker.py.  What must hold: `value` comes from the first attempt in which EVERY rank's worker
+succeeded and rank 0's line verified; a worker that hangs because its peer died is killed by its own supervisor (exact
+process group); the line carries `attempts`; the exit status is non-zero on every rank unless an attempt verified."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "helpers", "fake_bench_worker.py")
+DRIVER = ("import sys, argparse; sys.path.insert(0, %r); import bench; "
+          "a = argparse.Namespace(gpus=2, steps=2, warmup=1, no_cpu_baseline=True); "
+          "sys.exit(bench.supervise(a, worker_cmd=[sys.executable, %r]))" % (ROOT, FAKE))
+
+
+def run_supervisors(tmp_path, scenario, extra=None, world=2):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FAKE_SCENARIO=scenario, FAKE_LOG_DIR=str(tmp_path), IMT_BENCH_COLLECTIVE="gloo", IMT_BENCH_PEER_GRACE="1",
+                   TORCHELASTIC_USE_AGENT_STORE="False", **(extra or {}))
+        for k in ("IMT_BENCH_WORKER", "IMT_BENCH_ATTEMPTS", "IMT_BENCH_SLICED_TRANSPORT", "IMT_BENCH_MODE"):
+            if k not in (extra or {}):
+                env.pop(k, None)
+        procs.append(subprocess.Popen([sys.executable, "-c", DRIVER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    return [p.returncode for p in procs], outs, port
+
+
+def the_line(outs):
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs[0]
+    assert not any(l.startswith("{") for l in outs[1][0].splitlines())
+    return json.loads(lines[0])
+
+
+def test_second_attempt_in_fresh_workers(tmp_path):
+    rcs, outs, port = run_supervisors(tmp_path, "second_attempt", {"IMT_BENCH_ATTEMPTS": "rccl:pools,ipc:pools,rccl:one-pool"})
+    assert rcs == [0, 0], outs
+    res = the_line(outs)
+    assert res["value"] == 123.0 and res["verified"] is True
+    at = res["attempts"]
+    assert [a["outcome"] for a in at] == ["failed", "verified"]             # the third of the plan is never started
+    assert at[0]["asked_for"] == "rccl" and at[1]["transport"] == "ipc" and at[1]["layout"] == "pools"
+    assert at[0]["exit_status"][1] == 3 and at[0]["exit_status"][0] != 0       # rank 0's hung worker was killed, not waited for
+    assert at[0]["seconds"] < 60 and "fake dump" in at[0]["dump_tail"]
+    assert "rank 1: exit status 3" in at[0]["why"] and "a peer's worker had failed" in at[0]["why"]
+    assert "collective NOT COMPLETE" in outs[1][1]                           # the worker's stderr is relayed as it comes
+    w0, w1 = (json.load(open(tmp_path / f"worker_a{k}_r0.json")) for k in (0, 1))
+    for w in (w0, w1):
+        assert w["IMT_BENCH_WORKER"] == "1" and w["TORCHELASTIC_USE_AGENT_STORE"] is None and w["WORLD_SIZE"] == "2"
+        assert int(w["MASTER_PORT"]) != port                                # the workers rendezvous on a port of their own ...
+    assert w0["MASTER_PORT"] != w1["MASTER_PORT"]                            # ... a fresh one per attempt,
+    assert json.load(open(tmp_path / "worker_a1_r1.json"))["MASTER_PORT"] == w1["MASTER_PORT"]      # the same on every rank
+    assert not (tmp_path / "worker_a2_r0.json").exists()
+
+
+def test_every_attempt_fails(tmp_path):
+    rcs, outs, _ = run_supervisors(tmp_path, "all_fail")
+    assert rcs == [1, 1]
+    res = the_line(outs)
+    assert res["value"] is None and res["verified"] is False and res["ms_per_step"] is None
+    assert [a["asked_for"] + ":" + a["layout"] for a in res["attempts"]] == ["ipc:pools", "ipc:one-pool"]      # the gloo rehearsal's plan
+    assert all(a["outcome"] == "failed" and "-13" in a["why"] and "world state" in a["dump_tail"] for a in res["attempts"])
+    assert "-13 in attempt 1" in res["value_failed"]
+    # the other leg was measured and verified in attempt 0: not run again, and its figure stays under `modes` only
+    assert json.load(open(tmp_path / "worker_a0_r1.json"))["IMT_BENCH_MODE"] is None
+    assert json.load(open(tmp_path / "worker_a1_r1.json"))["IMT_BENCH_MODE"] == "single-list"
+    assert res["modes"]["subtrees"]["value"] == 5.0e6
+
+
+def test_an_unverified_line_is_a_failed_attempt_and_an_explicit_transport_is_one_attempt(tmp_path):
+    rcs, outs, _ = run_supervisors(tmp_path, "unverified_then_ok")
+    assert rcs == [0, 0]
+    res = the_line(outs)
+    assert res["value"] == 77.0 and [a["outcome"] for a in res["attempts"]] == ["failed", "verified"]
+    assert res["attempts"][0]["why"] == "did not verify" and res["attempts"][0]["exit_status"] == [0, 0]
+    sub = tmp_path / "one"
+    sub.mkdir()
+    rcs, outs, _ = run_supervisors(sub, "unverified_then_ok", {"IMT_BENCH_SLICED_TRANSPORT": "stall"})
+    assert rcs == [1, 1]
+    res = the_line(outs)
+    assert res["value"] is None and len(res["attempts"]) == 1 and res["attempts"][0]["asked_for"] == "stall"
+
+
+def test_the_attempt_limit_ends_a_silent_hang(tmp_path):
+    rcs, outs, _ = run_supervisors(tmp_path, "silent_hang", {"IMT_BENCH_ATTEMPT_TIMEOUT": "3"})
+    assert rcs == [0, 0]
+    res = the_line(outs)
+    assert res["value"] == 9.0 and "killed by its supervisor after 3 s" in res["attempts"][0]["why"]
+
+
+def test_plan():
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ("IMT_BENCH_ATTEMPTS", "IMT_BENCH_SLICED_TRANSPORT"):
+        os.environ.pop(k, None)
+    assert bench.attempts_plan("nccl") == [("rccl", "pools"), ("ipc", "pools"), ("rccl", "one-pool"), ("ipc", "one-pool")]
+    assert bench.attempts_plan("gloo") == [("ipc", "pools"), ("ipc", "one-pool")]
+    os.environ["IMT_BENCH_ATTEMPTS"] = "stall,local:one-pool"
+    try:
+        assert bench.attempts_plan("nccl") == [("stall", "pools"), ("local", "one-pool")]
+        os.environ["IMT_BENCH_ATTEMPTS"] = "rccl:fast"
+        with pytest.raises(SystemExit):
+            bench.attempts_plan("nccl")
+    finally:
+        del os.environ["IMT_BENCH_ATTEMPTS"]

@@ -358,3 +358,40 @@ def test_bench_says_where_a_hung_collective_stands():
     assert res["modes"]["subtrees"]["verified"] is True
     for text in ("failed with -13", "collective NOT COMPLETE on channel", "first incomplete: unit tick", "global tick"):
         assert text in r.stderr, r.stderr[-3000:]
+
+
+def test_bench_second_attempt_in_fresh_workers_after_a_hung_collective():
+    """the first multi-GPU run gets a second attempt.  Every launched rank of bench.py is a GPU-free
+    supervisor that runs the measurement in a child process; when the single-list leg hangs (here: the stall transport as
+    attempt 1, its 40th all-gather -- inside the PREFLIGHT's second short step -- holds its stream for 8 s, the preflight's
+    library watchdog at 1 s) the supervisor starts a FRESH child with the next transport of the plan.  The one JSON line
+    comes from the attempt that verifies, carries both attempts with the failed one's dump, and the exit status is 0."""
+    import json
+    import socket
+    import subprocess
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, IMT_BENCH_FORCE_DIST="1", IMT_BENCH_NO_TRACE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", IMT_BENCH_COLLECTIVE="gloo",
+               IMT_BENCH_DEVICE="0", IMT_BENCH_ATTEMPTS="stall,local", IMT_BENCH_LIBRARY_WATCHDOG_S="1", IMT_BENCH_STALL_S="8")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IMT_BENCH_SLICED_TRANSPORT", "IMT_BENCH_WORKER"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    at = res["attempts"]
+    assert len(at) == 2 and [a["outcome"] for a in at] == ["failed", "verified"], at
+    assert at[0]["asked_for"] == "stall" and "-13" in at[0]["why"] and "collective NOT COMPLETE on channel" in at[0]["dump_tail"]
+    assert at[0]["preflight"] is None and at[1]["preflight"]["verified"] is True and at[1]["transport"] == "local"
+    assert res["value"] > 0 and res["verified"] is True and res["value"] == res["modes"]["single_list"]["value"]
+    assert res["value_is"].startswith("single-list")
+    # the other leg ran once, in the first attempt, and its figure is still on the line
+    assert res["modes"]["subtrees"]["verified"] is True and res["modes"]["subtrees"].get("measured_in_attempt") == 0
+    assert "failed with -13" in r.stderr and "global tick" in r.stderr
