@@ -158,6 +158,7 @@ pub const IMT_SLICED_OPT_WATCHDOG_MS: c_int = 7;
 pub const IMT_SLICED_OPT_TIMING: c_int = 8;
 pub const IMT_SLICED_OPT_COMM_PLACEMENT: c_int = 9;
 pub const IMT_SLICED_OPT_POOLS: c_int = 10;
+pub const IMT_SLICED_OPT_RESET: c_int = 11;
 pub const IMT_SLICED_PLACEMENT_UNVERIFIED: c_int = 0;
 pub const IMT_SLICED_PLACEMENT_AS_CREATED: c_int = 1;
 pub const IMT_SLICED_PLACEMENT_REPAIRED: c_int = 2;
@@ -272,6 +273,7 @@ extern "C" {
     pub fn imt_transport_destroy(tp: *mut imt_transport) -> c_int;
     pub fn imt_transport_set_option(tp: *mut imt_transport, option: c_int, value: c_long) -> c_int;
     pub fn imt_transport_all_gather(tp: *mut imt_transport, send: *const c_void, recv: *mut c_void, bytes: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn imt_transport_poll_error(tp: *mut imt_transport) -> c_int;
     pub fn imt_transport_last_error(tp: *const imt_transport) -> *const c_char;
     pub fn imt_sliced_create(trees: *const *mut imt_itree, n_local: c_int, world: c_int, first_rank: c_int, tp: *mut imt_transport, max_slice: usize, lag: c_int, out: *mut *mut imt_sliced) -> c_int;
     pub fn imt_sliced_step(w: *mut imt_sliced, vals: *const c_void, n: usize, outs: *const imt_insert_out, flags: c_uint, round_out: *mut u64) -> c_int;

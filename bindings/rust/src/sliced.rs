@@ -100,6 +100,15 @@ impl SlicedTree {
         let rc = imt_transport_all_gather(tp, send, recv, bytes, stream);
         if rc == IMT_OK { Ok(()) } else { Err(rc) }
     }
+    /// after synchronising the stream of an `all_gather` and BEFORE reading `recv`: did a GPU-side wait give up on a peer?
+    /// (sticky; `recv` was not written then)
+    ///
+    /// # Safety
+    /// `tp` is a live transport handle.
+    pub unsafe fn poll_error(tp: *mut imt_transport) -> Result<(), i32> {
+        let rc = imt_transport_poll_error(tp);
+        if rc == IMT_OK { Ok(()) } else { Err(rc) }
+    }
 }
 
 impl Drop for SlicedTree {

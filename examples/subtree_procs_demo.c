@@ -160,6 +160,7 @@ static int child(int rank, int world, int use_rccl, int steps, size_t batch, int
                                        out[b].new_leaf, new_index, NULL, out[b].new_sib, out[b].is_largest, DEPTH, batch, fail, NULL,
                                        IMT_DEVICE_PTRS | IMT_ROOT_PER_ITEM));
         CHECK(imt_ctx_sync(ctx));
+        CHECK(imt_transport_poll_error(tp));     /* a peer that never came: the gathered roots were not written */
         for (size_t i = 0; i < batch; i++)
             if (fail[i]) { fprintf(stderr, "[rank %d] step %d insertion %zu: insert_leaf constraints 0x%02x fail at depth 32\n", rank, f, i, fail[i]); return 20; }
         for (size_t i = 1; i < batch; i++)       /* inside the rank's share the roots chain too */

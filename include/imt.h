@@ -57,7 +57,14 @@ extern "C" {
 #define IMT_ERR_FULL (-11)        /* indexed tree capacity exhausted */
 #define IMT_ERR_INTERNAL (-12)
 #define IMT_ERR_TIMEOUT (-13)     /* a host-side wait inside imt_sliced_* ran into the world's watchdog (a peer died or
-                                     hangs); the world's state has been written to stderr, see IMT_SLICED_OPT_WATCHDOG_MS */
+                                     hangs); the world's state has been written to stderr, see IMT_SLICED_OPT_WATCHDOG_MS.
+                                     AFTER IT: something of the world may still run on the device and may never end (a
+                                     collective whose peer is gone has no time limit of its own).  imt_sliced_destroy and
+                                     imt_transport_destroy then return without waiting for the device -- the world's device
+                                     buffers, streams and communicators are LEFT ALLOCATED -- but imt_itree_destroy /
+                                     imt_ctx_destroy / hipFree would wait.  The process should report and EXIT non-zero
+                                     (without those calls) and recovery (reload from a checkpoint) should happen in a
+                                     freshly started process -- never by exec'ing over one that has touched the GPU. */
 
 /* flags */
 #define IMT_FMT_CANONICAL 0u
@@ -305,7 +312,14 @@ int imt_tree_build(imt_ctx *ctx, const void *leaves, size_t n_leaves, void *leve
                    void *root /*[32]*/, unsigned flags);
 
 /* ---- a5 / a7 / a8 / a9: batched path recompute --------------------------------- */
-/* root_out[i] = fold of hash2 over depth siblings, order from the parity of index>>level
+/* WHEN A HOST CORE IS FASTER.  One call costs about 7 ms whatever it carries (a depth-32 path is 66 dependent
+ * permutations; small calls use the latency form): one depth-32 verify_proof 7.0 ms here against 1.2 ms
+ * on one host core, one insert_leaf witness check 8.5 against 2.6 ms (profiles/r05_latency_vs_cpu.txt).  The reference's
+ * own call pattern -- one proof, one insertion per call (src/utils.rs:87, src/indexed_merkle_tree.rs:231) -- is therefore a
+ * CPU job; these calls (and imt_non_membership_batch, imt_insert_witness_batch, imt_*_trace_batch below) win from about
+ * 4 - 8 items per call and reach their throughput from a few thousand.
+ *
+ * root_out[i] = fold of hash2 over depth siblings, order from the parity of index>>level
  * (verify_proof, src/utils.rs:87-107; compute_merkle_root, indexed_merkle_tree.rs:78-96). */
 int imt_path_root_batch(imt_ctx *ctx, const void *leaf /*[n][32]*/, const uint64_t *index /*[n]*/,
                         const void *sib, unsigned depth, size_t n, void *root_out /*[n][32]*/,
@@ -386,7 +400,14 @@ typedef struct imt_insert_out {
  * it, and writes the new leaf at index size+i.  All 2n path recomputes (2 + 2*depth hashes
  * per insertion) run on the device as a level sweep over time-versioned nodes.
  * vals[i] == 0, duplicates (within the batch or already present) -> IMT_ERR_VALUE, nothing
- * changes.  Exceeding capacity -> IMT_ERR_FULL. */
+ * changes.  Exceeding capacity -> IMT_ERR_FULL.
+ * HOW LONG THE CALL HOLDS THE CALLING THREAD.  IMT_ERR_VALUE must be the call's own return value with the tree
+ * untouched, so the call returns when the batch's values have been checked on the GPU (the preparation: sort, low-leaf
+ * search), and with IMT_PIPELINE that check is enqueued behind the hashing of the batches already in flight (at most four;
+ * the back-pressure that keeps the queues short).  At 2^16 insertions per batch the thread is inside the call for 18.75 ms
+ * of every 21.09 ms batch (BENCH_r05: host_call_ms_per_step), almost all of it waiting.  A host that needs its thread
+ * calls from a thread of its own -- one caller at a time per tree is all the library asks.  Without IMT_DEVICE_PTRS the
+ * call also copies the outputs back and returns when they are there. */
 int imt_itree_insert_batch(imt_itree *t, const void *vals /*[n][32]*/, size_t n,
                            const imt_insert_out *out /*may be NULL*/, unsigned flags);
 /* current siblings of leaf `index` for n indices (get_proof on the stored tree) */
@@ -567,6 +588,13 @@ int imt_transport_set_option(imt_transport *tp, int option, long value);
  * calls it the same number of times in the same order; not while an imt_sliced uses the transport.  With the IPC
  * transport between ranks that share a GPU the call waits ON THE HOST for the peers (as that transport's fence does). */
 int imt_transport_all_gather(imt_transport *tp, const void *send, void *recv, size_t bytes, void *hip_stream);
+/* Has a GPU-side wait of the transport given up on a peer (IMT_TRANSPORT_OPT_TIMEOUT_MS)?  IMT_OK, or IMT_ERR_INTERNAL
+ * (text in imt_transport_last_error): the error is STICKY -- every copy behind the wait was skipped on the device, `recv`
+ * of that gather and of every later one holds whatever it held before, and later imt_transport_all_gather calls return
+ * IMT_ERR_INTERNAL themselves.  The wait runs on the device: a caller of imt_transport_all_gather synchronises the stream
+ * it named and then asks here BEFORE it reads `recv` (sharded.py does; an imt_sliced asks by itself in every
+ * imt_sliced_step / _wait / _flush).  Transports without a GPU-side wait (RCCL, local, custom) always answer IMT_OK. */
+int imt_transport_poll_error(imt_transport *tp);
 
 /* trees[k] = the replica of rank first_rank + k (each on its own context; empty or with the same contents on every rank;
  * not placed, not partitioned); n_local = 1, or = world with the local transport.  max_slice = the largest n of a step.
@@ -609,7 +637,10 @@ int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first
                                               round AND collectives' streams HIGH, the collectives' on their rounds' queues (4 % more per
                                               rank on one GPU, but every tick a barrier across ranks: COMM_PLACEMENT); 0: everything in
                                               the normal pool, as the options above say; -1 (default): 1 for a world of more than one
-                                              rank with one rank in this process, else 0.  The runtime keeps a set of
+                                              rank with one rank in this process, else 0.
+                                              Options the caller has set explicitly (imt_sliced_set_option(NULL, ...)) are NOT
+                                              overwritten by a preset: the caller's value stands and imt_sliced_last_error of the new
+                                              world says which preset was left out.  The runtime keeps a set of
                                               hardware queues per priority, and everybody else's streams are in the normal one -- the
                                               host's, and RCCL's: a communicator creates three of its own and brackets every
                                               collective with one (the user's stream waits for it, it waits for the kernel).  Sharing
@@ -617,6 +648,8 @@ int imt_sliced_create(imt_itree *const *trees, int n_local, int world, int first
                                               behind the round's backlog, and this library can neither see nor move it; in the HIGH
                                               pool the rounds are alone.  Needs no GPU_MAX_HW_QUEUES.  One rank of 2 / 4 / 8 alone on
                                               a GPU: within 1 % of one pool */
+#define IMT_SLICED_OPT_RESET 11            /* w == NULL, value 0: every default back to the library's own, and no option counts as
+                                              "set explicitly by the caller" any more (see IMT_SLICED_OPT_POOLS) */
 int imt_sliced_set_option(imt_sliced *w, int option, long value);
 /* One step: vals = ALL world x n values of the step in insertion order (device pointer, identical contents on every
  * rank; format per flags), outs[k] = where local rank k's witnesses of ITS slice (insertions [rank * n, (rank + 1) * n)
@@ -679,7 +712,10 @@ int imt_sliced_get_info(const imt_sliced *w, imt_sliced_info *out);
  * channel.  Writes at most cap - 1 characters + NUL; returns the length of the full text.  For a host's own watchdog. */
 int imt_sliced_dump(imt_sliced *w, char *out, size_t cap);
 const char *imt_sliced_last_error(const imt_sliced *w);
-void imt_sliced_destroy(imt_sliced *w);          /* flushes first */
+/* flushes first.  A world that failed (IMT_ERR_TIMEOUT, IMT_ERR_INTERNAL) is not flushed; if its streams do not drain
+ * within the watchdog's limit the call returns anyway and leaves the world's device memory and streams allocated -- see
+ * IMT_ERR_TIMEOUT above for what the process should do next. */
+void imt_sliced_destroy(imt_sliced *w);
 
 /* The building blocks imt_sliced_* is made of (kept exported for hosts that bring their own scheduler; a host that calls
  * them owns the ordering rule above).  A slice is hashed unit by unit (unit 0 = its leaf hashes, unit 1 + l = level

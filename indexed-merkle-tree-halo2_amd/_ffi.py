@@ -177,6 +177,7 @@ SIGNATURES = {
     "imt_transport_destroy": (c_int, [c_void_p]),
     "imt_transport_set_option": (c_int, [c_void_p, c_int, ctypes.c_long]),
     "imt_transport_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "imt_transport_poll_error": (c_int, [c_void_p]),
     "imt_sliced_set_option": (c_int, [c_void_p, c_int, ctypes.c_long]),
     "imt_sliced_dump": (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),
     "imt_transport_last_error": (ctypes.c_char_p, [c_void_p]),
@@ -215,7 +216,8 @@ OPT_COOP_MAX_EVENTS = 1
 SEG_GLUE, SEG_HASH = 0, 1
 SLICED_ROUNDS = 4
 (SLICED_OPT_COMM_STREAMS, SLICED_OPT_COMM_PRIORITY, SLICED_OPT_ROUND_PRIORITIES, SLICED_OPT_APPLY_STREAMS, SLICED_OPT_PREP_STREAM,
- SLICED_OPT_VERIFY_QUEUES, SLICED_OPT_WATCHDOG_MS, SLICED_OPT_TIMING, SLICED_OPT_COMM_PLACEMENT, SLICED_OPT_POOLS) = range(1, 11)
+ SLICED_OPT_VERIFY_QUEUES, SLICED_OPT_WATCHDOG_MS, SLICED_OPT_TIMING, SLICED_OPT_COMM_PLACEMENT, SLICED_OPT_POOLS,
+ SLICED_OPT_RESET) = range(1, 12)
 TRANSPORT_OPT_TIMEOUT_MS, TRANSPORT_OPT_HOST_POLL = 1, 2
 PLACEMENT = {0: "unverified", 1: "as created", 2: "repaired", 3: "degraded"}
 RCCL_UNIQUE_ID_BYTES = 128

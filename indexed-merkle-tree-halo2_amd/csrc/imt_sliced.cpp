@@ -46,6 +46,7 @@ struct SlicedOptions {
     long verify_queues = 1;          // probe the stream -> hardware queue placement at creation and repair it
     long watchdog_ms = 120000;       // host waits inside imt_sliced_* give up after this long (0 = never)
     long timing = 0;                 // print the host's time per phase at destroy
+    unsigned long set_mask = 0;      // bit `option`: named explicitly (imt_sliced_set_option(NULL, ...) or the tools' environment variable)
 };
 SlicedOptions g_defaults;
 std::mutex g_defaults_mu;
@@ -90,7 +91,10 @@ SlicedOptions effective_options() {
         if (option == IMT_SLICED_OPT_PREP_STREAM) v = !strcmp(e, "side") ? 2 : !strcmp(e, "round") ? 1 : !strcmp(e, "comm") ? 0 : v;
         if (option == IMT_SLICED_OPT_ROUND_PRIORITIES) v = !strcmp(e, "pipe") ? 1 : !strcmp(e, "low") ? 2 : !strcmp(e, "high") ? 3 : v;
         long* f = nullptr;
-        if (option_value_ok(option, v) && option_field(oo, option, &f) == IMT_OK) *f = v;
+        if (option_value_ok(option, v) && option_field(oo, option, &f) == IMT_OK) {
+            *f = v;
+            oo.set_mask |= 1ul << option;
+        }
     };
     env("IMT_SLICED_COMM_STREAMS", IMT_SLICED_OPT_COMM_STREAMS, o);
     env("IMT_SLICED_COMM_PRIO", IMT_SLICED_OPT_COMM_PRIORITY, o);
@@ -184,6 +188,7 @@ struct HipBackend : Backend {
     int q_round[ROUNDS], q_comm[ROUNDS], q_apply[ROUNDS];
     int n_queues = 0, placement = IMT_SLICED_PLACEMENT_UNVERIFIED, streams_recreated = 0;
     bool comm_own_queues = false;
+    bool hung = false;                        // sync() ran into the watchdog: something of this world still runs on the device
     std::string placement_note;
 
     explicit HipBackend(imt_itree* t) : tree(t), ctx(imt_itree_ctx(t)) {
@@ -325,28 +330,35 @@ struct HipBackend : Backend {
             std::vector<hipStream_t> pool(arr, arr + count);
             std::vector<hipStream_t> placed(count, nullptr);
             int created = 0;
+            // An error return leaves arr[] as the caller gave it (~HipBackend destroys those): none of them may stay among
+            // the spares (~Spares would destroy them a second time), and every stream created here goes there.
+            auto bail = [&](int r, hipStream_t cur) -> int {
+                auto callers = [&](hipStream_t x) { return std::find(arr, arr + count, x) != arr + count; };
+                spare.erase(std::remove_if(spare.begin(), spare.end(), callers), spare.end());
+                std::vector<hipStream_t> mine(placed);
+                mine.insert(mine.end(), pool.begin(), pool.end());
+                mine.push_back(cur);
+                for (hipStream_t x : mine)
+                    if (x && !callers(x) && std::find(spare.begin(), spare.end(), x) == spare.end()) spare.push_back(x);
+                return r;
+            };
             while (true) {
                 bool full = true;
                 for (int i = 0; i < count; i++) full = full && placed[i];
                 if (full) break;
                 hipStream_t s;
-                bool fresh = false;
                 if (!pool.empty()) {
                     s = pool.back();
                     pool.pop_back();
                 } else {
                     if (created >= max_new) break;
                     int r = new_stream(&s, prio);
-                    if (r) return r;
+                    if (r) return bail(r, nullptr);
                     created++;
-                    fresh = true;
                 }
                 int p = -1;
                 int r = partner(s, &p);
-                if (r) {
-                    if (fresh) hipStreamDestroy(s);     // (the caller's own streams stay in arr: ~HipBackend destroys them)
-                    return r;
-                }
+                if (r) return bail(r, s);
                 int slot = -1;
                 if (want_partner) {
                     // with fewer than four queues under the rounds, the partner is the first round stream of the class
@@ -360,7 +372,7 @@ struct HipBackend : Backend {
                         if (placed[i]) others.push_back(placed[i]);
                     bool shared = false;
                     if (!others.empty()) {
-                        if ((r = pr.run(s, others.data(), (int)others.size(), behind))) return r;
+                        if ((r = pr.run(s, others.data(), (int)others.size(), behind))) return bail(r, s);
                         for (size_t j = 0; j < others.size(); j++) shared = shared || behind[j];
                     }
                     for (int i = 0; i < count && slot < 0 && !shared; i++)
@@ -453,9 +465,11 @@ struct HipBackend : Backend {
         for (hipStream_t* arr : {rs, cs, aps})
             for (int i = 0; i < ROUNDS; i++)
                 if (arr[i]) {
-                    hipStreamSynchronize(arr[i]);
+                    // a hung world's streams are LEFT (not waited for, not destroyed): one of them holds a collective or a
+                    // wait that may never end; the context forgets them so that imt_ctx_sync does not wait for them either
+                    if (!hung) hipStreamSynchronize(arr[i]);
                     ss.erase(std::remove(ss.begin(), ss.end(), arr[i]), ss.end());
-                    hipStreamDestroy(arr[i]);
+                    if (!hung) hipStreamDestroy(arr[i]);
                 }
         imt_itree_set_slice_poison(tree, nullptr);
         imt_itree_set_slice_wait_limit(tree, 0);
@@ -496,7 +510,11 @@ struct HipBackend : Backend {
         *out = p;
         return IMT_OK;
     }
-    void free_buffer(Buffer b) override { hipFree(b); }
+    // hipFree waits for the whole device to go idle: never after a timeout (the buffers of a hung world are leaked; the
+    // process is expected to exit, include/imt.h IMT_ERR_TIMEOUT)
+    void free_buffer(Buffer b) override {
+        if (!hung) hipFree(b);
+    }
     int copy(Buffer dst, size_t doff, Buffer src, size_t soff, size_t bytes, Stream s) override {
         IMT_HIP(ctx, hipMemcpyAsync((uint8_t*)dst + doff, (const uint8_t*)src + soff, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
         return IMT_OK;
@@ -548,8 +566,20 @@ struct HipBackend : Backend {
             for (int i = 0; i < ROUNDS; i++)
                 if (arr[i]) {
                     if (opt.watchdog_ms <= 0) IMT_HIP(ctx, hipStreamSynchronize(arr[i]));
-                    else if ((rc = bounded_wait(ctx, opt.watchdog_ms, [&] { return hipStreamQuery(arr[i]); }, "the world's streams to drain"))) return rc;
+                    else if ((rc = bounded_wait(ctx, opt.watchdog_ms, [&] { return hipStreamQuery(arr[i]); }, "the world's streams to drain"))) {
+                        hung = hung || rc == IMT_ERR_TIMEOUT;
+                        return rc;
+                    }
                 }
+        if (opt.watchdog_ms > 0) {          // the context's own streams under the same limit, then the unbounded call finds them idle
+            std::vector<hipStream_t> own(ctx->side_streams);
+            own.push_back(ctx->stream);
+            for (hipStream_t st : own)
+                if ((rc = bounded_wait(ctx, opt.watchdog_ms, [&] { return hipStreamQuery(st); }, "the context's streams to drain"))) {
+                    hung = hung || rc == IMT_ERR_TIMEOUT;
+                    return rc;
+                }
+        }
         return imt_ctx_sync(ctx);
     }
 };
@@ -839,11 +869,7 @@ struct IpcTransport : Transport {
         waited_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return ok;
     }
-    ~IpcTransport() override {
-        if (ht.on)
-            fprintf(stderr, "[imt ipc rank %d] host ms (calls): flag_set %.1f (%llu)  wait packed %.1f (%llu)  memcpy %.1f (%llu)  wait copied %.1f (%llu)\n",
-                    rank, ht.ms[0], (unsigned long long)ht.n[0], ht.ms[1], (unsigned long long)ht.n[1], ht.ms[2], (unsigned long long)ht.n[2], ht.ms[3],
-                    (unsigned long long)ht.n[3]);
+    void stop_worker() {
         if (worker.joinable()) {
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -852,6 +878,19 @@ struct IpcTransport : Transport {
             cv.notify_all();
             worker.join();
         }
+    }
+    // host side only (imt_transport_destroy after a world that never drained): no call that could wait for the device
+    void abandon() override {
+        stop_worker();
+        if (!shm_name.empty()) shm_unlink(shm_name.c_str());
+        shm_name.clear();
+    }
+    ~IpcTransport() override {
+        if (ht.on)
+            fprintf(stderr, "[imt ipc rank %d] host ms (calls): flag_set %.1f (%llu)  wait packed %.1f (%llu)  memcpy %.1f (%llu)  wait copied %.1f (%llu)\n",
+                    rank, ht.ms[0], (unsigned long long)ht.n[0], ht.ms[1], (unsigned long long)ht.n[1], ht.ms[2], (unsigned long long)ht.n[2], ht.ms[3],
+                    (unsigned long long)ht.n[3]);
+        stop_worker();
         if (!shm_name.empty()) shm_unlink(shm_name.c_str());      // whatever else fails: the name does not stay behind
         if (ctx->set_device()) {                                   // no device: give the host mappings back at least
             for (auto& p : peers)
@@ -885,6 +924,12 @@ struct IpcTransport : Transport {
     // `aux_copied` tells the peers.  GPU-polled between different GPUs, host-polled between ranks that share one.
     int small_gather(const void* send, void* recv, size_t bytes, Stream st_) override {
         if (!connected) return ctx->fail(IMT_ERR_ARG, "imt_transport_ipc_connect first");
+        // A GPU-side wait of an EARLIER gather that gave up set the sticky error word: every copy and acknowledgement
+        // enqueued since has been skipped on the device and would be again -- say so instead of returning IMT_OK over a
+        // receive buffer nobody wrote.  A wait of THIS gather that gives up is seen by the next call, or by
+        // imt_transport_poll_error after the caller has synchronised the stream.
+        int rc0 = poll_error();
+        if (rc0) return rc0;
         hipStream_t st = (hipStream_t)st_;
         const uint64_t k = ++aux_seq;
         const int r = (int)((k - 1) % IPC_AUX_RING);
@@ -1026,7 +1071,7 @@ struct imt_sliced {
     imt_transport* tp = nullptr;
     size_t max_slice = 0;
     SlicedOptions opt;
-    std::string error, first_failure;
+    std::string error, first_failure, presets_kept;
     double host_issue_ms = 0, host_wait_ms = 0;      // wall time inside imt_sliced_step: issuing / waiting for the GPU
     bool trees_marked = false;
 
@@ -1136,11 +1181,26 @@ int imt_transport_all_gather(imt_transport* tp, const void* send, void* recv, si
     return tp->impl->small_gather(send, recv, bytes, hip_stream ? hip_stream : (void*)tp->ctx->stream);
 }
 
+int imt_transport_poll_error(imt_transport* tp) {
+    if (!tp) return IMT_ERR_ARG;
+    if (tp->ctx) {
+        int rc = tp->ctx->set_device();
+        if (rc) return rc;
+    }
+    const int rc = tp->impl->poll_error();
+    if (rc && tp->ctx) tp->error = tp->ctx->last_error;
+    return rc;
+}
+
 int imt_transport_destroy(imt_transport* tp) {
     if (!tp) return IMT_OK;
     if (tp->users > 0) {            // an imt_sliced still holds it: destroying it now would leave that world with a dangling pointer
         tp->error = "imt_transport_destroy: an imt_sliced still uses this transport (imt_sliced_destroy first)";
         return IMT_ERR_ARG;
+    }
+    if (tp->abandoned) {            // its last world never drained: host-side cleanup only, the device side is leaked
+        tp->impl->abandon();
+        (void)tp->impl.release();
     }
     delete tp;
     return IMT_OK;
@@ -1153,6 +1213,12 @@ const char* imt_transport_last_error(const imt_transport* tp) {
 }
 
 int imt_sliced_set_option(imt_sliced* s, int option, long value) {
+    if (option == IMT_SLICED_OPT_RESET) {
+        if (s || value != 0) return s ? IMT_ERR_ARG : IMT_ERR_RANGE;
+        std::lock_guard<std::mutex> lk(g_defaults_mu);
+        g_defaults = SlicedOptions();
+        return IMT_OK;
+    }
     if (!option_value_ok(option, value)) return IMT_ERR_RANGE;
     long* f = nullptr;
     if (!s) {                       // the defaults later imt_sliced_create calls start from
@@ -1160,6 +1226,7 @@ int imt_sliced_set_option(imt_sliced* s, int option, long value) {
         int rc = option_field(g_defaults, option, &f);
         if (rc) return rc;
         *f = value;
+        g_defaults.set_mask |= 1ul << option;
         return IMT_OK;
     }
     // an existing world: only what does not change its streams
@@ -1186,11 +1253,23 @@ void imt_sliced_destroy(imt_sliced* s) {
     // a poisoned world is not flushed (nothing can be issued any more); its replicas stay marked: they hold half a step
     const bool clean = !s->w.poisoned;
     if (clean && !s->w.ranks.empty() && s->w.n_rounds) s->w.flush();
+    bool hung = false;
     for (auto& be : s->bes)
         if (be) {
-            be->sync();                                  // bounded by the watchdog; what is still running keeps its buffers busy
-            if (clean && !s->w.poisoned) imt_itree_mark_sliced(be->tree, false);
+            // bounded by the watchdog.  If it runs out, something of this world still runs on the device (a collective
+            // whose peer never came, a wait): nothing below may then WAIT for the device -- hipFree does -- so the world's
+            // buffers and streams are leaked, its transport is marked (imt_transport_destroy leaks its device side too) and
+            // the replicas stay marked busy.  The process is expected to exit (imt.h, IMT_ERR_TIMEOUT).
+            if (be->sync() == IMT_ERR_TIMEOUT) hung = true;
+            if (clean && !s->w.poisoned && !be->hung) imt_itree_mark_sliced(be->tree, false);
         }
+    if (hung) {
+        for (auto& be : s->bes)
+            if (be) be->hung = true;
+        if (s->tp) s->tp->abandoned = true;
+        fputs("[imt sliced] imt_sliced_destroy: the world's streams did not drain within the watchdog's limit; its device buffers and streams "
+              "are left allocated (hipFree would wait for the device).  This process should exit; recover in a fresh one.\n", stderr);
+    }
     for (auto& r : s->ranks)
         if (r) r->destroy();
     if (s->tp) s->tp->users--;
@@ -1239,18 +1318,33 @@ int imt_sliced_create(imt_itree* const* trees, int n_local, int world, int first
     // (it would crawl at low priority).  One rank of 2 / 4 / 8 alone on the GPU: within 1 % of everything in one pool
     // (profiles/r05_emu_priority_pools.txt).  Replicas of one process have no peers to wait for: one pool.
     if (s->opt.pools < 0) s->opt.pools = (n_local == 1 && world > 1) ? 1 : 0;
+    // The presets fill in what the caller has NOT named: an option set explicitly (imt_sliced_set_option(NULL, ...)) keeps
+    // the caller's value, and imt_sliced_last_error / the placement note say which preset was left out.
+    std::string kept;
+    auto preset = [&](int option, long* field, long value, const char* name) {
+        if (s->opt.set_mask & (1ul << option)) {
+            if (*field != value) {
+                char b[160];
+                snprintf(b, sizeof b, "%sIMT_SLICED_OPT_POOLS %ld: %s stays at the caller's %ld (the preset is %ld)", kept.empty() ? "" : "; ", s->opt.pools, name, *field, value);
+                kept += b;
+            }
+            return;
+        }
+        *field = value;
+    };
     if (s->opt.pools == 1) {
-        s->opt.round_priorities = 3;
-        s->opt.comm_priority = 8;        // clamped to the lowest the device has
-        s->opt.prep_stream = 1;
+        preset(IMT_SLICED_OPT_ROUND_PRIORITIES, &s->opt.round_priorities, 3, "ROUND_PRIORITIES");
+        preset(IMT_SLICED_OPT_COMM_PRIORITY, &s->opt.comm_priority, 8, "COMM_PRIORITY");       // clamped to the lowest the device has
+        preset(IMT_SLICED_OPT_PREP_STREAM, &s->opt.prep_stream, 1, "PREP_STREAM");
     } else if (s->opt.pools == 2) {
         // the one-pool layout moved into the HIGH pool: the collectives' streams on their rounds' queues -- no foreign stream
         // on a round's queue either, no barrier packet between a round and its gathers (same queue: in order), 4 % more
         // per rank on one GPU than the three pools, but every tick a barrier across ranks again (IMT_SLICED_OPT_COMM_PLACEMENT)
-        s->opt.round_priorities = 3;
-        s->opt.comm_priority = -8;       // clamped to the highest
-        s->opt.comm_placement = 1;
+        preset(IMT_SLICED_OPT_ROUND_PRIORITIES, &s->opt.round_priorities, 3, "ROUND_PRIORITIES");
+        preset(IMT_SLICED_OPT_COMM_PRIORITY, &s->opt.comm_priority, -8, "COMM_PRIORITY");      // clamped to the highest
+        preset(IMT_SLICED_OPT_COMM_PLACEMENT, &s->opt.comm_placement, 1, "COMM_PLACEMENT");
     }
+    s->presets_kept = kept;
     tp->users++;
     for (int k = 0; k < n_local; k++) {
         s->bes.emplace_back(new (std::nothrow) HipBackend(trees[k]));
@@ -1364,6 +1458,7 @@ const char* imt_sliced_last_error(const imt_sliced* s) {
     if (!s->error.empty()) return s->error.c_str();
     for (auto& be : s->bes)
         if (be && be->placement == IMT_SLICED_PLACEMENT_DEGRADED && be->ctx->last_error.empty()) return be->placement_note.c_str();
+    if (!s->presets_kept.empty() && !s->bes.empty() && s->bes[0] && s->bes[0]->ctx->last_error.empty()) return s->presets_kept.c_str();
     for (auto& be : s->bes)
         if (be && !be->ctx->last_error.empty()) return be->ctx->last_error.c_str();
     return imt_transport_last_error(s->tp);

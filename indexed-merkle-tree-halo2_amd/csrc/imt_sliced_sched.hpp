@@ -44,6 +44,13 @@
 namespace imt {
 namespace sliced {
 
+// The three switches below change the schedule this header compiles to.  They exist for tests (planted bugs the simulators
+// must catch) and A/B experiment builds, which say so with -DIMT_TEST_BUILD; a product build into which one of them
+// strays (a CXXFLAGS left over from an experiment) does not compile.  tests/test_sliced_schedule.py checks the guard.
+#if !defined(IMT_TEST_BUILD) && ((defined(IMT_SCHED_MUTATION) && IMT_SCHED_MUTATION != 0) || defined(IMT_SCHED_ALL_WAITS) || \
+                                 (defined(IMT_SLICED_ROUNDS_BUILD) && IMT_SLICED_ROUNDS_BUILD != 4))
+#error "IMT_SCHED_MUTATION / IMT_SCHED_ALL_WAITS / IMT_SLICED_ROUNDS_BUILD are test switches: define IMT_TEST_BUILD with them, never in a product build"
+#endif
 #ifndef IMT_SLICED_ROUNDS_BUILD       // (experiment builds only: more steps in flight need -DIMT_NPIPE to match and break include/imt.h's layout)
 #define IMT_SLICED_ROUNDS_BUILD 4
 #endif
@@ -182,6 +189,9 @@ struct Transport {
         return IMT_ERR_ARG;
     }
     virtual double take_wait_ms() { return 0; }    // host time spent WAITING for peers since the last call (not issuing)
+    // imt_transport_destroy after a world that never drained: host-side cleanup only (threads, names in /dev/shm); the
+    // object is then leaked instead of deleted -- its destructor would wait for the device
+    virtual void abandon() {}
     uint64_t collectives = 0, bytes_moved = 0;
 };
 

@@ -10,6 +10,7 @@ struct imt_transport {
     imt_ctx* ctx = nullptr;          // whose last_error carries the transport's messages (null: custom / local)
     std::string error;
     int users = 0;
+    bool abandoned = false;          // the last world on it never drained (imt_sliced_destroy): destroy leaks the device side
 };
 
 // takes ownership of t (deleted if the handle cannot be allocated)

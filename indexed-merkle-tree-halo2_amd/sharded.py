@@ -44,7 +44,9 @@ class GpuBackend:
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(device_index)
         self.ctx = imt.Context(device_index)
-        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.stream_ptr = torch.cuda.current_stream().cuda_stream      # 0 = the null stream
+        self.ctx.set_stream(self.stream_ptr)
+        self.transport = None        # ShardedIndexedTree(transport=...): sync() then also asks it for a GPU-side timeout
         self.tree = imt.IndexedTree(self.ctx, self.sub_height, capacity)
         self.tree.set_placement(depth, rank)
         self.ctx._check(imt.lib.imt_itree_set_value_partition(self.tree.h, world, rank))
@@ -127,20 +129,34 @@ class GpuBackend:
     def sync(self):
         self.ctx.sync()
         torch.cuda.synchronize()
+        if self.transport is not None:
+            # a GPU-side wait of the root exchange that gave up on a peer left the gathered roots unwritten (zeros) and
+            # everything computed from them wrong: say so before anybody reads the outputs (imt_transport_poll_error)
+            rc = self.imt.lib.imt_transport_poll_error(self.transport)
+            if rc:
+                raise self.imt.ImtError(rc, self.imt.lib.imt_transport_last_error(self.transport).decode())
 
 
 class ShardedIndexedTree:
     """step(vals) inserts this rank's batch and finishes -- root exchange + lift -- the PREVIOUS step,
     whose depth-D witnesses it returns; flush() finishes the last one."""
 
-    def __init__(self, backend, depth, world=1, rank=0, dist=None, via_host=False, transport=None):
+    def __init__(self, backend, depth, world=1, rank=0, dist=None, via_host=False, transport=None, transport_ctx=None):
         """transport: an imt_transport handle (RCCL or IPC, include/imt.h) -- the root exchange then goes through the
         LIBRARY's communicators (imt_transport_all_gather: what a host without torch.distributed uses, e.g.
-        examples/subtree_procs_demo.c) instead of `dist`"""
+        examples/subtree_procs_demo.c) instead of `dist`.  The gather is enqueued on the BACKEND's stream, named
+        explicitly; when that is the null stream (handle 0, which the C call reads as "the transport's own context's
+        stream") the transport must have been created on the backend's context -- say so with transport_ctx."""
         if world & (world - 1):
             raise ValueError("world size must be a power of two")
         self.backend, self.depth, self.world, self.rank, self.dist = backend, depth, world, rank, dist
         self.via_host, self.transport = via_host, transport
+        if transport is not None and backend is not None:
+            if not backend.stream_ptr and transport_ctx is not None and transport_ctx is not backend.ctx:
+                raise ValueError("the backend runs on the null stream and the transport was created on another context: its "
+                                 "gather would run on that context's stream, unordered with root_after() / lift() -- create "
+                                 "the transport on backend.ctx or run the backend on a stream of its own")
+            backend.transport = transport
         self.k = world.bit_length() - 1
         self.sub_height = depth - self.k
         self.pending = None
@@ -178,10 +194,14 @@ class ShardedIndexedTree:
         """[world, 32]: every rank's subtree root -- the one collective of the path"""
         if self.transport is not None and self.world > 1:      # the library's own collective, on the backend's stream
             be = self.backend
-            out = torch.empty((self.world, 32), dtype=torch.uint8, device=mine.device)
+            # zeros, not empty: if a GPU-side wait gives up the copies behind it are skipped, and what is read then must
+            # not be whatever the allocator left there (backend.sync() reports the timeout; so does the next gather)
+            out = torch.zeros((self.world, 32), dtype=torch.uint8, device=mine.device)
             src = mine.contiguous()
-            be.ctx._check(be.imt.lib.imt_transport_all_gather(self.transport, ctypes.c_void_p(src.data_ptr()),
-                                                              ctypes.c_void_p(out.data_ptr()), 32, None))
+            rc = be.imt.lib.imt_transport_all_gather(self.transport, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                     32, ctypes.c_void_p(be.stream_ptr) if be.stream_ptr else None)
+            if rc:
+                raise be.imt.ImtError(rc, be.imt.lib.imt_transport_last_error(self.transport).decode())
             return out
         if self.dist is None:
             return mine.reshape(1, 32).clone()

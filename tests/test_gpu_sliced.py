@@ -758,9 +758,7 @@ def test_sliced_options(imt, ctx):
         assert t.info()["pools"] == 0 and t.info()["queue_map"][1] == t.info()["queue_map"][0]
         t.close()
     finally:
-        lib.imt_sliced_set_option(None, F.SLICED_OPT_APPLY_STREAMS, 0)
-        lib.imt_sliced_set_option(None, F.SLICED_OPT_VERIFY_QUEUES, 1)
-        lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, -1)
+        lib.imt_sliced_set_option(None, F.SLICED_OPT_RESET, 0)
 
 
 def test_transport_is_one_world_at_a_time(imt, ctx):
@@ -910,3 +908,162 @@ def test_a_vanished_peer_poisons_the_world_instead_of_corrupting_it(imt):
     assert "did not arrive" in r0["msg"] and r0["at"] < 30.0, r0
     assert r0.get("steps_ok", 0) < 14 and r0.get("again") == F.ERR["INTERNAL"], r0
     assert got[1]["code"] is None and got[1]["steps_ok"] == 2
+
+
+def test_destroy_after_a_timeout_does_not_wait_for_the_device(imt, ctx, capfd):
+    """after the watchdog has fired the documented way out is to destroy the world -- which must not itself block
+    on the collective that never ends.  A custom transport whose fifth all-gather holds its stream for ~5 s; watchdog at
+    300 ms; imt_sliced_destroy + imt_transport_destroy right after IMT_ERR_TIMEOUT return within a couple of watchdog
+    periods (hipFree, which waits for the whole device, is skipped: the world's buffers and streams are left allocated and
+    stderr says so), long before the collective ends."""
+    import time
+    sl = load_sliced()
+    F, lib = imt._ffi, imt.lib
+    hip = _hip()
+    dev = torch.device("cuda", 0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.cuda._sleep(20_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    clock_hz = 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
+    calls = []
+
+    def all_gather(self_, channel, buffer, send, recv, nbytes, stream):
+        calls.append(channel)
+        if len(calls) == 5:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                torch.cuda._sleep(int(5.0 * clock_hz))
+        return 0 if hip.hipMemcpyAsync(recv, send, nbytes, 3, stream) == 0 else F.ERR["HIP"]
+
+    ops = F.TransportOps(None, F.TransportOps.ALL_GATHER(all_gather), F.TransportOps.DESTROY())
+    tp = ctypes.c_void_p()
+    assert lib.imt_transport_custom_create(ctypes.byref(ops), ctypes.byref(tp)) == 0
+    t = sl.SlicedTree(imt, 0, 32, 1 << 12, 64, 1, transport=tp)
+    t.set_option(F.SLICED_OPT_WATCHDOG_MS, 300)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(oracle_lib.synth_values(8 * 64, 0x494D5474))).cuda()
+    torch.cuda.synchronize()
+    t_stall = None
+    code = None
+    for r in range(8):
+        try:
+            t.step(arr[r * 64:(r + 1) * 64])
+        except imt.ImtError as e:
+            code = e.code
+            break
+        if len(calls) >= 5 and t_stall is None:
+            t_stall = time.perf_counter()
+    assert code == F.ERR["TIMEOUT"]
+    t0 = time.perf_counter()
+    lib.imt_sliced_destroy(t.h)
+    t.h = None
+    assert lib.imt_transport_destroy(tp) == 0
+    dt = time.perf_counter() - t0
+    err = capfd.readouterr().err
+    assert dt < 2.5, f"destroy took {dt:.2f} s"
+    assert "did not drain" in err and "left allocated" in err
+    # (this test lets the 5-s collective end and then closes trees and contexts; a real host would exit instead)
+    torch.cuda.synchronize()
+    for tr in t.trees:
+        tr.close()
+    for c in t.ctxs:
+        c.close()
+
+
+def test_pool_presets_leave_explicit_options_alone(imt, ctx):
+    """IMT_SLICED_OPT_POOLS 1 presets ROUND_PRIORITIES / COMM_PRIORITY / PREP_STREAM -- but not over a value the
+    caller has set explicitly; the new world's last_error says which preset was left out.  IMT_SLICED_OPT_RESET forgets."""
+    sl = load_sliced()
+    F, lib = imt._ffi, imt.lib
+    try:
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, 1) == 0
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_PREP_STREAM, 0) == 0
+        t = sl.SlicedTree(imt, 0, 32, 1 << 10, 32, 2, n_local=2)
+        msg = lib.imt_sliced_last_error(t.h).decode()
+        assert "PREP_STREAM stays at the caller's 0" in msg and "ROUND_PRIORITIES" not in msg, msg
+        info = t.info()
+        assert info["pools"] == 1 and sorted(info["queue_map"][0]) == [0, 1, 2, 3] and info["queue_map"][1] == [-2] * 4, info
+        vals = oracle_lib.synth_values(2 * 32 * 3, 0x494D547B)
+        want, want_root = reference_run(imt, ctx, 32, 1 << 10, vals, 64)
+        arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+        for r in range(3):
+            t.step(arr[r * 64:(r + 1) * 64])
+        t.flush()
+        assert t.trees[0].root() == want_root and t.trees[1].root() == want_root
+        t.close()
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_RESET, 1) == F.ERR["RANGE"]
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_RESET, 0) == 0
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, 1) == 0
+        t = sl.SlicedTree(imt, 0, 32, 1 << 10, 32, 2, n_local=2)
+        assert lib.imt_sliced_set_option(t.h, F.SLICED_OPT_RESET, 0) == F.ERR["ARG"]
+        assert "stays at the caller's" not in lib.imt_sliced_last_error(t.h).decode()
+        t.close()
+    finally:
+        lib.imt_sliced_set_option(None, F.SLICED_OPT_RESET, 0)
+
+
+def _gather_worker(rank, world, port, q):
+    """the subtree layout's one collective over the GPU-polled IPC transport; rank 1 takes part in the first gather only"""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import imt_amd
+    F, lib = imt_amd._ffi, imt_amd.lib
+    boot = imt_amd.Context(0)
+    nb = int(lib.imt_transport_ipc_blob_bytes())
+    mine = torch.zeros(nb, dtype=torch.uint8)
+    tp = ctypes.c_void_p()
+    assert lib.imt_transport_ipc_create(boot.h, world, rank, 32, 64, 0, ctypes.byref(tp), ctypes.c_void_p(mine.data_ptr())) == 0
+    assert lib.imt_transport_set_option(tp, F.TRANSPORT_OPT_HOST_POLL, 0) == 0
+    assert lib.imt_transport_set_option(tp, F.TRANSPORT_OPT_TIMEOUT_MS, 300) == 0
+    allb = torch.zeros(world * nb, dtype=torch.uint8)
+    dist.all_gather_into_tensor(allb, mine)
+    assert lib.imt_transport_ipc_connect(tp, ctypes.c_void_p(allb.data_ptr())) == 0
+    send = torch.full((32,), 10 + rank, dtype=torch.uint8, device="cuda")
+    out = dict(rank=rank)
+
+    def gather():
+        recv = torch.zeros((world, 32), dtype=torch.uint8, device="cuda")
+        rc = lib.imt_transport_all_gather(tp, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(recv.data_ptr()), 32, None)
+        boot.sync()
+        return rc, recv.cpu().numpy(), lib.imt_transport_poll_error(tp)
+    rc, recv, pe = gather()
+    out["first"] = (rc, recv[:, 0].tolist(), pe)
+    dist.barrier()
+    if rank == 0:
+        t0 = time.perf_counter()
+        rc, recv, pe = gather()                     # the peer never comes: the GPU-side wait gives up after 300 ms
+        out["second"] = (rc, recv[:, 0].tolist(), pe, time.perf_counter() - t0, lib.imt_transport_last_error(tp).decode())
+        rc, recv, pe = gather()                     # sticky: refused at the call, nothing enqueued
+        out["third"] = (rc, recv[:, 0].tolist(), pe)
+    q.put(out)
+    dist.barrier()
+    os._exit(0)
+
+
+def test_subtree_gather_reports_a_peer_that_never_comes(imt):
+    """imt_transport_all_gather over the GPU-polled IPC transport used to return IMT_OK for ever after a
+    GPU-side wait had given up -- with `recv` never written.  Now: the call whose wait gives up still returns IMT_OK (the
+    wait runs on the device), imt_transport_poll_error after the stream's sync says IMT_ERR_INTERNAL and `recv` holds
+    the caller's zeros for the missing rank; every later call is refused at once."""
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [mpctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {o["rank"]: o for o in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    F = imt._ffi
+    for r in (0, 1):
+        assert got[r]["first"] == (0, [10, 11], 0), got[r]
+    rc, col, pe, dt, msg = got[0]["second"]
+    assert rc == 0 and pe == F.ERR["INTERNAL"] and col == [10, 0] and dt < 10.0 and "did not arrive" in msg, got[0]
+    rc, col, pe = got[0]["third"]
+    assert rc == F.ERR["INTERNAL"] and pe == F.ERR["INTERNAL"] and col == [0, 0], got[0]

@@ -191,7 +191,7 @@ def test_in_process_world_on_four_shared_queues(lib):
 def mutated_lib(tmp_path, mutation):
     src = os.path.join(ROOT, "tests", "native", "sliced_sym.cpp")
     so = str(tmp_path / f"libslicedsym_m{mutation}.so")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", f"-DIMT_SCHED_MUTATION={mutation}", "-o", so, src], check=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DIMT_TEST_BUILD", f"-DIMT_SCHED_MUTATION={mutation}", "-o", so, src], check=True)
     mlib = ctypes.CDLL(so)
     ref = sliced_sim.load()
     for name in ("sym_schedule", "sym_unit_of", "sym_payload_units", "sym_world_create", "sym_world_create_channels", "sym_world_step",

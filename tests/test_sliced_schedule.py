@@ -94,7 +94,7 @@ def test_the_simulator_catches_planted_mutations(tmp_path):
 
     def outcome(mutation, extra=(), apply_on_round=False):
         so = str(tmp_path / f"libslicedsym_m{mutation}{len(extra)}{int(apply_on_round)}.so")
-        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", f"-DIMT_SCHED_MUTATION={mutation}", *extra, "-o", so, src],
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DIMT_TEST_BUILD", f"-DIMT_SCHED_MUTATION={mutation}", *extra, "-o", so, src],
                        check=True)
         mlib = ctypes.CDLL(so)
         for name in ("sym_schedule", "sym_unit_of", "sym_payload_units", "sym_world_create", "sym_world_step", "sym_world_flush",
@@ -195,3 +195,21 @@ def test_small_schedules_exhaustively(lib):
                 w.close()
                 done += 1
     assert done > 150
+
+
+def test_a_test_switch_does_not_compile_into_a_product_build(tmp_path):
+    """IMT_SCHED_MUTATION / IMT_SCHED_ALL_WAITS / IMT_SLICED_ROUNDS_BUILD change the shipped schedule.  A
+    build that defines one of them without IMT_TEST_BUILD (a stray CXXFLAGS) must fail at the header, not ship."""
+    hdr = os.path.join(ROOT, "indexed-merkle-tree-halo2_amd", "csrc", "imt_sliced_sched.hpp")
+    src = tmp_path / "x.cpp"
+    src.write_text(f'#include "{hdr}"\nint main() {{ return imt::sliced::ROUNDS; }}\n')
+
+    def compiles(*defs):
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", *defs, str(src)], capture_output=True, text=True)
+        return r.returncode == 0, r.stderr
+    assert compiles()[0]
+    assert compiles("-DIMT_SCHED_MUTATION=0", "-DIMT_SLICED_ROUNDS_BUILD=4")[0]        # the product's own values are not a switch
+    for d in ("-DIMT_SCHED_MUTATION=3", "-DIMT_SCHED_ALL_WAITS", "-DIMT_SLICED_ROUNDS_BUILD=6"):
+        ok, err = compiles(d)
+        assert not ok and "test switches" in err, (d, err)
+        assert compiles(d, "-DIMT_TEST_BUILD")[0], d
