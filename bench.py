@@ -977,7 +977,7 @@ def main():
         import threading
         limit = float(os.environ.get("IMT_BENCH_SINGLE_LIST_TIMEOUT", "240"))
 
-        pre_limit = min(limit, float(os.environ.get("IMT_BENCH_PREFLIGHT_TIMEOUT", "75")))
+        pre_limit = min(limit, float(os.environ.get("IMT_BENCH_PREFLIGHT_TIMEOUT", "120")))
 
         def give_up(why):
             w = getattr(env, "live_world", None)

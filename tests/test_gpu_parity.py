@@ -1228,6 +1228,44 @@ def test_config2_full_size_properties(imt, ctx, oracle):
     oracle.sparse_free(oh)
 
 
+def test_config2_size_descending_values_against_the_oracle_digest(imt, ctx, oracle):
+    """one full-size ORDERED case.  The 2^16 config-2 values inserted in DESCENDING order: every
+    insertion's low leaf is leaf 0 (the sentinel is rewritten 2^16 times, each new leaf points at the one inserted before
+    it) -- the opposite extreme of random values for the sort / lower bound / nearest-smaller search and for the (node, time)
+    runs (one run of 2^16 versions per level) that replace update_idx_leaf's scan (src/indexed_merkle_tree.rs:639-658).
+    Every interim / new root, low index and flag against the sequential CPU oracle's digests
+    (tests/golden/config2_descending_oracle_digest.json, make_config2_digest.py descending: six minutes of one core), in one
+    batch and in uneven batches; every insert_leaf constraint through the witness kernels; a prefix value by value."""
+    import hashlib
+    depth, n = 32, 1 << 16
+    vals = sorted(oracle_lib.synth_values(n, 0x494D5402), reverse=True)
+    dg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config2_descending_oracle_digest.json")))
+    assert dg["n"] == n and dg["depth"] == depth and dg["order"] == "descending"
+    t = imt.IndexedTree(ctx, depth, 1 << 17)
+    r = t.insert_batch(vals)
+    assert (r["low_index"] == 0).all() and r["is_largest"][0] == 1 and not r["is_largest"][1:].any()
+    fail = ctx.insert_witness(r["old_root"], r["low_leaf"], r["low_index"], r["low_sib"], r["new_root"],
+                              r["new_leaf"], r["new_index"], r["new_sib"], r["is_largest"], depth)
+    assert not fail.any()
+    assert hashlib.sha256(r["interim_root"].tobytes()).hexdigest() == dg["sha256_interim_roots"]
+    assert hashlib.sha256(r["new_root"].tobytes()).hexdigest() == dg["sha256_new_roots"]
+    assert hashlib.sha256(r["low_index"].astype("<u8").tobytes()).hexdigest() == dg["sha256_low_index"]
+    assert hashlib.sha256(r["is_largest"].tobytes()).hexdigest() == dg["sha256_is_largest"]
+    assert t.root() == int(dg["final_root"])
+    for k, v in dg["root_after"].items():
+        assert ints(r["new_root"][int(k) - 1]) == [int(v)]
+    for i, hx in dg["sha256_final_proofs"].items():
+        assert hashlib.sha256(t.get_proof_batch([int(i)], item_major=True).tobytes()).hexdigest() == hx
+    t2 = imt.IndexedTree(ctx, depth, 1 << 17)
+    cuts = [0, 1, 1000, 30000, 30001, n]
+    roots = [t2.insert_batch(vals[a:b], proofs=False)["new_root"] for a, b in zip(cuts, cuts[1:])]
+    assert (np.concatenate(roots) == r["new_root"]).all() and t2.root() == t.root()
+    oh, rows, _ = _oracle_run(oracle, depth, 512, vals[:256])
+    assert ints(r["new_root"][:256]) == [o["new_root"] for o in rows]
+    assert ints(r["interim_root"][:256]) == [o["interim_root"] for o in rows]
+    oracle.sparse_free(oh)
+
+
 def test_pipelined_growth_stress_properties(imt, ctx):
     """2^18 insertions as 8 pipelined device-pointer batches of 2^15 (L0 grows 15 -> 18 on the way, so
     both the overlapped and the joined schedule run), GPU prepare; every insert_leaf constraint is then

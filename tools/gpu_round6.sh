@@ -28,5 +28,24 @@ orderprof)
 tests)
   timeout -k 10 1150 python -m pytest tests -m gpu -x -q --durations=25 > $O/gpu_tests.log 2>&1
   rc=$?; tail -45 $O/gpu_tests.log; exit $rc ;;
+emu)   # one rank of N alone on the GPU under the production layout (three priority pools): today's fill (a one-wave sleep + N blits)
+       # against ONE RCCL-shaped kernel per collective (7 / 28 / 56 workgroups x 512 lanes polling a flag, then copying)
+  ( export EMU_RANKS=first EMU_ROUNDS=16
+    for fill in "memcpy 0" "rccl 7" "rccl 28" "rccl 56" "memcpy 0"; do set -- $fill
+      echo "== fill $1, $2 workgroups"
+      EMU_FILL=$1 EMU_GATHER_WGS=$2 timeout -k 10 300 python tools/rank_emulation.py 8 4 2 2>&1 | grep "^N =" | cut -c1-150 || exit 1
+    done ) > $O/emu_rccl_shape.txt 2>&1
+  rc=$?; cat $O/emu_rccl_shape.txt; exit $rc ;;
+flag)  # "the gather is complete" as a device-side counter polled by a one-wave kernel on the round's
+       # stream (IMT_SLICED_GATHER_FLAGS=1) instead of an event wait across hardware queues.  Correctness first, then one rank
+       # of 8 / 4 (production layout, both fills), the two forms alternating on ONE box.
+  ( IMT_SLICED_GATHER_FLAGS=1 timeout -k 10 600 python -m pytest tests/test_gpu_sliced.py -m gpu -x -q -k "sequential_oracle or equals_one_gpu_tree or bench_size or over_ipc or pool_presets" > $O/flag_tests.log 2>&1 ) &&
+  tail -3 $O/flag_tests.log &&
+  ( export EMU_RANKS=first EMU_ROUNDS=16
+    for rep in 1 2 3; do for fl in 0 1; do for fill in memcpy rccl; do
+      echo "== rep $rep: gather flags $fl, fill $fill"
+      IMT_SLICED_GATHER_FLAGS=$fl EMU_FILL=$fill EMU_GATHER_WGS=28 timeout -k 10 300 python tools/rank_emulation.py 8 4 2>&1 | grep "^N =" | grep links | cut -c1-110 || exit 1
+    done; done; done ) > $O/ab_gather_flags.txt 2>&1
+  rc=$?; cat $O/ab_gather_flags.txt; exit $rc ;;
 *) echo "unknown part $part"; exit 2 ;;
 esac

@@ -55,7 +55,22 @@ class _Raw:
 # broadcast copy kernel for all slots (a torch elementwise copy of 38 MB): cheaper for the host, but one fat low-priority
 # kernel competes with the hashing -- 2.2 - 2.5 against 2.6 - 2.7 M/s at N = 8 -- and without the modelled link time it
 # starts the moment the pack ends (then "free collectives" come out SLOWER than modelled links).
+# "rccl": ONE kernel of RCCL's shape per collective (tools/microbench/emu_gather.hip: EMU_GATHER_WGS workgroups of 512 lanes
+# that need wave slots beside the resident hash kernels, poll a flag until the modelled link time has passed, then copy)
+# instead of a one-wave sleep + world blits: what a real ncclAllGather asks of the device.
 FILL = os.environ.get("EMU_FILL", "memcpy")
+GATHER_WGS = int(os.environ.get("EMU_GATHER_WGS", "28"))
+emu = None
+if FILL == "rccl":
+    import subprocess
+    so = os.path.join(ROOT, "tools", "microbench", "libemu_gather.so")
+    src = os.path.join(ROOT, "tools", "microbench", "emu_gather.hip")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
+    emu = ctypes.CDLL(so)
+    emu.emu_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+    torch.cuda.set_device(0)
+    assert emu.emu_gather_init() == 0
 
 
 class ModelTransport:
@@ -75,6 +90,10 @@ class ModelTransport:
         try:
             self.calls += 1
             self.bytes += nbytes * (self.world - 1)
+            if FILL == "rccl":
+                us = self.lat + nbytes / (self.link * 1e3) if self.link > 0 else 0.0
+                self.model_ms += us * 1e-3
+                return 0 if emu.emu_gather(stream, recv, send, nbytes, self.world, us, GATHER_WGS) == 0 else F.ERR["HIP"]
             if self.link > 0:
                 us = self.lat + nbytes / (self.link * 1e3)             # every peer's slot arrives over its own link
                 self.model_ms += us * 1e-3
@@ -136,7 +155,8 @@ def main():
     link = float(os.environ.get("EMU_LINK_GBPS", "48"))
     lat = float(os.environ.get("EMU_LATENCY_US", "40"))
     print(f"one rank of an N-rank single-list run alone on the GPU, {ROUNDS} timed steps of N x 2^16 insertions after {WARM}; "
-          f"collectives modelled as {lat:.0f} us + bytes / {link:.0f} GB/s per peer link (EMU_LINK_GBPS=0: free)", flush=True)
+          f"collectives modelled as {lat:.0f} us + bytes / {link:.0f} GB/s per peer link (EMU_LINK_GBPS=0: free); fill = {FILL}"
+          + (f" ({GATHER_WGS} workgroups x 512 lanes per collective)" if FILL == "rccl" else ""), flush=True)
     for world in worlds:
         which = os.environ.get("EMU_RANKS", "first last").split()
         ranks = sorted({0 if w == "first" else world - 1 if w == "last" else int(w) for w in which})
