@@ -72,9 +72,10 @@ VALU_PEAK_GMADS = 36443.0           # measured v_mad_u64_u32 lane-ops/ns (profil
 # reports half of 16-B/lane reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, counter unit KB, mean over the k_sweep
 # dispatches of the run.  bench.py cannot read PMC counters itself, so this is a STATIC figure, reported as
 # roofline.traffic_static with its source.
-PMC_TRAFFIC_SWEEP_LEVEL = {"bytes": int((2 * 3580.0 + 8067.9) * 1024), "fetch_size_kb": 3580.0, "write_size_kb": 8067.9,
-                           "source": "profiles/r04_pmc_hbm_traffic_raw.txt (round 3: 3572.3 / 8067.9, "
-                                     "profiles/r03_pmc_hbm_traffic_raw.txt)", "measured_at_commit": "round-4 build"}
+PMC_TRAFFIC_SWEEP_LEVEL = {"bytes": int((2 * 3580.1 + 8067.9) * 1024), "fetch_size_kb": 3580.1, "write_size_kb": 8067.9,
+                           "source": "profiles/r05_pmc_hbm_traffic_raw.txt (rounds 3 / 4: 3572.3 / 3580.0 and 8067.9; the kernel has "
+                                     "not changed since; re-collected per round by tools/gpu_round6.sh bench)",
+                           "measured_at_commit": "round-5 build (k_sweep unchanged in round 6)"}
 TRACE_ROWS = 1208                   # witnesses per 2-input hash (imt_hash_trace_batch)
 DTYPE = "u32 limbs (9 x 29-bit, Montgomery mod p), 64-bit accumulate"
 METRIC = "indexed-tree insertions/sec at depth=32 (bn256::Fr)"
@@ -787,6 +788,11 @@ def bench_single_list(env):
     # IMT_ERR_TIMEOUT with the world's state on stderr; bench.py's timer is the net under it
     tree.set_option(env.F.SLICED_OPT_WATCHDOG_MS, lib_watchdog_ms)
     R0 = PREFLIGHT_STEPS            # round number of step 0
+    # TEST ONLY (tests/test_gpu_sharded_procs.py): IMT_BENCH_INJECT="attempt:rank:kind" makes THIS worker fail the way a real
+    # run can -- "die": the process is gone after its first timed step (its peers then wait for collectives that never
+    # complete); "corrupt": one byte of its last witnesses is flipped before they are verified
+    inj = os.environ.get("IMT_BENCH_INJECT", "").split(":")
+    inj = inj[2] if len(inj) == 3 and inj[0] == os.environ.get("IMT_BENCH_ATTEMPT", "0") and int(inj[1]) == rank else None
 
     for i in range(args.warmup):
         tree.step(vals[i * gb:(i + 1) * gb], env.F.INPUTS_READY)
@@ -800,9 +806,14 @@ def bench_single_list(env):
         th = time.perf_counter()
         tree.step(vals[i * gb:(i + 1) * gb], env.F.INPUTS_READY)
         host_s += time.perf_counter() - th
+        if inj == "die":
+            print(f"[rank {rank}] IMT_BENCH_INJECT: this worker dies now", file=sys.stderr, flush=True)
+            os._exit(17)
     tree.flush()
     env.barrier()
     dt = time.perf_counter() - t0
+    if inj == "corrupt":
+        tree.outputs(R0 + steps_total - 1)["new_sib"][3, 5, 7] ^= 1
     prof = (ctypes.c_double * 12)()
     lib.imt_profile_read(ctx.h, prof)
     lib.imt_profile_enable(ctx.h, 0)
@@ -900,9 +911,9 @@ def assemble_line(env, legs, failed, probes, headline):
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "ranks_seen": env.ranks_seen,
         "collective_backend": env.backend if dist is not None else None, "verified": ok,
-        "value_is": headline + (" (the reference's data structure, bit-exact with one GPU)"
-                                if headline != "subtrees" or dist is None else
-                                " (N sorted lists under one root: needs one more circuit constraint per witness, INTEGRATION.md sec. 4)"),
+        "value_is": ("single tree (the reference's data structure: one sorted list in one depth-32 tree on one GPU)" if dist is None else
+                     headline + (" (the reference's data structure, bit-exact with one GPU)" if headline != "subtrees" else
+                                 " (N sorted lists under one root: needs one more circuit constraint per witness, INTEGRATION.md sec. 4)")),
         "config": {"workload": "depth=32, 2^16 sequential-semantics insertions per step per GPU "
                                "(BASELINE configs[1]); per insertion: old/interim/new depth-32 root + two 32-sibling "
                                "proofs written to HBM; values resident in HBM",

@@ -395,3 +395,36 @@ def test_bench_second_attempt_in_fresh_workers_after_a_hung_collective():
     # the other leg ran once, in the first attempt, and its figure is still on the line
     assert res["modes"]["subtrees"]["verified"] is True and res["modes"]["subtrees"].get("measured_in_attempt") == 0
     assert "failed with -13" in r.stderr and "global tick" in r.stderr
+
+
+@pytest.mark.parametrize("kind", ["die", "corrupt"])
+def test_bench_retries_when_one_rank_of_two_fails(kind):
+    """Two ranks as separate processes on the one GPU, exactly as typed (`python bench.py --gpus 2`: launcher ->
+    torch.distributed.run -> two GPU-free supervisors -> two workers).  In attempt 0 rank 1's worker fails the way a real run
+    can: "die" -- the process is gone after its first timed step, rank 0's worker is left waiting for payloads that never
+    come and is killed by its own supervisor a few seconds after it hears of the peer's exit (not after the transport's
+    60 s); "corrupt" -- one byte of rank 1's last proof is wrong, so the attempt does not verify although every process
+    ends by itself.  Attempt 1 runs in FRESH workers with the plan's next layout (every collective on its round's own
+    stream, one pool) on the same GPU and verifies; the line carries both attempts; exit status 0."""
+    import json
+    import subprocess
+    env = dict(os.environ, IMT_BENCH_DEVICE="0", IMT_BENCH_COLLECTIVE="gloo", IMT_BENCH_NO_TRACE="1", IMT_BENCH_INJECT=f"0:1:{kind}",
+               IMT_BENCH_PEER_GRACE="3", IMT_BENCH_MODE="single-list")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IMT_BENCH_WORKER", "IMT_BENCH_ATTEMPTS", "IMT_BENCH_SLICED_TRANSPORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    at = res["attempts"]
+    assert [a["outcome"] for a in at] == ["failed", "verified"], at
+    assert (at[0]["layout"], at[1]["layout"]) == ("pools", "one-pool") and at[1]["transport"] == "ipc"
+    assert at[1]["comm_streams"] == 0 and at[1]["pools"] == 0 and at[1]["preflight"]["verified"] is True
+    if kind == "die":
+        assert at[0]["exit_status"][1] == 17 and at[0]["exit_status"][0] != 0 and at[0]["seconds"] < 60, at[0]
+        assert "rank 1: exit status 17" in at[0]["why"]
+    else:
+        assert "did not verify" in at[0]["why"], at[0]
+    assert res["value"] > 0 and res["verified"] is True and res["n_gpus"] == 2 and res["ranks_seen"] == 2

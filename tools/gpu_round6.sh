@@ -47,5 +47,7 @@ flag)  # "the gather is complete" as a device-side count
       IMT_SLICED_GATHER_FLAGS=$fl EMU_FILL=$fill EMU_GATHER_WGS=28 timeout -k 10 300 python tools/rank_emulation.py 8 4 2>&1 | grep "^N =" | grep links | cut -c1-110 || exit 1
     done; done; done ) > $O/ab_gather_flags.txt 2>&1
   rc=$?; cat $O/ab_gather_flags.txt; exit $rc ;;
+bench|multi|scale|soak|aux)   # the standing parts: tools/gpu_round4.sh writing into this round's directory
+  ROUND_DIR=$O bash tools/gpu_round4.sh $part ;;
 *) echo "unknown part $part"; exit 2 ;;
 esac
