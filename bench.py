@@ -244,6 +244,30 @@ def supervise(args, worker_cmd=None):
         os.close(keep)
     store = dist.distributed_c10d._get_default_store()
     attempts, kept_subtrees, line, all_ok = [], None, None, False
+    # a worker never outlives its supervisor: killed with it when the launcher ends the job (SIGTERM / SIGINT / SIGHUP to this
+    # process), and by the kernel if this process is killed outright (PR_SET_PDEATHSIG in the child)
+    live = {"child": None}
+
+    def end_with_child(signum, frame):
+        c = live["child"]
+        if c is not None and c.poll() is None:
+            try:
+                os.killpg(c.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        os._exit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, end_with_child)
+
+    try:
+        libc = ctypes.CDLL("libc.so.6", use_errno=True)       # loaded HERE: nothing is dlopen'ed between fork and exec
+    except OSError:
+        libc = None
+    kill_sig = int(signal.SIGKILL)
+
+    def die_with_parent():
+        if libc is not None:
+            libc.prctl(1, kill_sig, 0, 0, 0)                   # PR_SET_PDEATHSIG
     for k, (kind, layout) in enumerate(plan):
         port = [None]
         if rank == 0:
@@ -261,7 +285,8 @@ def supervise(args, worker_cmd=None):
                               "--warmup", str(args.warmup)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
         t0 = time.perf_counter()
         child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, errors="replace",
-                                 start_new_session=True)
+                                 start_new_session=True, preexec_fn=die_with_parent)
+        live["child"] = child
         out_lines, err_tail = [], []
 
         def drain(pipe, keep_lines, relay):
@@ -774,10 +799,8 @@ def bench_single_list(env):
     for i in range(PREFLIGHT_STEPS):
         tree.step(pvals[i * PREFLIGHT_N * world:(i + 1) * PREFLIGHT_N * world], env.F.INPUTS_READY)
     tree.flush()
-    pre_ok = True
-    for i in range(PREFLIGHT_STEPS):
-        pre_ok = pre_ok and slices_verify(env, ctx, tree, i, PREFLIGHT_N, i == PREFLIGHT_STEPS - 1)
-    pre_ok = env.all_true(pre_ok)
+    # (slices_verify holds a collective: every rank calls it for every round, whatever the earlier ones said)
+    pre_ok = env.all_true(all([slices_verify(env, ctx, tree, i, PREFLIGHT_N, i == PREFLIGHT_STEPS - 1) for i in range(PREFLIGHT_STEPS)]))
     env.preflight = {"steps": PREFLIGHT_STEPS, "insertions_per_rank_and_step": PREFLIGHT_N, "verified": pre_ok,
                      "seconds": round(time.perf_counter() - tp0, 2)}
     if not pre_ok:
@@ -823,7 +846,8 @@ def bench_single_list(env):
     # (rank g's first old root = rank g - 1's last new root); every replica holds the same root = the last new root
     ok = slices_verify(env, ctx, tree, R0 + steps_total - 1, BATCH, True)
     if nbuf == steps_total and args.steps >= 3:       # ... and a round from the middle of the timed region
-        ok = ok and slices_verify(env, ctx, tree, R0 + args.warmup + args.steps // 2, BATCH, False)
+        ok_mid = slices_verify(env, ctx, tree, R0 + args.warmup + args.steps // 2, BATCH, False)   # (a collective inside: never skipped)
+        ok = ok and ok_mid
     verified = env.all_true(ok)
     kern, pipe_ms = sweep_lines(prof, args.steps)
     rccl_lib = None

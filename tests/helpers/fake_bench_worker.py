@@ -43,6 +43,10 @@ if scenario == "unverified_then_ok":     # every worker exits 0 but rank 0's lin
     if rank == 0:
         line(None if attempt == 0 else 77.0, why="did not verify" if attempt == 0 else None)
     sys.exit(0)
+if scenario == "orphan":                 # hangs for good and says who it is: the test ends its supervisor and looks for it
+    with open(os.path.join(os.environ["FAKE_LOG_DIR"], f"pid_r{rank}"), "w") as f:
+        f.write(str(os.getpid()))
+    time.sleep(300)
 if scenario == "silent_hang":            # nobody fails, nobody finishes: the per-attempt limit ends it
     if attempt == 0:
         time.sleep(120)

@@ -113,3 +113,45 @@ def test_plan():
             bench.attempts_plan("nccl")
     finally:
         del os.environ["IMT_BENCH_ATTEMPTS"]
+
+
+@pytest.mark.parametrize("sig", ["TERM", "KILL"])
+def test_a_worker_does_not_outlive_its_supervisor(tmp_path, sig):
+    """the launcher ends the job (its time limit, a failed peer): SIGTERM to the supervisor takes the worker's process group
+    with it; a supervisor killed outright (SIGKILL) takes its worker along through PR_SET_PDEATHSIG -- no orphan keeps a GPU"""
+    import signal
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FAKE_SCENARIO="orphan",
+               FAKE_LOG_DIR=str(tmp_path), IMT_BENCH_COLLECTIVE="gloo", IMT_BENCH_FORCE_DIST="1")
+    for k in ("IMT_BENCH_WORKER", "IMT_BENCH_ATTEMPTS", "IMT_BENCH_SLICED_TRANSPORT", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    drv = DRIVER.replace("gpus=2", "gpus=1")
+    sup = subprocess.Popen([sys.executable, "-c", drv], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    pidfile = tmp_path / "pid_r0"
+    for _ in range(600):
+        if pidfile.exists() and pidfile.read_text():
+            break
+        time.sleep(0.1)
+    wpid = int(pidfile.read_text())
+    os.kill(wpid, 0)                                   # the worker lives
+    sup.send_signal(getattr(signal, "SIG" + sig))
+    sup.wait(timeout=30)
+    assert sup.returncode != 0
+    for _ in range(100):
+        try:
+            os.kill(wpid, 0)
+        except ProcessLookupError:
+            break
+        # (a zombie re-parented to init still answers kill 0 until it is reaped: look at its state)
+        try:
+            if open(f"/proc/{wpid}/stat").read().split()[2] == "Z":
+                break
+        except FileNotFoundError:
+            break
+        time.sleep(0.1)
+    else:
+        os.kill(wpid, signal.SIGKILL)
+        raise AssertionError("the worker outlived its supervisor")
