@@ -194,13 +194,24 @@ def test_config4_single_list_eight_slices_2pow22(imt, ctx):
     2^16 per step (8 replicas on this one GPU), 8 steps.  Size-independent properties at full size: every insertion's
     witnesses pass every insert_leaf constraint at depth 32 with global leaf indices (imt_insert_witness_batch), the
     roots chain insertion to insertion, slice to slice and step to step, all replicas end in the same root, and that
-    root is the one-GPU tree's over the same 2^22 values."""
+    root is the one-GPU tree's over the same 2^22 values.
+
+    And, item by item at full size: every interim / new root, low index and flag of all 2^22 insertions
+    equals the sequential CPU oracle's, through the committed per-step digests of its run
+    (tests/golden/config4_oracle_digest.json, make_config4_digest.py: update_idx_leaf + rebuild,
+    /root/reference/src/indexed_merkle_tree.rs:632-671, :715-735, about three core-hours)."""
+    import hashlib
+    import json
     import bench
     sl = load_sliced()
     depth, world, batch, rounds = 32, 8, 1 << 16, 8
     cap = 1 << 23
     gb = world * batch
-    vals = torch.from_numpy(bench.synth_values(gb * rounds, 0, 1, 0x494D5404)).cuda()
+    vals_h = bench.synth_values(gb * rounds, 0, 1, 0x494D5404)
+    dg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config4_oracle_digest.json")))
+    assert dg["n"] == gb * rounds and dg["steps"] == rounds and dg["depth"] == depth
+    assert hashlib.sha256(vals_h.tobytes()).hexdigest() == dg["sha256_values"], "the value generator changed: regenerate the digest"
+    vals = torch.from_numpy(vals_h).cuda()
     t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world)
     F, lib = imt._ffi, imt.lib
     P_ = lambda x: ctypes.c_void_p(x.data_ptr())
@@ -210,6 +221,16 @@ def test_config4_single_list_eight_slices_2pow22(imt, ctx):
 
     def check(r):
         nonlocal prev_last
+        # the oracle's digests of this step: the 8 slices in insertion order
+        want = dg["per_step"][r]
+        for field, key, cast in (("interim_root", "sha256_interim_roots", None), ("new_root", "sha256_new_roots", None),
+                                 ("low_index", "sha256_low_index", "<u8"), ("is_largest", "sha256_is_largest", None)):
+            h = hashlib.sha256()
+            for k in range(world):
+                a = t.outputs(r, k)[field].cpu().numpy()
+                h.update((a.astype(cast) if cast else a).tobytes())
+            assert h.hexdigest() == want[key], (r, field)
+        assert imt.to_int(t.outputs(r, world - 1)["new_root"][-1].cpu().numpy()) == int(want["root_after"]), r
         for k in range(world):
             o = t.outputs(r, k)
             first = o["first_insertion"]
@@ -239,7 +260,10 @@ def test_config4_single_list_eight_slices_2pow22(imt, ctx):
         checked += 1
     roots = {tr.root() for tr in t.trees}
     assert len(roots) == 1 and imt.to_int(prev_last.cpu().numpy()) in roots
+    assert roots == {int(dg["final_root"])}
     assert all(tr.size == 1 + gb * rounds for tr in t.trees)
+    for i, hx in dg["sha256_final_proofs"].items():
+        assert hashlib.sha256(t.trees[0].get_proof_batch([int(i)], item_major=True).tobytes()).hexdigest() == hx, i
     t.close()
     ref = imt.IndexedTree(ctx, depth, cap)
     for r in range(rounds):
