@@ -218,8 +218,8 @@ def is_supervisor(args):
 
 
 def supervise(args, worker_cmd=None):
-    """One rank's supervisor (see above).  Returns the process's exit status.  Never calls into HIP: `import torch` and a
-    gloo process group over the launcher's rendezvous are all it uses.  worker_cmd: the worker's command line (default:
+    """One rank's supervisor (see above).  Returns the process's exit status.  Never calls into HIP: `import torch` and the
+    launcher's rendezvous store (plain TCP key / value) are all it uses.  worker_cmd: the worker's command line (default:
     this file with the same arguments; tests/test_bench_supervisor.py passes a stand-in to exercise the retry logic
     without a GPU)."""
     import datetime
@@ -234,15 +234,21 @@ def supervise(args, worker_cmd=None):
     backend = os.environ.get("IMT_BENCH_COLLECTIVE", "nccl")
     plan = attempts_plan(backend)
     limit = float(os.environ.get("IMT_BENCH_ATTEMPT_TIMEOUT", "600"))
-    sys.stdout.flush()
-    keep = os.dup(1)                 # gloo announces its connections on stdout, which belongs to the ONE JSON line
-    os.dup2(2, 1)
-    try:
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=limit + 300))
-    finally:
-        os.dup2(keep, 1)
-        os.close(keep)
-    store = dist.distributed_c10d._get_default_store()
+    # The supervisors talk through the launcher's rendezvous STORE and nothing else (set / get / check of keys over TCP to
+    # MASTER_ADDR:MASTER_PORT -- under torch.distributed.run the agent's store, otherwise one rank 0 hosts): no process
+    # group, no gloo devices, no hostname to resolve.  Waiting for a key blocks until it is set (store timeout).
+    base, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=limit + 300)))
+    store = dist.PrefixStore("imt_bench_supervisors", base)
+    store.set_timeout(datetime.timedelta(seconds=limit + 300))
+
+    def share(key, obj=None, src=None):
+        """obj from rank `src` to everyone (src given) or everyone's obj to everyone (a list in rank order)"""
+        if src is not None:
+            if rank == src:
+                store.set(key, json.dumps(obj))
+            return json.loads(store.get(key))
+        store.set(f"{key}/{rank}", json.dumps(obj))
+        return [json.loads(store.get(f"{key}/{r}")) for r in range(world)]
     attempts, kept_subtrees, line, all_ok = [], None, None, False
     # a worker never outlives its supervisor: killed with it when the launcher ends the job (SIGTERM / SIGINT / SIGHUP to this
     # process), and by the kernel if this process is killed outright (PR_SET_PDEATHSIG in the child)
@@ -269,13 +275,13 @@ def supervise(args, worker_cmd=None):
         if libc is not None:
             libc.prctl(1, kill_sig, 0, 0, 0)                   # PR_SET_PDEATHSIG
     for k, (kind, layout) in enumerate(plan):
-        port = [None]
+        port = None
         if rank == 0:
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
-                port[0] = sk.getsockname()[1]
-        dist.broadcast_object_list(port, src=0)
-        env = dict(os.environ, IMT_BENCH_WORKER="1", IMT_BENCH_ATTEMPT=str(k), MASTER_PORT=str(port[0]),
+                port = sk.getsockname()[1]
+        port = share(f"attempt{k}/port", port, src=0)
+        env = dict(os.environ, IMT_BENCH_WORKER="1", IMT_BENCH_ATTEMPT=str(k), MASTER_PORT=str(port),
                    IMT_BENCH_SLICED_TRANSPORT=kind, IMT_BENCH_LAYOUT=layout)
         for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
             env.pop(v, None)         # the workers rendezvous on a port of their own: rank 0's worker hosts the store
@@ -301,7 +307,7 @@ def supervise(args, worker_cmd=None):
         for t in th:
             t.start()
         how, peer_failed_at = None, None
-        key = f"imt_bench/attempt{k}/failed"
+        key = f"attempt{k}/failed"
         while child.poll() is None:
             time.sleep(0.25)
             now = time.perf_counter()
@@ -330,16 +336,16 @@ def supervise(args, worker_cmd=None):
                 except ValueError:
                     pass
         mine_ok = rc == 0 and (rank != 0 or (got is not None and got.get("value") is not None and got.get("verified") is True))
-        seen = [None] * world
-        dist.all_gather_object(seen, {"rank": rank, "rc": rc, "ok": bool(mine_ok), "how": how,
-                                      "tail": None if mine_ok else "".join(err_tail)[-1500:]})
+        sub_ok = bool(rank == 0 and got is not None and ((got.get("modes") or {}).get("subtrees") or {}).get("verified"))
+        seen = share(f"attempt{k}/outcome", {"rank": rank, "rc": rc, "ok": bool(mine_ok), "how": how, "subtrees_verified": sub_ok,
+                                             "tail": None if mine_ok else "".join(err_tail)[-1500:]})
         all_ok = all(x["ok"] for x in seen)
         if rank == 0:
             if got is not None:
                 line = got
                 sub = (got.get("modes") or {}).get("subtrees")
                 if sub and sub.get("verified") and kept_subtrees is None:
-                    kept_subtrees = sub
+                    kept_subtrees = dict(sub, measured_in_attempt=k)
             bad = [x for x in seen if not x["ok"]]
             why = None
             if not all_ok:
@@ -353,9 +359,7 @@ def supervise(args, worker_cmd=None):
                              "preflight": (got or {}).get("preflight"),
                              # what the first worker that ended BY ITSELF said last (one killed for its peer's sake knows less)
                              "dump_tail": None if all_ok or not bad else sorted(bad, key=lambda x: x["how"] is not None)[0]["tail"]})
-        flag = [kept_subtrees is not None]
-        dist.broadcast_object_list(flag, src=0)
-        if flag[0] and kept_subtrees is None:
+        if seen[0]["subtrees_verified"] and kept_subtrees is None:
             kept_subtrees = {}       # every supervisor sets the same IMT_BENCH_MODE for the next attempt
         if all_ok:
             break
@@ -367,11 +371,15 @@ def supervise(args, worker_cmd=None):
             line["value"], line["verified"], line["ms_per_step"] = None, False, None
             line.setdefault("value_failed", attempts[-1]["why"] if attempts else "no attempt")
         if kept_subtrees and "subtrees" not in line.setdefault("modes", {}):
-            line["modes"]["subtrees"] = dict(kept_subtrees, measured_in_attempt=0)
+            line["modes"]["subtrees"] = kept_subtrees
         line["attempts"] = attempts
         print(json.dumps(line), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+    share("done", True)              # nobody leaves before everybody has read what it needs ...
+    if rank != 0:                    # ... and rank 0 (which hosts the store when no launcher does) leaves last
+        store.set(f"bye/{rank}", b"1")
+    else:
+        for r in range(1, world):
+            store.get(f"bye/{r}")
     return 0 if all_ok else 1
 
 

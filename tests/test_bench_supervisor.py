@@ -1,5 +1,5 @@
 """bench.py's supervisor (the GPU-free process every launched rank is): the retry logic over attempts
-in FRESH worker processes, exercised without a GPU -- two supervisors over gloo, the worker replaced by
+in FRESH worker processes, exercised without a GPU -- two supervisors over a rendezvous store, the worker replaced by
 tests/helpers/fake_bench_worker.py.  What must hold: `value` comes from the first attempt in which EVERY rank's worker
 succeeded and rank 0's line verified; a worker that hangs because its peer died is killed by its own supervisor (exact
 process group); the line carries `attempts`; the exit status is non-zero on every rank unless an attempt verified."""
