@@ -204,3 +204,47 @@ def test_insert_trace_depth32_golden(oracle):
             assert roots == [prev_root, r["interim_root"], r["interim_root"], r["new_root"]]
         prev_root = r["new_root"]
     oracle.sparse_free(h)
+
+
+def test_rebuild_from_preimages_equals_the_sequential_state(oracle):
+    """orc_sparse_load = the reference's rebuild after every insertion (hash_nullifier_pre_images
+    src/indexed_merkle_tree.rs:662-671 + IndexedMerkleTree::new src/utils.rs:38-51) on a sparse depth-32 tree: loaded with
+    the list after k sequential insertions (written down independently, by sorting) it has the sequential run's root, and
+    goes on exactly like it.  This is what lets tests/golden/make_config4_digest.py cut the 2^22-insertion oracle run into
+    segments; a list that is not one sorted chain from the sentinel is refused."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_config4_digest import preimages_after
+    n, depth = 400, 32
+    vals = ints_to_arr(oracle_lib.synth_values(n, 0x494D5404))
+    ints = oracle_lib.arr_ints(vals)
+    h = oracle.sparse_new(depth, 1024)
+    rows = [oracle.sparse_insert(h, depth, v) for v in ints]
+    assert all(r["rc"] == 0 for r in rows)
+    for k in (0, 1, 2, 3, 127, 128, 129, 333):
+        g = oracle.sparse_new(depth, 1024)
+        pre = preimages_after(vals, k)
+        assert oracle.sparse_load(g, pre) == 0
+        if k:
+            assert oracle.sparse_root(g) == rows[k - 1]["new_root"], k
+        for i in range(k, min(k + 40, n)):
+            o = oracle.sparse_insert(g, depth, ints[i])
+            assert (o["rc"], o["low"], o["largest"], o["interim_root"], o["new_root"]) == \
+                (0, rows[i]["low"], rows[i]["largest"], rows[i]["interim_root"], rows[i]["new_root"]), (k, i)
+            assert (o["low_proof"] == rows[i]["low_proof"]).all() and (o["new_proof"] == rows[i]["new_proof"]).all()
+        assert oracle.sparse_load(g, pre) != 0              # only into a fresh tree
+        oracle.sparse_free(g)
+    for breakage in ("pointer", "value", "sentinel", "duplicate"):
+        pre = preimages_after(vals, 10).copy()
+        if breakage == "pointer":
+            pre[3, 2, 0] ^= 1
+        elif breakage == "value":
+            pre[4, 1, 5] ^= 1
+        elif breakage == "sentinel":
+            pre[0, 0, 0] = 1
+        else:
+            pre[7, 0] = pre[6, 0]
+        g = oracle.sparse_new(depth, 1024)
+        assert oracle.sparse_load(g, pre) == -10, breakage
+        oracle.sparse_free(g)
+    oracle.sparse_free(h)
