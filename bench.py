@@ -188,7 +188,7 @@ def launch_ranks(args):
 ATTEMPT_LAYOUTS = ("pools", "one-pool")
 
 
-def attempts_plan(backend):
+def attempts_plan(backend, world=2):
     """[(transport, layout)] in the order tried.  layout "pools" = the library's default for one process per GPU (round
     streams HIGH, collectives LOW: IMT_SLICED_OPT_POOLS 1); "one-pool" = everything in the normal pool with every
     collective ON ITS ROUND'S OWN STREAM (IMT_SLICED_OPT_POOLS 0, COMM_STREAMS 0): no wait ever crosses a hardware queue
@@ -206,6 +206,8 @@ def attempts_plan(backend):
         return plan
     if os.environ.get("IMT_BENCH_SLICED_TRANSPORT"):
         return [(os.environ["IMT_BENCH_SLICED_TRANSPORT"], os.environ.get("IMT_BENCH_LAYOUT", "pools"))]
+    if world == 1:                   # IMT_BENCH_FORCE_DIST on one rank: the IPC transport joins processes, there are none
+        return [("rccl", "pools"), ("local", "pools")] if backend == "nccl" else [("local", "pools")]
     if backend == "nccl":
         return [("rccl", "pools"), ("ipc", "pools"), ("rccl", "one-pool"), ("ipc", "one-pool")]
     return [("ipc", "pools"), ("ipc", "one-pool")]
@@ -232,7 +234,7 @@ def supervise(args, worker_cmd=None):
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     backend = os.environ.get("IMT_BENCH_COLLECTIVE", "nccl")
-    plan = attempts_plan(backend)
+    plan = attempts_plan(backend, world)
     limit = float(os.environ.get("IMT_BENCH_ATTEMPT_TIMEOUT", "600"))
     # The supervisors talk through the launcher's rendezvous STORE and nothing else (set / get / check of keys over TCP to
     # MASTER_ADDR:MASTER_PORT -- under torch.distributed.run the agent's store, otherwise one rank 0 hosts): no process

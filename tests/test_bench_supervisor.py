@@ -105,6 +105,7 @@ def test_plan():
         os.environ.pop(k, None)
     assert bench.attempts_plan("nccl") == [("rccl", "pools"), ("ipc", "pools"), ("rccl", "one-pool"), ("ipc", "one-pool")]
     assert bench.attempts_plan("gloo") == [("ipc", "pools"), ("ipc", "one-pool")]
+    assert bench.attempts_plan("nccl", 1) == [("rccl", "pools"), ("local", "pools")] and bench.attempts_plan("gloo", 1) == [("local", "pools")]
     os.environ["IMT_BENCH_ATTEMPTS"] = "stall,local:one-pool"
     try:
         assert bench.attempts_plan("nccl") == [("stall", "pools"), ("local", "one-pool")]

@@ -1093,3 +1093,77 @@ def test_subtree_gather_reports_a_peer_that_never_comes(imt):
     assert rc == 0 and pe == F.ERR["INTERNAL"] and col == [10, 0] and dt < 10.0 and "did not arrive" in msg, got[0]
     rc, col, pe = got[0]["third"]
     assert rc == F.ERR["INTERNAL"] and pe == F.ERR["INTERNAL"] and col == [0, 0], got[0]
+
+
+def _hung_ipc_worker(rank, world, port, q):
+    """GPU-polled IPC world of two; rank 1 stops after two steps.  Rank 0's wait kernels would poll for 8 s (the transport's
+    limit) but its watchdog is at 500 ms: IMT_ERR_TIMEOUT, then the documented way out -- destroy world and transport while
+    the wait kernel is STILL polling -- must come back at once, with the name in /dev/shm gone."""
+    import glob
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import imt_amd
+    F, lib = imt_amd._ffi, imt_amd.lib
+    sl = load_sliced()
+    boot = imt_amd.Context(0)
+    nb = int(lib.imt_transport_ipc_blob_bytes())
+    mine = torch.zeros(nb, dtype=torch.uint8)
+    tp = ctypes.c_void_p()
+    assert lib.imt_transport_ipc_create(boot.h, world, rank, P_DEPTH, P_BATCH, 0, ctypes.byref(tp), ctypes.c_void_p(mine.data_ptr())) == 0
+    assert lib.imt_transport_set_option(tp, F.TRANSPORT_OPT_HOST_POLL, 0) == 0
+    assert lib.imt_transport_set_option(tp, F.TRANSPORT_OPT_TIMEOUT_MS, 8000) == 0
+    allb = torch.zeros(world * nb, dtype=torch.uint8)
+    dist.all_gather_into_tensor(allb, mine)
+    assert lib.imt_transport_ipc_connect(tp, ctypes.c_void_p(allb.data_ptr())) == 0
+    tree = sl.SlicedTree(imt_amd, 0, P_DEPTH, 1 << 14, P_BATCH, world, first_rank=rank, n_local=1, transport=tp)
+    tree.set_option(F.SLICED_OPT_WATCHDOG_MS, 500)
+    vals = oracle_lib.synth_values(world * P_BATCH * 14, 0x494D5473)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    gb = world * P_BATCH
+    out = dict(rank=rank, code=None)
+    shm_before = glob.glob(f"/dev/shm/imt_ipc_{os.getpid()}_*")
+    try:
+        for r in range(14):
+            if rank == 1 and r == 2:
+                break
+            tree.step(arr[r * gb:(r + 1) * gb])
+        if rank == 0:
+            tree.flush()
+    except imt_amd.ImtError as e:
+        out["code"] = e.code
+        t0 = time.perf_counter()
+        lib.imt_sliced_destroy(tree.h)
+        tree.h = None
+        out["destroy_rc"] = lib.imt_transport_destroy(tp)
+        out["destroy_s"] = time.perf_counter() - t0
+        out["shm_before"], out["shm_after"] = len(shm_before), len(glob.glob(f"/dev/shm/imt_ipc_{os.getpid()}_*"))
+    q.put(out)
+    dist.barrier()
+    os._exit(0)                 # what a real host does next: report and exit, recovery in a fresh process
+
+
+def test_a_hung_ipc_world_can_be_left_behind(imt):
+    """ADVICE r5 (medium), the IPC transport's side of it: after IMT_ERR_TIMEOUT, imt_sliced_destroy + imt_transport_destroy
+    return while a wait kernel is still polling for the vanished peer (no hipFree, no stream sync: the device side is
+    leaked, the host side -- worker thread, the name in /dev/shm -- is cleaned up)."""
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [mpctx.Process(target=_hung_ipc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {o["rank"]: o for o in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    F = imt._ffi
+    r0 = got[0]
+    assert r0["code"] == F.ERR["TIMEOUT"], r0
+    assert r0["destroy_rc"] == 0 and r0["destroy_s"] < 3.0, r0
+    assert r0["shm_before"] == 1 and r0["shm_after"] == 0, r0
+    assert got[1]["code"] is None
