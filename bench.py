@@ -365,6 +365,45 @@ def supervise(args, worker_cmd=None):
             kept_subtrees = {}       # every supervisor sets the same IMT_BENCH_MODE for the next attempt
         if all_ok:
             break
+    # No attempt of the headline leg verified and the OTHER leg was never reached (a worker runs it second): measure it now, in
+    # fresh workers of its own, so that the line still says what the machine does in that layout -- under `modes`, as ever,
+    # never as `value`.  One rendezvous, the worker's own time limit, no retry.
+    if not all_ok and kept_subtrees is None and os.environ.get("IMT_BENCH_MODE", "both") == "both":
+        k = len(plan)
+        port = None
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+        port = share(f"attempt{k}/port", port, src=0)
+        env = dict(os.environ, IMT_BENCH_WORKER="1", IMT_BENCH_ATTEMPT=str(k), MASTER_PORT=str(port), IMT_BENCH_MODE="subtrees")
+        for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+                  "IMT_BENCH_SLICED_TRANSPORT", "IMT_BENCH_INJECT"):
+            env.pop(v, None)
+        cmd = worker_cmd or ([sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
+                              "--warmup", str(args.warmup), "--no-cpu-baseline"])
+        sub_limit = float(os.environ.get("IMT_BENCH_SUBTREES_TIMEOUT", "180")) + 120
+        try:
+            child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, errors="replace",
+                                     start_new_session=True, preexec_fn=die_with_parent)
+            live["child"] = child
+            try:
+                out, _ = child.communicate(timeout=sub_limit)
+            except subprocess.TimeoutExpired:
+                os.killpg(child.pid, signal.SIGKILL)
+                out, _ = child.communicate()
+            if rank == 0:
+                for ln in out.splitlines():
+                    if ln.startswith("{"):
+                        try:
+                            sub = (json.loads(ln).get("modes") or {}).get("subtrees")
+                            if sub and "value" in sub:
+                                kept_subtrees = dict(sub, measured_in_attempt="after the last (its own workers)")
+                        except ValueError:
+                            pass
+        except OSError as e:
+            print(f"[supervisor {rank}] the subtree-only run could not start: {e!r}", file=sys.stderr, flush=True)
+        share(f"attempt{k}/over", True)
     if rank == 0:
         if line is None:
             line = {"metric": METRIC, "value": None, "unit": "insertions/s", "n_gpus": world, "steps": args.steps,
@@ -913,15 +952,19 @@ def headline_mode(dist, mode):
     return "single-list" if mode in ("both", "single-list") else "subtrees"
 
 
-def assemble_line(env, legs, failed, probes, headline):
-    """rank 0's JSON line.  `headline` names the leg `value` belongs to; if that leg did not finish (`failed` says why)
-    or did not verify, `value` is null, `verified` false and the process exits non-zero -- another mode's figure never
-    stands in for it (it stays under `modes`)."""
+def assemble_line(env, legs, errors, probes, headline):
+    """rank 0's JSON line.  `headline` names the leg `value` belongs to; if that leg did not finish (`errors[headline]` says
+    why) or did not verify, `value` is null, `verified` false and the process exits non-zero -- another mode's figure never
+    stands in for it (it stays under `modes`).  The OTHER leg cannot take the headline down either: if it hangs, fails or
+    does not verify, `modes.<leg>` says so (`error` / `verified`), `all_modes_verified` is false, and `value`, `verified`
+    and the exit status stay the headline leg's."""
     args, world, dist = env.args, env.world, env.dist
+    errors = errors or {}
+    failed = errors.get(headline)
     mad_peak, copy_gbps, trace_line = probes
     head = legs.get(headline)
     head_ok = head is not None and bool(head["verified"])
-    ok = head_ok and all(r["verified"] for r in legs.values())
+    ok = head_ok
     shown = head if head is not None else next(iter(legs.values()))      # for the static parts of the line only
     if head is not None:
         roof, valu = roofline_objects(head["ms_per_step"], head["alone_ms"], head["pipe_ms"], copy_gbps, mad_peak,
@@ -945,6 +988,7 @@ def assemble_line(env, legs, failed, probes, headline):
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "ranks_seen": env.ranks_seen,
         "collective_backend": env.backend if dist is not None else None, "verified": ok,
+        "all_modes_verified": ok and not errors and all(r["verified"] for r in legs.values()),
         "value_is": ("single tree (the reference's data structure: one sorted list in one depth-32 tree on one GPU)" if dist is None else
                      headline + (" (the reference's data structure, bit-exact with one GPU)" if headline != "subtrees" else
                                  " (N sorted lists under one root: needs one more circuit constraint per witness, INTEGRATION.md sec. 4)")),
@@ -974,8 +1018,8 @@ def assemble_line(env, legs, failed, probes, headline):
         res["host_prepare_ms_per_step"] = single["host_prepare_ms_per_step"]
     if dist is not None:
         res["modes"] = {name.replace("-", "_"): mode_summary(r, world) for name, r in legs.items()}
-        if failed:
-            res["modes"]["single_list"] = {"error": failed}
+        for name, why in errors.items():
+            res["modes"][name.replace("-", "_")] = {"error": why}
         if head is not None:
             res["collectives_per_step"] = head["collectives_per_step"]
             res["bytes_gathered_per_step_per_rank"] = head["bytes_gathered_per_step_per_rank"]
@@ -1007,21 +1051,20 @@ def main():
     # N > 1: "both" (default; `value` = single-list), or one of "single-list" / "subtrees" alone
     mode = os.environ.get("IMT_BENCH_MODE", "both" if dist is not None else "subtrees")
     headline = headline_mode(dist, mode)
-    legs, failed = {}, None
-    if mode in ("both", "subtrees") or dist is None:
-        legs["subtrees"] = bench_subtrees(env)
-    if dist is not None and mode in ("both", "single-list"):
-        watchdog = None
-        if "subtrees" in legs:      # free the first leg's tree and buffers; keep its context for the probes
-            legs["subtrees"]["be"].tree.close()
-            legs["subtrees"]["be"].sets = legs["subtrees"]["be"].structs = None
-            torch.cuda.empty_cache()
-        # A leg whose collectives hang must not hang the job: after the time limit every rank leaves with status 1; rank
-        # 0 first prints the line -- `value` null, the reason, the other leg's figures under `modes` only (no device
-        # probes: the device may be the thing that hangs).
-        import threading
-        limit = float(os.environ.get("IMT_BENCH_SINGLE_LIST_TIMEOUT", "240"))
+    legs, errors = {}, {}
+    import threading
 
+    def fallback_line(why):
+        return {"metric": METRIC, "value": None, "unit": "insertions/s", "n_gpus": env.world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": None, "verified": False, "value_failed": why, "value_is": headline,
+                "modes": {"single_list": {"error": why}}}
+    # N > 1: the HEADLINE leg (the single list) runs first, in a process that has done nothing else, its preflight in front:
+    # a hang costs seconds and the supervisors move on to the next attempt.  The subtree leg follows under a time limit of
+    # its own and cannot take the headline with it.
+    if dist is not None and mode in ("both", "single-list"):
+        # A leg whose collectives hang must not hang the job: after the time limit every rank leaves with status 1; rank
+        # 0 first prints the line -- `value` null and the reason (no device probes: the device may be the thing that hangs).
+        limit = float(os.environ.get("IMT_BENCH_SINGLE_LIST_TIMEOUT", "240"))
         pre_limit = min(limit, float(os.environ.get("IMT_BENCH_PREFLIGHT_TIMEOUT", "120")))
 
         def give_up(why):
@@ -1034,9 +1077,9 @@ def main():
             else:
                 print(f"[rank {rank}] {why}; no world exists yet (transport creation / imt_sliced_create)", file=sys.stderr, flush=True)
             if rank == 0:
-                res, _ = assemble_line(env, legs, why, (None, None, None), headline) if legs else \
-                    ({"metric": METRIC, "value": None, "verified": False, "value_failed": why, "n_gpus": env.world,
-                      "value_is": headline, "modes": {"single_list": {"error": why}}}, False)
+                res = fallback_line(why)
+                if getattr(env, "preflight", None) is not None:
+                    res["preflight"] = env.preflight
                 print(json.dumps(res), flush=True)
             os._exit(1)
         watchdog = threading.Timer(limit, give_up, args=(f"the single-list leg did not finish within {limit:.0f} s",))
@@ -1053,25 +1096,55 @@ def main():
         except Exception as e:      # the line says what happened; the status says it failed
             import traceback
             print(f"[rank {rank}] the single-list leg failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
-            failed = f"{type(e).__name__}: {e}"
+            errors["single-list"] = f"{type(e).__name__}: {e}"
         watchdog.cancel()
         env.preflight_timer.cancel()
+        if "single-list" in errors:
+            if rank == 0:
+                res = fallback_line(errors["single-list"])
+                if getattr(env, "preflight", None) is not None:
+                    res["preflight"] = env.preflight
+                print(json.dumps(res), flush=True)
+            os._exit(1)             # a process group that has failed is not torn down gracefully; the other leg is not attempted here
+    if mode in ("both", "subtrees") or dist is None:
+        sub_timer = None
+        if dist is not None and "single-list" in legs:
+            sub_limit = float(os.environ.get("IMT_BENCH_SUBTREES_TIMEOUT", "180"))
+
+            def sub_give_up():
+                why = f"the subtree leg did not finish within {sub_limit:.0f} s"
+                print(f"[rank {rank}] {why}", file=sys.stderr, flush=True)
+                head_ok = bool(legs["single-list"]["verified"])
+                if rank == 0:
+                    res, _ = assemble_line(env, legs, {"subtrees": why}, (None, None, None), headline)
+                    if getattr(env, "preflight", None) is not None:
+                        res["preflight"] = env.preflight
+                    print(json.dumps(res), flush=True)
+                os._exit(0 if head_ok else 1)      # the headline has been measured: its verdict is the status
+            sub_timer = threading.Timer(sub_limit, sub_give_up)
+            sub_timer.daemon = True
+            sub_timer.start()
+        try:
+            legs["subtrees"] = bench_subtrees(env)
+        except Exception as e:
+            if "single-list" not in legs:
+                raise
+            import traceback
+            print(f"[rank {rank}] the subtree leg failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+            errors["subtrees"] = f"{type(e).__name__}: {e}"
+        if sub_timer is not None:
+            sub_timer.cancel()
     ok = True
     if rank == 0:
-        if legs:
-            probe_leg = legs.get(headline) or next(iter(legs.values()))
-            # no device probes after a failed leg: the device may be the thing that hangs
-            probes = device_probes(env, probe_leg["ctx"]) if failed is None else (None, None, None)
-            res, ok = assemble_line(env, legs, failed, probes, headline)
-        else:
-            res, ok = {"metric": METRIC, "value": None, "unit": "insertions/s", "n_gpus": env.world, "steps": args.steps,
-                       "warmup": args.warmup, "ms_per_step": None, "verified": False, "value_failed": failed,
-                       "value_is": headline, "modes": {"single_list": {"error": failed}}}, False
+        probe_leg = legs.get(headline) or next(iter(legs.values()))
+        # no device probes after a failed leg: the device may be the thing that hangs
+        probes = device_probes(env, probe_leg["ctx"]) if not errors else (None, None, None)
+        res, ok = assemble_line(env, legs, errors, probes, headline)
         if getattr(env, "preflight", None) is not None:
             res["preflight"] = env.preflight
         print(json.dumps(res), flush=True)
-    if failed is not None:
-        os._exit(1)                 # a process group that has failed is not torn down gracefully
+    if errors:                      # (the subtree leg raised: the headline's verdict is the status; no graceful teardown)
+        os._exit(0 if legs.get(headline) is not None and legs[headline]["verified"] else 1)
     ok = env.all_true(ok)
     if dist is not None:
         dist.barrier()              # nobody closes the buffers it exports while a peer may still read them

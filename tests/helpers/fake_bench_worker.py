@@ -6,7 +6,7 @@ import sys
 import time
 
 rank, attempt = int(os.environ["RANK"]), int(os.environ["IMT_BENCH_ATTEMPT"])
-kind, layout = os.environ["IMT_BENCH_SLICED_TRANSPORT"], os.environ["IMT_BENCH_LAYOUT"]
+kind, layout = os.environ.get("IMT_BENCH_SLICED_TRANSPORT", "-"), os.environ.get("IMT_BENCH_LAYOUT", "-")
 scenario = os.environ["FAKE_SCENARIO"]
 with open(os.path.join(os.environ["FAKE_LOG_DIR"], f"worker_a{attempt}_r{rank}.json"), "w") as f:
     json.dump({k: os.environ.get(k) for k in ("IMT_BENCH_WORKER", "MASTER_PORT", "TORCHELASTIC_USE_AGENT_STORE", "IMT_BENCH_MODE",
@@ -20,6 +20,7 @@ def line(value, why=None, subtrees=True):
          "modes": {"single_list": {"schedule": {"transport": kind, "pools": 1 if layout == "pools" else 0, "comm_streams": 4}}}}
     if why:
         d["value_failed"] = why
+    # (a real worker runs the single list FIRST: its line carries the subtree leg only when the headline leg did not fail)
     if subtrees and os.environ.get("IMT_BENCH_MODE") != "single-list":
         d["modes"]["subtrees"] = SUB
     print(json.dumps(d), flush=True)
@@ -35,8 +36,12 @@ if scenario == "second_attempt":
         line(123.0)
     sys.exit(0)
 if scenario == "all_fail":
+    if os.environ.get("IMT_BENCH_MODE") == "subtrees":          # the supervisors' last run: the other leg alone, in workers of its own
+        if rank == 0:
+            line(5.0e6)
+        sys.exit(0)
     if rank == 0:
-        line(None, why=f"ImtError: -13 in attempt {attempt}")
+        line(None, why=f"ImtError: -13 in attempt {attempt}", subtrees=False)
     print(f"rank {rank}: world state (fake)", file=sys.stderr, flush=True)
     sys.exit(1)
 if scenario == "unverified_then_ok":     # every worker exits 0 but rank 0's line carries no value: still a failed attempt

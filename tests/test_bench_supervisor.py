@@ -71,10 +71,13 @@ def test_every_attempt_fails(tmp_path):
     assert [a["asked_for"] + ":" + a["layout"] for a in res["attempts"]] == ["ipc:pools", "ipc:one-pool"]      # the gloo rehearsal's plan
     assert all(a["outcome"] == "failed" and "-13" in a["why"] and "world state" in a["dump_tail"] for a in res["attempts"])
     assert "-13 in attempt 1" in res["value_failed"]
-    # the other leg was measured and verified in attempt 0: not run again, and its figure stays under `modes` only
+    # the other leg was never reached (a worker runs the headline leg first and leaves when it fails): the supervisors
+    # measure it at the end in workers of its own, and its figure goes under `modes` only
     assert json.load(open(tmp_path / "worker_a0_r1.json"))["IMT_BENCH_MODE"] is None
-    assert json.load(open(tmp_path / "worker_a1_r1.json"))["IMT_BENCH_MODE"] == "single-list"
-    assert res["modes"]["subtrees"]["value"] == 5.0e6
+    assert json.load(open(tmp_path / "worker_a1_r1.json"))["IMT_BENCH_MODE"] is None
+    assert json.load(open(tmp_path / "worker_a2_r1.json"))["IMT_BENCH_MODE"] == "subtrees"
+    assert res["modes"]["subtrees"]["value"] == 5.0e6 and "its own workers" in res["modes"]["subtrees"]["measured_in_attempt"]
+    assert len(res["attempts"]) == 2
 
 
 def test_an_unverified_line_is_a_failed_attempt_and_an_explicit_transport_is_one_attempt(tmp_path):

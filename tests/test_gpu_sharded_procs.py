@@ -278,9 +278,10 @@ def test_bench_gpus4_as_typed_rehearsal():
 
 def test_bench_keeps_the_first_leg_if_the_second_hangs():
     """A hung headline (single-list) leg must not look like a pass, and another mode's figure must never stand in for
-    it.  A time limit far below what the leg needs stands in for the hang: every rank leaves with a non-zero status,
-    rank 0 first prints the line with `value` null, `verified` false and the reason; the subtree leg's measurement
-    survives under `modes.subtrees` only."""
+    it.  A time limit far below what the leg needs stands in for the hang, in every attempt of the plan: every rank leaves
+    with a non-zero status, rank 0 first prints the line with `value` null, `verified` false and the reason; the subtree
+    leg -- which a worker runs BEHIND the headline leg since round 6 and therefore never reached -- is measured at the end
+    in workers of its own and appears under `modes.subtrees` only."""
     import json
     import subprocess
     env = dict(os.environ, IMT_BENCH_DEVICE="0", IMT_BENCH_COLLECTIVE="gloo", IMT_BENCH_NO_TRACE="1",
@@ -392,8 +393,8 @@ def test_bench_second_attempt_in_fresh_workers_after_a_hung_collective():
     assert at[0]["preflight"] is None and at[1]["preflight"]["verified"] is True and at[1]["transport"] == "local"
     assert res["value"] > 0 and res["verified"] is True and res["value"] == res["modes"]["single_list"]["value"]
     assert res["value_is"].startswith("single-list")
-    # the other leg ran once, in the first attempt, and its figure is still on the line
-    assert res["modes"]["subtrees"]["verified"] is True and res["modes"]["subtrees"].get("measured_in_attempt") == 0
+    # the other leg ran behind the headline leg of the attempt that verified
+    assert res["modes"]["subtrees"]["verified"] is True and res["all_modes_verified"] is True
     assert "failed with -13" in r.stderr and "global tick" in r.stderr
 
 
