@@ -429,3 +429,23 @@ def test_bench_retries_when_one_rank_of_two_fails(kind):
     else:
         assert "did not verify" in at[0]["why"], at[0]
     assert res["value"] > 0 and res["verified"] is True and res["n_gpus"] == 2 and res["ranks_seen"] == 2
+
+
+def test_bench_headline_survives_a_hung_subtree_leg():
+    """The other leg cannot take the headline down: the single list is measured and verified first; the subtree leg behind
+    it gets 50 ms (standing in for a hang in its one collective): the line keeps `value` and `verified`, says what happened
+    under `modes.subtrees.error`, `all_modes_verified` is false, exit status 0, one attempt."""
+    import json
+    import subprocess
+    env = dict(os.environ, IMT_BENCH_DEVICE="0", IMT_BENCH_COLLECTIVE="gloo", IMT_BENCH_NO_TRACE="1", IMT_BENCH_SUBTREES_TIMEOUT="0.05")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IMT_BENCH_WORKER", "IMT_BENCH_ATTEMPTS", "IMT_BENCH_SLICED_TRANSPORT", "IMT_BENCH_MODE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["value"] > 0 and res["verified"] is True and res["all_modes_verified"] is False
+    assert res["value"] == res["modes"]["single_list"]["value"] and "did not finish" in res["modes"]["subtrees"]["error"]
+    assert len(res["attempts"]) == 1 and res["attempts"][0]["outcome"] == "verified"
