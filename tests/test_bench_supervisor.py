@@ -30,7 +30,8 @@ def run_supervisors(tmp_path, scenario, extra=None, world=2):
         for k in ("IMT_BENCH_WORKER", "IMT_BENCH_ATTEMPTS", "IMT_BENCH_SLICED_TRANSPORT", "IMT_BENCH_MODE"):
             if k not in (extra or {}):
                 env.pop(k, None)
-        procs.append(subprocess.Popen([sys.executable, "-c", DRIVER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        procs.append(subprocess.Popen([sys.executable, "-c", DRIVER.replace("gpus=2", f"gpus={world}")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=240) for p in procs]
     return [p.returncode for p in procs], outs, port
 
@@ -159,3 +160,16 @@ def test_a_worker_does_not_outlive_its_supervisor(tmp_path, sig):
     else:
         os.kill(wpid, signal.SIGKILL)
         raise AssertionError("the worker outlived its supervisor")
+
+
+def test_eight_supervisors(tmp_path):
+    """the driver's largest form: eight ranks.  Attempt 0: rank 1's worker dies, the seven others hang and are killed by
+    their supervisors; attempt 1 verifies; every supervisor exits 0 and only rank 0 prints."""
+    rcs, outs, _ = run_supervisors(tmp_path, "second_attempt", {"IMT_BENCH_ATTEMPTS": "rccl:pools,ipc:pools"}, world=8)
+    assert rcs == [0] * 8, [o[1][-300:] for o in outs]
+    res = the_line(outs)
+    assert res["value"] == 123.0 and [a["outcome"] for a in res["attempts"]] == ["failed", "verified"]
+    st = res["attempts"][0]["exit_status"]
+    assert len(st) == 8 and st[1] == 3 and all(x != 0 for x in st)
+    ports = {json.load(open(tmp_path / f"worker_a1_r{r}.json"))["MASTER_PORT"] for r in range(8)}
+    assert len(ports) == 1
