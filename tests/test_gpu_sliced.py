@@ -208,11 +208,9 @@ def test_config4_single_list_eight_slices_2pow22(imt, ctx):
     cap = 1 << 23
     gb = world * batch
     vals_h = bench.synth_values(gb * rounds, 0, 1, 0x494D5404)
-    dg_path = os.path.join(os.path.dirname(__file__), "golden", "config4_oracle_digest.json")
-    dg = json.load(open(dg_path)) if os.path.exists(dg_path) else None      # TEMPORARY guard while the digest is being generated
-    if dg is not None:
-        assert dg["n"] == gb * rounds and dg["steps"] == rounds and dg["depth"] == depth
-        assert hashlib.sha256(vals_h.tobytes()).hexdigest() == dg["sha256_values"], "the value generator changed: regenerate the digest"
+    dg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config4_oracle_digest.json")))
+    assert dg["n"] == gb * rounds and dg["steps"] == rounds and dg["depth"] == depth
+    assert hashlib.sha256(vals_h.tobytes()).hexdigest() == dg["sha256_values"], "the value generator changed: regenerate the digest"
     vals = torch.from_numpy(vals_h).cuda()
     t = sl.SlicedTree(imt, 0, depth, cap, batch, world, n_local=world)
     F, lib = imt._ffi, imt.lib
@@ -224,15 +222,15 @@ def test_config4_single_list_eight_slices_2pow22(imt, ctx):
     def check(r):
         nonlocal prev_last
         # the oracle's digests of this step: the 8 slices in insertion order
-        want = dg["per_step"][r] if dg is not None else None
+        want = dg["per_step"][r]
         for field, key, cast in (("interim_root", "sha256_interim_roots", None), ("new_root", "sha256_new_roots", None),
                                  ("low_index", "sha256_low_index", "<u8"), ("is_largest", "sha256_is_largest", None)):
             h = hashlib.sha256()
             for k in range(world):
                 a = t.outputs(r, k)[field].cpu().numpy()
                 h.update((a.astype(cast) if cast else a).tobytes())
-            assert want is None or h.hexdigest() == want[key], (r, field)
-        assert want is None or imt.to_int(t.outputs(r, world - 1)["new_root"][-1].cpu().numpy()) == int(want["root_after"]), r
+            assert h.hexdigest() == want[key], (r, field)
+        assert imt.to_int(t.outputs(r, world - 1)["new_root"][-1].cpu().numpy()) == int(want["root_after"]), r
         for k in range(world):
             o = t.outputs(r, k)
             first = o["first_insertion"]
@@ -262,9 +260,9 @@ def test_config4_single_list_eight_slices_2pow22(imt, ctx):
         checked += 1
     roots = {tr.root() for tr in t.trees}
     assert len(roots) == 1 and imt.to_int(prev_last.cpu().numpy()) in roots
-    assert dg is None or roots == {int(dg["final_root"])}
+    assert roots == {int(dg["final_root"])}
     assert all(tr.size == 1 + gb * rounds for tr in t.trees)
-    for i, hx in (dg["sha256_final_proofs"] if dg is not None else {}).items():
+    for i, hx in dg["sha256_final_proofs"].items():
         assert hashlib.sha256(t.trees[0].get_proof_batch([int(i)], item_major=True).tobytes()).hexdigest() == hx, i
     t.close()
     ref = imt.IndexedTree(ctx, depth, cap)
