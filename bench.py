@@ -839,9 +839,9 @@ def bench_single_list(env):
     vals = torch.from_numpy(synth_values(steps_total * gb, 0, 1, 0x494D5403)).to(env.dev)
     # ---- preflight: two short steps (2^10 insertions per rank) through the SAME world, transport and streams as the timed
     # steps, under a short library watchdog, verified on the spot.  A collective that never completes, a rank that does
-    # not arrive or witnesses that do not chain across ranks cost 20 s and a dump here instead of the leg's whole limit.
+    # not arrive or witnesses that do not chain across ranks cost 30 s and a dump here instead of the leg's whole limit.
     lib_watchdog_ms = int(float(os.environ.get("IMT_BENCH_LIBRARY_WATCHDOG_S", "90")) * 1e3)
-    tree.set_option(env.F.SLICED_OPT_WATCHDOG_MS, min(lib_watchdog_ms, int(float(os.environ.get("IMT_BENCH_PREFLIGHT_WATCHDOG_S", "20")) * 1e3)))
+    tree.set_option(env.F.SLICED_OPT_WATCHDOG_MS, min(lib_watchdog_ms, int(float(os.environ.get("IMT_BENCH_PREFLIGHT_WATCHDOG_S", "30")) * 1e3)))
     tp0 = time.perf_counter()
     pvals = torch.from_numpy(synth_values(PREFLIGHT_STEPS * PREFLIGHT_N * world, 0, 1, 0x494D54F0)).to(env.dev)
     torch.cuda.synchronize()
