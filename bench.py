@@ -303,7 +303,7 @@ def supervise(args, worker_cmd=None):
                 if relay:
                     sys.stderr.write(ln)
                     sys.stderr.flush()
-                    del keep_lines[:-60]
+                    del keep_lines[:-200]
         th = [threading.Thread(target=drain, args=(child.stdout, out_lines, False), daemon=True),
               threading.Thread(target=drain, args=(child.stderr, err_tail, True), daemon=True)]
         for t in th:
@@ -339,7 +339,10 @@ def supervise(args, worker_cmd=None):
                     pass
         mine_ok = rc == 0 and (rank != 0 or (got is not None and got.get("value") is not None and got.get("verified") is True))
         sub_ok = bool(rank == 0 and got is not None and ((got.get("modes") or {}).get("subtrees") or {}).get("verified"))
+        # what a failed worker said: the lines that name an error (a runtime's parting warnings often come last), then its tail
+        said = [ln.rstrip()[:300] for ln in err_tail if any(w in ln for w in ("Error", "error", "Traceback", "failed", "NOT COMPLETE", "Duplicate"))]
         seen = share(f"attempt{k}/outcome", {"rank": rank, "rc": rc, "ok": bool(mine_ok), "how": how, "subtrees_verified": sub_ok,
+                                             "errors": None if mine_ok else said[-8:],
                                              "tail": None if mine_ok else "".join(err_tail)[-1500:]})
         all_ok = all(x["ok"] for x in seen)
         if rank == 0:
@@ -359,7 +362,8 @@ def supervise(args, worker_cmd=None):
                              "outcome": "verified" if all_ok else "failed", "why": why,
                              "exit_status": [x["rc"] for x in seen], "seconds": round(time.perf_counter() - t0, 1),
                              "preflight": (got or {}).get("preflight"),
-                             # what the first worker that ended BY ITSELF said last (one killed for its peer's sake knows less)
+                             # what the first worker that ended BY ITSELF said (one killed for its peer's sake knows less)
+                             "error_lines": None if all_ok or not bad else sorted(bad, key=lambda x: x["how"] is not None)[0]["errors"],
                              "dump_tail": None if all_ok or not bad else sorted(bad, key=lambda x: x["how"] is not None)[0]["tail"]})
         if seen[0]["subtrees_verified"] and kept_subtrees is None:
             kept_subtrees = {}       # every supervisor sets the same IMT_BENCH_MODE for the next attempt
@@ -407,7 +411,9 @@ def supervise(args, worker_cmd=None):
     if rank == 0:
         if line is None:
             line = {"metric": METRIC, "value": None, "unit": "insertions/s", "n_gpus": world, "steps": args.steps,
-                    "warmup": args.warmup, "verified": False, "value_failed": "no attempt printed a line"}
+                    "warmup": args.warmup, "verified": False,
+                    "value_failed": "no worker printed a line; the last attempt: " + str(attempts[-1]["why"] if attempts else None) +
+                                    " -- " + " / ".join((attempts[-1].get("error_lines") or [])[-2:] if attempts else [])}
         if not all_ok:
             line["value"], line["verified"], line["ms_per_step"] = None, False, None
             line.setdefault("value_failed", attempts[-1]["why"] if attempts else "no attempt")
