@@ -47,6 +47,22 @@ flag)  # "the gather is complete" as a device-side count
       IMT_SLICED_GATHER_FLAGS=$fl EMU_FILL=$fill EMU_GATHER_WGS=28 timeout -k 10 300 python tools/rank_emulation.py 8 4 2>&1 | grep "^N =" | grep links | cut -c1-110 || exit 1
     done; done; done ) > $O/ab_gather_flags.txt 2>&1
   rc=$?; cat $O/ab_gather_flags.txt; exit $rc ;;
+emuslack)   # how much later than the link model may a collective complete before one rank of 8 / 4 slows down?  (the slowest peer's
+            # kernel waiting for wave slots: up to ~450 us in profiles/r05_barrier_wakeup.txt; the schedule consumes a gather lag ticks later)
+  ( export EMU_RANKS=first EMU_ROUNDS=16 EMU_FILL=rccl EMU_GATHER_WGS=28
+    for extra in 0 100 200 450 900 1500 2500 0; do
+      echo "== every collective completes $extra us later than 40 us + bytes / 48 GB/s"
+      EMU_EXTRA_WAIT_US=$extra timeout -k 10 300 python tools/rank_emulation.py 8 4 2>&1 | grep "^N =" | grep links | cut -c1-110 || exit 1
+    done ) > $O/emu_slack.txt 2>&1
+  rc=$?; cat $O/emu_slack.txt; exit $rc ;;
+emulag)   # the same sensitivity with a longer lag (more ticks between a gather and its use, fewer rounds in flight): what to try on
+          # hardware if the collectives turn out to be late (IMT_BENCH_LAG)
+  ( export EMU_RANKS=first EMU_ROUNDS=16 EMU_FILL=rccl EMU_GATHER_WGS=28
+    for lag in 2 3 4; do for extra in 0 900 1500 2500; do
+      echo "== lag $lag, every collective $extra us late"
+      EMU_LAG=$lag EMU_EXTRA_WAIT_US=$extra timeout -k 10 300 python tools/rank_emulation.py 8 2>&1 | grep "^N =" | grep links | cut -c1-110 || exit 1
+    done; done ) > $O/emu_lag_slack.txt 2>&1
+  rc=$?; cat $O/emu_lag_slack.txt; exit $rc ;;
 bench|multi|scale|soak|aux)   # the standing parts: tools/gpu_round4.sh writing into this round's directory
   ROUND_DIR=$O bash tools/gpu_round4.sh $part ;;
 *) echo "unknown part $part"; exit 2 ;;

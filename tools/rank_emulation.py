@@ -91,7 +91,9 @@ class ModelTransport:
             self.calls += 1
             self.bytes += nbytes * (self.world - 1)
             if FILL == "rccl":
-                us = self.lat + nbytes / (self.link * 1e3) if self.link > 0 else 0.0
+                # EMU_EXTRA_WAIT_US: every collective completes this much LATER than latency + bytes / link rate -- the
+                # slowest of the N - 1 peers' kernels got its wave slots that much after this rank's did
+                us = (self.lat + nbytes / (self.link * 1e3) if self.link > 0 else 0.0) + float(os.environ.get("EMU_EXTRA_WAIT_US", "0"))
                 self.model_ms += us * 1e-3
                 return 0 if emu.emu_gather(stream, recv, send, nbytes, self.world, us, GATHER_WGS) == 0 else F.ERR["HIP"]
             if self.link > 0:
