@@ -655,6 +655,7 @@ struct IpcTransport : Transport {
     int world, rank, ring = 0;
     size_t payload_cap = 0;
     uint8_t* arena = nullptr;                    // [ROUNDS][ring][payload_cap], then [IPC_AUX_RING][IPC_AUX_BYTES]
+    const char* arena_kind = "";                 // "uncached" / "fine-grained" / "default": the memory the arena got (create)
     size_t aux_off = 0;
     uint64_t aux_seq = 0;
     IpcShm *my_shm = nullptr, *my_shm_dev = nullptr;
@@ -755,10 +756,30 @@ struct IpcTransport : Transport {
         payload_cap = imt_itree_slice_payload_bytes(max_slice);
         aux_off = (size_t)ROUNDS * ring * payload_cap;
         const size_t bytes = aux_off + IPC_AUX_RING * IPC_AUX_BYTES;
-        IMT_HIP(ctx, hipMalloc((void**)&arena, bytes));
-        IMT_HIP(ctx, hipMemset(arena, 0, bytes));
+        // The arena is what OTHER GPUs read, while this GPU keeps rewriting it, ordered by nothing but the counters in the
+        // flag pages: it lives in UNCACHED device memory (as RCCL's own buffers do), so that neither this GPU's per-XCD L2s
+        // (dirty lines of a pack kernel) nor a reader's L2 (lines of the slot's previous contents) can stand between a
+        // payload and its reader -- no reliance on what a kernel boundary writes back or invalidates for a peer.  The cost
+        // is the pack kernel's 36 B per written node going past the L2: nothing beside the hashing.  Fine-grained, then
+        // ordinary memory if the runtime cannot give it (or cannot export it); IMT_IPC_ARENA=default for tools' A/B runs.
         std::memset(blob, 0, sizeof *blob);
-        IMT_HIP(ctx, hipIpcGetMemHandle(&blob->mem, arena));
+        const char* want = getenv("IMT_IPC_ARENA");
+        const unsigned kinds[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, hipDeviceMallocDefault};
+        const char* names[3] = {"uncached", "fine-grained", "default"};
+        hipError_t e = hipErrorUnknown;
+        for (int k = (want && !strcmp(want, "default")) ? 2 : (want && !strcmp(want, "finegrained")) ? 1 : 0; k < 3; k++) {
+            void* p = nullptr;
+            e = k < 2 ? hipExtMallocWithFlags(&p, bytes, kinds[k]) : hipMalloc(&p, bytes);
+            if (e == hipSuccess && (e = hipIpcGetMemHandle(&blob->mem, p)) != hipSuccess) hipFree(p);
+            if (e == hipSuccess) {
+                arena = (uint8_t*)p;
+                arena_kind = names[k];
+                break;
+            }
+            (void)hipGetLastError();
+        }
+        if (e != hipSuccess) return ctx->hip_fail(e, "IPC transport: allocating / exporting the send arena");
+        IMT_HIP(ctx, hipMemset(arena, 0, bytes));
         char name[64];
         snprintf(name, sizeof name, "/imt_ipc_%d_%d_%llx", (int)getpid(), rank,
                  (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
@@ -887,8 +908,8 @@ struct IpcTransport : Transport {
     }
     ~IpcTransport() override {
         if (ht.on)
-            fprintf(stderr, "[imt ipc rank %d] host ms (calls): flag_set %.1f (%llu)  wait packed %.1f (%llu)  memcpy %.1f (%llu)  wait copied %.1f (%llu)\n",
-                    rank, ht.ms[0], (unsigned long long)ht.n[0], ht.ms[1], (unsigned long long)ht.n[1], ht.ms[2], (unsigned long long)ht.n[2], ht.ms[3],
+            fprintf(stderr, "[imt ipc rank %d] arena in %s memory; host ms (calls): flag_set %.1f (%llu)  wait packed %.1f (%llu)  memcpy %.1f (%llu)  wait copied %.1f (%llu)\n",
+                    rank, arena_kind, ht.ms[0], (unsigned long long)ht.n[0], ht.ms[1], (unsigned long long)ht.n[1], ht.ms[2], (unsigned long long)ht.n[2], ht.ms[3],
                     (unsigned long long)ht.n[3]);
         stop_worker();
         if (!shm_name.empty()) shm_unlink(shm_name.c_str());      // whatever else fails: the name does not stay behind

@@ -63,6 +63,17 @@ emulag)   # the same sensitivity with a longer lag (more ticks between a gather 
       EMU_LAG=$lag EMU_EXTRA_WAIT_US=$extra timeout -k 10 300 python tools/rank_emulation.py 8 2>&1 | grep "^N =" | grep links | cut -c1-110 || exit 1
     done; done ) > $O/emu_lag_slack.txt 2>&1
   rc=$?; cat $O/emu_lag_slack.txt; exit $rc ;;
+arena)   # the IPC transport's send arena in uncached device memory (the default now) against ordinary hipMalloc memory: the IPC GPU
+         # tests, then the 2- and 4-process rehearsals on the one GPU with both, alternating
+  timeout -k 10 600 python -m pytest tests/test_gpu_sliced.py tests/test_gpu_sharded_procs.py -m gpu -x -q -k "ipc or vanished or gather_reports or two_ranks or c_example or gpus2 or gpus4" > $O/arena_tests.log 2>&1 &&
+  tail -3 $O/arena_tests.log &&
+  ( for rep in 1 2; do for kind in uncached default; do for n in 2 4; do
+      echo "== rep $rep: arena $kind, N = $n"
+      ( export IMT_BENCH_DEVICE=0 IMT_BENCH_COLLECTIVE=gloo IMT_BENCH_MODE=single-list IMT_IPC_ARENA=$kind IMT_SLICED_TIMING=1
+        timeout -k 10 400 python3 bench.py --gpus $n --steps 12 --warmup 3 --no-cpu-baseline 2> $O/arena.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('value', round(d['value']/1e6,3), 'verified', d['verified'], 'attempts', len(d['attempts']))" ) || exit 1
+      grep -o "arena in [a-z-]* memory" $O/arena.err | sort | uniq -c
+    done; done; done ) > $O/ab_ipc_arena.txt 2>&1
+  rc=$?; cat $O/ab_ipc_arena.txt; exit $rc ;;
 bench|multi|scale|soak|aux)   # the standing parts: tools/gpu_round4.sh writing into this round's directory
   ROUND_DIR=$O bash tools/gpu_round4.sh $part ;;
 *) echo "unknown part $part"; exit 2 ;;
