@@ -236,6 +236,7 @@ def supervise(args, worker_cmd=None):
     backend = os.environ.get("IMT_BENCH_COLLECTIVE", "nccl")
     plan = attempts_plan(backend, world)
     limit = float(os.environ.get("IMT_BENCH_ATTEMPT_TIMEOUT", "600"))
+    t_start = time.perf_counter()
     # The supervisors talk through the launcher's rendezvous STORE and nothing else (set / get / check of keys over TCP to
     # MASTER_ADDR:MASTER_PORT -- under torch.distributed.run the agent's store, otherwise one rank 0 hosts): no process
     # group, no gloo devices, no hostname to resolve.  Waiting for a key blocks until it is set (store timeout).
@@ -251,7 +252,6 @@ def supervise(args, worker_cmd=None):
             return json.loads(store.get(key))
         store.set(f"{key}/{rank}", json.dumps(obj))
         return [json.loads(store.get(f"{key}/{r}")) for r in range(world)]
-    attempts, kept_subtrees, line, all_ok = [], None, None, False
     # a worker never outlives its supervisor: killed with it when the launcher ends the job (SIGTERM / SIGINT / SIGHUP to this
     # process), and by the kernel if this process is killed outright (PR_SET_PDEATHSIG in the child)
     live = {"child": None}
@@ -266,7 +266,6 @@ def supervise(args, worker_cmd=None):
         os._exit(128 + signum)
     for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         signal.signal(sg, end_with_child)
-
     try:
         libc = ctypes.CDLL("libc.so.6", use_errno=True)       # loaded HERE: nothing is dlopen'ed between fork and exec
     except OSError:
@@ -276,19 +275,25 @@ def supervise(args, worker_cmd=None):
     def die_with_parent():
         if libc is not None:
             libc.prctl(1, kill_sig, 0, 0, 0)                   # PR_SET_PDEATHSIG
-    for k, (kind, layout) in enumerate(plan):
+
+    def run_attempt(k, kind, layout, mode, time_limit):
+        """one attempt = one fresh worker per rank; returns (verified on every rank, rank 0's line or None, the `attempts` entry
+        (rank 0) or None, did rank 0's line carry a verified subtree leg).  mode: IMT_BENCH_MODE for the workers or None."""
         port = None
         if rank == 0:
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
         port = share(f"attempt{k}/port", port, src=0)
-        env = dict(os.environ, IMT_BENCH_WORKER="1", IMT_BENCH_ATTEMPT=str(k), MASTER_PORT=str(port),
-                   IMT_BENCH_SLICED_TRANSPORT=kind, IMT_BENCH_LAYOUT=layout)
+        env = dict(os.environ, IMT_BENCH_WORKER="1", IMT_BENCH_ATTEMPT=str(k), MASTER_PORT=str(port))
         for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
             env.pop(v, None)         # the workers rendezvous on a port of their own: rank 0's worker hosts the store
-        if kept_subtrees is not None and "IMT_BENCH_MODE" not in os.environ:
-            env["IMT_BENCH_MODE"] = "single-list"       # the other leg has been measured and verified: not again
+        if kind is not None:
+            env.update(IMT_BENCH_SLICED_TRANSPORT=kind, IMT_BENCH_LAYOUT=layout)
+        else:
+            env.pop("IMT_BENCH_SLICED_TRANSPORT", None)
+        if mode is not None:
+            env["IMT_BENCH_MODE"] = mode
         cmd = worker_cmd or ([sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
                               "--warmup", str(args.warmup)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
         t0 = time.perf_counter()
@@ -313,8 +318,8 @@ def supervise(args, worker_cmd=None):
         while child.poll() is None:
             time.sleep(0.25)
             now = time.perf_counter()
-            if now - t0 > limit:
-                how = f"killed by its supervisor after {limit:.0f} s"
+            if now - t0 > time_limit:
+                how = f"killed by its supervisor after {time_limit:.0f} s"
             elif peer_failed_at is None and store.check([key]):
                 peer_failed_at = now          # a peer's worker is gone: what is left of this one cannot finish a collective
             elif peer_failed_at is not None and now - peer_failed_at > float(os.environ.get("IMT_BENCH_PEER_GRACE", "15")):
@@ -344,70 +349,75 @@ def supervise(args, worker_cmd=None):
         seen = share(f"attempt{k}/outcome", {"rank": rank, "rc": rc, "ok": bool(mine_ok), "how": how, "subtrees_verified": sub_ok,
                                              "errors": None if mine_ok else said[-8:],
                                              "tail": None if mine_ok else "".join(err_tail)[-1500:]})
-        all_ok = all(x["ok"] for x in seen)
+        ok_all = all(x["ok"] for x in seen)
+        entry = None
         if rank == 0:
+            bad = [x for x in seen if not x["ok"]]
+            why = None
+            if not ok_all:
+                why = (got or {}).get("value_failed") or "; ".join(f"rank {x['rank']}: exit status {x['rc']}" + (f" ({x['how']})" if x["how"] else "")
+                                                                   for x in bad)
+            sch = ((got or {}).get("modes") or {}).get("single_list", {}).get("schedule") or {}
+            first = sorted(bad, key=lambda x: x["how"] is not None)[0] if bad else None     # the first worker that ended BY ITSELF
+            entry = {"attempt": k, "transport": sch.get("transport", kind), "asked_for": kind, "layout": layout,
+                     "pools": sch.get("pools"), "comm_streams": sch.get("comm_streams"),
+                     "outcome": "verified" if ok_all else "failed", "why": why,
+                     "value": (got or {}).get("value") if ok_all else None,
+                     "exit_status": [x["rc"] for x in seen], "seconds": round(time.perf_counter() - t0, 1),
+                     "preflight": (got or {}).get("preflight"),
+                     "error_lines": None if first is None else first["errors"], "dump_tail": None if first is None else first["tail"]}
+        return ok_all, got, entry, bool(seen[0]["subtrees_verified"])
+
+    attempts, kept_subtrees, line, all_ok, chosen = [], None, None, False, None
+    for k, (kind, layout) in enumerate(plan):
+        # (the other leg, once measured and verified, is not run again)
+        mode = "single-list" if kept_subtrees is not None and "IMT_BENCH_MODE" not in os.environ else None
+        all_ok, got, entry, sub_ok = run_attempt(k, kind, layout, mode, limit)
+        if rank == 0:
+            attempts.append(entry)
             if got is not None:
                 line = got
                 sub = (got.get("modes") or {}).get("subtrees")
                 if sub and sub.get("verified") and kept_subtrees is None:
                     kept_subtrees = dict(sub, measured_in_attempt=k)
-            bad = [x for x in seen if not x["ok"]]
-            why = None
-            if not all_ok:
-                why = (got or {}).get("value_failed") or "; ".join(f"rank {x['rank']}: exit status {x['rc']}" + (f" ({x['how']})" if x["how"] else "")
-                                                                   for x in bad)
-            sch = ((got or {}).get("modes") or {}).get("single_list", {}).get("schedule") or {}
-            attempts.append({"attempt": k, "transport": sch.get("transport", kind), "asked_for": kind, "layout": layout,
-                             "pools": sch.get("pools"), "comm_streams": sch.get("comm_streams"),
-                             "outcome": "verified" if all_ok else "failed", "why": why,
-                             "exit_status": [x["rc"] for x in seen], "seconds": round(time.perf_counter() - t0, 1),
-                             "preflight": (got or {}).get("preflight"),
-                             # what the first worker that ended BY ITSELF said (one killed for its peer's sake knows less)
-                             "error_lines": None if all_ok or not bad else sorted(bad, key=lambda x: x["how"] is not None)[0]["errors"],
-                             "dump_tail": None if all_ok or not bad else sorted(bad, key=lambda x: x["how"] is not None)[0]["tail"]})
-        if seen[0]["subtrees_verified"] and kept_subtrees is None:
-            kept_subtrees = {}       # every supervisor sets the same IMT_BENCH_MODE for the next attempt
+        if sub_ok and kept_subtrees is None:
+            kept_subtrees = {}       # every supervisor makes the same choice of IMT_BENCH_MODE for the next attempt
         if all_ok:
+            chosen = k
             break
+    # ---- one look at the OTHER stream layout.  Which of the two placements of the collectives' streams is faster on real
+    # links has only ever been modelled; when the first verified attempt was quick, the same transport is
+    # measured once more in the other layout -- fresh workers, the single list alone, a short limit -- and `value` is the
+    # better of the two verified figures (both are on the line: attempts[].value, value_from_attempt).  A failure here
+    # costs nothing but its time.  IMT_BENCH_EXPLORE=0 switches it off (default on with RCCL, off in the gloo rehearsal).
+    explore = os.environ.get("IMT_BENCH_EXPLORE", "1" if backend == "nccl" else "0") == "1"
+    budget = float(os.environ.get("IMT_BENCH_EXPLORE_WITHIN", "150"))
+    go = bool(all_ok and explore and world > 1 and "IMT_BENCH_ATTEMPTS" not in os.environ and "IMT_BENCH_SLICED_TRANSPORT" not in os.environ
+              and time.perf_counter() - t_start < budget)
+    go = share("explore", go, src=0)                # one decision (rank 0's clock)
+    if go:
+        kind, layout = plan[chosen]
+        other = "one-pool" if layout == "pools" else "pools"
+        k = len(plan)
+        ok2, got2, entry2, _ = run_attempt(k, kind, other, "single-list", float(os.environ.get("IMT_BENCH_EXPLORE_TIMEOUT", "150")))
+        if rank == 0:
+            entry2["exploratory"] = True
+            attempts.append(entry2)
+            if ok2 and got2 is not None and got2["value"] > line["value"]:
+                keep_modes = (line.get("modes") or {})
+                line = got2
+                for name, m in keep_modes.items():          # the other leg's figure was measured in the first verified attempt
+                    line.setdefault("modes", {}).setdefault(name, m)
+                chosen = k
     # No attempt of the headline leg verified and the OTHER leg was never reached (a worker runs it second): measure it now, in
     # fresh workers of its own, so that the line still says what the machine does in that layout -- under `modes`, as ever,
     # never as `value`.  One rendezvous, the worker's own time limit, no retry.
     if not all_ok and kept_subtrees is None and os.environ.get("IMT_BENCH_MODE", "both") == "both":
-        k = len(plan)
-        port = None
-        if rank == 0:
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-        port = share(f"attempt{k}/port", port, src=0)
-        env = dict(os.environ, IMT_BENCH_WORKER="1", IMT_BENCH_ATTEMPT=str(k), MASTER_PORT=str(port), IMT_BENCH_MODE="subtrees")
-        for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
-                  "IMT_BENCH_SLICED_TRANSPORT", "IMT_BENCH_INJECT"):
-            env.pop(v, None)
-        cmd = worker_cmd or ([sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
-                              "--warmup", str(args.warmup), "--no-cpu-baseline"])
-        sub_limit = float(os.environ.get("IMT_BENCH_SUBTREES_TIMEOUT", "180")) + 120
-        try:
-            child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, errors="replace",
-                                     start_new_session=True, preexec_fn=die_with_parent)
-            live["child"] = child
-            try:
-                out, _ = child.communicate(timeout=sub_limit)
-            except subprocess.TimeoutExpired:
-                os.killpg(child.pid, signal.SIGKILL)
-                out, _ = child.communicate()
-            if rank == 0:
-                for ln in out.splitlines():
-                    if ln.startswith("{"):
-                        try:
-                            sub = (json.loads(ln).get("modes") or {}).get("subtrees")
-                            if sub and "value" in sub:
-                                kept_subtrees = dict(sub, measured_in_attempt="after the last (its own workers)")
-                        except ValueError:
-                            pass
-        except OSError as e:
-            print(f"[supervisor {rank}] the subtree-only run could not start: {e!r}", file=sys.stderr, flush=True)
-        share(f"attempt{k}/over", True)
+        _, got3, _, _ = run_attempt(len(plan) + 1, None, None, "subtrees", float(os.environ.get("IMT_BENCH_SUBTREES_TIMEOUT", "180")) + 120)
+        if rank == 0 and got3 is not None:
+            sub = (got3.get("modes") or {}).get("subtrees")
+            if sub and "value" in sub:
+                kept_subtrees = dict(sub, measured_in_attempt="after the last (its own workers)")
     if rank == 0:
         if line is None:
             line = {"metric": METRIC, "value": None, "unit": "insertions/s", "n_gpus": world, "steps": args.steps,
@@ -420,6 +430,7 @@ def supervise(args, worker_cmd=None):
         if kept_subtrees and "subtrees" not in line.setdefault("modes", {}):
             line["modes"]["subtrees"] = kept_subtrees
         line["attempts"] = attempts
+        line["value_from_attempt"] = chosen
         print(json.dumps(line), flush=True)
     share("done", True)              # nobody leaves before everybody has read what it needs ...
     if rank != 0:                    # ... and rank 0 (which hosts the store when no launcher does) leaves last

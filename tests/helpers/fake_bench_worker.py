@@ -48,6 +48,17 @@ if scenario == "unverified_then_ok":     # every worker exits 0 but rank 0's lin
     if rank == 0:
         line(None if attempt == 0 else 77.0, why="did not verify" if attempt == 0 else None)
     sys.exit(0)
+if scenario.startswith("explore_"):      # attempt 0 verifies at 100; the exploratory attempt (other layout) is better / worse / fails
+    if layout == "pools":
+        if rank == 0:
+            line(100.0)
+        sys.exit(0)
+    if scenario == "explore_fails":
+        print(f"rank {rank}: preflight failed (fake)", file=sys.stderr, flush=True)
+        sys.exit(1)
+    if rank == 0:
+        line(120.0 if scenario == "explore_better" else 90.0)
+    sys.exit(0)
 if scenario == "orphan":                 # hangs for good and says who it is: the test ends its supervisor and looks for it
     with open(os.path.join(os.environ["FAKE_LOG_DIR"], f"pid_r{rank}"), "w") as f:
         f.write(str(os.getpid()))

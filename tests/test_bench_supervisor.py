@@ -76,7 +76,7 @@ def test_every_attempt_fails(tmp_path):
     # measure it at the end in workers of its own, and its figure goes under `modes` only
     assert json.load(open(tmp_path / "worker_a0_r1.json"))["IMT_BENCH_MODE"] is None
     assert json.load(open(tmp_path / "worker_a1_r1.json"))["IMT_BENCH_MODE"] is None
-    assert json.load(open(tmp_path / "worker_a2_r1.json"))["IMT_BENCH_MODE"] == "subtrees"
+    assert json.load(open(tmp_path / "worker_a3_r1.json"))["IMT_BENCH_MODE"] == "subtrees"      # (index 2 = the exploratory attempt's)
     assert res["modes"]["subtrees"]["value"] == 5.0e6 and "its own workers" in res["modes"]["subtrees"]["measured_in_attempt"]
     assert len(res["attempts"]) == 2
 
@@ -173,3 +173,30 @@ def test_eight_supervisors(tmp_path):
     assert len(st) == 8 and st[1] == 3 and all(x != 0 for x in st)
     ports = {json.load(open(tmp_path / f"worker_a1_r{r}.json"))["MASTER_PORT"] for r in range(8)}
     assert len(ports) == 1
+
+
+@pytest.mark.parametrize("scenario,want_value,want_from", [("explore_better", 120.0, 2), ("explore_worse", 100.0, 0), ("explore_fails", 100.0, 0)])
+def test_one_look_at_the_other_stream_layout(tmp_path, scenario, want_value, want_from):
+    """After a quick verified attempt the same transport is measured once in the OTHER stream layout (fresh workers, the
+    single list alone); `value` is the better of the two verified figures, both are on the line, and a failing exploratory
+    attempt costs nothing.  (On by default with RCCL; asked for here.)"""
+    rcs, outs, _ = run_supervisors(tmp_path, scenario, {"IMT_BENCH_EXPLORE": "1"})
+    assert rcs == [0, 0], outs
+    res = the_line(outs)
+    at = res["attempts"]
+    assert len(at) == 2 and at[0]["outcome"] == "verified" and at[0]["value"] == 100.0 and at[1].get("exploratory") is True
+    assert (at[0]["layout"], at[1]["layout"]) == ("pools", "one-pool") and at[1]["attempt"] == 2
+    assert res["value"] == want_value and res["value_from_attempt"] == want_from and res["verified"] is True
+    assert at[1]["outcome"] == ("failed" if scenario == "explore_fails" else "verified")
+    assert res["modes"]["subtrees"]["value"] == 5.0e6                       # measured once, in the first verified attempt
+    w = json.load(open(tmp_path / "worker_a2_r1.json"))
+    assert w["IMT_BENCH_MODE"] == "single-list" and w["IMT_BENCH_LAYOUT"] == "one-pool" and w["IMT_BENCH_SLICED_TRANSPORT"] == "ipc"
+
+
+def test_no_exploration_when_the_plan_was_given_or_time_is_short(tmp_path):
+    rcs, outs, _ = run_supervisors(tmp_path, "explore_better", {"IMT_BENCH_EXPLORE": "1", "IMT_BENCH_EXPLORE_WITHIN": "0"})
+    assert rcs == [0, 0] and len(the_line(outs)["attempts"]) == 1
+    sub = tmp_path / "given"
+    sub.mkdir()
+    rcs, outs, _ = run_supervisors(sub, "explore_better", {"IMT_BENCH_EXPLORE": "1", "IMT_BENCH_ATTEMPTS": "ipc:pools"})
+    assert rcs == [0, 0] and len(the_line(outs)["attempts"]) == 1 and the_line(outs)["value"] == 100.0

@@ -449,3 +449,30 @@ def test_bench_headline_survives_a_hung_subtree_leg():
     assert res["value"] > 0 and res["verified"] is True and res["all_modes_verified"] is False
     assert res["value"] == res["modes"]["single_list"]["value"] and "did not finish" in res["modes"]["subtrees"]["error"]
     assert len(res["attempts"]) == 1 and res["attempts"][0]["outcome"] == "verified"
+
+
+def test_bench_looks_once_at_the_other_stream_layout():
+    """`python bench.py --gpus 2` with the exploration the RCCL runs have by default (IMT_BENCH_EXPLORE=1 here, on the gloo
+    rehearsal): after the first verified attempt the same transport runs once more in the other stream layout (every
+    collective on its round's own stream), in fresh workers, the single list alone; `value` is the better of the two
+    verified figures and the line shows both; the subtree leg was measured once."""
+    import json
+    import subprocess
+    env = dict(os.environ, IMT_BENCH_DEVICE="0", IMT_BENCH_COLLECTIVE="gloo", IMT_BENCH_NO_TRACE="1", IMT_BENCH_EXPLORE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IMT_BENCH_WORKER", "IMT_BENCH_ATTEMPTS", "IMT_BENCH_SLICED_TRANSPORT", "IMT_BENCH_MODE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    at = res["attempts"]
+    assert len(at) == 2 and all(a["outcome"] == "verified" for a in at), at
+    assert (at[0]["layout"], at[1]["layout"]) == ("pools", "one-pool") and at[1]["exploratory"] is True
+    assert at[1]["comm_streams"] == 0 and at[0]["comm_streams"] == 4
+    best = max(range(2), key=lambda i: at[i]["value"])
+    assert res["value"] == at[best]["value"] and res["value_from_attempt"] == at[best]["attempt"]
+    assert res["value"] == res["modes"]["single_list"]["value"] and res["verified"] is True
+    assert res["modes"]["single_list"]["schedule"]["comm_streams"] == at[best]["comm_streams"]
+    assert res["modes"]["subtrees"]["verified"] is True
