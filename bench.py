@@ -11,9 +11,13 @@ interim / new root and both 32-sibling proofs.  Values are resident in HBM befor
       line and exits with their status.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU: the
       driver's form; --gpus must equal WORLD_SIZE)
+      In both forms every rank process (N > 1) is a GPU-free SUPERVISOR that runs the measurement in a child process
+      and, if the single-list leg hangs, dies or does not verify on any rank, tries again in fresh children with the
+      next transport / stream layout (`attempts` on the line; see supervise() below and DESIGN.md section 8).
 
 N = 1: one tree, imt_itree_insert_batch, four batches in flight.
-N > 1 runs BOTH multi-GPU modes in one invocation and reports both (`modes`); `value` is the first:
+N > 1 runs BOTH multi-GPU modes in one invocation (the single list first) and reports both (`modes`); `value` is the
+single list's and only the single list's; neither leg's failure takes the other's figure down:
   single-list  ONE indexed tree, the reference's data structure (one sorted list, update_idx_leaf's sequential
                semantics), bit-exact with one GPU at any N.  A step's N x 2^16 insertions are cut into N consecutive
                slices; rank g hashes slice g; every rank keeps a replica; what a slice writes back to the stored tree
@@ -28,7 +32,7 @@ Per-GPU work is fixed (weak scaling) in both.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, algorithmic bytes of SURVEY.md 8d,
 durations of the TIMED REGION) and `cpu_baseline` (the C oracle, 1 thread, bounded sample) added, plus a `valu` object:
 the path is integer-VALU bound, so that is the roofline that says something.  Exit status 1 if the outputs of the
-timed region do not verify.
+timed region (the headline leg's) do not verify.
 """
 import os
 
@@ -183,8 +187,9 @@ def launch_ranks(args):
 # on ANY rank, all supervisors start FRESH children with the next (transport, stream layout) of the plan: a process that
 # has a hung collective on its GPU is never reused, nothing is ever exec'ed over a process that has initialised the GPU.
 # The first hardware run of the single list may be the only one; a surprise in RCCL must not leave it without a number.
-# `value` is the single list's figure from the first attempt that verifies on every rank -- never the subtrees' -- and
-# the line carries `attempts`: what each attempt ran with and how it ended.
+# `value` is the single list's figure from the first attempt that verifies on every rank (or from the one exploratory
+# attempt in the other stream layout that may follow it, if that figure is better) -- never the subtrees' -- and the line
+# carries `attempts`: what each attempt ran with and how it ended.
 ATTEMPT_LAYOUTS = ("pools", "one-pool")
 
 
