@@ -18,14 +18,20 @@
 
 struct EmuSlot {
     unsigned int flag, done;
+    unsigned long long t_first, t_last;      // wall clock when workgroup 0 started / when the LAST workgroup started
+};
+struct EmuStat {
+    unsigned int spread_ticks, wgs;          // t_last - t_first of one collective: how long until all its workgroups had wave slots
 };
 constexpr int EMU_SLOTS = 4096;
 constexpr unsigned long long EMU_POLL_CAP_TICKS = 100000000ull;      // 1 s of the 100 MHz wall clock
 
 __global__ __launch_bounds__(512) void k_emu_gather(uint4* __restrict__ recv, const uint4* __restrict__ send, size_t n16, int world,
-                                                    unsigned long long wait_ticks, EmuSlot* slot) {
+                                                    unsigned long long wait_ticks, EmuSlot* slot, EmuStat* stat) {
     if (threadIdx.x == 0) {
         const unsigned long long t0 = wall_clock64();
+        if (blockIdx.x == 0) __hip_atomic_store(&slot->t_first, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicMax(&slot->t_last, t0);
         if (blockIdx.x == 0) {
             while (wall_clock64() - t0 < wait_ticks) __builtin_amdgcn_s_sleep(16);
             __hip_atomic_store(&slot->flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -43,6 +49,11 @@ __global__ __launch_bounds__(512) void k_emu_gather(uint4* __restrict__ recv, co
     __syncthreads();
     if (threadIdx.x == 0) {          // the last workgroup out gives the slot back
         if (__hip_atomic_fetch_add(&slot->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            const unsigned long long a = __hip_atomic_load(&slot->t_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long b = __hip_atomic_load(&slot->t_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stat->spread_ticks = b > a ? (unsigned int)(b - a) : 0u;
+            stat->wgs = gridDim.x;
+            __hip_atomic_store(&slot->t_last, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&slot->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&slot->flag, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -50,19 +61,35 @@ __global__ __launch_bounds__(512) void k_emu_gather(uint4* __restrict__ recv, co
 }
 
 static EmuSlot* g_slots = nullptr;
+static EmuStat* g_stats = nullptr;
 static unsigned g_next = 0;
+constexpr unsigned EMU_STATS = 1u << 16;
 
 extern "C" int emu_gather_init(void) {
     if (g_slots) return 0;
     if (hipMalloc((void**)&g_slots, sizeof(EmuSlot) * EMU_SLOTS) != hipSuccess) return -1;
+    if (hipMalloc((void**)&g_stats, sizeof(EmuStat) * EMU_STATS) != hipSuccess) return -1;
+    if (hipMemset(g_stats, 0, sizeof(EmuStat) * EMU_STATS) != hipSuccess) return -1;
     return hipMemset(g_slots, 0, sizeof(EmuSlot) * EMU_SLOTS) == hipSuccess ? 0 : -1;
 }
 
 // recv[k * nbytes, (k + 1) * nbytes) = send[0, nbytes) for k < world once wait_us have passed; nbytes a multiple of 16
 extern "C" int emu_gather(void* stream, void* recv, const void* send, size_t nbytes, int world, double wait_us, int wgs) {
     if (!g_slots || (nbytes & 15) || wgs < 1 || wgs > 256) return -1;
-    EmuSlot* slot = g_slots + (g_next++ % EMU_SLOTS);
+    const unsigned call = g_next++;
+    EmuSlot* slot = g_slots + (call % EMU_SLOTS);
     hipLaunchKernelGGL(k_emu_gather, dim3(wgs), dim3(512), 0, (hipStream_t)stream, (uint4*)recv, (const uint4*)send, nbytes / 16, world,
-                       (unsigned long long)(wait_us * 100.0), slot);
+                       (unsigned long long)(wait_us * 100.0), slot, g_stats + (call % EMU_STATS));
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// after a device sync: out[i] = microseconds between the start of workgroup 0 and the start of the LAST workgroup of call
+// first + i (how long the collective's kernel waited for all its wave slots); returns the number of calls made so far
+extern "C" unsigned emu_gather_spreads(unsigned first, unsigned n, float* out) {
+    if (!g_stats || n > EMU_STATS) return g_next;
+    EmuStat* h = new EmuStat[EMU_STATS];
+    if (hipMemcpy(h, g_stats, sizeof(EmuStat) * EMU_STATS, hipMemcpyDeviceToHost) == hipSuccess)
+        for (unsigned i = 0; i < n; i++) out[i] = h[(first + i) % EMU_STATS].spread_ticks / 100.0f;
+    delete[] h;
+    return g_next;
 }

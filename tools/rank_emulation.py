@@ -69,6 +69,8 @@ if FILL == "rccl":
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
     emu = ctypes.CDLL(so)
     emu.emu_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+    emu.emu_gather_spreads.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(ctypes.c_float)]
+    emu.emu_gather_spreads.restype = ctypes.c_uint
     torch.cuda.set_device(0)
     assert emu.emu_gather_init() == 0
 
@@ -135,6 +137,7 @@ def one_rank(world, rank, link, lat):
     t.flush()
     torch.cuda.synchronize()
     c0, m0 = tp.calls, tp.model_ms
+    g0 = emu.emu_gather_spreads(0, 0, None) if emu is not None else 0
     i0 = t.info()
     t0 = time.perf_counter()
     for r in range(WARM, steps):
@@ -146,6 +149,12 @@ def one_rank(world, rank, link, lat):
     info = dict(rate=ROUNDS * BATCH / dt, ms=dt / ROUNDS * 1e3, lag=i1["lag"], gathers=(tp.calls - c0) / ROUNDS,
                 model_ms=(tp.model_ms - m0) / ROUNDS, gb=(i1["bytes_gathered"] - i0["bytes_gathered"]) / ROUNDS / 1e9,
                 issue=(i1["host_issue_ms"] - i0["host_issue_ms"]) / ROUNDS, wait=(i1["host_wait_ms"] - i0["host_wait_ms"]) / ROUNDS)
+    if emu is not None:          # how long the collectives' kernels waited for their wave slots (last workgroup's start - first's)
+        n = min(tp.calls - c0, 1 << 16)
+        buf = (ctypes.c_float * n)()
+        emu.emu_gather_spreads(g0, n, buf)
+        sp = sorted(buf)
+        info["spread"] = dict(n=n, p50=sp[n // 2], p90=sp[int(n * 0.9)], p99=sp[int(n * 0.99)], max=sp[-1])
     t.close()
     del vals
     torch.cuda.empty_cache()
@@ -170,7 +179,10 @@ def main():
                       f"{world * r['rate'] / 1e6:.2f} M/s; {r['gathers']:.0f} all-gathers receiving {r['gb']:.3f} GB per step"
                       f"{'' if lk == 0 else ', modelled at %.2f ms of link time per step in total' % r['model_ms']}; "
                       f"host inside imt_sliced_step: {r['issue']:.2f} ms issuing + {r['wait']:.2f} ms waiting for the step's "
-                      f"value check per step", flush=True)
+                      f"value check per step"
+                      + ("" if "spread" not in r else "; the collectives' kernels had ALL their workgroups running p50 %.0f / p90 %.0f / p99 %.0f / max %.0f us "
+                         "after the first (%d collectives)" % (r["spread"]["p50"], r["spread"]["p90"], r["spread"]["p99"], r["spread"]["max"], r["spread"]["n"])),
+                      flush=True)
 
 
 if __name__ == "__main__":
