@@ -95,7 +95,9 @@ calls = [
     ("imt_transport_rccl_adopt", (None, 1, None)), ("imt_transport_rccl_adopt", ((vp * 1)(None), 1, ctypes.byref(vp()))),
     ("imt_transport_ipc_create", (None, 2, 0, 32, 8, 0, None, None)), ("imt_transport_ipc_create", (ctx.h, 1, 0, 32, 8, 0, ctypes.byref(vp()), ctypes.create_string_buffer(1 << 14))),
     ("imt_transport_ipc_create", (ctx.h, 2, 5, 32, 8, 0, ctypes.byref(vp()), ctypes.create_string_buffer(1 << 14))),
-    ("imt_transport_ipc_connect", (None, None)),
+    ("imt_transport_ipc_connect", (None, None)), ("imt_transport_poll_error", (None,)),
+    ("imt_transport_all_gather", (None, None, None, 32, None)),
+    ("imt_sliced_set_option", (None, 11, 1)),                # IMT_SLICED_OPT_RESET takes 0 only
     ("imt_sliced_create", (None, 1, 1, 0, None, 8, 0, None)), ("imt_sliced_create", ((vp * 1)(itree.h), 1, 1, 0, None, 8, 0, ctypes.byref(vp()))),
     ("imt_sliced_step", (None, None, 1, None, 0, None)), ("imt_sliced_wait", (None, 0, 0)), ("imt_sliced_flush", (None,)),
     ("imt_sliced_get_info", (None, None)),
@@ -114,6 +116,7 @@ for k, (name, args) in enumerate(calls):
 tp, w = vp(), vp()
 assert lib.imt_transport_local_create(ctypes.byref(tp)) == 0
 assert lib.imt_transport_ipc_connect(tp, ctypes.create_string_buffer(64)) == _ffi.ERR["ARG"]      # not an IPC transport
+assert lib.imt_transport_poll_error(tp) == 0                                                       # a transport without a GPU-side wait
 big = imt_amd.IndexedTree(ctx, 32, 64)
 assert lib.imt_sliced_create((vp * 1)(big.h), 1, 1, 0, tp, 8, 0, ctypes.byref(w)) == 0
 for k, (name, args) in enumerate((("imt_sliced_step", (w, None, 1, None, 0, None)), ("imt_sliced_step", (w, vp(odd), 1, None, _ffi.DEVICE_PTRS, None)),
