@@ -463,12 +463,30 @@ def test_processes_over_ipc_equal_one_gpu_tree(imt, ctx, world, host_poll):
                 assert (res[r][k] == w).all(), (rank, r, k)
 
 
-def test_rccl_transport_with_one_rank(imt, ctx):
+@pytest.mark.parametrize("layout", ["default", "pools", "one-pool"])
+def test_rccl_transport_with_one_rank(imt, ctx, layout):
     """the RCCL transport -- ncclCommInitRank and ncclAllGather called by the library on its own communicators and
-    streams -- needs one GPU per rank, so a one-GPU box runs it with a world of ONE: every tick's gather still goes
-    through RCCL (a one-rank all-gather is a copy of the send buffer into the receive buffer)"""
+    streams -- needs one GPU per rank (RCCL refuses two ranks on one device: profiles/r06_rccl_two_ranks_one_gpu.txt), so a
+    one-GPU box runs it with a world of ONE: every tick's gather still goes through RCCL (a one-rank all-gather is a copy
+    of the send buffer into the receive buffer).  layout: what a world of one resolves to by default; the THREE PRIORITY
+    POOLS a real multi-GPU run gets (forced here: ncclAllGather on LOW-priority streams of the library's beside
+    HIGH-priority round streams, RCCL's own bracket stream in the normal pool); every collective on its round's own
+    stream (bench.py's later attempts)."""
     sl = load_sliced()
     depth, cap, batch, rounds = 32, 1 << 12, 256, 5
+    F, lib = imt._ffi, imt.lib
+    if layout == "pools":
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, 1) == 0
+    elif layout == "one-pool":
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_POOLS, 0) == 0
+        assert lib.imt_sliced_set_option(None, F.SLICED_OPT_COMM_STREAMS, 0) == 0
+    try:
+        _rccl_one_rank(imt, ctx, sl, depth, cap, batch, rounds, layout)
+    finally:
+        lib.imt_sliced_set_option(None, F.SLICED_OPT_RESET, 0)
+
+
+def _rccl_one_rank(imt, ctx, sl, depth, cap, batch, rounds, layout):
     F, lib = imt._ffi, imt.lib
     ver = ctypes.c_int(0)
     boot = imt.Context(0)
@@ -485,7 +503,12 @@ def test_rccl_transport_with_one_rank(imt, ctx):
     for r in range(rounds):
         check_round(want[r], t.outputs(r), 0, batch)
     assert t.trees[0].root() == want_root
-    assert t.info()["collectives"] == rounds * depth          # unit 0 carries nothing; one gather per level
+    info = t.info()
+    assert info["collectives"] == rounds * depth          # unit 0 carries nothing; one gather per level
+    if layout == "pools":
+        assert info["pools"] == 1 and sorted(info["queue_map"][0]) == [0, 1, 2, 3] and info["queue_map"][1] == [-2] * 4, info
+    elif layout == "one-pool":
+        assert info["pools"] == 0 and info["comm_streams"] == 0, info
     t.close()
     boot.close()
 
