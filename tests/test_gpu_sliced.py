@@ -513,6 +513,55 @@ def _rccl_one_rank(imt, ctx, sl, depth, cap, batch, rounds, layout):
     boot.close()
 
 
+def test_rccl_transport_over_communicators_the_host_owns(imt, ctx):
+    """imt_transport_rccl_adopt: a host that already has communicators (its own NCCL program) hands them over; the library
+    issues its all-gathers on them and does NOT destroy them.  One rank (RCCL takes one rank per GPU), two communicators
+    made here with RCCL's C API through ctypes; afterwards they still work and are destroyed by their owner."""
+    sl = load_sliced()
+    F, lib = imt._ffi, imt.lib
+    ver = ctypes.c_int(0)
+    path = lib.imt_rccl_library(ctypes.byref(ver)).decode()
+    rccl = ctypes.CDLL(path)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rccl.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    torch.cuda.set_device(0)
+    comms = []
+    for _ in range(2):
+        uid = UniqueId()
+        assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+        c = ctypes.c_void_p()
+        assert rccl.ncclCommInitRank(ctypes.byref(c), 1, uid, 0) == 0
+        comms.append(c)
+    tp = ctypes.c_void_p()
+    arr_c = (ctypes.c_void_p * 2)(*[c.value for c in comms])
+    assert lib.imt_transport_rccl_adopt(arr_c, 2, ctypes.byref(tp)) == 0
+    depth, cap, batch, rounds = 32, 1 << 12, 128, 5
+    vals = oracle_lib.synth_values(batch * rounds, 0x494D5464)
+    want, want_root = reference_run(imt, ctx, depth, cap, vals, batch)
+    t = sl.SlicedTree(imt, 0, depth, cap, batch, 1, transport=tp)
+    arr = torch.from_numpy(oracle_lib.ints_to_arr(vals)).cuda()
+    for r in range(rounds):
+        t.step(arr[r * batch:(r + 1) * batch])
+    t.flush()
+    for r in range(rounds):
+        check_round(want[r], t.outputs(r), 0, batch)
+    assert t.trees[0].root() == want_root and t.info()["collectives"] == rounds * depth
+    t.close()                      # destroys the world and the transport -- not the communicators
+    a = torch.arange(64, dtype=torch.uint8, device="cuda")
+    b = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for c in comms:
+        assert rccl.ncclAllGather(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), 64, 2, c, ctypes.c_void_p(st)) == 0      # 2 = ncclUint8
+        torch.cuda.synchronize()
+        assert bool((a == b).all())
+        b.zero_()
+        assert rccl.ncclCommDestroy(c) == 0
+
+
 def test_custom_transport_vtable(imt, ctx):
     """a caller-supplied collective through imt_transport_custom_create: here a world of one, whose all-gather is a
     device-to-device copy issued on the stream the library hands over"""
