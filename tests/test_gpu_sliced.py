@@ -463,7 +463,7 @@ def test_processes_over_ipc_equal_one_gpu_tree(imt, ctx, world, host_poll):
                 assert (res[r][k] == w).all(), (rank, r, k)
 
 
-@pytest.mark.parametrize("layout", ["default", "pools", "one-pool"])
+@pytest.mark.parametrize("layout", ["default", "pools", "one-pool", "one-communicator"])
 def test_rccl_transport_with_one_rank(imt, ctx, layout):
     """the RCCL transport -- ncclCommInitRank and ncclAllGather called by the library on its own communicators and
     streams -- needs one GPU per rank (RCCL refuses two ranks on one device: profiles/r06_rccl_two_ranks_one_gpu.txt), so a
@@ -471,7 +471,8 @@ def test_rccl_transport_with_one_rank(imt, ctx, layout):
     of the send buffer into the receive buffer).  layout: what a world of one resolves to by default; the THREE PRIORITY
     POOLS a real multi-GPU run gets (forced here: ncclAllGather on LOW-priority streams of the library's beside
     HIGH-priority round streams, RCCL's own bracket stream in the normal pool); every collective on its round's own
-    stream (bench.py's later attempts)."""
+    stream (bench.py's later attempts); ONE communicator for all four round slots (IMT_BENCH_RCCL_COMMS=1: the slots'
+    collectives then share one stream, in issue order)."""
     sl = load_sliced()
     depth, cap, batch, rounds = 32, 1 << 12, 256, 5
     F, lib = imt._ffi, imt.lib
@@ -490,7 +491,7 @@ def _rccl_one_rank(imt, ctx, sl, depth, cap, batch, rounds, layout):
     F, lib = imt._ffi, imt.lib
     ver = ctypes.c_int(0)
     boot = imt.Context(0)
-    tp = sl.rccl_transport(imt, boot, None, 1, 0, n_comms=4)
+    tp = sl.rccl_transport(imt, boot, None, 1, 0, n_comms=1 if layout == "one-communicator" else 4)
     path = lib.imt_rccl_library(ctypes.byref(ver)).decode()
     assert "rccl" in path and ver.value >= 21000, (path, ver.value)
     vals = oracle_lib.synth_values(batch * rounds, 0x494D5463)
