@@ -190,14 +190,16 @@ def launch_ranks(args):
 # `value` is the single list's figure from the first attempt that verifies on every rank (or from the one exploratory
 # attempt in the other stream layout that may follow it, if that figure is better) -- never the subtrees' -- and the line
 # carries `attempts`: what each attempt ran with and how it ended.
-ATTEMPT_LAYOUTS = ("pools", "one-pool")
+ATTEMPT_LAYOUTS = ("pools", "one-pool", "one-comm")
 
 
 def attempts_plan(backend, world=2):
     """[(transport, layout)] in the order tried.  layout "pools" = the library's default for one process per GPU (round
     streams HIGH, collectives LOW: IMT_SLICED_OPT_POOLS 1); "one-pool" = everything in the normal pool with every
     collective ON ITS ROUND'S OWN STREAM (IMT_SLICED_OPT_POOLS 0, COMM_STREAMS 0): no wait ever crosses a hardware queue
-    of this library -- the layout the queue model proves cannot stall on placement, every tick a barrier across ranks.
+    of this library -- the layout the queue model proves cannot stall on placement, every tick a barrier across ranks;
+    "one-comm" = one pool and ONE RCCL communicator for all round slots, their collectives on one stream in issue order:
+    the most conservative way to use RCCL (nothing of RCCL's runs concurrently with anything else of RCCL's), last resort.
     IMT_BENCH_ATTEMPTS="rccl:pools,ipc:one-pool" overrides; IMT_BENCH_SLICED_TRANSPORT alone = that one attempt."""
     spec = os.environ.get("IMT_BENCH_ATTEMPTS")
     if spec:
@@ -214,7 +216,7 @@ def attempts_plan(backend, world=2):
     if world == 1:                   # IMT_BENCH_FORCE_DIST on one rank: the IPC transport joins processes, there are none
         return [("rccl", "pools"), ("local", "pools")] if backend == "nccl" else [("local", "pools")]
     if backend == "nccl":
-        return [("rccl", "pools"), ("ipc", "pools"), ("rccl", "one-pool"), ("ipc", "one-pool")]
+        return [("rccl", "pools"), ("ipc", "pools"), ("rccl", "one-pool"), ("ipc", "one-pool"), ("rccl", "one-comm")]
     return [("ipc", "pools"), ("ipc", "one-pool")]
 
 
@@ -824,7 +826,8 @@ def bench_single_list(env):
         # HIP IPC handles -- and the line says so.  (A rank that hangs in ncclCommInitRank is the watchdog's business.)
         tp, why = None, ""
         try:
-            tp = sliced.rccl_transport(env.imt, boot, dist, world, rank, n_comms=int(os.environ.get("IMT_BENCH_RCCL_COMMS", "4")),
+            n_comms = 1 if os.environ.get("IMT_BENCH_LAYOUT") == "one-comm" else int(os.environ.get("IMT_BENCH_RCCL_COMMS", "4"))
+            tp = sliced.rccl_transport(env.imt, boot, dist, world, rank, n_comms=n_comms,
                                        device=env.dev if env.backend == "nccl" else None)
         except Exception as e:            # noqa: BLE001 -- whatever it was, the ranks must agree on what to do next
             why = repr(e)
@@ -850,9 +853,9 @@ def bench_single_list(env):
     layout = os.environ.get("IMT_BENCH_LAYOUT", "pools")
     if "IMT_BENCH_DEVICE" in os.environ and "IMT_SLICED_POOLS" not in os.environ:      # the rehearsal: ranks share ONE device
         lib.imt_sliced_set_option(None, env.F.SLICED_OPT_POOLS, 0)
-    if layout == "one-pool":       # a later attempt's layout (attempts_plan): nothing of this library waits across queues
+    if layout in ("one-pool", "one-comm"):     # a later attempt's layout (attempts_plan): nothing of this library waits across queues
         lib.imt_sliced_set_option(None, env.F.SLICED_OPT_POOLS, 0)
-        lib.imt_sliced_set_option(None, env.F.SLICED_OPT_COMM_STREAMS, 0)
+        lib.imt_sliced_set_option(None, env.F.SLICED_OPT_COMM_STREAMS, 0)     # (one-comm: the one channel gets one stream of its own)
     tree = sliced.SlicedTree(env.imt, env.local_rank, DEPTH, cap, BATCH, world, first_rank=rank, n_local=1, transport=tp,
                              lag=lag, nbuf=nbuf + PREFLIGHT_STEPS)
     env.live_world = tree          # for the watchdog: where the world stands when the leg hangs (imt_sliced_dump)

@@ -107,7 +107,7 @@ def test_plan():
     import bench
     for k in ("IMT_BENCH_ATTEMPTS", "IMT_BENCH_SLICED_TRANSPORT"):
         os.environ.pop(k, None)
-    assert bench.attempts_plan("nccl") == [("rccl", "pools"), ("ipc", "pools"), ("rccl", "one-pool"), ("ipc", "one-pool")]
+    assert bench.attempts_plan("nccl") == [("rccl", "pools"), ("ipc", "pools"), ("rccl", "one-pool"), ("ipc", "one-pool"), ("rccl", "one-comm")]
     assert bench.attempts_plan("gloo") == [("ipc", "pools"), ("ipc", "one-pool")]
     assert bench.attempts_plan("nccl", 1) == [("rccl", "pools"), ("local", "pools")] and bench.attempts_plan("gloo", 1) == [("local", "pools")]
     os.environ["IMT_BENCH_ATTEMPTS"] = "stall,local:one-pool"

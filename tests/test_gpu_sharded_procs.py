@@ -476,3 +476,27 @@ def test_bench_looks_once_at_the_other_stream_layout():
     assert res["value"] == res["modes"]["single_list"]["value"] and res["verified"] is True
     assert res["modes"]["single_list"]["schedule"]["comm_streams"] == at[best]["comm_streams"]
     assert res["modes"]["subtrees"]["verified"] is True
+
+
+def test_bench_last_resort_layout_with_rccl_one_rank():
+    """the plan's last entry, `rccl:one-comm` (ONE communicator for all round slots, one pool, collectives on one stream in
+    issue order), through bench.py's worker with the only RCCL world a one-GPU box can have: one rank."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, IMT_BENCH_FORCE_DIST="1", IMT_BENCH_NO_TRACE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", IMT_BENCH_ATTEMPTS="rccl:one-comm",
+               IMT_BENCH_MODE="single-list")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IMT_BENCH_COLLECTIVE", "IMT_BENCH_DEVICE", "IMT_BENCH_WORKER", "IMT_BENCH_SLICED_TRANSPORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    sch = res["modes"]["single_list"]["schedule"]
+    assert res["verified"] is True and sch["transport"] == "rccl" and sch["pools"] == 0 and sch["comm_streams"] == 1, sch
+    assert res["attempts"][0]["layout"] == "one-comm" and res["attempts"][0]["preflight"]["verified"] is True
